@@ -1,0 +1,100 @@
+"""ORACLE — test infrastructure, not product code.
+
+CPU restatement of the reference frame-importance scorer (``SimNet.forward`` and
+everything below it, reference ``src/model/simnet.py``).  Only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this file;
+the product path (``video-summarization_amd/``) never does and fails loudly when its HIP
+library is missing.
+
+Pinning: the reference ships no tests or golden vectors for this path, so this
+restatement is pinned by outputs of the reference itself, imported on CPU in the build
+container by ``tests/golden/make_golden.py``; the resulting vectors are committed under
+``tests/golden/`` and checked by ``tests/test_oracle.py``.  Arithmetic is torch/ATen fp32 on
+CPU — the same third-party arithmetic the reference uses (unpinned there; torch 2.10.0 here).
+
+The op sequence mirrors the reference one-for-one (including the materialised [B,H,T,T]
+logits tensor and the separate scale multiply) so that timing it is a fair "port" CPU baseline.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+
+def _linear(x, sd, prefix):
+    return F.linear(x, sd[prefix + ".weight"], sd[prefix + ".bias"])
+
+
+def oracle_forward(sd: Dict[str, torch.Tensor], x: torch.Tensor,
+                   mask: Optional[torch.Tensor], num_heads: int,
+                   dtype: torch.dtype = torch.float32
+                   ) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Eval-mode forward.  Returns (logits [B,T,num_classes], hidden [B,T,d]).
+
+    sd    reference-keyed state dict
+    x     [B,T,in_features]
+    mask  bool [B,T], True = key is padding, or None / non-Tensor (ignored, simnet.py:38)
+    """
+    sd = {k: v.to(dtype) for k, v in sd.items()}
+    x = x.to(dtype)
+    B, T, _ = x.shape
+    d = sd["embedding_layer.feature_transform.weight"].shape[0]
+    H = num_heads
+    dh = d // H
+    # Embedding.forward simnet.py:208-217 (use_cls=False)
+    h = _linear(x, sd, "embedding_layer.feature_transform")                      # :211
+    pe_key = "embedding_layer.positional_encoding.pos_embedding"
+    if pe_key in sd:
+        h = h + sd[pe_key][:, :T]                                                # :237-238 (dropout: eval identity)
+    # SimNet.process_mask simnet.py:47-56
+    kmask = None
+    if isinstance(mask, torch.Tensor):
+        kmask = mask.view(B, 1, 1, T).expand(B, H, T, T)
+    scale = d ** -0.5                                                            # :126  (d_model, NOT head_dim)
+    L = 0
+    while ("encoder.module_list.%d.sa.q.weight" % L) in sd:
+        L += 1
+    for l in range(L):                                                           # Encoder.forward :78
+        p = "encoder.module_list.%d." % l
+        # MultiAttentionNetwork.forward :138-164
+        q = _linear(h, sd, p + "sa.q").view(B, T, H, dh).permute(0, 2, 1, 3)     # :148
+        k = _linear(h, sd, p + "sa.k").view(B, T, H, dh).permute(0, 2, 1, 3)     # :150
+        v = _linear(h, sd, p + "sa.v").view(B, T, H, dh).permute(0, 2, 1, 3)     # :152
+        s = torch.matmul(q, k.transpose(2, 3)) * scale                           # :155
+        if kmask is not None:
+            s = s.masked_fill(kmask, float("-inf"))                              # :157
+        w = F.softmax(s, dim=3)                                                  # :158
+        o = torch.matmul(w, v).permute(0, 2, 1, 3).contiguous().view(B, T, d)    # :160-161
+        o = _linear(o, sd, p + "sa.feature_projection")                          # :163
+        # EncoderBlock.forward :105-114  (post-LN)
+        h = F.layer_norm(o + h, (d,), sd[p + "norm1.weight"], sd[p + "norm1.bias"], 1e-5)   # :107
+        m = _linear(F.relu(_linear(h, sd, p + "mlp.fc1")), sd, p + "mlp.fc2")    # :181-182
+        h = F.layer_norm(m + h, (d,), sd[p + "norm2.weight"], sd[p + "norm2.bias"], 1e-5)   # :110
+    logits = _linear(h, sd, "final_layer")                                       # simnet.py:42
+    return logits, h
+
+
+def oracle_scores(sd, x, mask, num_heads):
+    """Caller-side head of val_step (reference train.py:143-144): sigmoid of the logits, [B,T]."""
+    logits, _ = oracle_forward(sd, x, mask, num_heads)
+    return torch.sigmoid(logits.squeeze(-1))
+
+
+def time_cpu_baseline(sd, num_heads: int, B: int, T: int, iters: int, seed: int = 1234,
+                      threads: Optional[int] = None):
+    """Times the restatement on host cores; returns (frames_per_s, threads_used, sample_desc)."""
+    import os
+    import time
+    n = threads or os.cpu_count() or 1
+    torch.set_num_threads(n)
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, T, sd["embedding_layer.feature_transform.weight"].shape[1], generator=g)
+    with torch.no_grad():
+        oracle_forward(sd, x[:1], None, num_heads)          # warm-up (thread pool, allocator)
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            oracle_forward(sd, x, None, num_heads)
+        dt = time.perf_counter() - t0
+    return B * T * iters / dt, torch.get_num_threads(), "B=%d,T=%d x%d iters" % (B, T, iters)

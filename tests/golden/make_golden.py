@@ -1,0 +1,102 @@
+#!/usr/bin/env python3
+"""Generates the golden vectors in this directory by IMPORTING the reference on CPU.
+
+Run in the build container only (the reference tree is not available on the GPU box):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+For every case in CASES it builds seeded weights/inputs with ``synth.py`` (this repo),
+loads them ``strict=True`` into the reference ``model.SimNet`` (reference
+``src/model/simnet.py:8``), runs ``forward`` in eval mode on CPU fp32 and stores the raw
+logits plus a strided sample of the hidden state.  Fixtures hold data only: seeds, shapes and
+expected outputs — never reference source.
+"""
+import importlib
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = os.environ.get("VS_REFERENCE", "/root/reference")
+sys.path.insert(0, os.path.join(REF, "src"))
+sys.dont_write_bytecode = True
+
+synth = importlib.import_module("video-summarization_amd.synth")
+
+# name, model cfg, input cfg
+CASES = [
+    dict(name="ma_t320", H=4, d=256, L=4, B=1, T=320, wseed=11, xseed=101, kind="randn"),
+    dict(name="ma_t320_pad", H=4, d=256, L=4, B=2, T=320, wseed=11, xseed=102, kind="pool5",
+         lengths=[320, 211]),
+    dict(name="mb_t320", H=4, d=512, L=3, B=1, T=320, wseed=12, xseed=103, kind="randn"),
+    dict(name="ma_t1024_b2", H=4, d=256, L=4, B=2, T=1024, wseed=11, xseed=104, kind="randn"),
+    dict(name="ma_ragged37", H=4, d=256, L=4, B=3, T=37, wseed=13, xseed=105, kind="randn",
+         lengths=[37, 20, 5]),
+    dict(name="ctor_default_t100", H=8, d=512, L=4, B=1, T=100, wseed=14, xseed=106, kind="pool5"),
+    dict(name="dh32_t65", H=8, d=256, L=2, B=2, T=65, wseed=15, xseed=107, kind="randn"),
+    dict(name="ma_randmask_t96", H=4, d=256, L=4, B=2, T=96, wseed=11, xseed=108, kind="randn",
+         randmask=7),
+    dict(name="mb_pad_t150", H=4, d=512, L=3, B=2, T=150, wseed=12, xseed=109, kind="pool5",
+         lengths=[150, 97]),
+    dict(name="ma_t2000", H=4, d=256, L=4, B=1, T=2000, wseed=11, xseed=110, kind="randn"),
+    dict(name="ma_nopos_t129", H=4, d=256, L=4, B=1, T=129, wseed=16, xseed=111, kind="randn",
+         use_pos=False),
+    dict(name="ma_nc3_t64", H=4, d=256, L=1, B=1, T=64, wseed=17, xseed=112, kind="randn",
+         num_classes=3),
+]
+HIDDEN_STRIDE = 7
+
+
+def build_inputs(c):
+    x = synth.make_features(c["B"], c["T"], c["xseed"], c["kind"], c.get("lengths"))
+    mask = None
+    if c.get("lengths") is not None:
+        mask = synth.padding_mask(x)
+    if c.get("randmask") is not None:
+        mask = synth.random_mask(c["B"], c["T"], c["randmask"])
+    return x, mask
+
+
+def main():
+    from model import SimNet          # the reference (reference src/model/__init__.py:2)
+    torch.set_num_threads(os.cpu_count() or 1)
+    index = []
+    for c in CASES:
+        nc = c.get("num_classes", 1)
+        use_pos = c.get("use_pos", True)
+        ref = SimNet(num_heads=c["H"], d_model=c["d"], num_layers=c["L"], sparsity=0.0,
+                     dropout=0.3, num_classes=nc, use_pos=use_pos).eval()
+        sd = synth.make_state_dict(c["d"], c["L"], c["wseed"], num_classes=nc, use_pos=use_pos)
+        assert list(sd.keys()) == list(ref.state_dict().keys()), "state_dict key set differs"
+        if use_pos:
+            k = "embedding_layer.positional_encoding.pos_embedding"
+            assert torch.equal(sd[k], ref.state_dict()[k]), "positional table not bit-equal"
+        ref.load_state_dict(sd, strict=True)
+        x, mask = build_inputs(c)
+        with torch.no_grad():
+            logits, hidden = ref(x, mask)
+            logits2, inter = ref(x, mask, model_score=True)
+        assert torch.equal(logits, logits2) and torch.equal(hidden, inter)
+        rows = np.arange(0, c["T"], HIDDEN_STRIDE)
+        np.savez_compressed(
+            os.path.join(HERE, c["name"] + ".npz"),
+            cfg=json.dumps(c),
+            logits=logits.numpy(),
+            hidden_rows=rows,
+            hidden=hidden[:, rows].numpy(),
+            mask=(mask.numpy() if mask is not None else np.zeros((0,), dtype=bool)),
+        )
+        index.append(c)
+        print("%-20s logits %s |max| %.4f  hidden |max| %.4f" % (
+            c["name"], tuple(logits.shape), logits.abs().max().item(), hidden.abs().max().item()))
+    with open(os.path.join(HERE, "index.json"), "w") as f:
+        json.dump({"torch": torch.__version__, "hidden_stride": HIDDEN_STRIDE, "cases": index}, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,7 @@
+"""MI355X-native frame-importance scorer (drop-in for the reference ``model.SimNet``).
+
+The directory name carries a hyphen, so import it with
+``importlib.import_module("video-summarization_amd")`` or through the root-level alias
+module ``video_summarization_amd``.
+"""
+from . import synth  # noqa: F401
