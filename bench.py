@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""Headline benchmark: frames/sec scored on synthetic [B, T=1024, D=1024] (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 50 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one scorer forward (reference ``SimNet.forward``, logits + hidden state) over one
+batch of B=64 videos x T=1024 frames x 1024-d features per GPU (BASELINE.json configs[2], model
+M-A = heads 4, d_model 256, layers 4 — run_finetune.sh:1), inputs already resident in HBM.  Videos
+are independent, so N GPUs score N disjoint batches (weak scaling) and RCCL only gathers the [B,T]
+score matrices (one async all_gather per step, overlapped with the next step's kernels).
+
+Prints ONE JSON line on rank 0 with the contract fields plus
+  roofline      the dominant kernel, from HIP events recorded around every launch of the timed region
+  cpu_baseline  the oracle (CPU restatement of the reference, "port") timed on this box's host cores
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
+
+
+def stage_flops(B, T, Din, d, H, L):
+    """Algorithmic FLOPs per LAUNCH of each stage (per-frame figure x B*T frames)."""
+    M = B * T
+    return {
+        "embed_pe": 2.0 * M * Din * d,
+        "qkv_proj": 2.0 * M * d * 3 * d,
+        "attention": 4.0 * M * T * d,            # QK^T + PV: 2*T*d each per frame
+        "outproj_ln": 2.0 * M * d * d,
+        "fc1_relu": 2.0 * M * d * 4 * d,
+        "fc2_ln_score": 2.0 * M * 4 * d * d + 2.0 * M * d,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=64, help="videos per GPU per step")
+    ap.add_argument("--frames", type=int, default=1024)
+    ap.add_argument("--model", default="A", choices=["A", "B"], help="A: H4 d256 L4 (run scripts); B: H4 d512 L3")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline sample length")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
+                     % (args.gpus, args.gpus))
+        args.gpus = world
+    assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU path for the scorer)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    pkg = importlib.import_module("video-summarization_amd")
+    lib = pkg._lib.load()
+    H, d, L = (4, 256, 4) if args.model == "A" else (4, 512, 3)
+    B, T, Din = args.batch, args.frames, 1024
+    sd = pkg.synth.make_state_dict(d, L, seed=1234)
+    model = pkg.SimNet(num_heads=H, d_model=d, num_layers=L, sparsity=0.0, dropout=0.3)
+    model.load_state_dict(sd, strict=True)
+    model = model.to(dev).eval()
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)       # disjoint videos per rank
+    x_host = torch.randn(B, T, Din, generator=g).pin_memory()
+    x = x_host.to(dev)
+    gathered = torch.empty((world, B, T), dtype=torch.float32, device=dev) if world > 1 else None
+
+    def step():
+        logits, _hidden = model(x)
+        if world > 1:
+            return dist.all_gather_into_tensor(gathered, logits.view(B, T), async_op=True)
+        return None
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            w = step()
+            if w is not None:
+                w.wait()
+        fence()
+        lib.vs_profile_enable(1)
+        t0 = time.perf_counter()
+        works = [step() for _ in range(args.steps)]
+        for w in works:
+            if w is not None:
+                w.wait()
+        fence()
+        dt = time.perf_counter() - t0
+        stages = pkg._lib.profile_collect()
+        lib.vs_profile_enable(0)
+
+        # PCIe-inclusive rate (never `value`): pinned host batch -> device -> forward, same stream
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            model(x_host.to(dev, non_blocking=True))
+        torch.cuda.synchronize()
+        pcie_fps = 3 * B * T / (time.perf_counter() - t1)
+
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    frames = B * T * world * args.steps
+    value = frames / dt
+
+    out = None
+    if rank == 0:
+        fl = stage_flops(B, T, Din, d, H, L)
+        table = {}
+        for name, (ms, n) in stages.items():
+            if n:
+                avg = ms / n
+                table[name] = {"launches": n, "avg_ms": round(avg, 4), "tflops": round(fl[name] / (avg * 1e-3) / 1e12, 2),
+                               "share": 0.0}
+        tot = sum(v["avg_ms"] * v["launches"] for v in table.values())
+        for v in table.values():
+            v["share"] = round(v["avg_ms"] * v["launches"] / tot, 3)
+        dom = max(table, key=lambda k: table[k]["share"])
+        flops_per_frame = 2 * Din * d + L * (24 * d * d + 4 * T * d) + 2 * d
+        roofline = {"bound": "mfma", "kernel": dom, "achieved": table[dom]["tflops"], "peak": PEAK_F32_MFMA_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(table[dom]["tflops"] / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "whole_forward": {"flop_per_frame": flops_per_frame,
+                                      "achieved": round(value / world * flops_per_frame / 1e12, 2),
+                                      "frac": round(value / world * flops_per_frame / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)},
+                    "stages": table}
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle.simnet_oracle import time_cpu_baseline      # the checker, timed as the CPU "port"
+            f1, cores, _ = time_cpu_baseline(sd, H, 8, T, 1)
+            iters = max(2, min(40, int(round(args.cpu_seconds / (8 * T / f1)))))
+            fps, cores, sample = time_cpu_baseline(sd, H, 8, T, iters)
+            cpu = {"value": round(fps, 1), "unit": "frames/s", "cores": cores, "kind": "port",
+                   "sample": "oracle/simnet_oracle.py (materialised [B,H,T,T] softmax, torch CPU fp32), " + sample}
+        out = {
+            "metric": "frames/sec scored (whole node), synthetic [B,T=1024,D=1024]",
+            "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[2]: B=%d videos x T=%d frames x D=%d per GPU, scorer cfg M-%s "
+                                   "(heads %d, d_model %d, layers %d), logits + hidden state" % (B, T, Din, args.model, H, d, L),
+                       "global_batch": B * world, "frames_per_step": B * T * world,
+                       "parallelism": "videos sharded over %d GPU(s), RCCL all_gather of scores" % world},
+            "pcie_inclusive_value": round(pcie_fps * world, 1),
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return out
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,143 @@
+/*
+ * vs_scorer.h — C ABI of libvsscore.so, the MI355X (gfx950) frame-importance scorer.
+ *
+ * The reference (BerserkerMother/Video-Summarization) has no FFI: its scorer is the Python
+ * nn.Module `SimNet` (reference src/model/simnet.py:8).  This ABI is what a binding for that
+ * module's eval forward binds; each entry point cites the reference interface it replaces.
+ * All pointers are DEVICE pointers unless stated otherwise; the library keeps no persistent
+ * state besides the packed weights a vs_weights handle owns.  Every function is thread-safe
+ * with respect to distinct handles; errors are returned as a non-zero status and a
+ * thread-local message (vs_last_error).  No function synchronises the device: work is
+ * enqueued on the caller's HIP stream.
+ */
+#ifndef VS_SCORER_H
+#define VS_SCORER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VS_ABI_VERSION 1
+
+/* status codes */
+#define VS_OK 0
+#define VS_ERR_INVALID 1     /* bad argument / unsupported shape  (reference: RuntimeError from ATen) */
+#define VS_ERR_WORKSPACE 2   /* workspace too small */
+#define VS_ERR_HIP 3         /* a HIP runtime call failed */
+
+/* forward flags */
+#define VS_FLAG_SIGMOID 1u   /* scores = sigmoid(logits): the caller-side head of reference
+                                train.py:144 / generate_summary_image.py:68, fused.  Default
+                                (flag clear) returns raw logits like SimNet.forward (simnet.py:42). */
+
+/* Model hyper-parameters: the ctor arguments of reference SimNet.__init__ (simnet.py:10-13)
+ * that shape the eval forward. */
+typedef struct vs_model_desc {
+    int32_t d_model;      /* simnet.py:16;  multiple of 64, <= 512 */
+    int32_t num_heads;    /* simnet.py:15;  d_model/num_heads in {32, 64, 128} */
+    int32_t num_layers;   /* simnet.py:17;  len(encoder.module_list), >= 1 */
+    int32_t in_features;  /* simnet.py:22 (1024 in the reference); multiple of 32 */
+    int32_t max_len;      /* rows of pos_embedding (simnet.py:188: 2000); 0 when use_pos=False */
+    int32_t num_classes;  /* simnet.py:21,30 */
+} vs_model_desc;
+
+/* One EncoderBlock's parameters (reference simnet.py:93-100), nn.Linear layout [out,in]. */
+typedef struct vs_layer_params {
+    const float *wq, *bq, *wk, *bk, *wv, *bv;   /* sa.q / sa.k / sa.v            simnet.py:130-132 */
+    const float *wo, *bo;                       /* sa.feature_projection         simnet.py:136 */
+    const float *ln1_g, *ln1_b;                 /* norm1                         simnet.py:99 */
+    const float *w1, *b1, *w2, *b2;             /* mlp.fc1 [4d,d], mlp.fc2 [d,4d] simnet.py:175-176 */
+    const float *ln2_g, *ln2_b;                 /* norm2                         simnet.py:100 */
+} vs_layer_params;
+
+/* The whole state_dict as raw device pointers. */
+typedef struct vs_model_params {
+    const float *embed_w, *embed_b;             /* embedding_layer.feature_transform  simnet.py:199 */
+    const float *pos_embedding;                 /* [max_len, d] or NULL (use_pos=False) simnet.py:234 */
+    const vs_layer_params *layers;              /* HOST array of num_layers entries */
+    const float *final_w, *final_b;             /* final_layer [num_classes, d]       simnet.py:30 */
+} vs_model_params;
+
+typedef struct vs_weights vs_weights;           /* opaque: packed device copy of the parameters */
+
+/* ABI version of the loaded library (== VS_ABI_VERSION of the header it was built from). */
+int vs_abi_version(void);
+
+/* Message of the last failing call on this thread ("" if none). */
+const char *vs_last_error(void);
+
+/* Replaces: SimNet.__init__/load_state_dict (simnet.py:10-30; train.py:42-43,76).
+ * Copies the parameters into one device blob in the layout the kernels want (Q/K/V weights
+ * concatenated to [3d, d]; everything else as is).  The copy is enqueued on `stream`; the
+ * source tensors may be modified afterwards.  Call again after any parameter update. */
+int vs_weights_pack(const vs_model_desc *desc, const vs_model_params *params,
+                    void *stream, vs_weights **out);
+void vs_weights_free(vs_weights *w);
+
+/* Bytes of scratch vs_scorer_forward needs for a [B,T] batch (0 on invalid arguments). */
+size_t vs_scorer_workspace_bytes(const vs_weights *w, int32_t B, int32_t T);
+
+/* Replaces: SimNet.forward(x, mask) in eval mode (simnet.py:32-45) including
+ * process_mask (simnet.py:47-56), Embedding/PositionalEncoding (:208-238), the Encoder block
+ * loop (:77-83, :105-114, :138-164, :180-183) and final_layer (:42).
+ *   x             [B, T, in_features] fp32, contiguous
+ *   key_pad_mask  [B, T] bytes, non-zero = key is padding (reference bool mask), or NULL
+ *   scores        [B, T, num_classes] fp32 out: raw logits, or sigmoid with VS_FLAG_SIGMOID
+ *   hidden        [B, T, d_model] fp32 out (second return value of forward), or NULL
+ *   workspace     >= vs_scorer_workspace_bytes(w, B, T) bytes, 256-byte aligned
+ * Errors mirror the reference's: T > max_len (when a positional table is present) -> VS_ERR_INVALID. */
+int vs_scorer_forward(const vs_weights *w, const float *x, const uint8_t *key_pad_mask,
+                      int32_t B, int32_t T, uint32_t flags,
+                      float *scores, float *hidden,
+                      void *workspace, size_t workspace_bytes, void *stream);
+
+/* Measurement hooks (no reference counterpart): while enabled, every stage of
+ * vs_scorer_forward is bracketed by HIP events recorded on the caller's stream.
+ * vs_profile_collect waits for the recorded events, returns per-stage summed milliseconds and launch
+ * counts (arrays of VS_NUM_STAGES) and clears the records. */
+#define VS_STAGE_EMBED 0       /* feature_transform + positional table      gemm_nt_128<PE>   */
+#define VS_STAGE_QKV 1         /* q/k/v projections, head-major store       gemm_nt_128<QKV>  */
+#define VS_STAGE_ATTENTION 2   /* softmax(q k^T) v                          attn_fwd          */
+#define VS_STAGE_OUTPROJ_LN 3  /* feature_projection + residual + norm1     gemm_res_ln       */
+#define VS_STAGE_FC1 4         /* mlp.fc1 + ReLU                            gemm_nt_128<RELU> */
+#define VS_STAGE_FC2_LN 5      /* mlp.fc2 + residual + norm2 (+ score head) gemm_res_ln       */
+#define VS_NUM_STAGES 6
+int vs_profile_enable(int32_t on);
+int vs_profile_collect(double *ms_sum, int64_t *launches);
+const char *vs_stage_name(int32_t stage);
+
+/* Per-kernel entry points (same stream/pointer conventions), exported so each HIP kernel can be
+ * parity-tested against the oracle in isolation.  Not needed by a drop-in binding. */
+
+/* C[M,N] = A[M,K] * W[N,K]^T + bias[N]  (nn.Linear, simnet.py:211 et al.), optional ReLU
+ * (simnet.py:181) and optional + pe[(row % T), :] (simnet.py:237-238; pe may be NULL). */
+int vs_linear_f32(const float *A, const float *W, const float *bias, float *C,
+                  int32_t M, int32_t N, int32_t K, int32_t relu,
+                  const float *pe, int32_t T, void *stream);
+
+/* qkv = h * Wqkv^T + b, scattered head-major: out[3][B][H][T][dh]  (simnet.py:148-153). */
+int vs_qkv_proj_f32(const float *h, const float *Wqkv, const float *bqkv, float *qkv,
+                    int32_t B, int32_t T, int32_t d, int32_t H, void *stream);
+
+/* softmax(q k^T * scale + keymask) v, output [B,T,H*dh] (simnet.py:155-161); q,k,v head-major
+ * [B,H,T,dh]; key_pad_mask [B,T] bytes or NULL. */
+int vs_attention_f32(const float *q, const float *k, const float *v, const uint8_t *key_pad_mask,
+                     float *out, int32_t B, int32_t H, int32_t T, int32_t dh, float scale,
+                     void *stream);
+
+/* out = LayerNorm(A*W^T + bias + residual) * gamma + beta, eps 1e-5 (simnet.py:107,110,163,182);
+ * N = d_model.  If score_w != NULL also scores[row, c] = out[row,:].score_w[c,:] + score_b[c]
+ * (final_layer, simnet.py:42), through sigmoid when `sigmoid` != 0. */
+int vs_linear_residual_layernorm_f32(const float *A, const float *W, const float *bias,
+                                     const float *residual, const float *gamma, const float *beta,
+                                     float *out, int32_t M, int32_t N, int32_t K,
+                                     const float *score_w, const float *score_b, int32_t num_classes,
+                                     int32_t sigmoid, float *scores, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VS_SCORER_H */

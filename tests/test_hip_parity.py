@@ -1,0 +1,277 @@
+"""GPU parity tests: the HIP path (through the C ABI of libvsscore.so) against the committed
+reference-generated golden vectors and against the CPU oracle on the same seeded inputs.
+
+Tolerance: 1e-4 absolute on fp32 logits / hidden state (BASELINE.json north_star)."""
+import ctypes as C
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import build_case, golden_cases, load_golden
+from oracle.simnet_oracle import oracle_forward
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _dev():
+    assert torch.cuda.is_available(), "these tests need a HIP device"
+    return torch.device("cuda:0")
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _model(vsa, c, sd):
+    m = vsa.SimNet(num_heads=c["H"], d_model=c["d"], num_layers=c["L"], sparsity=0.0, dropout=0.3,
+                   num_classes=c.get("num_classes", 1), use_pos=c.get("use_pos", True))
+    m.load_state_dict(sd, strict=True)
+    return m.to(_dev()).eval()
+
+
+@pytest.mark.parametrize("case", golden_cases(), ids=lambda c: c["name"])
+def test_forward_matches_reference_golden(vsa, case):
+    """Full scorer forward vs vectors produced by the imported reference (tests/golden/make_golden.py)."""
+    g = load_golden(case["name"])
+    sd, x, mask = build_case(vsa.synth, case)
+    model = _model(vsa, case, sd)
+    with torch.no_grad():
+        logits, hidden = model(x.to(_dev()), None if mask is None else mask.to(_dev()))
+        logits2, inter = model(x.to(_dev()), None if mask is None else mask.to(_dev()), model_score=True)
+    torch.cuda.synchronize()
+    assert logits.shape == g["logits"].shape and hidden.shape[:2] == x.shape[:2]
+    valid = torch.ones(x.shape[:2], dtype=torch.bool) if mask is None else ~mask
+    # padded QUERY rows are computed but never read by the callers (utils.py:47-51); compare valid frames
+    dl = (logits.cpu() - g["logits"])[valid].abs().max().item()
+    dh = (hidden.cpu()[:, g["rows"]] - g["hidden"])[valid[:, g["rows"]]].abs().max().item()
+    assert dl < TOL and dh < TOL, (dl, dh)
+    assert torch.equal(logits, logits2) and torch.equal(hidden, inter)
+
+
+def test_padded_query_rows_match_oracle_too(vsa):
+    """Even the padded query rows (finite garbage in the reference) agree with the oracle."""
+    synth = vsa.synth
+    sd = synth.make_state_dict(256, 4, 21)
+    x = synth.make_features(2, 140, 22, "randn", [140, 77])
+    mask = synth.padding_mask(x)
+    c = dict(H=4, d=256, L=4)
+    with torch.no_grad():
+        logits, hidden = _model(vsa, c, sd)(x.to(_dev()), mask.to(_dev()))
+        rl, rh = oracle_forward(sd, x, mask, 4)
+    # pad rows carry |x| = 1000 features, so their activations are large: relative bound
+    assert torch.allclose(logits.cpu(), rl, atol=TOL, rtol=1e-4)
+    assert torch.allclose(hidden.cpu(), rh, atol=TOL, rtol=1e-4)
+
+
+def test_non_tensor_mask_is_ignored(vsa):
+    """train.py:162 passes mask=True; the reference ignores non-Tensor masks (simnet.py:38)."""
+    synth = vsa.synth
+    sd = synth.make_state_dict(256, 2, 5)
+    x = synth.make_features(1, 70, 6).to(_dev())
+    m = _model(vsa, dict(H=4, d=256, L=2), sd)
+    with torch.no_grad():
+        a, _ = m(x, True)
+        b, _ = m(x)
+    assert torch.equal(a, b)
+
+
+def test_fused_sigmoid_and_score(vsa):
+    synth = vsa.synth
+    sd = synth.make_state_dict(256, 2, 8)
+    x = synth.make_features(2, 100, 9)
+    m = _model(vsa, dict(H=4, d=256, L=2), sd)
+    with torch.no_grad():
+        logits, _ = m(x.to(_dev()))
+        s = m.score(x.to(_dev()))
+        rl, _ = oracle_forward(sd, x, None, 4)
+    assert (s.cpu() - torch.sigmoid(rl.squeeze(-1))).abs().max().item() < TOL
+    assert (torch.sigmoid(logits.squeeze(-1)) - s).abs().max().item() < 1e-6
+
+
+def test_repack_after_parameter_update(vsa):
+    """Packed device weights must follow optimizer steps / load_state_dict (SURVEY §8(b) ownership)."""
+    synth = vsa.synth
+    sd1, sd2 = synth.make_state_dict(256, 2, 31), synth.make_state_dict(256, 2, 32)
+    x = synth.make_features(1, 64, 33)
+    m = _model(vsa, dict(H=4, d=256, L=2), sd1)
+    with torch.no_grad():
+        a, _ = m(x.to(_dev()))
+        m.load_state_dict(sd2)
+        b, _ = m(x.to(_dev()))
+        m.final_layer.bias.add_(1.0)
+        c, _ = m(x.to(_dev()))
+        rb, _ = oracle_forward(sd2, x, None, 4)
+    assert (b.cpu() - rb).abs().max().item() < TOL
+    assert (a - b).abs().max().item() > 1e-3
+    assert (c - b - 1.0).abs().max().item() < 1e-5
+
+
+def test_errors_mirror_reference(vsa):
+    synth = vsa.synth
+    m = _model(vsa, dict(H=4, d=256, L=1), synth.make_state_dict(256, 1, 1))
+    with torch.no_grad():
+        with pytest.raises(RuntimeError):          # T > 2000: reference raises on the PE add
+            m(torch.zeros(1, 2001, 1024, device=_dev()))
+        with pytest.raises(RuntimeError):          # D != 1024
+            m(torch.zeros(1, 10, 2048, device=_dev()))
+        with pytest.raises(RuntimeError):          # CPU tensors: no fallback
+            m.cpu()(torch.zeros(1, 10, 1024))
+
+
+# ---------------------------------------------------------------------------------------------
+# per-kernel parity through the exported C entry points
+# ---------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("M,N,K,relu,T", [(300, 256, 1024, 0, 0), (129, 1024, 256, 1, 0), (64, 768, 256, 0, 0),
+                                          (1000, 256, 1024, 0, 250), (37, 512, 2048, 0, 37), (2048, 2048, 512, 1, 0)])
+def test_linear_kernel(vsa, M, N, K, relu, T):
+    lib = vsa._lib.load()
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g)
+    pe = torch.randn(T, N, generator=g) if T else None
+    ref = F.linear(A.double(), W.double(), b.double())
+    if relu:
+        ref = F.relu(ref)
+    if T:
+        ref = ref + pe.double().repeat(M // T, 1)
+    dA, dW, db = A.to(_dev()), W.to(_dev()), b.to(_dev())
+    dpe = pe.to(_dev()) if T else None
+    out = torch.full((M, N), float("nan"), device=_dev())
+    vsa._lib.check(lib.vs_linear_f32(dA.data_ptr(), dW.data_ptr(), db.data_ptr(), out.data_ptr(), M, N, K, relu,
+                                     dpe.data_ptr() if T else None, T, _stream()))
+    torch.cuda.synchronize()
+    assert (out.cpu().double() - ref).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize("B,T,d,H", [(2, 100, 256, 4), (1, 33, 512, 4), (3, 64, 256, 8)])
+def test_qkv_kernel(vsa, B, T, d, H):
+    lib = vsa._lib.load()
+    g = torch.Generator().manual_seed(B * T + d)
+    h = torch.randn(B, T, d, generator=g)
+    W = torch.randn(3 * d, d, generator=g) / math.sqrt(d)
+    b = torch.randn(3 * d, generator=g)
+    ref = F.linear(h.double(), W.double(), b.double()).view(B, T, 3, H, d // H).permute(2, 0, 3, 1, 4)
+    out = torch.full((3, B, H, T, d // H), float("nan"), device=_dev())
+    dh_, dW, db = h.to(_dev()), W.to(_dev()), b.to(_dev())
+    vsa._lib.check(lib.vs_qkv_proj_f32(dh_.data_ptr(), dW.data_ptr(), db.data_ptr(), out.data_ptr(), B, T, d, H, _stream()))
+    torch.cuda.synchronize()
+    assert (out.cpu().double() - ref).abs().max().item() < 2e-5
+
+
+def _attn_ref(q, k, v, mask, scale):
+    s = torch.matmul(q.double(), k.double().transpose(2, 3)) * scale
+    if mask is not None:
+        s = s.masked_fill(mask[:, None, None, :], float("-inf"))
+    o = torch.matmul(torch.softmax(s, dim=3), v.double())
+    B, H, T, dh = q.shape
+    return o.permute(0, 2, 1, 3).reshape(B, T, H * dh)
+
+
+@pytest.mark.parametrize("B,H,T,dh,masked", [(2, 4, 320, 64, False), (1, 4, 1024, 64, False), (2, 4, 200, 64, True),
+                                             (2, 4, 150, 128, True), (1, 8, 65, 32, True), (1, 4, 31, 64, False),
+                                             (1, 2, 129, 128, False)])
+def test_attention_kernel(vsa, B, H, T, dh, masked):
+    lib = vsa._lib.load()
+    g = torch.Generator().manual_seed(T + dh)
+    q, k, v = (torch.randn(B, H, T, dh, generator=g) * 2.0 for _ in range(3))
+    mask = vsa.synth.random_mask(B, T, 3) if masked else None
+    scale = (H * dh) ** -0.5
+    ref = _attn_ref(q, k, v, mask, scale)
+    dq, dk, dv = q.to(_dev()), k.to(_dev()), v.to(_dev())
+    dm = mask.to(_dev()) if masked else None
+    out = torch.full((B, T, H * dh), float("nan"), device=_dev())
+    vsa._lib.check(lib.vs_attention_f32(dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), dm.data_ptr() if masked else None,
+                                        out.data_ptr(), B, H, T, dh, scale, _stream()))
+    torch.cuda.synchronize()
+    assert (out.cpu().double() - ref).abs().max().item() < 2e-5
+
+
+def test_attention_online_softmax_rescale_branch(vsa):
+    """Force the running-max jump: one key row spikes against every query in a LATE tile, so every
+    block has to rescale its accumulated O and l (guide rule: a rare data-dependent branch needs its own test)."""
+    lib = vsa._lib.load()
+    B, H, T, dh = 1, 4, 512, 64
+    g = torch.Generator().manual_seed(99)
+    q, k, v = (torch.randn(B, H, T, dh, generator=g) for _ in range(3))
+    k[:, :, 300] = q.mean(dim=2) * 50.0 + 20.0
+    k[:, :, 77] = -k[:, :, 300]
+    scale = 1.0
+    ref = _attn_ref(q, k, v, None, scale)
+    dq, dk, dv = q.to(_dev()), k.to(_dev()), v.to(_dev())
+    out = torch.full((B, T, H * dh), float("nan"), device=_dev())
+    vsa._lib.check(lib.vs_attention_f32(dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), None, out.data_ptr(), B, H, T, dh,
+                                        scale, _stream()))
+    torch.cuda.synchronize()
+    assert (out.cpu().double() - ref).abs().max().item() < 5e-5
+
+
+@pytest.mark.parametrize("M,N,K,nc,sig", [(300, 256, 256, 0, 0), (100, 256, 1024, 1, 0), (65, 512, 2048, 1, 1),
+                                          (64, 128, 512, 3, 0), (1000, 320, 320, 2, 1), (33, 64, 256, 1, 0)])
+def test_linear_residual_layernorm_kernel(vsa, M, N, K, nc, sig):
+    lib = vsa._lib.load()
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b, res = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    gam, bet = 1 + 0.1 * torch.randn(N, generator=g), 0.1 * torch.randn(N, generator=g)
+    sw, sb = torch.randn(max(nc, 1), N, generator=g) / math.sqrt(N), torch.randn(max(nc, 1), generator=g)
+    y = F.layer_norm(F.linear(A.double(), W.double(), b.double()) + res.double(), (N,), gam.double(), bet.double(), 1e-5)
+    sc = F.linear(y, sw.double(), sb.double())
+    if sig:
+        sc = torch.sigmoid(sc)
+    d = [t.to(_dev()) for t in (A, W, b, res, gam, bet, sw, sb)]
+    out = torch.full((M, N), float("nan"), device=_dev())
+    scores = torch.full((M, max(nc, 1)), float("nan"), device=_dev())
+    vsa._lib.check(lib.vs_linear_residual_layernorm_f32(
+        d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), d[4].data_ptr(), d[5].data_ptr(),
+        out.data_ptr(), M, N, K, d[6].data_ptr() if nc else None, d[7].data_ptr() if nc else None, nc, sig,
+        scores.data_ptr() if nc else None, _stream()))
+    torch.cuda.synchronize()
+    assert (out.cpu().double() - y).abs().max().item() < 2e-5
+    if nc:
+        assert (scores.cpu().double() - sc).abs().max().item() < 2e-5
+
+
+def test_c_abi_rejects_bad_arguments(vsa):
+    lib = vsa._lib.load()
+    desc = vsa._lib.ModelDesc(100, 4, 1, 1024, 2000, 1)        # d_model not a multiple of 64
+    out = C.c_void_p()
+    P = vsa._lib.ModelParams()
+    rc = lib.vs_weights_pack(C.byref(desc), C.byref(P), None, C.byref(out))
+    assert rc == vsa._lib.VS_ERR_INVALID and b"d_model" in lib.vs_last_error()
+    assert lib.vs_scorer_workspace_bytes(None, 1, 1) == 0
+
+
+# ---------------------------------------------------------------------------------------------
+# full-size properties (BASELINE.json configs[2]: B=64, T=1024) that need no CPU oracle run
+# ---------------------------------------------------------------------------------------------
+
+def test_full_size_batch_properties(vsa):
+    """At B=64,T=1024 (bench size): (i) videos are independent — scoring a slice of the batch gives
+    bit-identical rows; (ii) a padded+masked copy of a short video scores its valid frames like the
+    unpadded video within fp32 noise; (iii) outputs are finite."""
+    synth = vsa.synth
+    sd = synth.make_state_dict(256, 4, 41)
+    m = _model(vsa, dict(H=4, d=256, L=4), sd)
+    g = torch.Generator(device="cpu").manual_seed(1234)
+    x = torch.randn(64, 1024, 1024, generator=g).to(_dev())
+    with torch.no_grad():
+        full, hid = m(x)
+        part, _ = m(x[5:9].contiguous())
+        assert torch.isfinite(full).all() and torch.isfinite(hid).all()
+        assert torch.equal(full[5:9], part)
+        short = x[:2, :700].contiguous()
+        padded = torch.full((2, 1024, 1024), 1000.0, device=_dev())
+        padded[:, :700] = short
+        a, _ = m(padded, padded[:, :, 0] == 1000.0)
+        b, _ = m(short)
+    assert (a[:, :700] - b).abs().max().item() < 2e-5
+    # and the oracle on two of the 64 videos (CPU cost ~1 s)
+    with torch.no_grad():
+        rl, _ = oracle_forward(sd, x[:2].cpu(), None, 4)
+    assert (full[:2].cpu() - rl).abs().max().item() < TOL

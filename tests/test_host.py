@@ -1,0 +1,103 @@
+"""CPU (no GPU): host logic, the C-ABI surface, and the module's drop-in contract."""
+import ctypes as C
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import ROOT
+
+
+def test_library_builds_and_exports_every_declared_symbol(vsa):
+    """libvsscore.so loads without a GPU and exports exactly what include/vs_scorer.h declares."""
+    vsa._lib.build()
+    lib = vsa._lib.load()
+    hdr = open(os.path.join(ROOT, "include", "vs_scorer.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(vs_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(vsa._lib.EXPORTS), declared ^ set(vsa._lib.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.vs_abi_version() == vsa._lib.ABI_VERSION
+
+
+def test_c_abi_argument_checks_need_no_gpu(vsa):
+    lib = vsa._lib.load()
+    out = C.c_void_p()
+    P = vsa._lib.ModelParams()
+    for desc, word in ((vsa._lib.ModelDesc(100, 4, 1, 1024, 2000, 1), b"d_model"),
+                       (vsa._lib.ModelDesc(256, 3, 1, 1024, 2000, 1), b"num_heads"),
+                       (vsa._lib.ModelDesc(256, 16, 1, 1024, 2000, 1), b"head_dim"),
+                       (vsa._lib.ModelDesc(256, 4, 0, 1024, 2000, 1), b"num_layers"),
+                       (vsa._lib.ModelDesc(256, 4, 1, 1000, 2000, 1), b"in_features")):
+        assert lib.vs_weights_pack(C.byref(desc), C.byref(P), None, C.byref(out)) == vsa._lib.VS_ERR_INVALID
+        assert word in lib.vs_last_error()
+    assert lib.vs_scorer_forward(None, None, None, 1, 1, 0, None, None, None, 0, None) == vsa._lib.VS_ERR_INVALID
+
+
+def test_state_dict_key_set_matches_reference_layout(vsa):
+    """Key names/shapes of SURVEY.md §8(a) row 1; loads strict=True."""
+    m = vsa.SimNet(num_heads=4, d_model=256, num_layers=4, sparsity=0.0, dropout=0.3)
+    sd = vsa.synth.make_state_dict(256, 4, 1)
+    assert list(m.state_dict().keys()) == list(sd.keys())
+    assert all(m.state_dict()[k].shape == v.shape for k, v in sd.items())
+    m.load_state_dict(sd, strict=True)
+    assert sum(p.numel() for p in m.parameters()) == 3421697      # M-A parameter count
+    assert m.state_dict()["embedding_layer.positional_encoding.pos_embedding"].shape == (1, 2000, 256)
+    assert len(m.encoder.module_score) == 0
+
+
+def test_ctor_defaults_and_attributes(vsa):
+    m = vsa.SimNet()
+    assert (m.num_heads, m.d_model, m.num_layers, m.num_classes, m.in_features, m.max_len) == (8, 512, 4, 1, 1024, 2500)
+    with pytest.raises(NotImplementedError):
+        vsa.SimNet(use_cls=True)
+    with pytest.raises(AssertionError):
+        vsa.SimNet(num_heads=3, d_model=256)
+    mask = torch.zeros(2, 7, dtype=torch.bool)
+    assert vsa.SimNet(num_heads=4, d_model=256, num_layers=1).process_mask(mask).shape == (2, 4, 7, 7)
+
+
+def test_scoring_has_no_cpu_fallback(vsa):
+    m = vsa.SimNet(num_heads=4, d_model=256, num_layers=1).eval()
+    with torch.no_grad(), pytest.raises(RuntimeError, match="HIP"):
+        m(torch.zeros(1, 8, 1024))
+
+
+def test_autograd_path_matches_oracle_in_eval_and_trains(vsa):
+    """train.py:111-131 needs forward+backward; in eval mode (dropout off) the autograd path must
+    agree with the oracle, and a few Adam steps must reduce the masked MSE."""
+    from oracle.simnet_oracle import oracle_forward
+    synth = vsa.synth
+    sd = synth.make_state_dict(256, 2, 3)
+    m = vsa.SimNet(num_heads=4, d_model=256, num_layers=2, sparsity=0.0, dropout=0.0)
+    m.load_state_dict(sd)
+    x = synth.make_features(2, 60, 4, "randn", [60, 41])
+    mask = synth.padding_mask(x)
+    m.eval()
+    logits, hidden = m(x, mask)                    # grad enabled + params require grad -> autograd path
+    assert logits.requires_grad
+    rl, rh = oracle_forward(sd, x, mask, 4)
+    valid = ~mask
+    assert (logits.detach() - rl)[valid].abs().max().item() < 2e-5
+    assert (hidden.detach() - rh)[valid].abs().max().item() < 2e-5
+    m.train()
+    opt = torch.optim.Adam(m.parameters(), lr=1e-4)
+    target = torch.rand(2, 60)
+    losses = []
+    for _ in range(8):
+        pred, _ = m(x, mask)
+        keep = (~mask).float()
+        loss = (((pred.squeeze(2) - target) * keep) ** 2).mean()
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    assert losses[-1] < losses[0]
+
+
+def test_positional_table_formula(vsa):
+    pe = vsa.synth.positional_table(256, 2000)
+    assert pe.shape == (1, 2000, 256) and pe[0, 0, 0] == 0 and pe[0, 0, 1] == 1
+    assert abs(pe[0, 3, 0].item() - float(torch.sin(torch.tensor(3.0)))) < 1e-6

@@ -4,4 +4,7 @@ The directory name carries a hyphen, so import it with
 ``importlib.import_module("video-summarization_amd")`` or through the root-level alias
 module ``video_summarization_amd``.
 """
-from . import synth  # noqa: F401
+from . import _lib, synth  # noqa: F401
+from .simnet import SimNet, score_frames  # noqa: F401
+
+__all__ = ["SimNet", "score_frames", "synth"]

@@ -1,0 +1,152 @@
+"""ctypes binding of libvsscore.so (C ABI: ``include/vs_scorer.h``) and its in-tree build.
+
+The library is the product path; nothing here falls back to PyTorch or to the oracle.  If the
+shared object is missing or a symbol is absent, ``load()`` raises — loudly — instead.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import threading
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+INCLUDE = os.path.join(ROOT, "include")
+LIB_PATH = os.path.join(HERE, "libvsscore.so")
+SOURCES = ("vs_kernels.hip", "vs_scorer.cpp")
+ABI_VERSION = 1
+
+VS_OK, VS_ERR_INVALID, VS_ERR_WORKSPACE, VS_ERR_HIP = 0, 1, 2, 3
+VS_FLAG_SIGMOID = 1
+
+# every symbol include/vs_scorer.h declares
+EXPORTS = ("vs_abi_version", "vs_last_error", "vs_weights_pack", "vs_weights_free",
+           "vs_scorer_workspace_bytes", "vs_scorer_forward", "vs_linear_f32", "vs_qkv_proj_f32",
+           "vs_attention_f32", "vs_linear_residual_layernorm_f32",
+           "vs_profile_enable", "vs_profile_collect", "vs_stage_name")
+NUM_STAGES = 6
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [("d_model", C.c_int32), ("num_heads", C.c_int32), ("num_layers", C.c_int32),
+                ("in_features", C.c_int32), ("max_len", C.c_int32), ("num_classes", C.c_int32)]
+
+
+_LAYER_FIELDS = ("wq", "bq", "wk", "bk", "wv", "bv", "wo", "bo", "ln1_g", "ln1_b",
+                 "w1", "b1", "w2", "b2", "ln2_g", "ln2_b")
+
+
+class LayerParams(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in _LAYER_FIELDS]
+
+
+class ModelParams(C.Structure):
+    _fields_ = [("embed_w", C.c_void_p), ("embed_b", C.c_void_p), ("pos_embedding", C.c_void_p),
+                ("layers", C.POINTER(LayerParams)), ("final_w", C.c_void_p), ("final_b", C.c_void_p)]
+
+
+def hipcc_path() -> str:
+    for p in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc"):
+        if p and os.path.exists(p):
+            return p
+    return "hipcc"
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(INCLUDE, "vs_scorer.h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Cross-compiles the HIP sources for gfx950 into the in-tree ``libvsscore.so``
+    (works without a GPU).  Returns the library path."""
+    if not force and not needs_build():
+        return LIB_PATH
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-Wno-unused-value", "-I" + INCLUDE, "-I" + CSRC]
+    cmd += [os.path.join(CSRC, s) for s in SOURCES]
+    tmp = LIB_PATH + ".tmp.%d" % os.getpid()
+    cmd += ["-o", tmp]
+    if verbose:
+        print(" ".join(cmd))
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed building libvsscore.so:\n" + r.stdout + r.stderr)
+    os.replace(tmp, LIB_PATH)
+    return LIB_PATH
+
+
+_lib = None
+_lock = threading.Lock()
+
+
+def load() -> C.CDLL:
+    """dlopen + signature setup.  Raises RuntimeError when the library is missing/stale-ABI."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libvsscore.so not found at %s — the HIP scorer library is not built. "
+                "Run `python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). "
+                "There is no PyTorch/CPU fallback for the scoring path." % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name in EXPORTS:
+            if not hasattr(lib, name):
+                raise RuntimeError("libvsscore.so lacks symbol %s (stale build?)" % name)
+        lib.vs_abi_version.restype = C.c_int
+        if lib.vs_abi_version() != ABI_VERSION:
+            raise RuntimeError("libvsscore.so ABI %d != binding ABI %d" % (lib.vs_abi_version(), ABI_VERSION))
+        lib.vs_last_error.restype = C.c_char_p
+        lib.vs_weights_pack.restype = C.c_int
+        lib.vs_weights_pack.argtypes = [C.POINTER(ModelDesc), C.POINTER(ModelParams), C.c_void_p,
+                                        C.POINTER(C.c_void_p)]
+        lib.vs_weights_free.restype = None
+        lib.vs_weights_free.argtypes = [C.c_void_p]
+        lib.vs_scorer_workspace_bytes.restype = C.c_size_t
+        lib.vs_scorer_workspace_bytes.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+        lib.vs_scorer_forward.restype = C.c_int
+        lib.vs_scorer_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                          C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                          C.c_void_p]
+        lib.vs_linear_f32.restype = C.c_int
+        lib.vs_linear_f32.argtypes = [C.c_void_p] * 4 + [C.c_int32] * 4 + [C.c_void_p, C.c_int32, C.c_void_p]
+        lib.vs_qkv_proj_f32.restype = C.c_int
+        lib.vs_qkv_proj_f32.argtypes = [C.c_void_p] * 4 + [C.c_int32] * 4 + [C.c_void_p]
+        lib.vs_attention_f32.restype = C.c_int
+        lib.vs_attention_f32.argtypes = [C.c_void_p] * 5 + [C.c_int32] * 4 + [C.c_float, C.c_void_p]
+        lib.vs_linear_residual_layernorm_f32.restype = C.c_int
+        lib.vs_linear_residual_layernorm_f32.argtypes = ([C.c_void_p] * 7 + [C.c_int32] * 3 + [C.c_void_p] * 2
+                                                         + [C.c_int32] * 2 + [C.c_void_p] * 2)
+        lib.vs_profile_enable.restype = C.c_int
+        lib.vs_profile_enable.argtypes = [C.c_int32]
+        lib.vs_profile_collect.restype = C.c_int
+        lib.vs_profile_collect.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+        lib.vs_stage_name.restype = C.c_char_p
+        lib.vs_stage_name.argtypes = [C.c_int32]
+        _lib = lib
+    return _lib
+
+
+def profile_collect():
+    """{stage_name: (ms_sum, launches)} of the stages recorded since vs_profile_enable(1)."""
+    lib = load()
+    ms = (C.c_double * NUM_STAGES)()
+    n = (C.c_int64 * NUM_STAGES)()
+    check(lib.vs_profile_collect(ms, n))
+    return {lib.vs_stage_name(i).decode(): (ms[i], n[i]) for i in range(NUM_STAGES)}
+
+
+def check(rc: int) -> None:
+    """Non-zero status -> RuntimeError with the library's message (reference: ATen RuntimeError)."""
+    if rc != VS_OK:
+        msg = load().vs_last_error().decode("utf-8", "replace")
+        raise RuntimeError("libvsscore: %s (status %d)" % (msg, rc))

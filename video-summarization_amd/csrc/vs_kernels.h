@@ -1,0 +1,16 @@
+// Internal C++ launcher interface between the C ABI (vs_scorer.cpp) and the kernels (vs_kernels.hip).
+// Every launcher enqueues on `st`, never synchronises, and returns 0 or a hipError_t / -1 (unsupported shape).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+int vsk_linear(const float *A, const float *W, const float *bias, float *C, int M, int N, int K,
+               int relu, const float *pe, int T, hipStream_t st);
+int vsk_qkv(const float *h, const float *Wqkv, const float *bqkv, float *qkv, int B, int T, int d,
+            int H, hipStream_t st);
+int vsk_attention(const float *q, const float *k, const float *v, const uint8_t *mask, float *out,
+                  int B, int H, int T, int dh, float scale, hipStream_t st);
+int vsk_linear_res_ln(const float *A, const float *W, const float *bias, const float *res,
+                      const float *gamma, const float *beta, float *out, int M, int N, int K,
+                      const float *score_w, const float *score_b, int num_classes, int sigmoid,
+                      float *scores, hipStream_t st);

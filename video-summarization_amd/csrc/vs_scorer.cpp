@@ -1,0 +1,327 @@
+// vs_scorer.cpp — the C ABI of include/vs_scorer.h: argument checks, weight packing, workspace
+// carving and the per-layer launch sequence of the scorer's eval forward.
+#include "vs_scorer.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "vs_kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define VS_HIP(call)                                                                       \
+    do {                                                                                   \
+        hipError_t e_ = (call);                                                            \
+        if (e_ != hipSuccess) return fail(VS_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+#define VS_LAUNCH(call)                                                                     \
+    do {                                                                                    \
+        int e_ = (call);                                                                    \
+        if (e_ > 0) return fail(VS_ERR_HIP, "%s: %s", #call, hipGetErrorString((hipError_t)e_)); \
+        if (e_ < 0) return fail(VS_ERR_INVALID, "%s: unsupported shape", #call);            \
+    } while (0)
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ---- optional per-stage HIP-event timing (bench.py's roofline leg) ----
+const char *const kStageNames[VS_NUM_STAGES] = {"embed_pe", "qkv_proj", "attention", "outproj_ln", "fc1_relu", "fc2_ln_score"};
+struct StageRec { int stage; hipEvent_t a, b; };
+std::mutex g_prof_mu;
+bool g_prof_on = false;
+std::vector<StageRec> g_prof;
+
+struct StageScope {
+    hipStream_t st; int stage; hipEvent_t a = nullptr, b = nullptr; bool on;
+    StageScope(int stage_, hipStream_t st_) : st(st_), stage(stage_), on(g_prof_on) {
+        if (!on) return;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { on = false; return; }
+        (void)hipEventRecord(a, st);
+    }
+    ~StageScope() {
+        if (!on) return;
+        (void)hipEventRecord(b, st);
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        g_prof.push_back({stage, a, b});
+    }
+};
+
+struct LayerOff {
+    size_t wqkv, bqkv, wo, bo, ln1g, ln1b, w1, b1, w2, b2, ln2g, ln2b;
+};
+
+int check_desc(const vs_model_desc *d) {
+    if (!d) return fail(VS_ERR_INVALID, "desc is NULL");
+    if (d->d_model <= 0 || d->d_model % 64 || d->d_model > 512)
+        return fail(VS_ERR_INVALID, "d_model=%d unsupported (multiple of 64, <= 512)", d->d_model);
+    if (d->num_heads <= 0 || d->d_model % d->num_heads)
+        return fail(VS_ERR_INVALID, "d_model=%d not divisible by num_heads=%d", d->d_model, d->num_heads);
+    const int dh = d->d_model / d->num_heads;
+    if (dh != 32 && dh != 64 && dh != 128)
+        return fail(VS_ERR_INVALID, "head_dim=%d unsupported (32, 64 or 128)", dh);
+    if (d->num_layers < 1) return fail(VS_ERR_INVALID, "num_layers=%d unsupported (>= 1)", d->num_layers);
+    if (d->in_features <= 0 || d->in_features % 32)
+        return fail(VS_ERR_INVALID, "in_features=%d unsupported (multiple of 32)", d->in_features);
+    if (d->num_classes <= 0) return fail(VS_ERR_INVALID, "num_classes=%d", d->num_classes);
+    if (d->max_len < 0) return fail(VS_ERR_INVALID, "max_len=%d", d->max_len);
+    return VS_OK;
+}
+
+}  // namespace
+
+struct vs_weights {
+    vs_model_desc desc;
+    float *blob = nullptr;        // one device allocation
+    size_t blob_floats = 0;
+    size_t embed_w = 0, embed_b = 0, pe = 0, final_w = 0, final_b = 0;
+    bool has_pe = false;
+    std::vector<LayerOff> layers;
+    const float *p(size_t off) const { return blob + off; }
+};
+
+extern "C" {
+
+int vs_abi_version(void) { return VS_ABI_VERSION; }
+
+const char *vs_last_error(void) { return g_err.c_str(); }
+
+int vs_weights_pack(const vs_model_desc *desc, const vs_model_params *params, void *stream,
+                    vs_weights **out) {
+    if (int rc = check_desc(desc)) return rc;
+    if (!params || !out) return fail(VS_ERR_INVALID, "params/out is NULL");
+    if (!params->embed_w || !params->embed_b || !params->final_w || !params->final_b ||
+        (desc->num_layers > 0 && !params->layers))
+        return fail(VS_ERR_INVALID, "a required parameter pointer is NULL");
+    if ((params->pos_embedding != nullptr) != (desc->max_len > 0))
+        return fail(VS_ERR_INVALID, "pos_embedding / max_len mismatch");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t d = desc->d_model, din = desc->in_features, nc = desc->num_classes;
+
+    vs_weights *w = new vs_weights();
+    w->desc = *desc;
+    size_t off = 0;
+    auto take = [&](size_t n) { size_t o = off; off += align_up(n, 64); return o; };   // 256-B aligned
+    w->embed_w = take(d * din);
+    w->embed_b = take(d);
+    w->has_pe = params->pos_embedding != nullptr;
+    if (w->has_pe) w->pe = take((size_t)desc->max_len * d);
+    w->layers.resize(desc->num_layers);
+    for (auto &L : w->layers) {
+        L.wqkv = take(3 * d * d); L.bqkv = take(3 * d);
+        L.wo = take(d * d);       L.bo = take(d);
+        L.ln1g = take(d);         L.ln1b = take(d);
+        L.w1 = take(4 * d * d);   L.b1 = take(4 * d);
+        L.w2 = take(4 * d * d);   L.b2 = take(d);
+        L.ln2g = take(d);         L.ln2b = take(d);
+    }
+    w->final_w = take(nc * d);
+    w->final_b = take(nc);
+    w->blob_floats = off;
+    hipError_t e = hipMalloc((void **)&w->blob, off * sizeof(float));
+    if (e != hipSuccess) { delete w; return fail(VS_ERR_HIP, "hipMalloc(%zu): %s", off * sizeof(float), hipGetErrorString(e)); }
+
+    auto copy = [&](size_t dst, const float *src, size_t n) -> hipError_t {
+        if (!src) return hipErrorInvalidValue;
+        return hipMemcpyAsync(w->blob + dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, st);
+    };
+    bool ok = true;
+    ok &= copy(w->embed_w, params->embed_w, d * din) == hipSuccess;
+    ok &= copy(w->embed_b, params->embed_b, d) == hipSuccess;
+    if (w->has_pe) ok &= copy(w->pe, params->pos_embedding, (size_t)desc->max_len * d) == hipSuccess;
+    for (int l = 0; l < desc->num_layers; ++l) {
+        const vs_layer_params &P = params->layers[l];
+        const LayerOff &L = w->layers[l];
+        ok &= copy(L.wqkv, P.wq, d * d) == hipSuccess;
+        ok &= copy(L.wqkv + d * d, P.wk, d * d) == hipSuccess;
+        ok &= copy(L.wqkv + 2 * d * d, P.wv, d * d) == hipSuccess;
+        ok &= copy(L.bqkv, P.bq, d) == hipSuccess;
+        ok &= copy(L.bqkv + d, P.bk, d) == hipSuccess;
+        ok &= copy(L.bqkv + 2 * d, P.bv, d) == hipSuccess;
+        ok &= copy(L.wo, P.wo, d * d) == hipSuccess;
+        ok &= copy(L.bo, P.bo, d) == hipSuccess;
+        ok &= copy(L.ln1g, P.ln1_g, d) == hipSuccess;
+        ok &= copy(L.ln1b, P.ln1_b, d) == hipSuccess;
+        ok &= copy(L.w1, P.w1, 4 * d * d) == hipSuccess;
+        ok &= copy(L.b1, P.b1, 4 * d) == hipSuccess;
+        ok &= copy(L.w2, P.w2, 4 * d * d) == hipSuccess;
+        ok &= copy(L.b2, P.b2, d) == hipSuccess;
+        ok &= copy(L.ln2g, P.ln2_g, d) == hipSuccess;
+        ok &= copy(L.ln2b, P.ln2_b, d) == hipSuccess;
+    }
+    ok &= copy(w->final_w, params->final_w, nc * d) == hipSuccess;
+    ok &= copy(w->final_b, params->final_b, nc) == hipSuccess;
+    if (!ok) {
+        (void)hipFree(w->blob);
+        delete w;
+        return fail(VS_ERR_HIP, "parameter copy failed (NULL pointer or hipMemcpyAsync error: %s)",
+                    hipGetErrorString(hipGetLastError()));
+    }
+    *out = w;
+    return VS_OK;
+}
+
+void vs_weights_free(vs_weights *w) {
+    if (!w) return;
+    if (w->blob) (void)hipFree(w->blob);
+    delete w;
+}
+
+size_t vs_scorer_workspace_bytes(const vs_weights *w, int32_t B, int32_t T) {
+    if (!w || B <= 0 || T <= 0) return 0;
+    const size_t md = align_up((size_t)B * T * w->desc.d_model * sizeof(float), 256);
+    return 10 * md;     // h0, h1, q, k, v, att, ffn(4)
+}
+
+int vs_scorer_forward(const vs_weights *w, const float *x, const uint8_t *key_pad_mask, int32_t B,
+                      int32_t T, uint32_t flags, float *scores, float *hidden, void *workspace,
+                      size_t workspace_bytes, void *stream) {
+    if (!w || !x || !scores) return fail(VS_ERR_INVALID, "weights/x/scores is NULL");
+    if (B <= 0 || T <= 0) return fail(VS_ERR_INVALID, "B=%d T=%d", B, T);
+    const vs_model_desc &D = w->desc;
+    if (w->has_pe && T > D.max_len)
+        return fail(VS_ERR_INVALID, "T=%d exceeds the positional table (max_len=%d)", T, D.max_len);
+    if ((long long)B * T > (1ll << 30)) return fail(VS_ERR_INVALID, "B*T too large");
+    const size_t need = vs_scorer_workspace_bytes(w, B, T);
+    if (!workspace || workspace_bytes < need)
+        return fail(VS_ERR_WORKSPACE, "workspace %zu bytes < %zu needed", workspace_bytes, need);
+    if (((uintptr_t)workspace & 255) || ((uintptr_t)x & 15) || (hidden && ((uintptr_t)hidden & 15)))
+        return fail(VS_ERR_INVALID, "workspace must be 256-byte, x/hidden 16-byte aligned");
+
+    hipStream_t st = (hipStream_t)stream;
+    const int d = D.d_model, H = D.num_heads, L = D.num_layers, M = B * T;
+    const size_t md = align_up((size_t)M * d * sizeof(float), 256) / sizeof(float);
+    float *ws = (float *)workspace;
+    float *h0 = ws, *h1 = ws + md, *qkv = ws + 2 * md, *att = ws + 5 * md, *ffn = ws + 6 * md;
+    const float scale = 1.0f / sqrtf((float)d);        // reference simnet.py:126: d_model ** -0.5
+    const int sig = (flags & VS_FLAG_SIGMOID) ? 1 : 0;
+
+    // Embedding + positional table (simnet.py:211, 237-238)
+    {
+        StageScope ps(VS_STAGE_EMBED, st);
+        VS_LAUNCH(vsk_linear(x, w->p(w->embed_w), w->p(w->embed_b), h0, M, d, D.in_features, 0,
+                             w->has_pe ? w->p(w->pe) : nullptr, T, st));
+    }
+    for (int l = 0; l < L; ++l) {
+        const LayerOff &P = w->layers[l];
+        const bool last = l == L - 1;
+        {
+            StageScope ps(VS_STAGE_QKV, st);
+            VS_LAUNCH(vsk_qkv(h0, w->p(P.wqkv), w->p(P.bqkv), qkv, B, T, d, H, st));
+        }
+        {
+            StageScope ps(VS_STAGE_ATTENTION, st);
+            VS_LAUNCH(vsk_attention(qkv, qkv + (size_t)M * d, qkv + 2 * (size_t)M * d, key_pad_mask, att, B, H,
+                                    T, d / H, scale, st));
+        }
+        {
+            StageScope ps(VS_STAGE_OUTPROJ_LN, st);
+            VS_LAUNCH(vsk_linear_res_ln(att, w->p(P.wo), w->p(P.bo), h0, w->p(P.ln1g), w->p(P.ln1b), h1, M, d, d,
+                                        nullptr, nullptr, 0, 0, nullptr, st));
+        }
+        {
+            StageScope ps(VS_STAGE_FC1, st);
+            VS_LAUNCH(vsk_linear(h1, w->p(P.w1), w->p(P.b1), ffn, M, 4 * d, d, 1, nullptr, 1, st));
+        }
+        float *dst = (last && hidden) ? hidden : h0;
+        {
+            StageScope ps(VS_STAGE_FC2_LN, st);
+            VS_LAUNCH(vsk_linear_res_ln(ffn, w->p(P.w2), w->p(P.b2), h1, w->p(P.ln2g), w->p(P.ln2b), dst, M, d,
+                                        4 * d, last ? w->p(w->final_w) : nullptr,
+                                        last ? w->p(w->final_b) : nullptr, D.num_classes, sig,
+                                        last ? scores : nullptr, st));
+        }
+    }
+    return VS_OK;
+}
+
+int vs_profile_enable(int32_t on) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (auto &r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    g_prof.clear();
+    g_prof_on = on != 0;
+    return VS_OK;
+}
+
+int vs_profile_collect(double *ms_sum, int64_t *launches) {
+    if (!ms_sum || !launches) return fail(VS_ERR_INVALID, "NULL pointer");
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (int i = 0; i < VS_NUM_STAGES; ++i) { ms_sum[i] = 0.0; launches[i] = 0; }
+    for (auto &r : g_prof) {
+        VS_HIP(hipEventSynchronize(r.b));
+        float ms = 0.f;
+        VS_HIP(hipEventElapsedTime(&ms, r.a, r.b));
+        ms_sum[r.stage] += ms;
+        launches[r.stage] += 1;
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    g_prof.clear();
+    return VS_OK;
+}
+
+const char *vs_stage_name(int32_t stage) {
+    return (stage >= 0 && stage < VS_NUM_STAGES) ? kStageNames[stage] : "";
+}
+
+int vs_linear_f32(const float *A, const float *W, const float *bias, float *C, int32_t M, int32_t N,
+                  int32_t K, int32_t relu, const float *pe, int32_t T, void *stream) {
+    if (!A || !W || !bias || !C) return fail(VS_ERR_INVALID, "NULL pointer");
+    if (M <= 0 || N <= 0 || N % 32 || K <= 0 || K % 32)
+        return fail(VS_ERR_INVALID, "M=%d N=%d K=%d unsupported (N, K multiples of 32)", M, N, K);
+    if (pe && (T <= 0 || relu)) return fail(VS_ERR_INVALID, "pe needs T > 0 and relu == 0");
+    VS_LAUNCH(vsk_linear(A, W, bias, C, M, N, K, relu, pe, T > 0 ? T : 1, (hipStream_t)stream));
+    return VS_OK;
+}
+
+int vs_qkv_proj_f32(const float *h, const float *Wqkv, const float *bqkv, float *qkv, int32_t B,
+                    int32_t T, int32_t d, int32_t H, void *stream) {
+    if (!h || !Wqkv || !bqkv || !qkv) return fail(VS_ERR_INVALID, "NULL pointer");
+    if (B <= 0 || T <= 0 || d <= 0 || d % 32 || H <= 0 || d % H || (d / H) % 32)
+        return fail(VS_ERR_INVALID, "B=%d T=%d d=%d H=%d unsupported", B, T, d, H);
+    VS_LAUNCH(vsk_qkv(h, Wqkv, bqkv, qkv, B, T, d, H, (hipStream_t)stream));
+    return VS_OK;
+}
+
+int vs_attention_f32(const float *q, const float *k, const float *v, const uint8_t *key_pad_mask,
+                     float *out, int32_t B, int32_t H, int32_t T, int32_t dh, float scale, void *stream) {
+    if (!q || !k || !v || !out) return fail(VS_ERR_INVALID, "NULL pointer");
+    if (B <= 0 || H <= 0 || T <= 0) return fail(VS_ERR_INVALID, "B=%d H=%d T=%d", B, H, T);
+    if (dh != 32 && dh != 64 && dh != 128) return fail(VS_ERR_INVALID, "head_dim=%d unsupported", dh);
+    VS_LAUNCH(vsk_attention(q, k, v, key_pad_mask, out, B, H, T, dh, scale, (hipStream_t)stream));
+    return VS_OK;
+}
+
+int vs_linear_residual_layernorm_f32(const float *A, const float *W, const float *bias,
+                                     const float *residual, const float *gamma, const float *beta,
+                                     float *out, int32_t M, int32_t N, int32_t K, const float *score_w,
+                                     const float *score_b, int32_t num_classes, int32_t sigmoid,
+                                     float *scores, void *stream) {
+    if (!A || !W || !bias || !residual || !gamma || !beta || !out) return fail(VS_ERR_INVALID, "NULL pointer");
+    if (M <= 0 || N <= 0 || N % 64 || N > 512 || K <= 0 || K % 16)
+        return fail(VS_ERR_INVALID, "M=%d N=%d K=%d unsupported (N multiple of 64 <= 512, K multiple of 16)", M, N, K);
+    if (score_w && (!score_b || !scores || num_classes <= 0))
+        return fail(VS_ERR_INVALID, "score head needs score_b, scores and num_classes > 0");
+    VS_LAUNCH(vsk_linear_res_ln(A, W, bias, residual, gamma, beta, out, M, N, K, score_w, score_b, num_classes,
+                                sigmoid, scores, (hipStream_t)stream));
+    return VS_OK;
+}
+
+}  // extern "C"

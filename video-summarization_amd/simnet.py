@@ -1,0 +1,256 @@
+"""``SimNet`` — drop-in for the reference frame-importance scorer, MI355X-native.
+
+Same constructor, ``forward`` signature/return tuple and ``state_dict`` key set as the reference
+``model.SimNet`` (reference ``src/model/simnet.py:8-56``; key list SURVEY.md §8(a) row 1), so
+``src/train.py``, ``src/pretrain.py``, ``src/evaluation`` and ``PretrainModel`` call it unchanged
+and reference checkpoints load ``strict=True``.
+
+Scoring (eval / no-grad) runs entirely in the hand-written gfx950 kernels of ``libvsscore.so``
+through the custom op ``vs_amd::score_frames`` — there is NO PyTorch or CPU fallback for it: a
+missing library or a non-HIP tensor raises.  Calls that need autograd (``train.py:121``,
+``pretrain.py:61``: train mode, dropout, backward) take ``_forward_autograd``, a composed-torch
+path on the same device; a HIP backward is a later row of SURVEY.md §8(f).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+from torch import Tensor, nn
+
+from . import _lib
+from .synth import IN_FEATURES, PE_MAX_LEN, positional_table
+
+# --------------------------------------------------------------------------------------------
+# packed-weight handles (vs_weights*) live in a registry so the custom op can take a plain int
+# --------------------------------------------------------------------------------------------
+
+
+class _Packed:
+    """Owns one ``vs_weights*`` (device copy of the parameters in kernel layout)."""
+
+    def __init__(self, handle: int, device: torch.device):
+        self.handle = handle
+        self.device = device
+
+    def __del__(self):
+        try:
+            if self.handle:
+                _lib.load().vs_weights_free(self.handle)
+                self.handle = 0
+        except Exception:
+            pass
+
+
+def _ptr(t: Optional[Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+@torch.library.custom_op("vs_amd::score_frames", mutates_args=(), device_types="cuda")
+def score_frames(x: Tensor, mask: Optional[Tensor], handle: int, d_model: int, num_classes: int,
+                 flags: int, want_hidden: bool) -> Tuple[Tensor, Tensor]:
+    """x [B,T,Din] fp32 (HIP device), mask bool/uint8 [B,T] or None, handle = vs_weights*.
+    Returns (scores [B,T,num_classes], hidden [B,T,d_model] or an empty tensor)."""
+    lib = _lib.load()
+    B, T, _ = x.shape
+    x = x.contiguous()
+    scores = torch.empty((B, T, num_classes), dtype=torch.float32, device=x.device)
+    hidden = torch.empty((B, T, d_model) if want_hidden else (0,), dtype=torch.float32, device=x.device)
+    m = None
+    if mask is not None:
+        m = mask.contiguous()
+        m = m.view(torch.uint8) if m.dtype == torch.bool else m.to(torch.uint8)
+    with torch.cuda.device(x.device):
+        need = lib.vs_scorer_workspace_bytes(handle, B, T)
+        ws = torch.empty((max(need, 256),), dtype=torch.uint8, device=x.device)
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        _lib.check(lib.vs_scorer_forward(handle, x.data_ptr(), _ptr(m), B, T, flags, scores.data_ptr(),
+                                         hidden.data_ptr() if want_hidden else None, ws.data_ptr(),
+                                         ws.numel(), stream))
+    return scores, hidden
+
+
+@score_frames.register_fake
+def _(x, mask, handle, d_model, num_classes, flags, want_hidden):
+    B, T, _ = x.shape
+    return (x.new_empty((B, T, num_classes), dtype=torch.float32),
+            x.new_empty((B, T, d_model) if want_hidden else (0,), dtype=torch.float32))
+
+
+# --------------------------------------------------------------------------------------------
+# parameter containers: only there to give the state_dict its reference key names
+# --------------------------------------------------------------------------------------------
+
+
+class _Bag(nn.Module):
+    """A named group of sub-modules / buffers with no behaviour of its own."""
+
+    def __init__(self, **children):
+        super().__init__()
+        for name, child in children.items():
+            setattr(self, name, child)
+
+
+class _SinusoidTable(nn.Module):
+    def __init__(self, d_model: int, max_len: int):
+        super().__init__()
+        self.register_buffer("pos_embedding", positional_table(d_model, max_len))
+
+
+def _encoder_block(d: int) -> nn.Module:
+    return _Bag(
+        sa=_Bag(q=nn.Linear(d, d), k=nn.Linear(d, d), v=nn.Linear(d, d), feature_projection=nn.Linear(d, d)),
+        mlp=_Bag(fc1=nn.Linear(d, 4 * d), fc2=nn.Linear(4 * d, d)),
+        norm1=nn.LayerNorm(d), norm2=nn.LayerNorm(d))
+
+
+class SimNet(nn.Module):
+    """Transformer-encoder frame scorer: features [B,T,1024] -> (logits [B,T,num_classes], hidden [B,T,d])."""
+
+    def __init__(self, num_heads: int = 8, d_model: int = 512, num_layers: int = 4,
+                 sparsity: float = 0.5, use_cls: bool = False, dropout: float = 0.2,
+                 num_classes: int = 1, use_pos: bool = True, max_len=2500):
+        super().__init__()
+        if use_cls:
+            # no reference caller enables it (train.py:33, simnet_pretrain.py:30) and the reference's own
+            # branch hard-codes device "cuda" (simnet.py:49); out of scope — see DESIGN.md
+            raise NotImplementedError("use_cls=True is not supported by the MI355X scorer")
+        if d_model % num_heads:
+            raise AssertionError("d_model must be divisible by num_heads")      # simnet.py:123
+        self.num_heads, self.d_model, self.num_layers = num_heads, d_model, num_layers
+        self.sparsity, self.use_cls, self.max_len = sparsity, use_cls, max_len
+        self.num_classes, self.in_features = num_classes, IN_FEATURES           # simnet.py:22
+        self.use_pos, self.drop_rate = use_pos, dropout
+
+        emb = dict(feature_transform=nn.Linear(self.in_features, d_model))
+        if use_pos:
+            emb["positional_encoding"] = _SinusoidTable(d_model, PE_MAX_LEN)    # simnet.py:188 (2000, not max_len)
+        self.embedding_layer = _Bag(**emb)
+        self.encoder = _Bag(module_list=nn.ModuleList(_encoder_block(d_model) for _ in range(num_layers)),
+                            module_score=nn.ModuleList())                        # stays empty: SURVEY Q2
+        self.final_layer = nn.Linear(d_model, num_classes)
+        self.fused_sigmoid = False        # opt-in: fold the callers' torch.sigmoid (train.py:144) into the kernel
+        self._packed: Optional[_Packed] = None
+        self._packed_key = None
+
+    # ---- reference helper kept for API parity (simnet.py:47-56) ----
+    def process_mask(self, mask: Tensor) -> Tensor:
+        B, N = mask.size()
+        return mask.view(B, 1, 1, N).expand(B, self.num_heads, N, N)
+
+    # ---- weight packing -------------------------------------------------------------------
+    def _tensors(self):
+        yield self.embedding_layer.feature_transform.weight
+        yield self.embedding_layer.feature_transform.bias
+        if self.use_pos:
+            yield self.embedding_layer.positional_encoding.pos_embedding
+        for blk in self.encoder.module_list:
+            for lin in (blk.sa.q, blk.sa.k, blk.sa.v, blk.sa.feature_projection):
+                yield lin.weight
+                yield lin.bias
+            yield blk.norm1.weight
+            yield blk.norm1.bias
+            yield blk.mlp.fc1.weight
+            yield blk.mlp.fc1.bias
+            yield blk.mlp.fc2.weight
+            yield blk.mlp.fc2.bias
+            yield blk.norm2.weight
+            yield blk.norm2.bias
+        yield self.final_layer.weight
+        yield self.final_layer.bias
+
+    def _packed_weights(self, device: torch.device) -> _Packed:
+        """vs_weights* for the current parameter values; re-packed whenever any parameter was
+        written (optimizer step, load_state_dict, .to()) — detected by (data_ptr, _version)."""
+        key = (device,) + tuple((t.data_ptr(), t._version) for t in self._tensors())
+        if self._packed is not None and key == self._packed_key:
+            return self._packed
+        lib = _lib.load()
+        ts = []
+        for t in self._tensors():
+            if t.device != device:
+                raise RuntimeError("SimNet parameters are on %s but the input is on %s" % (t.device, device))
+            ts.append(t.detach().to(torch.float32).contiguous())
+        it = iter(ts)
+        P = _lib.ModelParams()
+        P.embed_w, P.embed_b = next(it).data_ptr(), next(it).data_ptr()
+        P.pos_embedding = next(it).data_ptr() if self.use_pos else None
+        layers = (_lib.LayerParams * max(self.num_layers, 1))()
+        for l in range(self.num_layers):
+            for name in ("wq", "bq", "wk", "bk", "wv", "bv", "wo", "bo", "ln1_g", "ln1_b",
+                         "w1", "b1", "w2", "b2", "ln2_g", "ln2_b"):
+                setattr(layers[l], name, next(it).data_ptr())
+        P.layers = layers
+        P.final_w, P.final_b = next(it).data_ptr(), next(it).data_ptr()
+        desc = _lib.ModelDesc(self.d_model, self.num_heads, self.num_layers, self.in_features,
+                              PE_MAX_LEN if self.use_pos else 0, self.num_classes)
+        out = C.c_void_p()
+        with torch.cuda.device(device):
+            stream = torch.cuda.current_stream(device).cuda_stream
+            _lib.check(lib.vs_weights_pack(C.byref(desc), C.byref(P), stream, C.byref(out)))
+        del ts      # stream-ordered: the async copies are already enqueued on the current stream
+        self._packed, self._packed_key = _Packed(out.value, device), key
+        return self._packed
+
+    # ---- forward --------------------------------------------------------------------------
+    def _needs_autograd(self, x: Tensor) -> bool:
+        if not torch.is_grad_enabled():
+            return False
+        return self.training or x.requires_grad or any(p.requires_grad for p in self.parameters())
+
+    def forward(self, x: Tensor, mask=None, vis_attention=None, model_score: bool = False):
+        """Same contract as reference ``SimNet.forward`` (simnet.py:32-45): returns
+        ``(final_out [B,T,num_classes] raw logits, hidden [B,T,d])``; a non-Tensor ``mask`` is ignored
+        (:38); ``vis_attention`` is ignored (:41); ``model_score`` selects ``intermediate`` which is the
+        same tensor because ``module_score`` is empty."""
+        if x.dim() != 3 or x.size(2) != self.in_features:
+            raise RuntimeError("expected x of shape [B, T, %d], got %s" % (self.in_features, tuple(x.shape)))
+        mask = mask if isinstance(mask, Tensor) else None
+        if self.use_pos and x.size(1) > PE_MAX_LEN:
+            raise RuntimeError("T=%d exceeds the positional table (%d rows)" % (x.size(1), PE_MAX_LEN))
+        if self._needs_autograd(x):
+            return self._forward_autograd(x, mask)
+        if not x.is_cuda:
+            raise RuntimeError("SimNet scoring runs on the MI355X HIP kernels only: move the module and its "
+                               "input to a HIP device (there is no CPU path for the scorer)")
+        flags = _lib.VS_FLAG_SIGMOID if self.fused_sigmoid else 0
+        x32 = x if x.dtype == torch.float32 else x.float()
+        packed = self._packed_weights(x.device)
+        scores, hidden = torch.ops.vs_amd.score_frames(x32, mask, packed.handle, self.d_model,
+                                                       self.num_classes, flags, True)
+        return scores, hidden
+
+    @torch.no_grad()
+    def score(self, x: Tensor, mask: Optional[Tensor] = None) -> Tensor:
+        """Sigmoid importance scores [B,T] in one launch sequence: the ``val_step`` head
+        (train.py:143-144) with the sigmoid fused and the hidden-state store skipped."""
+        if self.num_classes != 1:
+            raise RuntimeError("score() needs num_classes == 1")
+        x32 = x if x.dtype == torch.float32 else x.float()
+        packed = self._packed_weights(x.device)
+        scores, _ = torch.ops.vs_amd.score_frames(x32, mask, packed.handle, self.d_model, 1,
+                                                  _lib.VS_FLAG_SIGMOID, False)
+        return scores.squeeze(-1)
+
+    # ---- autograd-capable path for train.py / pretrain.py (dropout, backward, autocast) -----
+    def _forward_autograd(self, x: Tensor, mask: Optional[Tensor]):
+        B, T, _ = x.shape
+        H, d = self.num_heads, self.d_model
+        p_drop = self.drop_rate if self.training else 0.0
+        emb = self.embedding_layer
+        h = emb.feature_transform(x)
+        if self.use_pos:
+            h = F.dropout(h + emb.positional_encoding.pos_embedding[:, :T], self.sparsity, self.training)
+        keep = None if mask is None else ~mask.view(B, 1, 1, T)      # True = attend
+        for blk in self.encoder.module_list:
+            q, k, v = (lin(h).view(B, T, H, d // H).transpose(1, 2) for lin in (blk.sa.q, blk.sa.k, blk.sa.v))
+            a = F.scaled_dot_product_attention(q, k, v, attn_mask=keep, dropout_p=p_drop,
+                                               scale=1.0 / math.sqrt(d))          # scale = d_model^-0.5 (Q1)
+            a = blk.sa.feature_projection(a.transpose(1, 2).reshape(B, T, d))
+            h = blk.norm1(F.dropout(a, p_drop, self.training) + h)
+            f = blk.mlp.fc2(F.dropout(F.relu(blk.mlp.fc1(h)), p_drop, self.training))
+            h = blk.norm2(F.dropout(f, p_drop, self.training) + h)
+        return self.final_layer(h), h
