@@ -151,9 +151,7 @@ def main():
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             from oracle.simnet_oracle import time_cpu_baseline      # the checker, timed as the CPU "port"
-            f1, cores, _ = time_cpu_baseline(sd, H, 8, T, 1)
-            iters = max(2, min(40, int(round(args.cpu_seconds / (8 * T / f1)))))
-            fps, cores, sample = time_cpu_baseline(sd, H, 8, T, iters)
+            fps, cores, sample = time_cpu_baseline(sd, H, 8, T, args.cpu_seconds)
             cpu = {"value": round(fps, 1), "unit": "frames/s", "cores": cores, "kind": "port",
                    "sample": "oracle/simnet_oracle.py (materialised [B,H,T,T] softmax, torch CPU fp32), " + sample}
         out = {
