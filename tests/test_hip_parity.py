@@ -275,3 +275,29 @@ def test_full_size_batch_properties(vsa):
     with torch.no_grad():
         rl, _ = oracle_forward(sd, x[:2].cpu(), None, 4)
     assert (full[:2].cpu() - rl).abs().max().item() < TOL
+
+
+def test_corpus_scoring_is_sharding_invariant_bit_for_bit(vsa):
+    """BASELINE configs[3] shape (ragged corpus, key masks on): scoring the corpus as 1, 2 or 8 shards
+    gives bit-identical per-frame scores (videos are independent; the kernels are batch-invariant),
+    and matches the oracle per video."""
+    import importlib
+    corpus = importlib.import_module("video-summarization_amd.corpus")
+    synth = vsa.synth
+    sd = synth.make_state_dict(256, 4, 51)
+    m = _model(vsa, dict(H=4, d=256, L=4), sd)
+    g = torch.Generator().manual_seed(7)
+    lens = torch.randint(100, 650, (24,), generator=g).tolist()
+    vids = [torch.randn(t, 1024, generator=g) for t in lens]
+    fn = lambda x, mask: m.score(x, mask)
+    base = corpus.score_corpus(fn, vids, device=_dev(), max_frames=4096)
+    for world in (2, 8):
+        for rank in range(world):
+            mine = corpus.plan_shards(lens, world)[rank]
+            part = corpus.score_corpus(fn, [vids[i] for i in mine], device=_dev(), max_frames=2048)
+            for slot, i in enumerate(mine):
+                assert torch.equal(part[slot], base[i])
+    with torch.no_grad():
+        for i in (0, 5, 23):
+            rl, _ = oracle_forward(sd, vids[i].unsqueeze(0), None, 4)
+            assert (base[i] - torch.sigmoid(rl[0, :, 0])).abs().max().item() < TOL

@@ -1,0 +1,114 @@
+"""Scoring a corpus of ragged videos on 1..N GPUs (BASELINE configs[3]).
+
+Videos are independent units (attention is within-video), so the corpus is dealt to ranks with no
+exchange during compute; the only collective is the gather of the per-frame scores at the end
+(`all_gather`, RCCL over xGMI when the backend is "nccl"; "gloo" in the CPU tests).
+
+The batching mirrors what the reference's loader feeds the scorer (right-padding with 1000.0 and a
+key mask, `data/dataset.py:157-161`, `train.py:118`) but buckets videos by length so the padding
+waste stays small.
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, List, Optional, Sequence
+
+import torch
+
+from .synth import PAD_VALUE
+
+
+def video_cost(T: int, d_model: int = 256, in_features: int = 1024, num_layers: int = 4) -> float:
+    """Algorithmic FLOPs of scoring one T-frame video: T·(2·Din·d + L·(24d² + 4Td))."""
+    return float(T) * (2.0 * in_features * d_model + num_layers * (24.0 * d_model ** 2 + 4.0 * T * d_model))
+
+
+def plan_shards(lengths: Sequence[int], world: int, **cost_kw) -> List[List[int]]:
+    """Deterministic longest-processing-time assignment of video indices to `world` ranks.
+    Every rank computes the same plan from the same lengths — no communication."""
+    order = sorted(range(len(lengths)), key=lambda i: (-lengths[i], i))
+    load = [0.0] * world
+    shards: List[List[int]] = [[] for _ in range(world)]
+    for i in order:
+        r = min(range(world), key=lambda k: (load[k], k))
+        shards[r].append(i)
+        load[r] += video_cost(lengths[i], **cost_kw)
+    return shards
+
+
+def bucket_batches(indices: Sequence[int], lengths: Sequence[int], max_frames: int = 65536,
+                   max_waste: float = 0.25) -> List[List[int]]:
+    """Groups a shard's videos (sorted by length) into padded batches of at most `max_frames`
+    padded frames whose padding waste stays under `max_waste`."""
+    order = sorted(indices, key=lambda i: (lengths[i], i))
+    batches: List[List[int]] = []
+    cur: List[int] = []
+    for i in order:
+        if cur:
+            tmax = lengths[i]                       # sorted ascending: newest is the longest
+            total = sum(lengths[j] for j in cur) + lengths[i]
+            padded = tmax * (len(cur) + 1)
+            if padded > max_frames or 1.0 - total / padded > max_waste:
+                batches.append(cur)
+                cur = []
+        cur.append(i)
+    if cur:
+        batches.append(cur)
+    return batches
+
+
+def pad_batch(videos: Sequence[torch.Tensor], device=None):
+    """[T_i, D] tensors -> (x [B, Tmax, D] right-padded with 1000.0, mask [B, Tmax] bool or None)."""
+    tmax = max(v.shape[0] for v in videos)
+    D = videos[0].shape[1]
+    x = torch.full((len(videos), tmax, D), PAD_VALUE, dtype=torch.float32, device=device)
+    ragged = False
+    for b, v in enumerate(videos):
+        x[b, : v.shape[0]] = v.to(device=device, dtype=torch.float32)
+        ragged |= v.shape[0] != tmax
+    mask = None
+    if ragged:
+        mask = torch.zeros((len(videos), tmax), dtype=torch.bool, device=device)
+        for b, v in enumerate(videos):
+            mask[b, v.shape[0]:] = True
+    return x, mask
+
+
+ScoreFn = Callable[[torch.Tensor, Optional[torch.Tensor]], torch.Tensor]   # (x, mask) -> scores [B, T]
+
+
+def score_corpus(score_fn: ScoreFn, videos: Sequence[torch.Tensor], rank: int = 0, world: int = 1,
+                 group=None, device=None, max_frames: int = 65536) -> Dict[int, torch.Tensor]:
+    """Scores every video once across `world` ranks and returns {video index: scores [T_i]} on EVERY
+    rank (CPU tensors).  `score_fn` is `SimNet.score` on a GPU box.  With world == 1 no
+    `torch.distributed` call is made."""
+    lengths = [int(v.shape[0]) for v in videos]
+    mine = plan_shards(lengths, world)[rank]
+    local: Dict[int, torch.Tensor] = {}
+    for batch in bucket_batches(mine, lengths, max_frames):
+        x, mask = pad_batch([videos[i] for i in batch], device)
+        s = score_fn(x, mask)
+        for b, i in enumerate(batch):
+            local[i] = s[b, : lengths[i]].detach().float().cpu()
+    if world == 1:
+        return local
+    import torch.distributed as dist
+    # one padded all_gather: [n_max, 1 + t_max] rows = (video id, scores...), -1 id = empty slot
+    shards = plan_shards(lengths, world)
+    n_max = max(len(s) for s in shards)
+    t_max = max(lengths) if lengths else 0
+    comm_dev = device if (device is not None and dist.get_backend(group) == "nccl") else torch.device("cpu")
+    send = torch.zeros((n_max, 1 + t_max), dtype=torch.float32, device=comm_dev)
+    send[:, 0] = -1.0
+    for slot, i in enumerate(mine):
+        send[slot, 0] = float(i)
+        send[slot, 1: 1 + lengths[i]] = local[i].to(comm_dev)
+    recv = torch.empty((world * n_max, 1 + t_max), dtype=torch.float32, device=comm_dev)
+    dist.all_gather_into_tensor(recv, send, group=group)      # concatenated along dim 0 (gloo and nccl)
+    recv = recv.view(world, n_max, 1 + t_max).cpu()
+    out: Dict[int, torch.Tensor] = {}
+    for r in range(world):
+        for slot in range(n_max):
+            i = int(recv[r, slot, 0].item())
+            if i >= 0:
+                out[i] = recv[r, slot, 1: 1 + lengths[i]].clone()
+    return out
