@@ -67,7 +67,7 @@ def test_single_process_corpus_equals_per_video_scoring(vsa):
 def _framewise_fn(x, mask):
     """Batch-invariant stand-in scorer (each frame's score depends on that frame only), so the
     sharding/gather plumbing can be held to bit-equality on CPU."""
-    return torch.sigmoid(x[..., :8].sum(-1) * 0.1)
+    return x[..., 0] * 0.5 + x[..., 1]          # exactly-rounded elementwise ops only
 
 
 def _worker(rank, world, port, q):
