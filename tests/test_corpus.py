@@ -81,7 +81,8 @@ def _worker(rank, world, port, q):
     sd = vsa.synth.make_state_dict(256, 1, 5)
     res = corpus.score_corpus(_oracle_score_fn(sd, 4), _videos(9, 11), rank=rank, world=world, max_frames=150)
     res2 = corpus.score_corpus(_framewise_fn, _videos(9, 11), rank=rank, world=world, max_frames=150)
-    q.put((rank, {k: v.clone() for k, v in res.items()}, {k: v.clone() for k, v in res2.items()}))
+    # plain lists: torch tensors would travel as shared-memory handles that die with the worker
+    q.put((rank, {k: v.tolist() for k, v in res.items()}, {k: v.tolist() for k, v in res2.items()}))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -101,8 +102,8 @@ def test_two_rank_gather_equals_single_rank_bit_for_bit(vsa):
     for p in procs:
         p.start()
     got = [q.get(timeout=120) for _ in range(2)]
-    results = {r: a for r, a, _ in got}
-    results2 = {r: b for r, _, b in got}
+    results = {r: {k: torch.tensor(v) for k, v in a.items()} for r, a, _ in got}
+    results2 = {r: {k: torch.tensor(v) for k, v in b.items()} for r, _, b in got}
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
