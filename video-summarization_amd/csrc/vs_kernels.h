@@ -14,3 +14,5 @@ int vsk_linear_res_ln(const float *A, const float *W, const float *bias, const f
                       const float *gamma, const float *beta, float *out, int M, int N, int K,
                       const float *score_w, const float *score_b, int num_classes, int sigmoid,
                       float *scores, hipStream_t st);
+int vsk_diag_gemm(const float *A, const float *W, const float *bias, float *C, int M, int N, int K,
+                  int grid, unsigned long long *diag, hipStream_t st);

@@ -16,6 +16,10 @@
 // The k order inside a sum is irrelevant as long as A and B use the same one.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+
+#include <type_traits>
+#include <utility>
 
 #include "vs_kernels.h"
 
@@ -27,6 +31,16 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 namespace {
 
 __device__ __forceinline__ int acc_row(int t, int h) { return (t & 3) + 8 * (t >> 2) + 4 * h; }
+
+// compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N-1>{})
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
 
 // Blocks b and b+8 share an XCD (round-robin dispatch): give each XCD a contiguous run of
 // logical tile ids so tiles that share an A row-panel hit the same L2.  Bijective for any n.
@@ -49,119 +63,229 @@ __device__ __forceinline__ float half_sum(float v) {   // sum over the 32 lanes 
 //   128x128 block tile, BK = 32, 4 waves as 2x2, each wave 64x64 = 2x2 MFMA tiles.
 //   LDS rows are padded to 36 floats: 16 distinct rows then cover all 64 banks with their
 //   16-byte reads (36*r mod 64 = 4*(9r mod 16)), so ds_read_b128 is conflict-free.
+//   PERSISTENT: the grid is sized to the chip (2 blocks per CU) and every block walks a list of
+//   output tiles with ONE continuous global->register->LDS pipeline: the first k-tile of the next
+//   output tile is prefetched under the last k-tile of the current one, and the epilogue's stores
+//   drain under the next tile's MFMAs.  Without this every block of the chip loads, computes and
+//   stores in the same phase and the load latency / store bursts are exposed once per round.
+//   Blocks that share an XCD (blockIdx % 8) own one contiguous chunk of the tile list, so the
+//   N-tiles of one A row-panel are consumed through one L2.
 // ------------------------------------------------------------------------------------------
 enum { EPI_BIAS = 0, EPI_RELU = 1, EPI_PE = 2, EPI_QKV = 3 };
 
-template <int EPI>
+// Diagnostic stamps (cdna guide §7 "In-kernel stamps"): compiled only into the DIAG instantiation,
+// which is reachable only through vs_diag_gemm(); no product launch executes a stamp.
+__device__ __forceinline__ unsigned long long stamp() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+
+template <int EPI, int DIAG = 0>     // DIAG 1: phase stamps; 2: epilogue skipped (wrong output) + total cycles; 3: total cycles only
 __global__ __launch_bounds__(256, 2) void gemm_nt_128(
     const float *__restrict__ A, const float *__restrict__ W, const float *__restrict__ bias,
-    float *__restrict__ C, int M, int N, int K, const float *__restrict__ pe, int T, int H, int dh) {
+    float *__restrict__ C, int M, int N, int K, const float *__restrict__ pe, int T, int H, int dh,
+    unsigned long long *__restrict__ diag = nullptr) {
     constexpr int BM = 128, BN = 128, BK = 32, LD = BK + 4;
     __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LD];
 
     const int tiles_n = (N + BN - 1) / BN;
-    const int tiles_m = (M + BM - 1) / BM;
-    const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+    const int ntiles = ((M + BM - 1) / BM) * tiles_n;
+    // this block's tile list: start + j, start + j + G, ...   (chunk [start, start+len) per XCD label)
+    const int xl = blockIdx.x & 7, j = blockIdx.x >> 3, G = gridDim.x >> 3;
+    const int cq = ntiles >> 3, cr = ntiles & 7;
+    const int start = xl * cq + (xl < cr ? xl : cr), len = cq + (xl < cr ? 1 : 0);
+    const int my_tiles = len > j ? (len - j + G - 1) / G : 0;
+    if (my_tiles == 0) return;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int wr = wave >> 1, wc = wave & 1;
-
-    // global -> register staging map: 4 float4 of A and 4 of W per thread per k-tile
-    const int lrow = tid >> 3, lc4 = (tid & 7) * 4;
-    const float *ag[4], *wg[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int ar = m0 + lrow + 32 * i; ar = ar < M ? ar : M - 1;
-        int wrow = n0 + lrow + 32 * i; wrow = wrow < N ? wrow : N - 1;
-        ag[i] = A + (size_t)ar * K + lc4;
-        wg[i] = W + (size_t)wrow * K + lc4;
-    }
-    f32x4 pa[4], pw[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { pa[i] = *(const f32x4 *)ag[i]; pw[i] = *(const f32x4 *)wg[i]; }
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int t = 0; t < 16; ++t) acc[i][j][t] = 0.f;
-
+    const int lrow = tid >> 3, lc4 = (tid & 7) * 4;      // staging map: 4 float4 of A and of W per thread
     const int nk = K / BK;
-    {
-        float *As = smem, *Ws = smem + BM * LD;
+
+    // Per-output-tile state, set up ONCE per tile (integer division, 64-bit row pointers): the
+    // per-k-tile work is then 8 loads at pointer + kt*BK.  `nx_*` belongs to the tile being
+    // prefetched, `cu_*` to the tile whose epilogue is still to come.
+    const float *aptr[4], *wptr[4];
+    int nx_m0 = 0, nx_n0 = 0, cu_m0 = 0, cu_n0 = 0;
+    auto set_tile = [&](int it) {
+        const int tile = start + j + it * G;
+        nx_m0 = (tile / tiles_n) * BM;
+        nx_n0 = (tile % tiles_n) * BN;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int ar = nx_m0 + lrow + 32 * i; ar = ar < M ? ar : M - 1;
+            int wrow = nx_n0 + lrow + 32 * i; wrow = wrow < N ? wrow : N - 1;
+            aptr[i] = A + (size_t)ar * K + lc4;
+            wptr[i] = W + (size_t)wrow * K + lc4;
+        }
+    };
+    f32x4 pa[4], pw[4];
+    auto stage = [&](int buf) {
+        float *As = smem + buf * (BM + BN) * LD, *Ws = As + BM * LD;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             *(f32x4 *)&As[(lrow + 32 * i) * LD + lc4] = pa[i];
             *(f32x4 *)&Ws[(lrow + 32 * i) * LD + lc4] = pw[i];
         }
-    }
+    };
+
+    // acc[i][jj][t] = C[m = 64wr + 32i + r][n = 64wc + 32jj + acc_row(t,h)]  (lane = output ROW:
+    // the W fragment is the MFMA A operand, the activation fragment the B operand)
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) acc[i][jj][t] = 0.f;
+
+    set_tile(0);
+    cu_m0 = nx_m0; cu_n0 = nx_n0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { pa[i] = *(const f32x4 *)aptr[i]; pw[i] = *(const f32x4 *)wptr[i]; }
+    stage(0);
     __syncthreads();
 
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        const float *As = smem + cur * (BM + BN) * LD, *Ws = As + BM * LD;
-        const bool more = kt + 1 < nk;
-        if (more) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                pa[i] = *(const f32x4 *)(ag[i] + (kt + 1) * BK);
-                pw[i] = *(const f32x4 *)(wg[i] + (kt + 1) * BK);
-            }
-        }
+    int it = 0, kt = 0;
+    const int total = my_tiles * nk;
+    unsigned long long dsum[5] = {0, 0, 0, 0, 0}, ts0 = 0, ts1 = 0;
+    if (DIAG != 0) ts0 = stamp();
+    const unsigned long long tbegin = ts0;
+    if (DIAG >= 2) dsum[3] = __builtin_amdgcn_s_memrealtime();      // 100 MHz wall clock: wave start
+    for (int f = 0; f < total; ++f) {
+        int kt2 = kt + 1, it2 = it;
+        if (kt2 == nk) { kt2 = 0; ++it2; }
+        // the last step of the last tile prefetches a harmless duplicate (no branch in the MFMA stream)
+        if (it2 >= my_tiles) { it2 = my_tiles - 1; kt2 = 0; }
+        if (kt2 == 0) set_tile(it2);
+        const int koff = kt2 * BK;
+        if (DIAG == 1) { ts1 = stamp(); dsum[0] += ts1 - ts0; ts0 = ts1; }
+
+        const float *As = smem + (f & 1) * (BM + BN) * LD, *Ws = As + BM * LD;
         const float *ap = As + (64 * wr + r) * LD + 4 * h;
         const float *wp = Ws + (64 * wc + r) * LD + 4 * h;
+        f32x4 fa[2][2], fw[2][2];
+        fa[0][0] = *(const f32x4 *)(ap);           fa[0][1] = *(const f32x4 *)(ap + 32 * LD);
+        fw[0][0] = *(const f32x4 *)(wp);           fw[0][1] = *(const f32x4 *)(wp + 32 * LD);
 #pragma unroll
         for (int g = 0; g < BK / 8; ++g) {
-            f32x4 a0 = *(const f32x4 *)(ap + 8 * g), a1 = *(const f32x4 *)(ap + 32 * LD + 8 * g);
-            f32x4 b0 = *(const f32x4 *)(wp + 8 * g), b1 = *(const f32x4 *)(wp + 32 * LD + 8 * g);
+            const int c = g & 1, n = c ^ 1;
+            if (g + 1 < BK / 8) {
+                fa[n][0] = *(const f32x4 *)(ap + 8 * (g + 1)); fa[n][1] = *(const f32x4 *)(ap + 32 * LD + 8 * (g + 1));
+                fw[n][0] = *(const f32x4 *)(wp + 8 * (g + 1)); fw[n][1] = *(const f32x4 *)(wp + 32 * LD + 8 * (g + 1));
+            }
+            if (g < 2) {     // next k-tile's global loads ride in the first half of this k-tile's MFMAs
+                pa[2 * g] = *(const f32x4 *)(aptr[2 * g] + koff);         pw[2 * g] = *(const f32x4 *)(wptr[2 * g] + koff);
+                pa[2 * g + 1] = *(const f32x4 *)(aptr[2 * g + 1] + koff); pw[2 * g + 1] = *(const f32x4 *)(wptr[2 * g + 1] + koff);
+            }
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                acc[0][0] = MFMA32(a0[s], b0[s], acc[0][0]);
-                acc[0][1] = MFMA32(a0[s], b1[s], acc[0][1]);
-                acc[1][0] = MFMA32(a1[s], b0[s], acc[1][0]);
-                acc[1][1] = MFMA32(a1[s], b1[s], acc[1][1]);
+                acc[0][0] = MFMA32(fw[c][0][s], fa[c][0][s], acc[0][0]);
+                acc[0][1] = MFMA32(fw[c][1][s], fa[c][0][s], acc[0][1]);
+                acc[1][0] = MFMA32(fw[c][0][s], fa[c][1][s], acc[1][0]);
+                acc[1][1] = MFMA32(fw[c][1][s], fa[c][1][s], acc[1][1]);
             }
-        }
-        if (more) {
-            float *An = smem + (cur ^ 1) * (BM + BN) * LD, *Wn = An + BM * LD;
+            if (g == BK / 8 - 1) stage((f + 1) & 1);     // LDS writes ride in the last quarter
+            if (g < 2) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                *(f32x4 *)&An[(lrow + 32 * i) * LD + lc4] = pa[i];
-                *(f32x4 *)&Wn[(lrow + 32 * i) * LD + lc4] = pw[i];
-            }
-        }
-        __syncthreads();
-    }
-
-    // epilogue: lane owns column (n) and 16 rows per tile
+                for (int q = 0; q < 4; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);   // 4 MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM read
+                }
+            } else if (g == BK / 8 - 1) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int col = n0 + 64 * wc + 32 * j + r;
-        if (col >= N) continue;
-        const float bv = bias[col];
-        int which = 0, head = 0, e = 0;
-        if (EPI == EPI_QKV) { const int d = H * dh; which = col / d; const int c = col - which * d; head = c / dh; e = c - head * dh; }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-#pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                const int row = m0 + 64 * wr + 32 * i + acc_row(t, h);
-                if (row >= M) continue;
-                float v = acc[i][j][t] + bv;
-                if (EPI == EPI_RELU) v = fmaxf(v, 0.f);
-                if (EPI == EPI_PE) v += pe[(size_t)(row % T) * N + col];
-                if (EPI == EPI_QKV) {
-                    const int b = row / T, tt = row - b * T;
-                    C[(size_t)which * M * (H * dh) + (((size_t)b * H + head) * T + tt) * dh + e] = v;
-                } else {
-                    C[(size_t)row * N + col] = v;
+                for (int q = 0; q < 8; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // 2 MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // 1 DS write
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
+
+        if (DIAG == 1) { ts1 = stamp(); dsum[1] += ts1 - ts0; ts0 = ts1; }
+        if (DIAG == 2 && kt == nk - 1) {
+            // keep the accumulators live and reset them, but store nothing
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) { asm volatile("" ::"v"(acc[i][jj])); for (int t = 0; t < 16; ++t) acc[i][jj][t] = 0.f; }
+            cu_m0 = nx_m0; cu_n0 = nx_n0;
+        }
+        if (DIAG != 2 && kt == nk - 1) {
+            // ---- epilogue of the current output tile.  A lane owns 2 rows x 2x16 columns, 4
+            // consecutive columns per register quad -> 16-byte row-contiguous stores (store ISSUE, not
+            // bytes, is what costs).  Every load (bias, positional table) precedes every store, so no
+            // load's s_waitcnt has to drain this tile's stores (vmcnt retires in order).
+            const int m0 = cu_m0, n0 = cu_n0;
+            int b0 = 0, t0 = 0;                       // (video, frame) of row m0, for EPI_PE / EPI_QKV
+            if (EPI == EPI_PE || EPI == EPI_QKV) { b0 = m0 / T; t0 = m0 - b0 * T; }
+            int row[2], bb[2], tt[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                row[i] = m0 + 64 * wr + 32 * i + r;
+                bb[i] = b0; tt[i] = t0 + 64 * wr + 32 * i + r;
+                if (EPI == EPI_PE || EPI == EPI_QKV) { while (tt[i] >= T) { tt[i] -= T; ++bb[i]; } }
+            }
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int cb = n0 + 64 * wc + 32 * jj + 4 * h;      // + 8*q: first of 4 consecutive columns
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int col = cb + 8 * q;
+                    const f32x4 bv = *(const f32x4 *)(bias + (col < N ? col : 0));
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        f32x4 pv = {0.f, 0.f, 0.f, 0.f};
+                        if (EPI == EPI_PE) pv = *(const f32x4 *)(pe + (size_t)tt[i] * N + (col < N ? col : 0));
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float v = acc[i][jj][4 * q + e] + bv[e];
+                            if (EPI == EPI_RELU) v = fmaxf(v, 0.f);
+                            if (EPI == EPI_PE) v += pv[e];
+                            acc[i][jj][4 * q + e] = v;
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int c32 = n0 + 64 * wc + 32 * jj;               // a 32-column block never straddles a head
+                int which = 0, head = 0, e0 = 0;
+                if (EPI == EPI_QKV) { const int d = H * dh; which = c32 / d; const int c = c32 - which * d; head = c / dh; e0 = c - head * dh; }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int co = 8 * q + 4 * h;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        f32x4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v[e] = acc[i][jj][4 * q + e]; acc[i][jj][4 * q + e] = 0.f; }
+                        if (row[i] < M && c32 + co < N) {
+                            if (EPI == EPI_QKV)
+                                *(f32x4 *)(C + (size_t)which * M * (H * dh) + (((size_t)bb[i] * H + head) * T + tt[i]) * dh + e0 + co) = v;
+                            else
+                                *(f32x4 *)(C + (size_t)row[i] * N + c32 + co) = v;
+                        }
+                    }
+                }
+            }
+            cu_m0 = nx_m0; cu_n0 = nx_n0;
+        }
+        if (DIAG == 1) { ts1 = stamp(); dsum[2] += ts1 - ts0; ts0 = ts1; }
+        __syncthreads();
+        if (DIAG == 1) { ts1 = stamp(); dsum[4] += ts1 - ts0; ts0 = ts1; }
+        it = it2; kt = kt2;
+    }
+    if (DIAG >= 2) { ts0 = stamp(); dsum[4] = __builtin_amdgcn_s_memrealtime(); }
+    if (DIAG != 0 && diag != nullptr && lane == 0) {
+        unsigned long long *o = diag + ((size_t)blockIdx.x * 4 + wave) * 8;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) o[i] = dsum[i];
+        o[5] = ts0 - tbegin; o[6] = (unsigned long long)total; o[7] = tbegin;
     }
 }
 
@@ -329,6 +453,181 @@ __global__ __launch_bounds__(256) void gemm_res_ln(
 }
 
 // ------------------------------------------------------------------------------------------
+// Projection + residual + LayerNorm (+ score head), d_model <= 256: each WAVE owns 32 full rows.
+//   out = LN(A*W^T + bias + residual)*gamma + beta;  scores = out . score_w + score_b
+//   Swapped operands (W fragment = MFMA A operand) put one output ROW on each lane pair (l, l^32):
+//   lane (r,h) holds row 32w+r, columns 32j + 8q + 4h + e of all N = 32*NT columns in acc[NT].
+//   So mean, variance and the score dot product are in-lane sums plus ONE exchange with lane^32 -
+//   no LDS reduction and no block barrier in the epilogue - and the stores are 16-byte row pieces.
+//   residual + bias are loaded straight into the accumulators before the first MFMA (C-in), so the
+//   epilogue issues no loads from HBM at all; gamma/beta/score_w sit in LDS.
+//   Block = 4 waves = 128 rows, BK = 16 (LDS rows padded to 20 floats), 2 blocks per CU.
+// ------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(256, 2) void gemm_ln_rows(
+    const float *__restrict__ A, const float *__restrict__ W, const float *__restrict__ bias,
+    const float *__restrict__ res, const float *__restrict__ gamma, const float *__restrict__ beta,
+    float *__restrict__ out, int M, int K,
+    const float *__restrict__ score_w, const float *__restrict__ score_b, int num_classes,
+    int sigmoid, float *__restrict__ scores) {
+    constexpr int BM = 128, N = 32 * NT, BK = 16, LD = BK + 4;
+    constexpr int WL = (N * BK / 4 + 255) / 256;       // float4 of W per thread per k-tile (N=256: 4)
+    __shared__ __attribute__((aligned(16))) float smem[2 * (BM + N) * LD + 4 * N];
+    float *gam_s = smem + 2 * (BM + N) * LD, *bet_s = gam_s + N, *sw_s = bet_s + N, *bias_s = sw_s + N;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int ntiles = (M + BM - 1) / BM;
+    const int nk = K / BK;
+
+    for (int i = tid; i < N; i += 256) { gam_s[i] = gamma[i]; bet_s[i] = beta[i]; bias_s[i] = bias[i]; }
+
+    // staging map: A 128 rows x 4 float4 (2 per thread), W N rows x 4 float4 (WL per thread)
+    const int lrow = tid >> 2, lc4 = (tid & 3) * 4;
+    f32x4 pa[2], pw[WL];
+    const float *aptr[2], *wptr[WL];
+#pragma unroll
+    for (int i = 0; i < WL; ++i) {
+        int wrow = lrow + 64 * i; wrow = wrow < N ? wrow : N - 1;
+        wptr[i] = W + (size_t)wrow * K + lc4;
+    }
+    auto stage = [&](int buf) {
+        float *As = smem + buf * (BM + N) * LD, *Ws = As + BM * LD;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) *(f32x4 *)&As[(lrow + 64 * i) * LD + lc4] = pa[i];
+#pragma unroll
+        for (int i = 0; i < WL; ++i)
+            if (lrow + 64 * i < N) *(f32x4 *)&Ws[(lrow + 64 * i) * LD + lc4] = pw[i];
+    };
+
+    f32x16 acc[NT];
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int m0 = tile * BM;
+        int row = m0 + 32 * wave + r;
+        const bool row_ok = row < M;
+        row = row_ok ? row : M - 1;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int ar = m0 + lrow + 64 * i; ar = ar < M ? ar : M - 1;
+            aptr[i] = A + (size_t)ar * K + lc4;
+            pa[i] = *(const f32x4 *)aptr[i];
+        }
+#pragma unroll
+        for (int i = 0; i < WL; ++i) pw[i] = *(const f32x4 *)wptr[i];
+        // accumulators start at the residual (C-in of the first MFMA); bias joins in the epilogue from LDS
+        {
+            const float *rp = res + (size_t)row * N + 4 * h;
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 rv = *(const f32x4 *)(rp + 32 * j + 8 * q);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[j][4 * q + e] = rv[e];
+                }
+        }
+        __syncthreads();                 // previous tile's readers are done with both LDS buffers
+        stage(0);
+        __syncthreads();
+
+        for (int kt = 0; kt < nk; ++kt) {
+            const int kn = kt + 1 < nk ? kt + 1 : kt;         // last step reloads a duplicate: branch-free stream
+            const float *As = smem + (kt & 1) * (BM + N) * LD, *Ws = As + BM * LD;
+            const float *ap = As + (32 * wave + r) * LD + 4 * h;
+            const float *wp = Ws + r * LD + 4 * h;
+#pragma unroll
+            for (int g = 0; g < BK / 8; ++g) {
+                const f32x4 fa = *(const f32x4 *)(ap + 8 * g);
+                if (g == 0) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) pa[i] = *(const f32x4 *)(aptr[i] + kn * BK);
+#pragma unroll
+                    for (int i = 0; i < WL; ++i) pw[i] = *(const f32x4 *)(wptr[i] + kn * BK);
+                }
+                // one 32-column tile at a time: a 4-step dependent chain on acc[j] issues back-to-back
+                // (latency == issue interval for 32x32x2), and only one weight fragment is live
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const f32x4 fw = *(const f32x4 *)(wp + 32 * j * LD + 8 * g);
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) acc[j] = MFMA32(fw[s], fa[s], acc[j]);
+                }
+                if (g == BK / 8 - 1) stage((kt + 1) & 1);
+                if (g == 0) {
+#pragma unroll
+                    for (int q = 0; q < 2 + WL; ++q) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, (4 * NT) / (2 + WL), 0);
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 2 + WL; ++q) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, (4 * NT) / (2 + WL), 0);
+                        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __syncthreads();
+        }
+
+        // ---- epilogue: LayerNorm over the row (lane-local + one lane^32 exchange), 16-byte stores ----
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 bv = *(const f32x4 *)&bias_s[32 * j + 8 * q + 4 * h];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { acc[j][4 * q + e] += bv[e]; sum += acc[j][4 * q + e]; }
+            }
+        sum += __shfl_xor(sum, 32);
+        const float mean = sum * (1.0f / N);
+        float sq = 0.f;
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) { const float c = acc[j][t] - mean; acc[j][t] = c; sq += c * c; }
+        sq += __shfl_xor(sq, 32);
+        const float rstd = 1.0f / sqrtf(sq * (1.0f / N) + 1e-5f);
+        float *op = out + (size_t)row * N + 4 * h;
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 gv = *(const f32x4 *)&gam_s[32 * j + 8 * q + 4 * h];
+                const f32x4 bv = *(const f32x4 *)&bet_s[32 * j + 8 * q + 4 * h];
+                f32x4 y;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { y[e] = acc[j][4 * q + e] * rstd * gv[e] + bv[e]; acc[j][4 * q + e] = y[e]; }
+                if (row_ok) *(f32x4 *)(op + 32 * j + 8 * q) = y;
+            }
+        if (score_w != nullptr) {
+            for (int c = 0; c < num_classes; ++c) {
+                __syncthreads();
+                for (int i = tid; i < N; i += 256) sw_s[i] = score_w[(size_t)c * N + i];
+                __syncthreads();
+                float dot = 0.f;
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 wv = *(const f32x4 *)&sw_s[32 * j + 8 * q + 4 * h];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) dot += acc[j][4 * q + e] * wv[e];
+                    }
+                dot += __shfl_xor(dot, 32);
+                if (h == 0 && row_ok) {
+                    float sc = dot + score_b[c];
+                    if (sigmoid) sc = 1.0f / (1.0f + expf(-sc));
+                    scores[(size_t)row * num_classes + c] = sc;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Attention: softmax(q k^T * scale + keymask) v without materialising [T,T].
 //   grid = (ceil(T/128), B*H); 4 waves, each owns 32 query rows and walks all key tiles.
 //   Both products keep the QUERY on the lane: S^T = K * Q^T  (A = K tile from LDS, B = Q in
@@ -489,6 +788,262 @@ __global__ __launch_bounds__(256, 2) void attn_fwd(
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Attention, software-pipelined (head dim 32 / 64): same math and operand trick as attn_fwd, but
+// the wave's MFMA stream never waits for the softmax.  Keys are consumed in 32-key blocks; while
+// block b+1's S^T = K*Q^T MFMAs issue, block b's online-softmax (max, exp2, sum, rescale of O) runs
+// on the VALU in their shadow; then O^T += V_b^T * P_b^T.  K/V tiles of 64 keys are double-buffered
+// in LDS; the global loads of tile t+2 and the LDS writes of tile t+1 ride in the MFMA stream of
+// tile t, and the two barriers per tile only separate MFMA runs (no load latency behind them).
+// The row max / row sum exchange between lane and lane^32 uses v_permlane32_swap (VALU, no LDS).
+// ------------------------------------------------------------------------------------------
+// v_permlane32_swap of a register with itself yields {x_lo | x_lo} and {x_hi | x_hi}: every lane then
+// sees both its own and its lane^32 partner's value, so a symmetric combine needs no select.
+__device__ __forceinline__ float pair_max(float x) {
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    auto pr = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return fmaxf(__builtin_bit_cast(float, (unsigned)pr[0]), __builtin_bit_cast(float, (unsigned)pr[1]));
+}
+__device__ __forceinline__ float pair_sum(float x) {
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    auto pr = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __builtin_bit_cast(float, (unsigned)pr[0]) + __builtin_bit_cast(float, (unsigned)pr[1]);
+}
+
+template <int DH, bool HAS_MASK, int LDS_PAD = 0>
+__global__ __launch_bounds__(256, 2) void attn_fwd_pipe(
+    const float *__restrict__ Q, const float *__restrict__ Kg, const float *__restrict__ Vg,
+    const uint8_t *__restrict__ mask, float *__restrict__ out, int H, int T, float scale_log2e) {
+    constexpr int KT = 64, LD = DH + 4, NJ = DH / 8, ND = DH / 32;
+    constexpr int F4 = KT * DH / 4 / 256;           // float4 per thread per operand tile
+    constexpr int TILE = KT * LD;                   // floats per K (or V) tile in LDS
+    __shared__ __attribute__((aligned(16))) float smem[4 * TILE + 2 * KT + LDS_PAD];   // [buf]{K,V} + mask bias
+    float *mbs = smem + 4 * TILE;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int bh = blockIdx.y, b = bh / H, head = bh - b * H;
+    const size_t base = (size_t)bh * T * DH;
+    const int q0 = blockIdx.x * 128 + 32 * wave;
+    const float NEG_INF = -__builtin_inff();
+    const int ntiles = (T + KT - 1) / KT;
+
+    float qreg[4 * NJ];
+    {
+        int qr = q0 + r; qr = qr < T ? qr : T - 1;
+        const float *qp = Q + base + (size_t)qr * DH + 4 * h;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const f32x4 v = *(const f32x4 *)(qp + 8 * j);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) qreg[4 * j + s] = v[s] * scale_log2e;
+        }
+    }
+    f32x16 o[ND];
+#pragma unroll
+    for (int d = 0; d < ND; ++d)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) o[d][t] = 0.f;
+    float m_run = NEG_INF, l_run = 0.f;
+
+    // staging: thread owns F4 float4 of K and of V per tile
+    f32x4 pk[F4], pv[F4];
+    float pm = 0.f;
+    auto gload = [&](int tile) {
+        tile = tile < ntiles ? tile : ntiles - 1;
+#pragma unroll
+        for (int i = 0; i < F4; ++i) {
+            const int idx = tid + 256 * i;
+            int row = tile * KT + idx / (DH / 4);
+            row = row < T ? row : T - 1;
+            const size_t off = base + (size_t)row * DH + (idx % (DH / 4)) * 4;
+            pk[i] = *(const f32x4 *)(Kg + off);
+            pv[i] = *(const f32x4 *)(Vg + off);
+        }
+        {   // every thread computes the bias of key (tid & 63): no divergent branch in the stream
+            const int key = tile * KT + (tid & (KT - 1));
+            float pmv = key >= T ? NEG_INF : 0.f;
+            if (HAS_MASK) pmv = mask[(size_t)b * T + (key < T ? key : T - 1)] != 0 ? NEG_INF : pmv;
+            pm = pmv;
+        }
+    };
+    auto stage = [&](int buf) {
+        float *Ks = smem + buf * 2 * TILE, *Vs = Ks + TILE;
+#pragma unroll
+        for (int i = 0; i < F4; ++i) {
+            const int idx = tid + 256 * i;
+            const int row = idx / (DH / 4), c = (idx % (DH / 4)) * 4;
+            *(f32x4 *)&Ks[row * LD + c] = pk[i];
+            *(f32x4 *)&Vs[row * LD + c] = pv[i];
+        }
+        mbs[buf * KT + (tid & (KT - 1))] = pm;       // 4 threads write the same value: benign
+    };
+    // S^T block = K[32 keys] * Q^T : 4*NJ MFMAs (plain form, used for the very first block)
+    auto qk = [&](const float *Ks, int blk, f32x16 &s) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) s[t] = 0.f;
+        const float *kp = Ks + (32 * blk + r) * LD + 4 * h;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const f32x4 ka = *(const f32x4 *)(kp + 8 * j);
+#pragma unroll
+            for (int st = 0; st < 4; ++st) s = MFMA32(ka[st], qreg[4 * j + st], s);
+        }
+    };
+
+    // ---- the pipelined half-step -------------------------------------------------------------------
+    // MFMA stream: s_out = K[blk] * Q^T (4*NJ MFMAs).  Between consecutive MFMAs one "unit" of the
+    // independent work is issued, so it executes in the MFMA's 64-cycle shadow:
+    //   units 0-3   key-mask bias add to s_in (LDS broadcast read + 4 adds each)
+    //   units 4-6   row max (in-lane, then lane^32), running max, rescale factor alpha
+    //   units 8-15  p = exp2(s - m) two at a time, row-sum, and O *= alpha a slice at a time
+    //   unit  16    row-sum exchange, running sum
+    //   STAGE only: units 0-7 LDS writes of tile t+1, units 17-25 global loads of tile t+2
+    // A sched_barrier after every slot pins this order (the scheduler otherwise lumps the VALU work
+    // after the MFMAs, where it stalls the matrix pipe).
+    float sm_mx = 0.f, sm_muse = 0.f, sm_alpha = 1.f, sm_psum = 0.f;
+    auto sm_unit = [&](auto uc, f32x16 &sv, const float *mb, auto stage_tag, int nbuf, int ntile) {
+        constexpr int U = decltype(uc)::value;
+        constexpr bool STAGE = decltype(stage_tag)::value;
+        if constexpr (U < 4) {
+            const f32x4 bv = *(const f32x4 *)(mb + 8 * U + 4 * h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sv[4 * U + e] += bv[e];
+        }
+        if constexpr (U == 4) {
+            sm_mx = sv[0];
+#pragma unroll
+            for (int t = 1; t < 8; ++t) sm_mx = fmaxf(sm_mx, sv[t]);
+        }
+        if constexpr (U == 5) {
+#pragma unroll
+            for (int t = 8; t < 16; ++t) sm_mx = fmaxf(sm_mx, sv[t]);
+        }
+        if constexpr (U == 6) {
+            const float mx = pair_max(sm_mx);
+            const float m_new = fmaxf(m_run, mx);
+            sm_muse = (m_new == NEG_INF) ? 0.f : m_new;
+            sm_alpha = __builtin_amdgcn_exp2f(m_run - sm_muse);
+            m_run = m_new;
+            sm_psum = 0.f;
+        }
+        if constexpr (U >= 8 && U < 16) {
+            constexpr int k = U - 8;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const float pe_ = __builtin_amdgcn_exp2f(sv[2 * k + e] - sm_muse);
+                sv[2 * k + e] = pe_;
+                sm_psum += pe_;
+            }
+#pragma unroll
+            for (int d = 0; d < ND; ++d)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) o[d][2 * k + e] *= sm_alpha;
+        }
+        if constexpr (U == 16) l_run = l_run * sm_alpha + pair_sum(sm_psum);
+        if constexpr (STAGE) {
+            if constexpr (U < 2 * F4) {
+                constexpr int i = U / 2;
+                float *Kd = smem + nbuf * 2 * TILE, *Vd = Kd + TILE;
+                const int idx = tid + 256 * i;
+                const int row = idx / (DH / 4), c = (idx % (DH / 4)) * 4;
+                if constexpr (U % 2 == 0) *(f32x4 *)&Kd[row * LD + c] = pk[i];
+                else                      *(f32x4 *)&Vd[row * LD + c] = pv[i];
+            }
+            if constexpr (U == 2 * F4) mbs[nbuf * KT + (tid & (KT - 1))] = pm;
+            if constexpr (U >= 17 && U < 17 + 2 * F4) {
+                constexpr int i = (U - 17) / 2;
+                const int idx = tid + 256 * i;
+                int row = ntile * KT + idx / (DH / 4);
+                row = row < T ? row : T - 1;
+                const size_t off = base + (size_t)row * DH + (idx % (DH / 4)) * 4;
+                if constexpr ((U - 17) % 2 == 0) pk[i] = *(const f32x4 *)(Kg + off);
+                else                             pv[i] = *(const f32x4 *)(Vg + off);
+            }
+            if constexpr (U == 17 + 2 * F4) {
+                const int key = ntile * KT + (tid & (KT - 1));
+                float pmv = key >= T ? NEG_INF : 0.f;
+                if (HAS_MASK) pmv = mask[(size_t)b * T + (key < T ? key : T - 1)] != 0 ? NEG_INF : pmv;
+                pm = pmv;
+            }
+        }
+    };
+    auto qk_softmax = [&](const float *Ksrc, int blk, f32x16 &s_out, f32x16 &s_in, const float *mb,
+                          auto stage_tag, int nbuf, int ntile) {
+        constexpr int NSLOT = 4 * NJ, R = 32 / NSLOT;      // units per MFMA slot (DH=64: 1, DH=32: 2)
+        const float *kp = Ksrc + (32 * blk + r) * LD + 4 * h;
+        f32x4 ka[2];
+        ka[0] = *(const f32x4 *)kp;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) s_out[t] = 0.f;
+        static_for<NSLOT>([&](auto ic) {
+            constexpr int i = decltype(ic)::value, j = i / 4, st = i % 4;
+            if constexpr (st == 0 && j + 1 < NJ) ka[(j + 1) & 1] = *(const f32x4 *)(kp + 8 * (j + 1));
+            s_out = MFMA32(ka[j & 1][st], qreg[4 * j + st], s_out);
+            static_for<R>([&](auto rc) {
+                sm_unit(std::integral_constant<int, i * R + decltype(rc)::value>{}, s_in, mb, stage_tag, nbuf, ntile);
+            });
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+    // softmax alone (last block of the video: nothing left to overlap with)
+    auto softmax_only = [&](f32x16 &sv, const float *mb) {
+        static_for<32>([&](auto uc) { sm_unit(uc, sv, mb, std::false_type{}, 0, 0); });
+    };
+    // O^T += V[32 keys]^T * P^T : 16*ND MFMAs
+    auto pv_acc = [&](const float *Vs, int blk, const f32x16 &p) {
+        const float *vp = Vs + (32 * blk + 4 * h) * LD + r;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+#pragma unroll
+            for (int d = 0; d < ND; ++d) {
+                const float va = vp[((t & 3) + 8 * (t >> 2)) * LD + 32 * d];
+                o[d] = MFMA32(va, p[t], o[d]);
+            }
+        }
+    };
+
+    gload(0);
+    stage(0);
+    gload(1);
+    __syncthreads();
+    f32x16 s_cur, s_nxt;
+    qk(smem, 0, s_cur);
+
+    for (int t = 0; t < ntiles; ++t) {
+        const int buf = t & 1;
+        const float *Ks = smem + buf * 2 * TILE, *Vs = Ks + TILE;
+        const float *Kn = smem + (buf ^ 1) * 2 * TILE;
+        __syncthreads();                       // everyone is done with buffer buf^1 (tile t-1)
+        // S of block (t,1)  ||  softmax of block (t,0), LDS writes of tile t+1, global loads of tile t+2
+        qk_softmax(Ks, 1, s_nxt, s_cur, mbs + buf * KT, std::true_type{}, buf ^ 1, t + 2 < ntiles ? t + 2 : ntiles - 1);
+        pv_acc(Vs, 0, s_cur);
+        __syncthreads();                       // tile t+1 is visible in buffer buf^1
+        if (t + 1 < ntiles) {
+            // S of block (t+1,0)  ||  softmax of block (t,1)
+            qk_softmax(Kn, 0, s_cur, s_nxt, mbs + buf * KT + 32, std::false_type{}, 0, 0);
+        } else {
+            softmax_only(s_nxt, mbs + buf * KT + 32);
+        }
+        pv_acc(Vs, 1, s_nxt);
+    }
+
+    const int q = q0 + r;
+    if (q < T) {
+        const float inv = 1.0f / l_run;
+        float *op = out + ((size_t)b * T + q) * (H * DH) + head * DH;
+#pragma unroll
+        for (int d = 0; d < ND; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = o[d][4 * g + e] * inv;
+                *(f32x4 *)(op + 32 * d + 8 * g + 4 * h) = v;
+            }
+    }
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------
@@ -496,9 +1051,25 @@ __global__ __launch_bounds__(256, 2) void attn_fwd(
 // ------------------------------------------------------------------------------------------
 #define VSK_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)
 
+// persistent grid: 2 blocks per CU (LDS-limited), a multiple of 8 so the XCD chunking is exact
+static int persistent_blocks(int ntiles) {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0; hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
+        cus = prop.multiProcessorCount;
+    }
+    int g = 2 * cus;
+    g -= g % 8;
+    if (g < 8) g = 8;
+    const int need = (ntiles + 7) / 8 * 8;
+    return need < g ? need : g;
+}
+
 int vsk_linear(const float *A, const float *W, const float *bias, float *C, int M, int N, int K,
                int relu, const float *pe, int T, hipStream_t st) {
-    const int blocks = ((M + 127) / 128) * ((N + 127) / 128);
+    const int blocks = persistent_blocks(((M + 127) / 128) * ((N + 127) / 128));
+    if (blocks < 0) return (int)hipErrorInvalidDevice;
     if (pe != nullptr)
         hipLaunchKernelGGL(gemm_nt_128<EPI_PE>, dim3(blocks), dim3(256), 0, st, A, W, bias, C, M, N, K, pe, T, 0, 0);
     else if (relu)
@@ -509,10 +1080,35 @@ int vsk_linear(const float *A, const float *W, const float *bias, float *C, int 
     return 0;
 }
 
+// diagnostic: the fc1-shaped GEMM with per-wave phase stamps; `grid` <= 0 selects the product grid
+int vsk_diag_gemm(const float *A, const float *W, const float *bias, float *C, int M, int N, int K,
+                  int grid, unsigned long long *diag, hipStream_t st) {
+    int blocks = persistent_blocks(((M + 127) / 128) * ((N + 127) / 128));
+    if (blocks < 0) return (int)hipErrorInvalidDevice;
+    if (grid > 0) blocks = grid;
+    const char *mode = getenv("VS_DIAG_MODE");
+    const int m = mode ? atoi(mode) : 1;
+    if (diag != nullptr && m == 1)
+        hipLaunchKernelGGL((gemm_nt_128<EPI_RELU, 1>), dim3(blocks), dim3(256), 0, st, A, W, bias, C, M, N, K,
+                           nullptr, 1, 0, 0, diag);
+    else if (diag != nullptr && m == 2)
+        hipLaunchKernelGGL((gemm_nt_128<EPI_RELU, 2>), dim3(blocks), dim3(256), 0, st, A, W, bias, C, M, N, K,
+                           nullptr, 1, 0, 0, diag);
+    else if (diag != nullptr && m == 3)
+        hipLaunchKernelGGL((gemm_nt_128<EPI_RELU, 3>), dim3(blocks), dim3(256), 0, st, A, W, bias, C, M, N, K,
+                           nullptr, 1, 0, 0, diag);
+    else
+        hipLaunchKernelGGL((gemm_nt_128<EPI_RELU, 0>), dim3(blocks), dim3(256), 0, st, A, W, bias, C, M, N, K,
+                           nullptr, 1, 0, 0, nullptr);
+    VSK_CHECK_LAUNCH();
+    return 0;
+}
+
 int vsk_qkv(const float *h, const float *Wqkv, const float *bqkv, float *qkv, int B, int T, int d,
             int H, hipStream_t st) {
     const int M = B * T, N = 3 * d;
-    const int blocks = ((M + 127) / 128) * ((N + 127) / 128);
+    const int blocks = persistent_blocks(((M + 127) / 128) * ((N + 127) / 128));
+    if (blocks < 0) return (int)hipErrorInvalidDevice;
     hipLaunchKernelGGL(gemm_nt_128<EPI_QKV>, dim3(blocks), dim3(256), 0, st, h, Wqkv, bqkv, qkv, M, N, d,
                        nullptr, T, H, d / H);
     VSK_CHECK_LAUNCH();
@@ -523,10 +1119,21 @@ int vsk_attention(const float *q, const float *k, const float *v, const uint8_t 
                   int B, int H, int T, int dh, float scale, hipStream_t st) {
     const float sl2 = scale * 1.4426950408889634f;
     dim3 grid((T + 127) / 128, B * H);
-    if (dh == 32)
+    static const bool legacy = getenv("VS_ATTN_LEGACY") != nullptr;      // A/B switch for tools/, not a fallback
+    if (dh == 32 && legacy)
         hipLaunchKernelGGL((attn_fwd<32, 2>), grid, dim3(256), 0, st, q, k, v, mask, out, H, T, sl2);
-    else if (dh == 64)
+    else if (dh == 64 && legacy)
         hipLaunchKernelGGL((attn_fwd<64, 2>), grid, dim3(256), 0, st, q, k, v, mask, out, H, T, sl2);
+    else if (dh == 32 && mask)
+        hipLaunchKernelGGL((attn_fwd_pipe<32, true>), grid, dim3(256), 0, st, q, k, v, mask, out, H, T, sl2);
+    else if (dh == 32)
+        hipLaunchKernelGGL((attn_fwd_pipe<32, false>), grid, dim3(256), 0, st, q, k, v, mask, out, H, T, sl2);
+    else if (dh == 64 && mask)
+        hipLaunchKernelGGL((attn_fwd_pipe<64, true>), grid, dim3(256), 0, st, q, k, v, mask, out, H, T, sl2);
+    else if (dh == 64 && getenv("VS_ATTN_1WG"))      // diagnostic: LDS padded so only one block fits per CU
+        hipLaunchKernelGGL((attn_fwd_pipe<64, false, 4096>), grid, dim3(256), 0, st, q, k, v, mask, out, H, T, sl2);
+    else if (dh == 64)
+        hipLaunchKernelGGL((attn_fwd_pipe<64, false>), grid, dim3(256), 0, st, q, k, v, mask, out, H, T, sl2);
     else if (dh == 128)
         hipLaunchKernelGGL((attn_fwd<128, 1>), grid, dim3(256), 0, st, q, k, v, mask, out, H, T, sl2);
     else
@@ -539,6 +1146,23 @@ int vsk_linear_res_ln(const float *A, const float *W, const float *bias, const f
                       const float *gamma, const float *beta, float *out, int M, int N, int K,
                       const float *score_w, const float *score_b, int num_classes, int sigmoid,
                       float *scores, hipStream_t st) {
+    if (N <= 256 && N % 32 == 0) {
+        int blocks = persistent_blocks((M + 127) / 128);
+        if (blocks < 0) return (int)hipErrorInvalidDevice;
+        if (blocks > (M + 127) / 128) blocks = (M + 127) / 128;
+#define VSK_LNR_CASE(NT_)                                                                             \
+    case NT_:                                                                                         \
+        hipLaunchKernelGGL(gemm_ln_rows<NT_>, dim3(blocks), dim3(256), 0, st, A, W, bias, res, gamma, \
+                           beta, out, M, K, score_w, score_b, num_classes, sigmoid, scores);          \
+        break;
+        switch (N / 32) {
+            VSK_LNR_CASE(2) VSK_LNR_CASE(4) VSK_LNR_CASE(6) VSK_LNR_CASE(8)
+            default: return -1;
+        }
+#undef VSK_LNR_CASE
+        VSK_CHECK_LAUNCH();
+        return 0;
+    }
     const int blocks = (M + 63) / 64;
 #define VSK_LN_CASE(NB_)                                                                             \
     case NB_:                                                                                        \

@@ -281,6 +281,14 @@ const char *vs_stage_name(int32_t stage) {
     return (stage >= 0 && stage < VS_NUM_STAGES) ? kStageNames[stage] : "";
 }
 
+// Diagnostic entry (not part of include/vs_scorer.h): fc1-shaped GEMM with s_memtime phase stamps.
+// diag = [grid*4 waves][8] u64: issue, mfma, epilogue, stage, barrier, total cycles, k-tiles, t_begin.
+int vs_diag_gemm(const float *A, const float *W, const float *bias, float *C, int32_t M, int32_t N, int32_t K,
+                 int32_t grid, unsigned long long *diag, void *stream) {
+    VS_LAUNCH(vsk_diag_gemm(A, W, bias, C, M, N, K, grid, diag, (hipStream_t)stream));
+    return VS_OK;
+}
+
 int vs_linear_f32(const float *A, const float *W, const float *bias, float *C, int32_t M, int32_t N,
                   int32_t K, int32_t relu, const float *pe, int32_t T, void *stream) {
     if (!A || !W || !bias || !C) return fail(VS_ERR_INVALID, "NULL pointer");
