@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -79,12 +80,14 @@ template <int VAR>
 void run(const char *name, int grid, const float *src, float *dst, unsigned long long *cyc, int iters) {
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    probe<VAR><<<grid, 256>>>(src, dst, cyc, iters);
+    const int reps = getenv("PROBE_REPS") ? atoi(getenv("PROBE_REPS")) : 1;   // sustained-load mode: many launches
+    for (int i = 0; i < reps; ++i) probe<VAR><<<grid, 256>>>(src, dst, cyc, iters);
     hipEventRecord(e0);
-    probe<VAR><<<grid, 256>>>(src, dst, cyc, iters);
+    for (int i = 0; i < reps; ++i) probe<VAR><<<grid, 256>>>(src, dst, cyc, iters);
     hipEventRecord(e1);
     hipDeviceSynchronize();
     float ms; hipEventElapsedTime(&ms, e0, e1);
+    ms /= reps;
     std::vector<unsigned long long> c(grid * 4);
     hipMemcpy(c.data(), cyc, c.size() * 8, hipMemcpyDeviceToHost);
     std::sort(c.begin(), c.end());

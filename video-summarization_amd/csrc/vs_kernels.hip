@@ -49,6 +49,24 @@ __device__ __forceinline__ int xcd_remap(int bid, int n) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
 }
 
+// Attention block -> (video*head, query tile).  Blocks b and b+8 share an XCD and are dispatched in
+// order, so the nq query tiles of one (video, head) are given to nq CONSECUTIVE blocks of one XCD:
+// they run at the same time and that head's K/V is fetched from HBM/MALL into one L2 once instead
+// of once per query tile (measured: 5.7x the algorithmic bytes without this).  Speed only.
+__device__ __forceinline__ bool attn_block_map(int nq, int BH, int &bh, int &qt) {
+    const int L = blockIdx.x, x = L & 7, s = L >> 3;
+    qt = s % nq;
+    bh = x + 8 * (s / nq);
+    return bh < BH;
+}
+
+// max(x, 0) as ONE instruction (fmaxf first canonicalises its MFMA-produced input with a second v_max)
+__device__ __forceinline__ float relu1(float x) {
+    float y;
+    asm("v_max_f32 %0, 0, %1" : "=v"(y) : "v"(x));
+    return y;
+}
+
 __device__ __forceinline__ float half_sum(float v) {   // sum over the 32 lanes of a half-wave
     v += __shfl_xor(v, 16);
     v += __shfl_xor(v, 8);
@@ -83,12 +101,19 @@ __device__ __forceinline__ unsigned long long stamp() {
     return t;
 }
 
-template <int EPI, int DIAG = 0>     // DIAG 1: phase stamps; 2: epilogue skipped (wrong output) + total cycles; 3: total cycles only
-__global__ __launch_bounds__(256, 2) void gemm_nt_128(
+// NWM = waves along M (block = NWM x 2 waves, tile = 64*NWM x 128).  NWM = 4: one 8-wave block per CU -
+// the two waves of every SIMD then belong to the same block and are coupled by its barriers, so neither
+// can starve the other and all blocks finish together (two independent 4-wave blocks per CU share the
+// SIMD unfairly: the older one finishes ~25 % earlier and the younger runs a lonely tail).
+template <int EPI, int NWM = 2, int DIAG = 0>     // DIAG 1: phase stamps; 2: epilogue skipped (wrong output) + total cycles; 3: total cycles only
+__global__ __launch_bounds__(128 * NWM, 2) void gemm_nt_128(
     const float *__restrict__ A, const float *__restrict__ W, const float *__restrict__ bias,
     float *__restrict__ C, int M, int N, int K, const float *__restrict__ pe, int T, int H, int dh,
     unsigned long long *__restrict__ diag = nullptr) {
-    constexpr int BM = 128, BN = 128, BK = 32, LD = BK + 4;
+    constexpr int BM = 64 * NWM, BN = 128, BK = 32, LD = BK + 4;
+    constexpr int NT = 128 * NWM;                       // threads
+    constexpr int LA = BM * 8 / NT, LW = BN * 8 / NT;   // float4 of A / of W per thread per k-tile (4, 4 | 4, 2)
+    constexpr int RS = NT / 8;                          // row stride of the staging map
     __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LD];
 
     const int tiles_n = (N + BN - 1) / BN;
@@ -103,69 +128,54 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_128(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int wr = wave >> 1, wc = wave & 1;
-    const int lrow = tid >> 3, lc4 = (tid & 7) * 4;      // staging map: 4 float4 of A and of W per thread
+    const int lrow = tid >> 3, lc4 = (tid & 7) * 4;      // staging map: rows lrow + RS*i
     const int nk = K / BK;
 
-    // Per-output-tile state, set up ONCE per tile (integer division, 64-bit row pointers): the
-    // per-k-tile work is then 8 loads at pointer + kt*BK.  `nx_*` belongs to the tile being
-    // prefetched, `cu_*` to the tile whose epilogue is still to come.
-    const float *aptr[4], *wptr[4];
+    // Per-output-tile state, set up ONCE per tile (integer division, 64-bit row pointers, this lane's
+    // bias values).  `nx_*` belongs to the tile being prefetched, `cu_*` to the tile being accumulated.
+    const float *aptr[LA], *wptr[LW];
     int nx_m0 = 0, nx_n0 = 0, cu_m0 = 0, cu_n0 = 0;
-    auto set_tile = [&](int it) {
+    float nx_bias[2] = {0.f, 0.f}, cu_bias[2] = {0.f, 0.f};
+    auto set_tile = [&](int it) __attribute__((always_inline)) {
         const int tile = start + j + it * G;
         nx_m0 = (tile / tiles_n) * BM;
         nx_n0 = (tile % tiles_n) * BN;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int ar = nx_m0 + lrow + 32 * i; ar = ar < M ? ar : M - 1;
-            int wrow = nx_n0 + lrow + 32 * i; wrow = wrow < N ? wrow : N - 1;
+        for (int i = 0; i < LA; ++i) {
+            int ar = nx_m0 + lrow + RS * i; ar = ar < M ? ar : M - 1;
             aptr[i] = A + (size_t)ar * K + lc4;
+        }
+#pragma unroll
+        for (int i = 0; i < LW; ++i) {
+            int wrow = nx_n0 + lrow + RS * i; wrow = wrow < N ? wrow : N - 1;
             wptr[i] = W + (size_t)wrow * K + lc4;
         }
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int col = nx_n0 + 64 * wc + 32 * jj + r;
+            const float bv = bias[col < N ? col : N - 1];
+            nx_bias[jj] = h == 0 ? bv : 0.f;      // A operand of the bias step: A[n = r][k = h]
+        }
     };
-    f32x4 pa[4], pw[4];
-    auto stage = [&](int buf) {
+    f32x4 pa[LA], pw[LW];
+    auto stage = [&](int buf) __attribute__((always_inline)) {
         float *As = smem + buf * (BM + BN) * LD, *Ws = As + BM * LD;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *(f32x4 *)&As[(lrow + 32 * i) * LD + lc4] = pa[i];
-            *(f32x4 *)&Ws[(lrow + 32 * i) * LD + lc4] = pw[i];
-        }
+        for (int i = 0; i < LA; ++i) *(f32x4 *)&As[(lrow + RS * i) * LD + lc4] = pa[i];
+#pragma unroll
+        for (int i = 0; i < LW; ++i) *(f32x4 *)&Ws[(lrow + RS * i) * LD + lc4] = pw[i];
     };
 
     // acc[i][jj][t] = C[m = 64wr + 32i + r][n = 64wc + 32jj + acc_row(t,h)]  (lane = output ROW:
     // the W fragment is the MFMA A operand, the activation fragment the B operand)
     f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-            for (int t = 0; t < 16; ++t) acc[i][jj][t] = 0.f;
-
-    set_tile(0);
-    cu_m0 = nx_m0; cu_n0 = nx_n0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { pa[i] = *(const f32x4 *)aptr[i]; pw[i] = *(const f32x4 *)wptr[i]; }
-    stage(0);
-    __syncthreads();
-
-    int it = 0, kt = 0;
-    const int total = my_tiles * nk;
     unsigned long long dsum[5] = {0, 0, 0, 0, 0}, ts0 = 0, ts1 = 0;
-    if (DIAG != 0) ts0 = stamp();
-    const unsigned long long tbegin = ts0;
-    if (DIAG >= 2) dsum[3] = __builtin_amdgcn_s_memrealtime();      // 100 MHz wall clock: wave start
-    for (int f = 0; f < total; ++f) {
-        int kt2 = kt + 1, it2 = it;
-        if (kt2 == nk) { kt2 = 0; ++it2; }
-        // the last step of the last tile prefetches a harmless duplicate (no branch in the MFMA stream)
-        if (it2 >= my_tiles) { it2 = my_tiles - 1; kt2 = 0; }
-        if (kt2 == 0) set_tile(it2);
-        const int koff = kt2 * BK;
-        if (DIAG == 1) { ts1 = stamp(); dsum[0] += ts1 - ts0; ts0 = ts1; }
+    int fpar = 0;                                   // LDS buffer holding the k-tile about to be consumed
 
-        const float *As = smem + (f & 1) * (BM + BN) * LD, *Ws = As + BM * LD;
+    // One k-tile: 64 MFMAs from LDS buffer `fpar`, with the global loads of the NEXT k-tile (at
+    // aptr/wptr + koff) in the first half of the MFMA stream and their LDS writes in the last quarter.
+    auto ktile = [&](int koff) __attribute__((always_inline)) {
+        const float *As = smem + fpar * (BM + BN) * LD, *Ws = As + BM * LD;
         const float *ap = As + (64 * wr + r) * LD + 4 * h;
         const float *wp = Ws + (64 * wc + r) * LD + 4 * h;
         f32x4 fa[2][2], fw[2][2];
@@ -178,9 +188,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_128(
                 fa[n][0] = *(const f32x4 *)(ap + 8 * (g + 1)); fa[n][1] = *(const f32x4 *)(ap + 32 * LD + 8 * (g + 1));
                 fw[n][0] = *(const f32x4 *)(wp + 8 * (g + 1)); fw[n][1] = *(const f32x4 *)(wp + 32 * LD + 8 * (g + 1));
             }
-            if (g < 2) {     // next k-tile's global loads ride in the first half of this k-tile's MFMAs
-                pa[2 * g] = *(const f32x4 *)(aptr[2 * g] + koff);         pw[2 * g] = *(const f32x4 *)(wptr[2 * g] + koff);
-                pa[2 * g + 1] = *(const f32x4 *)(aptr[2 * g + 1] + koff); pw[2 * g + 1] = *(const f32x4 *)(wptr[2 * g + 1] + koff);
+            if (g < 2) {
+#pragma unroll
+                for (int i = 0; i < LA / 2; ++i) pa[g * (LA / 2) + i] = *(const f32x4 *)(aptr[g * (LA / 2) + i] + koff);
+#pragma unroll
+                for (int i = 0; i < LW / 2; ++i) pw[g * (LW / 2) + i] = *(const f32x4 *)(wptr[g * (LW / 2) + i] + koff);
             }
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
@@ -189,103 +201,120 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_128(
                 acc[1][0] = MFMA32(fw[c][0][s], fa[c][1][s], acc[1][0]);
                 acc[1][1] = MFMA32(fw[c][1][s], fa[c][1][s], acc[1][1]);
             }
-            if (g == BK / 8 - 1) stage((f + 1) & 1);     // LDS writes ride in the last quarter
+            if (g == BK / 8 - 1) stage(fpar ^ 1);
             if (g < 2) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);   // 4 MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM read
+                for (int q = 0; q < (LA + LW) / 2; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 16 / ((LA + LW) / 2), 0);   // MFMAs
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                       // 1 VMEM read
                 }
             } else if (g == BK / 8 - 1) {
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // 2 MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // 1 DS write
+                for (int q = 0; q < LA + LW; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 16 / (LA + LW), 0);          // MFMAs
+                    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                       // 1 DS write
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        __syncthreads();
+        fpar ^= 1;
+    };
 
-        if (DIAG == 1) { ts1 = stamp(); dsum[1] += ts1 - ts0; ts0 = ts1; }
-        if (DIAG == 2 && kt == nk - 1) {
-            // keep the accumulators live and reset them, but store nothing
+    set_tile(0);
+#pragma unroll
+    for (int i = 0; i < LA; ++i) pa[i] = *(const f32x4 *)aptr[i];
+#pragma unroll
+    for (int i = 0; i < LW; ++i) pw[i] = *(const f32x4 *)wptr[i];
+    stage(0);
+    __syncthreads();
+    if (DIAG != 0) ts0 = stamp();
+    const unsigned long long tbegin = ts0;
+    if (DIAG >= 2) dsum[3] = __builtin_amdgcn_s_memrealtime();      // 100 MHz wall clock: wave start
+
+    for (int it = 0; it < my_tiles; ++it) {
+        cu_m0 = nx_m0; cu_n0 = nx_n0; cu_bias[0] = nx_bias[0]; cu_bias[1] = nx_bias[1];
+        // accumulators start at the bias: one "bias x ones" MFMA per 32x32 tile with C = 0 replaces the
+        // zero-init and 64 adds, and keeps every load out of the epilogue
+        {
+            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int jj = 0; jj < 2; ++jj) { asm volatile("" ::"v"(acc[i][jj])); for (int t = 0; t < 16; ++t) acc[i][jj][t] = 0.f; }
-            cu_m0 = nx_m0; cu_n0 = nx_n0;
+                for (int jj = 0; jj < 2; ++jj) acc[i][jj] = MFMA32(cu_bias[jj], 1.0f, zero);
         }
-        if (DIAG != 2 && kt == nk - 1) {
-            // ---- epilogue of the current output tile.  A lane owns 2 rows x 2x16 columns, 4
-            // consecutive columns per register quad -> 16-byte row-contiguous stores (store ISSUE, not
-            // bytes, is what costs).  Every load (bias, positional table) precedes every store, so no
-            // load's s_waitcnt has to drain this tile's stores (vmcnt retires in order).
-            const int m0 = cu_m0, n0 = cu_n0;
-            int b0 = 0, t0 = 0;                       // (video, frame) of row m0, for EPI_PE / EPI_QKV
-            if (EPI == EPI_PE || EPI == EPI_QKV) { b0 = m0 / T; t0 = m0 - b0 * T; }
-            int row[2], bb[2], tt[2];
+        for (int kt = 0; kt + 1 < nk; ++kt) ktile((kt + 1) * BK);
+        // last k-tile of this output tile: prefetch the first k-tile of the next one (or a harmless
+        // duplicate after the final tile - no branch in the MFMA stream)
+        if (it + 1 < my_tiles) set_tile(it + 1);
+        ktile(0);
+
+        if (DIAG == 2) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                row[i] = m0 + 64 * wr + 32 * i + r;
-                bb[i] = b0; tt[i] = t0 + 64 * wr + 32 * i + r;
-                if (EPI == EPI_PE || EPI == EPI_QKV) { while (tt[i] >= T) { tt[i] -= T; ++bb[i]; } }
-            }
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
-                const int cb = n0 + 64 * wc + 32 * jj + 4 * h;      // + 8*q: first of 4 consecutive columns
+                for (int jj = 0; jj < 2; ++jj) asm volatile("" ::"v"(acc[i][jj]));
+            continue;
+        }
+        // ---- epilogue: a lane owns 2 rows x 2x16 columns, 4 consecutive columns per register quad ->
+        // 16-byte row-contiguous stores (store ISSUE, not bytes, is what costs); no loads except the
+        // positional table (EPI_PE), which precede every store of the tile
+        const int m0 = cu_m0, n0 = cu_n0;
+        int b0 = 0, t0 = 0;                       // (video, frame) of row m0, for EPI_PE / EPI_QKV
+        if (EPI == EPI_PE || EPI == EPI_QKV) { b0 = m0 / T; t0 = m0 - b0 * T; }
+        int row[2], bb[2], tt[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            row[i] = m0 + 64 * wr + 32 * i + r;
+            bb[i] = b0; tt[i] = t0 + 64 * wr + 32 * i + r;
+            if (EPI == EPI_PE || EPI == EPI_QKV) { while (tt[i] >= T) { tt[i] -= T; ++bb[i]; } }
+        }
+        if (EPI == EPI_PE) {
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const int col = cb + 8 * q;
-                    const f32x4 bv = *(const f32x4 *)(bias + (col < N ? col : 0));
+                    const int col = n0 + 64 * wc + 32 * jj + 4 * h + 8 * q;
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
-                        f32x4 pv = {0.f, 0.f, 0.f, 0.f};
-                        if (EPI == EPI_PE) pv = *(const f32x4 *)(pe + (size_t)tt[i] * N + (col < N ? col : 0));
+                        const f32x4 pv = *(const f32x4 *)(pe + (size_t)tt[i] * N + (col < N ? col : 0));
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            float v = acc[i][jj][4 * q + e] + bv[e];
-                            if (EPI == EPI_RELU) v = fmaxf(v, 0.f);
-                            if (EPI == EPI_PE) v += pv[e];
-                            acc[i][jj][4 * q + e] = v;
-                        }
+                        for (int e = 0; e < 4; ++e) acc[i][jj][4 * q + e] += pv[e];
+                    }
+                }
+        }
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int c32 = n0 + 64 * wc + 32 * jj;               // a 32-column block never straddles a head
+            int which = 0, head = 0, e0 = 0;
+            if (EPI == EPI_QKV) { const int d = H * dh; which = c32 / d; const int c = c32 - which * d; head = c / dh; e0 = c - head * dh; }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int co = 8 * q + 4 * h;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = acc[i][jj][4 * q + e];
+                        if (EPI == EPI_RELU) v[e] = relu1(v[e]);
+                    }
+                    if (row[i] < M && c32 + co < N) {
+                        if (EPI == EPI_QKV)
+                            *(f32x4 *)(C + (size_t)which * M * (H * dh) + (((size_t)bb[i] * H + head) * T + tt[i]) * dh + e0 + co) = v;
+                        else
+                            *(f32x4 *)(C + (size_t)row[i] * N + c32 + co) = v;
                     }
                 }
             }
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
-                const int c32 = n0 + 64 * wc + 32 * jj;               // a 32-column block never straddles a head
-                int which = 0, head = 0, e0 = 0;
-                if (EPI == EPI_QKV) { const int d = H * dh; which = c32 / d; const int c = c32 - which * d; head = c / dh; e0 = c - head * dh; }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int co = 8 * q + 4 * h;
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        f32x4 v;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { v[e] = acc[i][jj][4 * q + e]; acc[i][jj][4 * q + e] = 0.f; }
-                        if (row[i] < M && c32 + co < N) {
-                            if (EPI == EPI_QKV)
-                                *(f32x4 *)(C + (size_t)which * M * (H * dh) + (((size_t)bb[i] * H + head) * T + tt[i]) * dh + e0 + co) = v;
-                            else
-                                *(f32x4 *)(C + (size_t)row[i] * N + c32 + co) = v;
-                        }
-                    }
-                }
-            }
-            cu_m0 = nx_m0; cu_n0 = nx_n0;
         }
-        if (DIAG == 1) { ts1 = stamp(); dsum[2] += ts1 - ts0; ts0 = ts1; }
-        __syncthreads();
-        if (DIAG == 1) { ts1 = stamp(); dsum[4] += ts1 - ts0; ts0 = ts1; }
-        it = it2; kt = kt2;
     }
     if (DIAG >= 2) { ts0 = stamp(); dsum[4] = __builtin_amdgcn_s_memrealtime(); }
     if (DIAG != 0 && diag != nullptr && lane == 0) {
-        unsigned long long *o = diag + ((size_t)blockIdx.x * 4 + wave) * 8;
+        unsigned long long *o = diag + ((size_t)blockIdx.x * (2 * NWM) + wave) * 8;
 #pragma unroll
         for (int i = 0; i < 5; ++i) o[i] = dsum[i];
-        o[5] = ts0 - tbegin; o[6] = (unsigned long long)total; o[7] = tbegin;
+        o[5] = ts0 - tbegin; o[6] = (unsigned long long)(my_tiles * nk); o[7] = tbegin;
     }
 }
 
@@ -640,7 +669,7 @@ __global__ __launch_bounds__(256, 2) void gemm_ln_rows(
 template <int DH, int NKB>   // NKB 32-key blocks per tile
 __global__ __launch_bounds__(256, 2) void attn_fwd(
     const float *__restrict__ Q, const float *__restrict__ Kg, const float *__restrict__ Vg,
-    const uint8_t *__restrict__ mask, float *__restrict__ out, int H, int T, float scale_log2e) {
+    const uint8_t *__restrict__ mask, float *__restrict__ out, int H, int T, float scale_log2e, int BH) {
     constexpr int KT = 32 * NKB, LD = DH + 4, NJ = DH / 8, ND = DH / 32;
     constexpr int F4 = KT * DH / 4 / 256;          // float4 per thread per operand tile
     __shared__ __attribute__((aligned(16))) float Ks[KT * LD];
@@ -649,9 +678,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd(
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int bh = blockIdx.y, b = bh / H, head = bh - b * H;
+    int bh, qt;
+    if (!attn_block_map((T + 127) / 128, BH, bh, qt)) return;
+    const int b = bh / H, head = bh - b * H;
     const size_t base = (size_t)bh * T * DH;
-    const int q0 = blockIdx.x * 128 + 32 * wave;
+    const int q0 = qt * 128 + 32 * wave;
     const float NEG_INF = -__builtin_inff();
 
     // Q fragment (B operand), pre-multiplied by scale*log2(e) so that p = exp2(s - m)
@@ -789,13 +820,23 @@ __global__ __launch_bounds__(256, 2) void attn_fwd(
 }
 
 // ------------------------------------------------------------------------------------------
-// Attention, software-pipelined (head dim 32 / 64): same math and operand trick as attn_fwd, but
-// the wave's MFMA stream never waits for the softmax.  Keys are consumed in 32-key blocks; while
-// block b+1's S^T = K*Q^T MFMAs issue, block b's online-softmax (max, exp2, sum, rescale of O) runs
-// on the VALU in their shadow; then O^T += V_b^T * P_b^T.  K/V tiles of 64 keys are double-buffered
-// in LDS; the global loads of tile t+2 and the LDS writes of tile t+1 ride in the MFMA stream of
-// tile t, and the two barriers per tile only separate MFMA runs (no load latency behind them).
-// The row max / row sum exchange between lane and lane^32 uses v_permlane32_swap (VALU, no LDS).
+// Attention, software-pipelined (head dim 32 / 64): same math and operand trick as attn_fwd.
+//
+// Measured on gfx950 (profiles/): the fp32 MFMA shares the SIMD's FP32 lanes with
+// ordinary VALU work — every VALU instruction costs ~4 of the 64 cycles an MFMA owns, "in its shadow"
+// or not.  So this kernel is built to issue as few VALU instructions per MFMA as possible:
+//  * K/V tiles arrive through buffer loads whose per-tile offset is a scalar (no address VALU, and the
+//    hardware bounds check zero-fills the ragged tail);
+//  * the running row max m is folded into the product: S' = [K,1]*[Q,-m]^T costs one extra MFMA per
+//    32-key block and replaces the accumulator zero-init and the 16 subtracts before exp2;
+//  * deferred max: m is only raised (and O, l rescaled) when a block's max exceeds it by more than
+//    2^8 — exact in fp32 (p <= 256 instead of <= 1) and almost never taken after the first block;
+//  * the key-mask bias (0/-inf) is added only on tiles that have masked keys or the ragged tail.
+// Keys are consumed in 32-key blocks; block b+1's S' MFMAs issue while block b's softmax (max check,
+// exp2, row sum) runs between them; then O^T += V_b^T * P_b^T with the V operands prefetched into
+// registers.  K/V tiles of 64 keys are double-buffered in LDS; global loads of tile t+2 and LDS writes
+// of tile t+1 ride in the MFMA stream of tile t.  NW waves per block (8: one block per CU, all
+// blocks take the same time; 4: for short videos).
 // ------------------------------------------------------------------------------------------
 // v_permlane32_swap of a register with itself yields {x_lo | x_lo} and {x_hi | x_hi}: every lane then
 // sees both its own and its lane^32 partner's value, so a symmetric combine needs no select.
@@ -809,22 +850,27 @@ __device__ __forceinline__ float pair_sum(float x) {
     auto pr = __builtin_amdgcn_permlane32_swap(u, u, false, false);
     return __builtin_bit_cast(float, (unsigned)pr[0]) + __builtin_bit_cast(float, (unsigned)pr[1]);
 }
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-template <int DH, bool HAS_MASK, int LDS_PAD = 0>
-__global__ __launch_bounds__(256, 2) void attn_fwd_pipe(
+template <int DH, bool HAS_MASK, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void attn_fwd_pipe(
     const float *__restrict__ Q, const float *__restrict__ Kg, const float *__restrict__ Vg,
-    const uint8_t *__restrict__ mask, float *__restrict__ out, int H, int T, float scale_log2e) {
+    const uint8_t *__restrict__ mask, float *__restrict__ out, int H, int T, float scale_log2e, int BH) {
     constexpr int KT = 64, LD = DH + 4, NJ = DH / 8, ND = DH / 32;
-    constexpr int F4 = KT * DH / 4 / 256;           // float4 per thread per operand tile
+    constexpr int NT = 64 * NW;                     // threads per block
+    constexpr int F4 = KT * DH / 4 / NT;            // float4 per thread per operand tile
     constexpr int TILE = KT * LD;                   // floats per K (or V) tile in LDS
-    __shared__ __attribute__((aligned(16))) float smem[4 * TILE + 2 * KT + LDS_PAD];   // [buf]{K,V} + mask bias
+    constexpr float THR = 8.0f;                     // deferred-max threshold (log2 units)
+    __shared__ __attribute__((aligned(16))) float smem[4 * TILE + 2 * KT];   // [buf]{K,V} + mask bias
     float *mbs = smem + 4 * TILE;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int bh = blockIdx.y, b = bh / H, head = bh - b * H;
+    int bh, qt;
+    if (!attn_block_map((T + 32 * NW - 1) / (32 * NW), BH, bh, qt)) return;
+    const int b = bh / H, head = bh - b * H;
     const size_t base = (size_t)bh * T * DH;
-    const int q0 = blockIdx.x * 128 + 32 * wave;
+    const int q0 = qt * (32 * NW) + 32 * wave;
     const float NEG_INF = -__builtin_inff();
     const int ntiles = (T + KT - 1) / KT;
 
@@ -844,189 +890,200 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_pipe(
     for (int d = 0; d < ND; ++d)
 #pragma unroll
         for (int t = 0; t < 16; ++t) o[d][t] = 0.f;
+    // m_run: running max (log2 units) actually applied to O and l; -inf until the first live key.
+    // m_use(m) = m, or 0 while m is still -inf (keeps exp2 arguments finite-or--inf, never inf-inf).
     float m_run = NEG_INF, l_run = 0.f;
+    const float ones_a = h == 0 ? 1.0f : 0.0f;      // A operand of the bias step: adds B[0][q] to every key row
 
-    // staging: thread owns F4 float4 of K and of V per tile
+    // ---- staging: buffer loads (scalar per-tile offset, zero fill beyond T), then LDS writes ----
+    const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(Kg + base), 0, T * DH * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(Vg + base), 0, T * DH * 4, 0x00020000);
+    int voff[F4];
+#pragma unroll
+    for (int i = 0; i < F4; ++i) {
+        const int idx = tid + NT * i;
+        voff[i] = ((idx / (DH / 4)) * DH + (idx % (DH / 4)) * 4) * 4;
+    }
     f32x4 pk[F4], pv[F4];
     float pm = 0.f;
-    auto gload = [&](int tile) {
-        tile = tile < ntiles ? tile : ntiles - 1;
-#pragma unroll
-        for (int i = 0; i < F4; ++i) {
-            const int idx = tid + 256 * i;
-            int row = tile * KT + idx / (DH / 4);
-            row = row < T ? row : T - 1;
-            const size_t off = base + (size_t)row * DH + (idx % (DH / 4)) * 4;
-            pk[i] = *(const f32x4 *)(Kg + off);
-            pv[i] = *(const f32x4 *)(Vg + off);
-        }
-        {   // every thread computes the bias of key (tid & 63): no divergent branch in the stream
-            const int key = tile * KT + (tid & (KT - 1));
-            float pmv = key >= T ? NEG_INF : 0.f;
-            if (HAS_MASK) pmv = mask[(size_t)b * T + (key < T ? key : T - 1)] != 0 ? NEG_INF : pmv;
-            pm = pmv;
-        }
+    auto gload_k = [&](int i, int tile) __attribute__((always_inline)) { pk[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(krs, voff[i], tile * (KT * DH * 4), 0)); };
+    auto gload_v = [&](int i, int tile) __attribute__((always_inline)) { pv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(vrs, voff[i], tile * (KT * DH * 4), 0)); };
+    auto gload_m = [&](int tile) __attribute__((always_inline)) {      // key-mask bias of key (tid & 63): 0 or -inf (also for keys >= T)
+        const int key = tile * KT + (tid & (KT - 1));
+        float pmv = key >= T ? NEG_INF : 0.f;
+        if (HAS_MASK) pmv = mask[(size_t)b * T + (key < T ? key : T - 1)] != 0 ? NEG_INF : pmv;
+        pm = pmv;
     };
-    auto stage = [&](int buf) {
-        float *Ks = smem + buf * 2 * TILE, *Vs = Ks + TILE;
-#pragma unroll
-        for (int i = 0; i < F4; ++i) {
-            const int idx = tid + 256 * i;
-            const int row = idx / (DH / 4), c = (idx % (DH / 4)) * 4;
-            *(f32x4 *)&Ks[row * LD + c] = pk[i];
-            *(f32x4 *)&Vs[row * LD + c] = pv[i];
-        }
-        mbs[buf * KT + (tid & (KT - 1))] = pm;       // 4 threads write the same value: benign
+    auto stage_k = [&](int i, int buf) __attribute__((always_inline)) {
+        const int idx = tid + NT * i;
+        *(f32x4 *)&smem[buf * 2 * TILE + (idx / (DH / 4)) * LD + (idx % (DH / 4)) * 4] = pk[i];
     };
-    // S^T block = K[32 keys] * Q^T : 4*NJ MFMAs (plain form, used for the very first block)
-    auto qk = [&](const float *Ks, int blk, f32x16 &s) {
-#pragma unroll
-        for (int t = 0; t < 16; ++t) s[t] = 0.f;
-        const float *kp = Ks + (32 * blk + r) * LD + 4 * h;
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const f32x4 ka = *(const f32x4 *)(kp + 8 * j);
-#pragma unroll
-            for (int st = 0; st < 4; ++st) s = MFMA32(ka[st], qreg[4 * j + st], s);
-        }
+    auto stage_v = [&](int i, int buf) __attribute__((always_inline)) {
+        const int idx = tid + NT * i;
+        *(f32x4 *)&smem[buf * 2 * TILE + TILE + (idx / (DH / 4)) * LD + (idx % (DH / 4)) * 4] = pv[i];
     };
 
-    // ---- the pipelined half-step -------------------------------------------------------------------
-    // MFMA stream: s_out = K[blk] * Q^T (4*NJ MFMAs).  Between consecutive MFMAs one "unit" of the
-    // independent work is issued, so it executes in the MFMA's 64-cycle shadow:
-    //   units 0-3   key-mask bias add to s_in (LDS broadcast read + 4 adds each)
-    //   units 4-6   row max (in-lane, then lane^32), running max, rescale factor alpha
-    //   units 8-15  p = exp2(s - m) two at a time, row-sum, and O *= alpha a slice at a time
-    //   unit  16    row-sum exchange, running sum
-    //   STAGE only: units 0-7 LDS writes of tile t+1, units 17-25 global loads of tile t+2
-    // A sched_barrier after every slot pins this order (the scheduler otherwise lumps the VALU work
-    // after the MFMAs, where it stalls the matrix pipe).
-    float sm_mx = 0.f, sm_muse = 0.f, sm_alpha = 1.f, sm_psum = 0.f;
-    auto sm_unit = [&](auto uc, f32x16 &sv, const float *mb, auto stage_tag, int nbuf, int ntile) {
+    // ---- softmax state of the block in flight ----
+    float sm_mx = 0.f, sm_psum = 0.f;
+    float vreg[16 * ND];
+    // Rare path (first live block, or a max jump > 2^THR, or a block whose bias is stale): bring the
+    // block's S' onto the (possibly raised) running max and rescale O, l.  Wave-uniform branch.
+    auto fixup = [&](f32x16 &sv, float m_bias, float raw_max) __attribute__((always_inline)) {
+        const float m_new = (raw_max > m_run + THR || m_run == NEG_INF) ? fmaxf(m_run, raw_max) : m_run;
+        const float u_new = (m_new == NEG_INF) ? 0.f : m_new;
+        const float shift = m_bias - u_new;                     // finite
+        const float alpha = __builtin_amdgcn_exp2f(m_run - u_new);   // m_run = -inf -> 0 (O = l = 0 then anyway)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) sv[t] += shift;
+#pragma unroll
+        for (int d = 0; d < ND; ++d)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) o[d][t] *= alpha;
+        l_run *= alpha;
+        m_run = m_new;
+    };
+    // One unit of block-b softmax work, issued between two MFMAs of block b+1's S'.  sv = S' of block b
+    // (biased by -m_bias), MASKED: add the key-mask bias first.
+    auto sm_unit = [&](auto uc, f32x16 &sv, float m_bias, const float *mb, auto masked_tag) __attribute__((always_inline)) {
         constexpr int U = decltype(uc)::value;
-        constexpr bool STAGE = decltype(stage_tag)::value;
-        if constexpr (U < 4) {
+        constexpr bool MASKED = decltype(masked_tag)::value;
+        if constexpr (MASKED && U < 4) {
             const f32x4 bv = *(const f32x4 *)(mb + 8 * U + 4 * h);
 #pragma unroll
             for (int e = 0; e < 4; ++e) sv[4 * U + e] += bv[e];
         }
         if constexpr (U == 4) {
-            sm_mx = sv[0];
+            sm_mx = fmaxf(fmaxf(sv[0], sv[1]), sv[2]);
 #pragma unroll
-            for (int t = 1; t < 8; ++t) sm_mx = fmaxf(sm_mx, sv[t]);
+            for (int t = 3; t < 15; t += 2) sm_mx = fmaxf(fmaxf(sm_mx, sv[t]), sv[t + 1]);
+            sm_mx = fmaxf(sm_mx, sv[15]);
         }
         if constexpr (U == 5) {
-#pragma unroll
-            for (int t = 8; t < 16; ++t) sm_mx = fmaxf(sm_mx, sv[t]);
-        }
-        if constexpr (U == 6) {
-            const float mx = pair_max(sm_mx);
-            const float m_new = fmaxf(m_run, mx);
-            sm_muse = (m_new == NEG_INF) ? 0.f : m_new;
-            sm_alpha = __builtin_amdgcn_exp2f(m_run - sm_muse);
-            m_run = m_new;
+            const float raw_max = pair_max(sm_mx) + m_bias;      // -inf if every key so far is masked
+            const float u_run = (m_run == NEG_INF) ? 0.f : m_run;
+            const bool fix = (m_bias != u_run) || (raw_max > m_run + THR) || (m_run == NEG_INF && raw_max != NEG_INF);
+            if (__builtin_expect(__any(fix), 0)) fixup(sv, m_bias, raw_max);
             sm_psum = 0.f;
         }
         if constexpr (U >= 8 && U < 16) {
             constexpr int k = U - 8;
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-                const float pe_ = __builtin_amdgcn_exp2f(sv[2 * k + e] - sm_muse);
+                const float pe_ = __builtin_amdgcn_exp2f(sv[2 * k + e]);
                 sv[2 * k + e] = pe_;
                 sm_psum += pe_;
             }
-#pragma unroll
-            for (int d = 0; d < ND; ++d)
-#pragma unroll
-                for (int e = 0; e < 2; ++e) o[d][2 * k + e] *= sm_alpha;
         }
-        if constexpr (U == 16) l_run = l_run * sm_alpha + pair_sum(sm_psum);
-        if constexpr (STAGE) {
-            if constexpr (U < 2 * F4) {
-                constexpr int i = U / 2;
-                float *Kd = smem + nbuf * 2 * TILE, *Vd = Kd + TILE;
-                const int idx = tid + 256 * i;
-                const int row = idx / (DH / 4), c = (idx % (DH / 4)) * 4;
-                if constexpr (U % 2 == 0) *(f32x4 *)&Kd[row * LD + c] = pk[i];
-                else                      *(f32x4 *)&Vd[row * LD + c] = pv[i];
-            }
-            if constexpr (U == 2 * F4) mbs[nbuf * KT + (tid & (KT - 1))] = pm;
-            if constexpr (U >= 17 && U < 17 + 2 * F4) {
-                constexpr int i = (U - 17) / 2;
-                const int idx = tid + 256 * i;
-                int row = ntile * KT + idx / (DH / 4);
-                row = row < T ? row : T - 1;
-                const size_t off = base + (size_t)row * DH + (idx % (DH / 4)) * 4;
-                if constexpr ((U - 17) % 2 == 0) pk[i] = *(const f32x4 *)(Kg + off);
-                else                             pv[i] = *(const f32x4 *)(Vg + off);
-            }
-            if constexpr (U == 17 + 2 * F4) {
-                const int key = ntile * KT + (tid & (KT - 1));
-                float pmv = key >= T ? NEG_INF : 0.f;
-                if (HAS_MASK) pmv = mask[(size_t)b * T + (key < T ? key : T - 1)] != 0 ? NEG_INF : pmv;
-                pm = pmv;
-            }
-        }
+        if constexpr (U == 16) l_run += pair_sum(sm_psum);
     };
-    auto qk_softmax = [&](const float *Ksrc, int blk, f32x16 &s_out, f32x16 &s_in, const float *mb,
-                          auto stage_tag, int nbuf, int ntile) {
-        constexpr int NSLOT = 4 * NJ, R = 32 / NSLOT;      // units per MFMA slot (DH=64: 1, DH=32: 2)
+    // MFMA stream of one half-step:  s_out = [K_blk,1]*[Q,-m_bias]^T  (1 + 4*NJ MFMAs), with between
+    // consecutive MFMAs: one V operand of block (Vsrc,vblk) into vreg, one softmax unit of s_in, and
+    // (STAGE) the LDS writes of tile t+1 / buffer loads of tile t+2.
+    auto half_step = [&](const float *Ksrc, int blk, f32x16 &s_out, float m_bias_out, f32x16 &s_in, float m_bias_in,
+                         const float *mb, const float *Vsrc, int vblk, auto masked_tag, auto stage_tag, int nbuf, int ntile) __attribute__((always_inline)) {
+        constexpr bool STAGE = decltype(stage_tag)::value;
+        constexpr int NSLOT = 4 * NJ, R = 32 / NSLOT;      // softmax units per MFMA slot (DH=64: 1, DH=32: 2)
+        static_assert(NSLOT == 16 * ND, "one V operand per MFMA slot");
         const float *kp = Ksrc + (32 * blk + r) * LD + 4 * h;
+        const float *vp = Vsrc + (32 * vblk + 4 * h) * LD + r;
         f32x4 ka[2];
         ka[0] = *(const f32x4 *)kp;
-#pragma unroll
-        for (int t = 0; t < 16; ++t) s_out[t] = 0.f;
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        s_out = MFMA32(ones_a, -m_bias_out, zero);
+        __builtin_amdgcn_sched_barrier(0);
         static_for<NSLOT>([&](auto ic) {
             constexpr int i = decltype(ic)::value, j = i / 4, st = i % 4;
             if constexpr (st == 0 && j + 1 < NJ) ka[(j + 1) & 1] = *(const f32x4 *)(kp + 8 * (j + 1));
             s_out = MFMA32(ka[j & 1][st], qreg[4 * j + st], s_out);
+            {
+                constexpr int t = i / ND, d = i % ND;
+                vreg[i] = vp[((t & 3) + 8 * (t >> 2)) * LD + 32 * d];
+            }
             static_for<R>([&](auto rc) {
-                sm_unit(std::integral_constant<int, i * R + decltype(rc)::value>{}, s_in, mb, stage_tag, nbuf, ntile);
+                constexpr int U = i * R + decltype(rc)::value;
+                sm_unit(std::integral_constant<int, U>{}, s_in, m_bias_in, mb, masked_tag);
+                if constexpr (STAGE) {
+                    if constexpr (U < 2 * F4) { if constexpr (U % 2 == 0) stage_k(U / 2, nbuf); else stage_v(U / 2, nbuf); }
+                    if constexpr (U == 2 * F4) mbs[nbuf * KT + (tid & (KT - 1))] = pm;
+                    if constexpr (U >= 17 && U < 17 + 2 * F4) { if constexpr ((U - 17) % 2 == 0) gload_k((U - 17) / 2, ntile); else gload_v((U - 17) / 2, ntile); }
+                    if constexpr (U == 17 + 2 * F4) gload_m(ntile);
+                }
             });
             __builtin_amdgcn_sched_barrier(0);
         });
     };
     // softmax alone (last block of the video: nothing left to overlap with)
-    auto softmax_only = [&](f32x16 &sv, const float *mb) {
-        static_for<32>([&](auto uc) { sm_unit(uc, sv, mb, std::false_type{}, 0, 0); });
+    auto softmax_only = [&](f32x16 &sv, float m_bias, const float *mb, const float *Vsrc, int vblk, auto masked_tag) __attribute__((always_inline)) {
+        const float *vp = Vsrc + (32 * vblk + 4 * h) * LD + r;
+#pragma unroll
+        for (int i = 0; i < 16 * ND; ++i) vreg[i] = vp[(((i / ND) & 3) + 8 * ((i / ND) >> 2)) * LD + 32 * (i % ND)];
+        static_for<32>([&](auto uc) { sm_unit(uc, sv, m_bias, mb, masked_tag); });
     };
-    // O^T += V[32 keys]^T * P^T : 16*ND MFMAs
-    auto pv_acc = [&](const float *Vs, int blk, const f32x16 &p) {
-        const float *vp = Vs + (32 * blk + 4 * h) * LD + r;
+    // O^T += V[32 keys]^T * P^T : 16*ND MFMAs, operands already in registers
+    auto pv_acc = [&](const f32x16 &p) __attribute__((always_inline)) {
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {
+        for (int t = 0; t < 16; ++t)
 #pragma unroll
-            for (int d = 0; d < ND; ++d) {
-                const float va = vp[((t & 3) + 8 * (t >> 2)) * LD + 32 * d];
-                o[d] = MFMA32(va, p[t], o[d]);
-            }
-        }
+            for (int d = 0; d < ND; ++d) o[d] = MFMA32(vreg[ND * t + d], p[t], o[d]);
     };
 
-    gload(0);
-    stage(0);
-    gload(1);
+    // ---- prologue: tile 0 into LDS, tile 1 into registers, S' of block (0,0) with bias 0 ----
+#pragma unroll
+    for (int i = 0; i < F4; ++i) { gload_k(i, 0); gload_v(i, 0); }
+    gload_m(0);
+#pragma unroll
+    for (int i = 0; i < F4; ++i) { stage_k(i, 0); stage_v(i, 0); }
+    mbs[tid & (KT - 1)] = pm;
+    {
+        const int t1 = ntiles > 1 ? 1 : 0;
+#pragma unroll
+        for (int i = 0; i < F4; ++i) { gload_k(i, t1); gload_v(i, t1); }
+        gload_m(t1);
+    }
     __syncthreads();
     f32x16 s_cur, s_nxt;
-    qk(smem, 0, s_cur);
+    float mb_cur = 0.f, mb_nxt = 0.f;            // bias each in-flight block was started with
+    {
+        const float *kp = smem + r * LD + 4 * h;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) s_cur[t] = 0.f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const f32x4 ka = *(const f32x4 *)(kp + 8 * j);
+#pragma unroll
+            for (int st = 0; st < 4; ++st) s_cur = MFMA32(ka[st], qreg[4 * j + st], s_cur);
+        }
+    }
 
-    for (int t = 0; t < ntiles; ++t) {
+    // One 64-key tile.  LAST (the video's final tile) is peeled out of the loop so that the loop body has
+    // no branch besides the rare fix-up: a branch there costs 64 accumulator-register copies per tile.
+    auto tile_step = [&](int t, auto masked_tag, auto last_tag) __attribute__((always_inline)) {
+        constexpr bool LAST = decltype(last_tag)::value;
         const int buf = t & 1;
         const float *Ks = smem + buf * 2 * TILE, *Vs = Ks + TILE;
         const float *Kn = smem + (buf ^ 1) * 2 * TILE;
         __syncthreads();                       // everyone is done with buffer buf^1 (tile t-1)
-        // S of block (t,1)  ||  softmax of block (t,0), LDS writes of tile t+1, global loads of tile t+2
-        qk_softmax(Ks, 1, s_nxt, s_cur, mbs + buf * KT, std::true_type{}, buf ^ 1, t + 2 < ntiles ? t + 2 : ntiles - 1);
-        pv_acc(Vs, 0, s_cur);
+        // S' of block (t,1)  ||  softmax of block (t,0), LDS writes of tile t+1, loads of tile t+2
+        mb_nxt = (m_run == NEG_INF) ? 0.f : m_run;
+        half_step(Ks, 1, s_nxt, mb_nxt, s_cur, mb_cur, mbs + buf * KT, Vs, 0, masked_tag, std::integral_constant<bool, !LAST>{},
+                  buf ^ 1, t + 2 < ntiles ? t + 2 : ntiles - 1);
+        pv_acc(s_cur);
         __syncthreads();                       // tile t+1 is visible in buffer buf^1
-        if (t + 1 < ntiles) {
-            // S of block (t+1,0)  ||  softmax of block (t,1)
-            qk_softmax(Kn, 0, s_cur, s_nxt, mbs + buf * KT + 32, std::false_type{}, 0, 0);
+        if constexpr (!LAST) {
+            // S' of block (t+1,0)  ||  softmax of block (t,1)
+            mb_cur = (m_run == NEG_INF) ? 0.f : m_run;
+            half_step(Kn, 0, s_cur, mb_cur, s_nxt, mb_nxt, mbs + buf * KT + 32, Vs, 1, masked_tag, std::false_type{}, 0, 0);
         } else {
-            softmax_only(s_nxt, mbs + buf * KT + 32);
+            softmax_only(s_nxt, mb_nxt, mbs + buf * KT + 32, Vs, 1, masked_tag);
         }
-        pv_acc(Vs, 1, s_nxt);
-    }
+        pv_acc(s_nxt);
+    };
+    // without a mask only the ragged last tile carries dead keys
+    for (int t = 0; t + 1 < ntiles; ++t) tile_step(t, std::integral_constant<bool, HAS_MASK>{}, std::false_type{});
+    if (HAS_MASK || (T % KT) != 0) tile_step(ntiles - 1, std::true_type{}, std::true_type{});
+    else                           tile_step(ntiles - 1, std::false_type{}, std::true_type{});
 
     const int q = q0 + r;
     if (q < T) {
@@ -1051,91 +1108,108 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_pipe(
 // ------------------------------------------------------------------------------------------
 #define VSK_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)
 
-// persistent grid: 2 blocks per CU (LDS-limited), a multiple of 8 so the XCD chunking is exact
-static int persistent_blocks(int ntiles) {
+// persistent grid: `per_cu` blocks per CU, a multiple of 8 so the XCD chunking is exact
+static int persistent_blocks(int ntiles, int per_cu = 2) {
     static int cus = 0;
     if (cus == 0) {
         int dev = 0; hipDeviceProp_t prop;
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
         cus = prop.multiProcessorCount;
     }
-    int g = 2 * cus;
+    int g = per_cu * cus;
     g -= g % 8;
     if (g < 8) g = 8;
     const int need = (ntiles + 7) / 8 * 8;
     return need < g ? need : g;
 }
 
-int vsk_linear(const float *A, const float *W, const float *bias, float *C, int M, int N, int K,
-               int relu, const float *pe, int T, hipStream_t st) {
-    const int blocks = persistent_blocks(((M + 127) / 128) * ((N + 127) / 128));
-    if (blocks < 0) return (int)hipErrorInvalidDevice;
-    if (pe != nullptr)
-        hipLaunchKernelGGL(gemm_nt_128<EPI_PE>, dim3(blocks), dim3(256), 0, st, A, W, bias, C, M, N, K, pe, T, 0, 0);
-    else if (relu)
-        hipLaunchKernelGGL(gemm_nt_128<EPI_RELU>, dim3(blocks), dim3(256), 0, st, A, W, bias, C, M, N, K, nullptr, 1, 0, 0);
-    else
-        hipLaunchKernelGGL(gemm_nt_128<EPI_BIAS>, dim3(blocks), dim3(256), 0, st, A, W, bias, C, M, N, K, nullptr, 1, 0, 0);
+// 256x128 tiles on 8-wave blocks when there is enough work to give every CU >= 2 such tiles and the
+// ragged M edge does not waste more than 128-row tiles would; else 128x128 tiles on 4-wave blocks
+static bool use_wide_tiles(int M, int N) {
+    if (getenv("VS_GEMM_NWM2")) return false;
+    const long r256 = (M + 255) / 256 * 256, r128 = (M + 127) / 128 * 128;
+    const long tiles = (r256 / 256) * ((N + 127) / 128);
+    return r256 * 100 <= r128 * 105 && tiles >= 512;
+}
+
+template <int EPI>
+static int launch_gemm(const float *A, const float *W, const float *bias, float *C, int M, int N, int K,
+                       const float *pe, int T, int H, int dh, hipStream_t st) {
+    if (use_wide_tiles(M, N)) {
+        const int blocks = persistent_blocks(((M + 255) / 256) * ((N + 127) / 128), 1);
+        if (blocks < 0) return (int)hipErrorInvalidDevice;
+        hipLaunchKernelGGL((gemm_nt_128<EPI, 4>), dim3(blocks), dim3(512), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr);
+    } else {
+        const int blocks = persistent_blocks(((M + 127) / 128) * ((N + 127) / 128), 2);
+        if (blocks < 0) return (int)hipErrorInvalidDevice;
+        hipLaunchKernelGGL((gemm_nt_128<EPI, 2>), dim3(blocks), dim3(256), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr);
+    }
     VSK_CHECK_LAUNCH();
     return 0;
 }
 
-// diagnostic: the fc1-shaped GEMM with per-wave phase stamps; `grid` <= 0 selects the product grid
+int vsk_linear(const float *A, const float *W, const float *bias, float *C, int M, int N, int K,
+               int relu, const float *pe, int T, hipStream_t st) {
+    if (pe != nullptr) return launch_gemm<EPI_PE>(A, W, bias, C, M, N, K, pe, T, 0, 0, st);
+    if (relu) return launch_gemm<EPI_RELU>(A, W, bias, C, M, N, K, nullptr, 1, 0, 0, st);
+    return launch_gemm<EPI_BIAS>(A, W, bias, C, M, N, K, nullptr, 1, 0, 0, st);
+}
+
+// diagnostic: the fc1-shaped GEMM with per-wave stamps (VS_DIAG_MODE 1..3, VS_DIAG_NWM 2|4); `grid` <= 0
+// selects the product grid.  diag == nullptr runs the product kernel.
 int vsk_diag_gemm(const float *A, const float *W, const float *bias, float *C, int M, int N, int K,
                   int grid, unsigned long long *diag, hipStream_t st) {
-    int blocks = persistent_blocks(((M + 127) / 128) * ((N + 127) / 128));
+    const char *mode = getenv("VS_DIAG_MODE"), *nw = getenv("VS_DIAG_NWM");
+    const int m = mode ? atoi(mode) : 1, nwm = nw ? atoi(nw) : 2;
+    int blocks = nwm == 4 ? persistent_blocks(((M + 255) / 256) * ((N + 127) / 128), 1)
+                          : persistent_blocks(((M + 127) / 128) * ((N + 127) / 128), 2);
     if (blocks < 0) return (int)hipErrorInvalidDevice;
     if (grid > 0) blocks = grid;
-    const char *mode = getenv("VS_DIAG_MODE");
-    const int m = mode ? atoi(mode) : 1;
-    if (diag != nullptr && m == 1)
-        hipLaunchKernelGGL((gemm_nt_128<EPI_RELU, 1>), dim3(blocks), dim3(256), 0, st, A, W, bias, C, M, N, K,
-                           nullptr, 1, 0, 0, diag);
-    else if (diag != nullptr && m == 2)
-        hipLaunchKernelGGL((gemm_nt_128<EPI_RELU, 2>), dim3(blocks), dim3(256), 0, st, A, W, bias, C, M, N, K,
-                           nullptr, 1, 0, 0, diag);
-    else if (diag != nullptr && m == 3)
-        hipLaunchKernelGGL((gemm_nt_128<EPI_RELU, 3>), dim3(blocks), dim3(256), 0, st, A, W, bias, C, M, N, K,
-                           nullptr, 1, 0, 0, diag);
-    else
-        hipLaunchKernelGGL((gemm_nt_128<EPI_RELU, 0>), dim3(blocks), dim3(256), 0, st, A, W, bias, C, M, N, K,
-                           nullptr, 1, 0, 0, nullptr);
+#define VSK_DG(NWM_, D_) hipLaunchKernelGGL((gemm_nt_128<EPI_RELU, NWM_, D_>), dim3(blocks), dim3(128 * NWM_), 0, st, A, W, bias, C, M, N, K, nullptr, 1, 0, 0, diag)
+    if (diag == nullptr) { if (nwm == 4) VSK_DG(4, 0); else VSK_DG(2, 0); }
+    else if (m == 1) { if (nwm == 4) VSK_DG(4, 1); else VSK_DG(2, 1); }
+    else if (m == 2) { if (nwm == 4) VSK_DG(4, 2); else VSK_DG(2, 2); }
+    else { if (nwm == 4) VSK_DG(4, 3); else VSK_DG(2, 3); }
+#undef VSK_DG
     VSK_CHECK_LAUNCH();
     return 0;
 }
 
 int vsk_qkv(const float *h, const float *Wqkv, const float *bqkv, float *qkv, int B, int T, int d,
             int H, hipStream_t st) {
-    const int M = B * T, N = 3 * d;
-    const int blocks = persistent_blocks(((M + 127) / 128) * ((N + 127) / 128));
-    if (blocks < 0) return (int)hipErrorInvalidDevice;
-    hipLaunchKernelGGL(gemm_nt_128<EPI_QKV>, dim3(blocks), dim3(256), 0, st, h, Wqkv, bqkv, qkv, M, N, d,
-                       nullptr, T, H, d / H);
-    VSK_CHECK_LAUNCH();
-    return 0;
+    return launch_gemm<EPI_QKV>(h, Wqkv, bqkv, qkv, B * T, 3 * d, d, nullptr, T, H, d / H, st);
 }
 
 int vsk_attention(const float *q, const float *k, const float *v, const uint8_t *mask, float *out,
                   int B, int H, int T, int dh, float scale, hipStream_t st) {
     const float sl2 = scale * 1.4426950408889634f;
-    dim3 grid((T + 127) / 128, B * H);
+    const int BH = B * H;
+    dim3 grid(8 * ((BH + 7) / 8) * ((T + 127) / 128));
     static const bool legacy = getenv("VS_ATTN_LEGACY") != nullptr;      // A/B switch for tools/, not a fallback
     if (dh == 32 && legacy)
-        hipLaunchKernelGGL((attn_fwd<32, 2>), grid, dim3(256), 0, st, q, k, v, mask, out, H, T, sl2);
+        hipLaunchKernelGGL((attn_fwd<32, 2>), grid, dim3(256), 0, st, q, k, v, mask, out, H, T, sl2, BH);
     else if (dh == 64 && legacy)
-        hipLaunchKernelGGL((attn_fwd<64, 2>), grid, dim3(256), 0, st, q, k, v, mask, out, H, T, sl2);
-    else if (dh == 32 && mask)
-        hipLaunchKernelGGL((attn_fwd_pipe<32, true>), grid, dim3(256), 0, st, q, k, v, mask, out, H, T, sl2);
-    else if (dh == 32)
-        hipLaunchKernelGGL((attn_fwd_pipe<32, false>), grid, dim3(256), 0, st, q, k, v, mask, out, H, T, sl2);
-    else if (dh == 64 && mask)
-        hipLaunchKernelGGL((attn_fwd_pipe<64, true>), grid, dim3(256), 0, st, q, k, v, mask, out, H, T, sl2);
-    else if (dh == 64 && getenv("VS_ATTN_1WG"))      // diagnostic: LDS padded so only one block fits per CU
-        hipLaunchKernelGGL((attn_fwd_pipe<64, false, 4096>), grid, dim3(256), 0, st, q, k, v, mask, out, H, T, sl2);
-    else if (dh == 64)
-        hipLaunchKernelGGL((attn_fwd_pipe<64, false>), grid, dim3(256), 0, st, q, k, v, mask, out, H, T, sl2);
+        hipLaunchKernelGGL((attn_fwd<64, 2>), grid, dim3(256), 0, st, q, k, v, mask, out, H, T, sl2, BH);
+    else if (dh == 32 || dh == 64) {
+        // 8-wave blocks (one per CU, 256 query rows) unless the ragged tail would waste more rows than
+        // 4-wave blocks (two per CU, 128 query rows) do
+        const int r8 = (T + 255) / 256 * 256, r4 = (T + 127) / 128 * 128;
+        const bool wide = !getenv("VS_ATTN_NW4") && r8 * 100 <= r4 * 105;
+        const int nq = wide ? r8 / 256 : r4 / 128;
+        dim3 g(8 * ((BH + 7) / 8) * nq), blk(wide ? 512 : 256);
+#define VSK_ATTN(DH_, MASK_, NW_) \
+    hipLaunchKernelGGL((attn_fwd_pipe<DH_, MASK_, NW_>), g, blk, 0, st, q, k, v, mask, out, H, T, sl2, BH)
+        if (dh == 32) {
+            if (mask) { if (wide) VSK_ATTN(32, true, 8); else VSK_ATTN(32, true, 4); }
+            else      { if (wide) VSK_ATTN(32, false, 8); else VSK_ATTN(32, false, 4); }
+        } else {
+            if (mask) { if (wide) VSK_ATTN(64, true, 8); else VSK_ATTN(64, true, 4); }
+            else      { if (wide) VSK_ATTN(64, false, 8); else VSK_ATTN(64, false, 4); }
+        }
+#undef VSK_ATTN
+    }
     else if (dh == 128)
-        hipLaunchKernelGGL((attn_fwd<128, 1>), grid, dim3(256), 0, st, q, k, v, mask, out, H, T, sl2);
+        hipLaunchKernelGGL((attn_fwd<128, 1>), grid, dim3(256), 0, st, q, k, v, mask, out, H, T, sl2, BH);
     else
         return -1;
     VSK_CHECK_LAUNCH();
