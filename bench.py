@@ -28,6 +28,23 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
+# HBM bytes per launch per kernel come from separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; see
+# tools/collect_traffic.sh), committed under profiles/: counters cannot be read from inside the timed run.
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_v3_hbm_traffic.json")
+STAGE_KERNEL = {"attention": "attn_fwd_pipe", "embed_pe": "gemm_nt_128<2", "qkv_proj": "gemm_nt_128<3",
+                "fc1_relu": "gemm_nt_128<1", "outproj_ln": "gemm_ln_rows", "fc2_ln_score": "gemm_ln_rows"}
+
+
+def measured_traffic(stage):
+    """HBM bytes per launch of the kernel behind `stage` from the committed PMC passes, or None."""
+    try:
+        t = json.load(open(TRAFFIC_FILE))
+    except (OSError, ValueError):
+        return None
+    for name, v in t.items():
+        if name.startswith(STAGE_KERNEL.get(stage, "?")):
+            return int(v["hbm_bytes_per_launch"])
+    return None
 
 
 def stage_flops(B, T, Din, d, H, L):
@@ -143,7 +160,8 @@ def main():
         dom = max(table, key=lambda k: table[k]["share"])
         flops_per_frame = 2 * Din * d + L * (24 * d * d + 4 * T * d) + 2 * d
         roofline = {"bound": "mfma", "kernel": dom, "achieved": table[dom]["tflops"], "peak": PEAK_F32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(table[dom]["tflops"] / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "unit": "TFLOP/s", "frac": round(table[dom]["tflops"] / PEAK_F32_MFMA_TFLOPS, 4),
+                    "traffic": measured_traffic(dom) if (B, T, args.model) == (64, 1024, "A") else None,
                     "whole_forward": {"flop_per_frame": flops_per_frame,
                                       "achieved": round(value / world * flops_per_frame / 1e12, 2),
                                       "frac": round(value / world * flops_per_frame / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)},
