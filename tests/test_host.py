@@ -20,6 +20,12 @@ def test_library_builds_and_exports_every_declared_symbol(vsa):
     for name in declared:
         assert hasattr(lib, name), name
     assert lib.vs_abi_version() == vsa._lib.ABI_VERSION
+    hdr = open(os.path.join(ROOT, "include", "vs_eval.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(vs_eval_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(vsa._lib.EVAL_EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
 
 
 def test_c_abi_argument_checks_need_no_gpu(vsa):

@@ -15,7 +15,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(ROOT, "include")
 LIB_PATH = os.path.join(HERE, "libvsscore.so")
-SOURCES = ("vs_kernels.hip", "vs_scorer.cpp")
+SOURCES = ("vs_kernels.hip", "vs_scorer.cpp", "vs_eval.cpp")
 ABI_VERSION = 1
 
 VS_OK, VS_ERR_INVALID, VS_ERR_WORKSPACE, VS_ERR_HIP = 0, 1, 2, 3
@@ -26,6 +26,9 @@ EXPORTS = ("vs_abi_version", "vs_last_error", "vs_weights_pack", "vs_weights_fre
            "vs_scorer_workspace_bytes", "vs_scorer_forward", "vs_linear_f32", "vs_qkv_proj_f32",
            "vs_attention_f32", "vs_linear_residual_layernorm_f32",
            "vs_profile_enable", "vs_profile_collect", "vs_stage_name")
+# include/vs_eval.h
+EVAL_EXPORTS = ("vs_eval_upsample", "vs_eval_knapsack", "vs_eval_generate_summary", "vs_eval_fscore",
+                "vs_eval_rank_correlation")
 NUM_STAGES = 6
 
 
@@ -58,7 +61,7 @@ def needs_build() -> bool:
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(INCLUDE, "vs_scorer.h")]
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(INCLUDE, f) for f in os.listdir(INCLUDE)]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -101,7 +104,7 @@ def load() -> C.CDLL:
                 "Run `python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). "
                 "There is no PyTorch/CPU fallback for the scoring path." % LIB_PATH)
         lib = C.CDLL(LIB_PATH)
-        for name in EXPORTS:
+        for name in EXPORTS + EVAL_EXPORTS:
             if not hasattr(lib, name):
                 raise RuntimeError("libvsscore.so lacks symbol %s (stale build?)" % name)
         lib.vs_abi_version.restype = C.c_int
@@ -128,6 +131,16 @@ def load() -> C.CDLL:
         lib.vs_linear_residual_layernorm_f32.restype = C.c_int
         lib.vs_linear_residual_layernorm_f32.argtypes = ([C.c_void_p] * 7 + [C.c_int32] * 3 + [C.c_void_p] * 2
                                                          + [C.c_int32] * 2 + [C.c_void_p] * 2)
+        for name in EVAL_EXPORTS:
+            getattr(lib, name).restype = C.c_int
+        lib.vs_eval_upsample.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+        lib.vs_eval_knapsack.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(C.c_int32)]
+        lib.vs_eval_generate_summary.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
+                                                 C.c_int32, C.c_void_p, C.c_int32]
+        lib.vs_eval_fscore.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                       C.POINTER(C.c_double)]
+        lib.vs_eval_rank_correlation.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_double),
+                                                 C.POINTER(C.c_double)]
         lib.vs_profile_enable.restype = C.c_int
         lib.vs_profile_enable.argtypes = [C.c_int32]
         lib.vs_profile_collect.restype = C.c_int

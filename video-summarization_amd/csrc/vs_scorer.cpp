@@ -27,6 +27,13 @@ int fail(int code, const char *fmt, ...) {
     return code;
 }
 
+}  // namespace
+
+// shared with vs_eval.cpp
+int vs_fail_msg(int code, const char *msg) { g_err = msg; return code; }
+
+namespace {
+
 #define VS_HIP(call)                                                                       \
     do {                                                                                   \
         hipError_t e_ = (call);                                                            \

@@ -1,0 +1,101 @@
+"""Keyshot evaluation of the scorer's output — drop-in for the reference ``evaluation`` package.
+
+Same call surface as reference ``src/evaluation/compute_metrics.py:42`` ``eval_metrics(data, user_dict)``
+(called from ``train.py:150``): ``data`` maps video name -> per-(sub-sampled)-frame scores, ``user_dict``
+maps video name -> a record with ``user_summary, user_scores, change_points, n_frames, picks``
+(reference ``data/dataset.py:146-154``).  The work (up-sampling, float32 shot means, 0/1 knapsack,
+F-score, Kendall tau / Spearman rho) runs in host C++ (``csrc/vs_eval.cpp``) through the C ABI of
+``include/vs_eval.h``; there is no Python fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+def _i32(a):
+    return np.ascontiguousarray(np.asarray(a), dtype=np.int32)
+
+
+def _f32(a):
+    return np.ascontiguousarray(np.asarray(a), dtype=np.float32)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def upsample(scores, n_frames, positions) -> np.ndarray:
+    """compute_metrics.py:19-39."""
+    lib = _lib.load()
+    s, pos = _f32(scores), _i32(positions)
+    out = np.empty(int(n_frames), dtype=np.float32)
+    _lib.check(lib.vs_eval_upsample(_p(s), s.size, _p(pos), pos.size, int(n_frames), _p(out)))
+    return out
+
+
+def knapSack(W, wt, val, n):
+    """knapsack_implementation.py:1-30 -> list of selected shot indices."""
+    lib = _lib.load()
+    w = _i32(wt)[:n]
+    v = np.ascontiguousarray(np.asarray(val, dtype=np.float64)[:n])
+    sel = np.empty(max(n, 1), dtype=np.int32)
+    cnt = C.c_int32()
+    _lib.check(lib.vs_eval_knapsack(int(W), _p(w), _p(v), int(n), _p(sel), C.byref(cnt)))
+    return sel[: cnt.value].tolist()
+
+
+def generate_summary(all_shot_bound, all_scores, all_nframes, all_positions):
+    """generate_summary.py:6-57 -> list of int8 summaries, one per video."""
+    lib = _lib.load()
+    out = []
+    for sb, sc, nf, pos in zip(all_shot_bound, all_scores, all_nframes, all_positions):
+        sb, sc, pos = _i32(sb), _f32(sc), _i32(pos)
+        n = int(sb[-1, 1]) + 1
+        summary = np.empty(n, dtype=np.int8)
+        _lib.check(lib.vs_eval_generate_summary(_p(sc), sc.size, _p(pos), pos.size, int(nf), _p(sb), sb.shape[0],
+                                                _p(summary), n))
+        out.append(summary)
+    return out
+
+
+def evaluate_summary(predicted_summary, user_summary, eval_method):
+    """evaluation_metrics.py:4-33."""
+    lib = _lib.load()
+    s = np.ascontiguousarray(np.asarray(predicted_summary), dtype=np.int8)
+    us = np.ascontiguousarray(np.asarray(user_summary), dtype=np.int8)
+    f = C.c_double()
+    _lib.check(lib.vs_eval_fscore(_p(s), s.size, _p(us), us.shape[0], us.shape[1], 1 if eval_method == "max" else 0,
+                                  C.byref(f)))
+    return f.value
+
+
+def evaluate_scores(predicted_scores, user_scores):
+    """compute_correlation.py:4-15 -> (mean Kendall tau, mean Spearman rho)."""
+    lib = _lib.load()
+    ps = _f32(predicted_scores)
+    us = np.ascontiguousarray(np.asarray(user_scores), dtype=np.float64)
+    if us.shape[1] != ps.size:
+        raise ValueError("user_scores has %d frames, prediction %d" % (us.shape[1], ps.size))
+    k, s = C.c_double(), C.c_double()
+    _lib.check(lib.vs_eval_rank_correlation(_p(ps), ps.size, _p(us), us.shape[0], C.byref(k), C.byref(s)))
+    return k.value, s.value
+
+
+def eval_metrics(data, user_dict):
+    """compute_metrics.py:42-92 -> (mean F-score ['avg' protocol, :43], mean Kendall tau, mean Spearman rho)."""
+    keys = list(data.keys())
+    users = [user_dict[k] for k in keys]
+    scores = [np.asarray(data[k]) for k in keys]
+    summaries = generate_summary([u.change_points for u in users], scores, [u.n_frames for u in users],
+                                 [u.picks for u in users])
+    f, kt, sp = [], [], []
+    for summary, sc, u in zip(summaries, scores, users):
+        f.append(evaluate_summary(summary, u.user_summary, "avg"))
+        k, s = evaluate_scores(upsample(sc, u.n_frames, u.picks), u.user_scores)
+        kt.append(k)
+        sp.append(s)
+    return float(np.mean(f)), float(np.mean(kt)), float(np.mean(sp))
