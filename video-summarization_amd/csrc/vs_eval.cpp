@@ -90,15 +90,15 @@ void knapsack(int W, const int32_t *wt, const double *val, int n, std::vector<in
 // scipy.stats.rankdata(-x) with method 'average', as doubles
 template <class T>
 void rank_neg_average(const T *x, int n, std::vector<double> &rk) {
-    std::vector<int> idx(n);
-    std::iota(idx.begin(), idx.end(), 0);
-    std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return -(double)x[a] < -(double)x[b]; });
+    std::vector<std::pair<double, int>> kv(n);          // (key, index) pairs sort ~3x faster than indirect compares
+    for (int i = 0; i < n; ++i) kv[i] = {-(double)x[i], i};
+    std::sort(kv.begin(), kv.end(), [](const std::pair<double, int> &a, const std::pair<double, int> &b) { return a.first < b.first; });
     rk.assign(n, 0.0);
     for (int i = 0; i < n;) {
         int j = i;
-        while (j + 1 < n && (double)x[idx[j + 1]] == (double)x[idx[i]]) ++j;
-        const double r = 0.5 * ((i + 1) + (j + 1));
-        for (int k = i; k <= j; ++k) rk[idx[k]] = r;
+        while (j + 1 < n && kv[j + 1].first == kv[i].first) ++j;
+        const double r = 0.5 * ((i + 1) + (j + 1));     // average rank of the tie group (order inside it is irrelevant)
+        for (int k = i; k <= j; ++k) rk[kv[k].second] = r;
         i = j + 1;
     }
 }
@@ -142,20 +142,24 @@ long long count_discordant(std::vector<int> &y) {
 double kendall_tau_b(const std::vector<double> &xr, const std::vector<double> &yr) {
     const int n = (int)xr.size();
     if (n < 2) return NAN;
-    std::vector<int> perm(n);
-    std::iota(perm.begin(), perm.end(), 0);
-    // sort by y then (stable) by x  -> x ascending, ties in x ordered by y
-    std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return yr[a] < yr[b]; });
-    std::vector<int> ydense(n);
-    {   // dense ranks of y in that order
-        int d = 0;
-        for (int i = 0; i < n; ++i) { if (i > 0 && yr[perm[i]] != yr[perm[i - 1]]) ++d; ydense[perm[i]] = d; }
-    }
-    std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return xr[a] < xr[b]; });
+    // one sort by (x, y) gives x ascending with ties in x ordered by y (what scipy's two stable sorts build);
+    // ranks are multiples of 0.5, so 2*rank is an exact integer key
+    std::vector<std::pair<long long, int>> kv(n);
+    for (int i = 0; i < n; ++i) kv[i] = {(long long)(2.0 * xr[i]) * (4LL * n + 4) + (long long)(2.0 * yr[i]), i};
+    std::sort(kv.begin(), kv.end());
     std::vector<int> xs(n), ys(n);
     {
+        std::vector<std::pair<long long, int>> ykv(n);
+        for (int i = 0; i < n; ++i) ykv[i] = {(long long)(2.0 * yr[i]), i};
+        std::sort(ykv.begin(), ykv.end());
+        std::vector<int> ydense(n);
         int d = 0;
-        for (int i = 0; i < n; ++i) { if (i > 0 && xr[perm[i]] != xr[perm[i - 1]]) ++d; xs[i] = d; ys[i] = ydense[perm[i]]; }
+        for (int i = 0; i < n; ++i) { if (i > 0 && ykv[i].first != ykv[i - 1].first) ++d; ydense[ykv[i].second] = d; }
+        d = 0;
+        for (int i = 0; i < n; ++i) {
+            if (i > 0 && xr[kv[i].second] != xr[kv[i - 1].second]) ++d;
+            xs[i] = d; ys[i] = ydense[kv[i].second];
+        }
     }
     auto tie_pairs = [&](const std::vector<int> &v_sorted) {
         long long t = 0;
