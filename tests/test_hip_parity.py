@@ -301,3 +301,22 @@ def test_corpus_scoring_is_sharding_invariant_bit_for_bit(vsa):
         for i in (0, 5, 23):
             rl, _ = oracle_forward(sd, vids[i].unsqueeze(0), None, 4)
             assert (base[i] - torch.sigmoid(rl[0, :, 0])).abs().max().item() < TOL
+
+
+def test_long_video_shape_beyond_reference_envelope(vsa):
+    """BASELINE configs[4] shape (T=8192, 2048-d features), fp32: needs in_features=2048 and an 8192-row
+    positional table, both outside the reference's hard-coded envelope, so the checker is the
+    oracle restatement re-parameterised the same way.  One video, M-A, 2 layers (CPU oracle
+    materialises [1,4,8192,8192] per layer)."""
+    synth = vsa.synth
+    sd = synth.make_state_dict(256, 2, 61, in_features=2048, max_len=8192)
+    x = synth.make_features(1, 8192, 62, "randn", in_features=2048)
+    m = vsa.SimNet(num_heads=4, d_model=256, num_layers=2, sparsity=0.0, dropout=0.3, in_features=2048, pe_len=8192)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(_dev()).eval()
+    with torch.no_grad():
+        logits, hidden = m(x.to(_dev()))
+        torch.set_num_threads(16)
+        rl, rh = oracle_forward(sd, x, None, 4)
+    assert (logits.cpu() - rl).abs().max().item() < TOL
+    assert (hidden.cpu() - rh).abs().max().item() < TOL

@@ -112,7 +112,12 @@ class SimNet(nn.Module):
 
     def __init__(self, num_heads: int = 8, d_model: int = 512, num_layers: int = 4,
                  sparsity: float = 0.5, use_cls: bool = False, dropout: float = 0.2,
-                 num_classes: int = 1, use_pos: bool = True, max_len=2500):
+                 num_classes: int = 1, use_pos: bool = True, max_len=2500, *,
+                 in_features: int = IN_FEATURES, pe_len: int = PE_MAX_LEN):
+        """Positional arguments are the reference's (simnet.py:10-13).  Keyword-only extensions, both
+        defaulting to the reference's hard-coded values: ``in_features`` (simnet.py:22: 1024) and ``pe_len``
+        (rows of the positional table, simnet.py:188: 2000) — BASELINE configs[4] (T=8192, 2048-d CLIP
+        features) needs both; the oracle for it is the re-parameterised restatement."""
         super().__init__()
         if use_cls:
             # no reference caller enables it (train.py:33, simnet_pretrain.py:30) and the reference's own
@@ -122,12 +127,13 @@ class SimNet(nn.Module):
             raise AssertionError("d_model must be divisible by num_heads")      # simnet.py:123
         self.num_heads, self.d_model, self.num_layers = num_heads, d_model, num_layers
         self.sparsity, self.use_cls, self.max_len = sparsity, use_cls, max_len
-        self.num_classes, self.in_features = num_classes, IN_FEATURES           # simnet.py:22
+        self.num_classes, self.in_features = num_classes, in_features            # simnet.py:22
+        self.pe_len = pe_len
         self.use_pos, self.drop_rate = use_pos, dropout
 
         emb = dict(feature_transform=nn.Linear(self.in_features, d_model))
         if use_pos:
-            emb["positional_encoding"] = _SinusoidTable(d_model, PE_MAX_LEN)    # simnet.py:188 (2000, not max_len)
+            emb["positional_encoding"] = _SinusoidTable(d_model, pe_len)        # simnet.py:188 (2000, not max_len)
         self.embedding_layer = _Bag(**emb)
         self.encoder = _Bag(module_list=nn.ModuleList(_encoder_block(d_model) for _ in range(num_layers)),
                             module_score=nn.ModuleList())                        # stays empty: SURVEY Q2
@@ -186,7 +192,7 @@ class SimNet(nn.Module):
         P.layers = layers
         P.final_w, P.final_b = next(it).data_ptr(), next(it).data_ptr()
         desc = _lib.ModelDesc(self.d_model, self.num_heads, self.num_layers, self.in_features,
-                              PE_MAX_LEN if self.use_pos else 0, self.num_classes)
+                              self.pe_len if self.use_pos else 0, self.num_classes)
         out = C.c_void_p()
         with torch.cuda.device(device):
             stream = torch.cuda.current_stream(device).cuda_stream
@@ -209,8 +215,8 @@ class SimNet(nn.Module):
         if x.dim() != 3 or x.size(2) != self.in_features:
             raise RuntimeError("expected x of shape [B, T, %d], got %s" % (self.in_features, tuple(x.shape)))
         mask = mask if isinstance(mask, Tensor) else None
-        if self.use_pos and x.size(1) > PE_MAX_LEN:
-            raise RuntimeError("T=%d exceeds the positional table (%d rows)" % (x.size(1), PE_MAX_LEN))
+        if self.use_pos and x.size(1) > self.pe_len:
+            raise RuntimeError("T=%d exceeds the positional table (%d rows)" % (x.size(1), self.pe_len))
         if self._needs_autograd(x):
             return self._forward_autograd(x, mask)
         if not x.is_cuda:
