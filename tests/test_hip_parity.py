@@ -32,8 +32,17 @@ def _model(vsa, c, sd):
     return m.to(_dev()).eval()
 
 
+@pytest.fixture(params=["auto", "tiled"])
+def kernel_path(request, monkeypatch):
+    """Small inputs take the skinny latency kernels by default; VS_SKINNY_ROWS=0 pins the LDS-tiled
+    throughput kernels so both families are held to the same vectors."""
+    if request.param == "tiled":
+        monkeypatch.setenv("VS_SKINNY_ROWS", "0")
+    return request.param
+
+
 @pytest.mark.parametrize("case", golden_cases(), ids=lambda c: c["name"])
-def test_forward_matches_reference_golden(vsa, case):
+def test_forward_matches_reference_golden(vsa, case, kernel_path):
     """Full scorer forward vs vectors produced by the imported reference (tests/golden/make_golden.py)."""
     g = load_golden(case["name"])
     sd, x, mask = build_case(vsa.synth, case)
@@ -127,7 +136,7 @@ def test_errors_mirror_reference(vsa):
 
 @pytest.mark.parametrize("M,N,K,relu,T", [(300, 256, 1024, 0, 0), (129, 1024, 256, 1, 0), (64, 768, 256, 0, 0),
                                           (1000, 256, 1024, 0, 250), (37, 512, 2048, 0, 37), (2048, 2048, 512, 1, 0)])
-def test_linear_kernel(vsa, M, N, K, relu, T):
+def test_linear_kernel(vsa, M, N, K, relu, T, kernel_path):
     lib = vsa._lib.load()
     g = torch.Generator().manual_seed(M + N + K)
     A = torch.randn(M, K, generator=g)
@@ -149,7 +158,7 @@ def test_linear_kernel(vsa, M, N, K, relu, T):
 
 
 @pytest.mark.parametrize("B,T,d,H", [(2, 100, 256, 4), (1, 33, 512, 4), (3, 64, 256, 8)])
-def test_qkv_kernel(vsa, B, T, d, H):
+def test_qkv_kernel(vsa, B, T, d, H, kernel_path):
     lib = vsa._lib.load()
     g = torch.Generator().manual_seed(B * T + d)
     h = torch.randn(B, T, d, generator=g)
@@ -212,7 +221,7 @@ def test_attention_online_softmax_rescale_branch(vsa):
 
 @pytest.mark.parametrize("M,N,K,nc,sig", [(300, 256, 256, 0, 0), (100, 256, 1024, 1, 0), (65, 512, 2048, 1, 1),
                                           (64, 128, 512, 3, 0), (1000, 320, 320, 2, 1), (33, 64, 256, 1, 0)])
-def test_linear_residual_layernorm_kernel(vsa, M, N, K, nc, sig):
+def test_linear_residual_layernorm_kernel(vsa, M, N, K, nc, sig, kernel_path):
     lib = vsa._lib.load()
     g = torch.Generator().manual_seed(M + N + K)
     A = torch.randn(M, K, generator=g)

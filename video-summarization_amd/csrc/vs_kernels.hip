@@ -60,6 +60,19 @@ __device__ __forceinline__ bool attn_block_map(int nq, int BH, int &bh, int &qt)
     return bh < BH;
 }
 
+// v_permlane32_swap of a register with itself yields {x_lo | x_lo} and {x_hi | x_hi}: every lane then
+// sees both its own and its lane^32 partner's value, so a symmetric combine needs no select.
+__device__ __forceinline__ float pair_max(float x) {
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    auto pr = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return fmaxf(__builtin_bit_cast(float, (unsigned)pr[0]), __builtin_bit_cast(float, (unsigned)pr[1]));
+}
+__device__ __forceinline__ float pair_sum(float x) {
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    auto pr = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __builtin_bit_cast(float, (unsigned)pr[0]) + __builtin_bit_cast(float, (unsigned)pr[1]);
+}
+
 // max(x, 0) as ONE instruction (fmaxf first canonicalises its MFMA-produced input with a second v_max)
 __device__ __forceinline__ float relu1(float x) {
     float y;
@@ -601,23 +614,30 @@ __global__ __launch_bounds__(256, 2) void gemm_ln_rows(
         }
 
         // ---- epilogue: LayerNorm over the row (lane-local + one lane^32 exchange), 16-byte stores ----
+        // (reduction order shared with skinny_ln: per 32-column block, blocks ascending, partner last)
         float sum = 0.f;
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
+        for (int j = 0; j < NT; ++j) {
+            float pj = 0.f;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const f32x4 bv = *(const f32x4 *)&bias_s[32 * j + 8 * q + 4 * h];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { acc[j][4 * q + e] += bv[e]; sum += acc[j][4 * q + e]; }
+                for (int e = 0; e < 4; ++e) { acc[j][4 * q + e] += bv[e]; pj += acc[j][4 * q + e]; }
             }
-        sum += __shfl_xor(sum, 32);
+            sum += pj;
+        }
+        sum = pair_sum(sum);
         const float mean = sum * (1.0f / N);
         float sq = 0.f;
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
+        for (int j = 0; j < NT; ++j) {
+            float pj = 0.f;
 #pragma unroll
-            for (int t = 0; t < 16; ++t) { const float c = acc[j][t] - mean; acc[j][t] = c; sq += c * c; }
-        sq += __shfl_xor(sq, 32);
+            for (int t = 0; t < 16; ++t) { const float c = acc[j][t] - mean; acc[j][t] = c; pj += c * c; }
+            sq += pj;
+        }
+        sq = pair_sum(sq);
         const float rstd = 1.0f / sqrtf(sq * (1.0f / N) + 1e-5f);
         float *op = out + (size_t)row * N + 4 * h;
 #pragma unroll
@@ -638,19 +658,186 @@ __global__ __launch_bounds__(256, 2) void gemm_ln_rows(
                 __syncthreads();
                 float dot = 0.f;
 #pragma unroll
-                for (int j = 0; j < NT; ++j)
+                for (int j = 0; j < NT; ++j) {
+                    float pj = 0.f;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const f32x4 wv = *(const f32x4 *)&sw_s[32 * j + 8 * q + 4 * h];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) dot += acc[j][4 * q + e] * wv[e];
+                        for (int e = 0; e < 4; ++e) pj += acc[j][4 * q + e] * wv[e];
                     }
-                dot += __shfl_xor(dot, 32);
+                    dot += pj;
+                }
+                dot = pair_sum(dot);
                 if (h == 0 && row_ok) {
                     float sc = dot + score_b[c];
                     if (sigmoid) sc = 1.0f / (1.0f + expf(-sc));
                     scores[(size_t)row * num_classes + c] = sc;
                 }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Skinny-M kernels (latency path, M <= a few thousand rows: single videos, small batches).
+// The tiled kernels above put a whole K loop on each of a handful of blocks when M is small (fc2 + LN
+// of one 320-frame video: 152 us on 3 blocks).  Here every WAVE owns one 32x32 output tile and streams
+// both operands straight from L2 into registers (16 bytes per lane per 8 k; 4 groups in flight): no LDS
+// staging and no barrier in the K loop, so the chip is filled with (M/32)*(N/32) independent waves and a
+// stage costs K/2 MFMAs = 3.4 us (K=256) .. 13.7 us (K=1024).  At large M this form is L1-bandwidth-bound
+// (2 KiB per 4 MFMAs per wave) and the LDS-tiled kernels take over.
+//   skinny_gemm<EPI>: block = 4 waves = 32 rows x 128 columns.
+//   skinny_ln<NW>:    block = NW waves = 32 rows x 32*NW = d_model columns; LayerNorm statistics and the
+//                     score dot product are exchanged between the waves through LDS.
+// Same operand convention as everywhere: weight fragment = MFMA A operand, so lane (r,h) ends up with
+// row m0+r and columns n0 + 8q + 4h + e in acc[4q+e]; bias enters as a "bias x ones" MFMA.
+// ------------------------------------------------------------------------------------------
+// K loop of one wave: chunks of 32 k (4 groups of 8 = 16 MFMAs), FOUR register sets so that the loads of
+// chunks c+1..c+3 are in flight while chunk c computes (~3000 MFMA cycles of cover for an L2 round trip);
+// unrolled by the four sets so no register rotation is needed.  Requires K % 128 == 0.  The MFMA order
+// (groups ascending, steps 0..3) is the same as in the LDS-tiled kernels, so both families produce
+// bit-identical sums.
+__device__ __forceinline__ void skinny_mainloop(f32x16 &acc, const float *__restrict__ ap,
+                                                const float *__restrict__ wp, int K) {
+    f32x4 a[4][4], w[4][4];
+    auto load = [&](int set, int off) __attribute__((always_inline)) {      // off in floats from ap / wp
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            a[set][g] = *(const f32x4 *)(ap + off + 8 * g);
+            w[set][g] = *(const f32x4 *)(wp + off + 8 * g);
+        }
+    };
+    auto mma = [&](int set) __attribute__((always_inline)) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int st = 0; st < 4; ++st) acc = MFMA32(w[set][g][st], a[set][g][st], acc);
+    };
+    const int nc = K / 32;
+    load(0, 0); load(1, 32); load(2, 64);
+    for (int c = 0; c < nc - 4; c += 4) {
+        load(3, 96);  mma(0);
+        load(0, 128); mma(1);
+        load(1, 160); mma(2);
+        load(2, 192); mma(3);
+        ap += 128; wp += 128;
+    }
+    load(3, 96);
+    mma(0); mma(1); mma(2); mma(3);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256) void skinny_gemm(
+    const float *__restrict__ A, const float *__restrict__ W, const float *__restrict__ bias,
+    float *__restrict__ C, int M, int N, int K, const float *__restrict__ pe, int T, int H, int dh) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+    const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 128 + 32 * wave;
+    if (n0 >= N) return;
+    const int row = m0 + r;
+    const int arow = row < M ? row : M - 1;
+    const float *ap = A + (size_t)arow * K + 4 * h, *wp = W + (size_t)(n0 + r) * K + 4 * h;
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    f32x16 acc = MFMA32(h == 0 ? bias[n0 + r] : 0.f, 1.0f, zero);
+    skinny_mainloop(acc, ap, wp, K);
+    if (row >= M) return;
+    int bb = 0, tt = 0;
+    if (EPI == EPI_PE || EPI == EPI_QKV) { bb = row / T; tt = row - bb * T; }
+    int which = 0, head = 0, e0 = 0;
+    if (EPI == EPI_QKV) { const int d = H * dh; which = n0 / d; const int c = n0 - which * d; head = c / dh; e0 = c - head * dh; }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int co = 8 * q + 4 * h;
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[4 * q + e];
+        if (EPI == EPI_RELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = relu1(v[e]);
+        }
+        if (EPI == EPI_PE) {
+            const f32x4 pv = *(const f32x4 *)(pe + (size_t)tt * N + n0 + co);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += pv[e];
+        }
+        if (EPI == EPI_QKV)
+            *(f32x4 *)(C + (size_t)which * M * (H * dh) + (((size_t)bb * H + head) * T + tt) * dh + e0 + co) = v;
+        else
+            *(f32x4 *)(C + (size_t)row * N + n0 + co) = v;
+    }
+}
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void skinny_ln(
+    const float *__restrict__ A, const float *__restrict__ W, const float *__restrict__ bias,
+    const float *__restrict__ res, const float *__restrict__ gamma, const float *__restrict__ beta,
+    float *__restrict__ out, int M, int K,
+    const float *__restrict__ score_w, const float *__restrict__ score_b, int num_classes,
+    int sigmoid, float *__restrict__ scores) {
+    constexpr int N = 32 * NW;
+    __shared__ float red[NW * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+    const int m0 = blockIdx.x * 32, n0 = 32 * wave;
+    const int row = m0 + r;
+    const bool row_ok = row < M;
+    const int arow = row_ok ? row : M - 1;
+    const float *ap = A + (size_t)arow * K + 4 * h, *wp = W + (size_t)(n0 + r) * K + 4 * h;
+    // Same arithmetic order as gemm_ln_rows, so a video scores bit-identically through either family:
+    // accumulator starts at the residual, the K loop, then + bias; row statistics are summed per 32-column
+    // block in-lane, the blocks in ascending order, and the lane^32 partner last.
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 rv = *(const f32x4 *)(res + (size_t)arow * N + n0 + 8 * q + 4 * h);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[4 * q + e] = rv[e];
+    }
+    skinny_mainloop(acc, ap, wp, K);
+
+    auto row_total = [&](float v) __attribute__((always_inline)) {      // v: this lane's sum over its 16 columns
+        __syncthreads();                       // previous use of red[] is finished
+        red[wave * 64 + lane] = v;
+        __syncthreads();
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) t += red[w * 64 + lane];            // blocks ascending, own half
+        return pair_sum(t);                                              // + lane^32 partner
+    };
+    float s1 = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 bv = *(const f32x4 *)(bias + n0 + 8 * q + 4 * h);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { acc[4 * q + e] += bv[e]; s1 += acc[4 * q + e]; }
+    }
+    const float mean = row_total(s1) * (1.0f / N);
+    float s2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) { const float c = acc[t] - mean; acc[t] = c; s2 += c * c; }
+    const float rstd = 1.0f / sqrtf(row_total(s2) * (1.0f / N) + 1e-5f);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int co = n0 + 8 * q + 4 * h;
+        const f32x4 gv = *(const f32x4 *)(gamma + co), bv = *(const f32x4 *)(beta + co);
+        f32x4 y;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { y[e] = acc[4 * q + e] * rstd * gv[e] + bv[e]; acc[4 * q + e] = y[e]; }
+        if (row_ok) *(f32x4 *)(out + (size_t)row * N + co) = y;
+    }
+    if (score_w != nullptr) {
+        for (int c = 0; c < num_classes; ++c) {
+            float dot = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 wv = *(const f32x4 *)(score_w + (size_t)c * N + n0 + 8 * q + 4 * h);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dot += acc[4 * q + e] * wv[e];
+            }
+            const float tot = row_total(dot);
+            if (wave == 0 && h == 0 && row_ok) {
+                float sc = tot + score_b[c];
+                if (sigmoid) sc = 1.0f / (1.0f + expf(-sc));
+                scores[(size_t)row * num_classes + c] = sc;
             }
         }
     }
@@ -838,18 +1025,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd(
 // of tile t+1 ride in the MFMA stream of tile t.  NW waves per block (8: one block per CU, all
 // blocks take the same time; 4: for short videos).
 // ------------------------------------------------------------------------------------------
-// v_permlane32_swap of a register with itself yields {x_lo | x_lo} and {x_hi | x_hi}: every lane then
-// sees both its own and its lane^32 partner's value, so a symmetric combine needs no select.
-__device__ __forceinline__ float pair_max(float x) {
-    const unsigned u = __builtin_bit_cast(unsigned, x);
-    auto pr = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    return fmaxf(__builtin_bit_cast(float, (unsigned)pr[0]), __builtin_bit_cast(float, (unsigned)pr[1]));
-}
-__device__ __forceinline__ float pair_sum(float x) {
-    const unsigned u = __builtin_bit_cast(unsigned, x);
-    auto pr = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    return __builtin_bit_cast(float, (unsigned)pr[0]) + __builtin_bit_cast(float, (unsigned)pr[1]);
-}
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 template <int DH, bool HAS_MASK, int NW>
@@ -1132,9 +1307,21 @@ static bool use_wide_tiles(int M, int N) {
     return r256 * 100 <= r128 * 105 && tiles >= 512;
 }
 
+// latency path: below this many rows the LDS-tiled kernels cannot fill the chip
+static int skinny_max_rows() {
+    const char *e = getenv("VS_SKINNY_ROWS");      // read per call so tests can pin either path
+    return e ? atoi(e) : 4096;
+}
+
 template <int EPI>
 static int launch_gemm(const float *A, const float *W, const float *bias, float *C, int M, int N, int K,
                        const float *pe, int T, int H, int dh, hipStream_t st) {
+    if (M <= skinny_max_rows() && N % 32 == 0 && K % 128 == 0) {
+        dim3 grid((M + 31) / 32, (N + 127) / 128);
+        hipLaunchKernelGGL((skinny_gemm<EPI>), grid, dim3(256), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh);
+        VSK_CHECK_LAUNCH();
+        return 0;
+    }
     if (use_wide_tiles(M, N)) {
         const int blocks = persistent_blocks(((M + 255) / 256) * ((N + 127) / 128), 1);
         if (blocks < 0) return (int)hipErrorInvalidDevice;
@@ -1220,6 +1407,21 @@ int vsk_linear_res_ln(const float *A, const float *W, const float *bias, const f
                       const float *gamma, const float *beta, float *out, int M, int N, int K,
                       const float *score_w, const float *score_b, int num_classes, int sigmoid,
                       float *scores, hipStream_t st) {
+    if (M <= skinny_max_rows() && N <= 256 && N % 32 == 0 && K % 128 == 0) {
+        const int blocks = (M + 31) / 32;
+#define VSK_SLN_CASE(NW_)                                                                          \
+    case NW_:                                                                                      \
+        hipLaunchKernelGGL(skinny_ln<NW_>, dim3(blocks), dim3(64 * NW_), 0, st, A, W, bias, res, gamma, \
+                           beta, out, M, K, score_w, score_b, num_classes, sigmoid, scores);       \
+        break;
+        switch (N / 32) {
+            VSK_SLN_CASE(2) VSK_SLN_CASE(4) VSK_SLN_CASE(6) VSK_SLN_CASE(8)
+            default: return -1;
+        }
+#undef VSK_SLN_CASE
+        VSK_CHECK_LAUNCH();
+        return 0;
+    }
     if (N <= 256 && N % 32 == 0) {
         int blocks = persistent_blocks((M + 127) / 128);
         if (blocks < 0) return (int)hipErrorInvalidDevice;
