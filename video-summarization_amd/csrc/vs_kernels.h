@@ -4,13 +4,15 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-int vsk_linear(const float *A, const float *W, const float *bias, float *C, int M, int N, int K,
+// Wf: the weight in fragment-major order (vsk_pack_fragments) or nullptr; enables the packed latency kernels
+int vsk_linear(const float *A, const float *W, const float *Wf, const float *bias, float *C, int M, int N, int K,
                int relu, const float *pe, int T, hipStream_t st);
-int vsk_qkv(const float *h, const float *Wqkv, const float *bqkv, float *qkv, int B, int T, int d,
+int vsk_pack_fragments(const float *W, float *Wf, int N, int K, hipStream_t st);
+int vsk_qkv(const float *h, const float *Wqkv, const float *Wf, const float *bqkv, float *qkv, int B, int T, int d,
             int H, hipStream_t st);
 int vsk_attention(const float *q, const float *k, const float *v, const uint8_t *mask, float *out,
                   int B, int H, int T, int dh, float scale, hipStream_t st);
-int vsk_linear_res_ln(const float *A, const float *W, const float *bias, const float *res,
+int vsk_linear_res_ln(const float *A, const float *W, const float *Wf, const float *bias, const float *res,
                       const float *gamma, const float *beta, float *out, int M, int N, int K,
                       const float *score_w, const float *score_b, int num_classes, int sigmoid,
                       float *scores, hipStream_t st);

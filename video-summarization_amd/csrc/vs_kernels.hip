@@ -844,6 +844,193 @@ __global__ __launch_bounds__(64 * NW) void skinny_ln(
 }
 
 // ------------------------------------------------------------------------------------------
+// Skinny-M kernels, packed form (used by vs_scorer_forward).  The gather above costs ~260 ns per wave
+// load (32 rows x 16 B).  Here (a) the weights are pre-packed once, at vs_weights_pack time, in
+// FRAGMENT-MAJOR order  Wf[n/32][k/8][lane][4] = W[32*(n/32) + (lane&31)][8*(k/8) + 4*(lane>>5) + e],
+// so every wave load is one contiguous 1 KiB; (b) the block's 32 activation rows are staged once per
+// 1024-wide K phase through LDS with coalesced loads and read back as fragments (ds_read_b128).
+// MFMA order and reductions are unchanged -> results stay bit-identical to the other kernels.
+// ------------------------------------------------------------------------------------------
+__global__ void pack_fragments(const float *__restrict__ W, float *__restrict__ Wf, int N, int K) {
+    const size_t total = (size_t)N * K / 4;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int lane = (int)(idx & 63);
+        const size_t gi = idx >> 6;
+        const int g = (int)(gi % (K / 8)), nb = (int)(gi / (K / 8));
+        const int row = 32 * nb + (lane & 31), col = 8 * g + 4 * (lane >> 5);
+        *(f32x4 *)(Wf + idx * 4) = *(const f32x4 *)(W + (size_t)row * K + col);
+    }
+}
+
+// K loop of one wave over one K phase [k0, k0 + kp): activation fragments from LDS (As, row stride lda),
+// weight fragments from the packed array; 4 register sets of one 32-k chunk each, as skinny_mainloop.
+__device__ __forceinline__ void skinny2_phase(f32x16 &acc, const float *__restrict__ As_row,
+                                              const float *__restrict__ wf, int kp) {
+    // wf points at this lane's 4 floats of the phase's first group; consecutive groups are 256 floats apart
+    f32x4 w[4][4];
+    auto load = [&](int set, int chunk) __attribute__((always_inline)) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) w[set][g] = *(const f32x4 *)(wf + (size_t)(4 * chunk + g) * 256);
+    };
+    auto mma = [&](int set, int chunk) __attribute__((always_inline)) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 a = *(const f32x4 *)(As_row + 32 * chunk + 8 * g);
+#pragma unroll
+            for (int st = 0; st < 4; ++st) acc = MFMA32(w[set][g][st], a[st], acc);
+        }
+    };
+    const int nc = kp / 32;                         // multiple of 4
+    load(0, 0); load(1, 1); load(2, 2);
+    int c = 0;
+    for (; c < nc - 4; c += 4) {
+        load(3, c + 3); mma(0, c);
+        load(0, c + 4); mma(1, c + 1);
+        load(1, c + 5); mma(2, c + 2);
+        load(2, c + 6); mma(3, c + 3);
+    }
+    load(3, c + 3);
+    mma(0, c); mma(1, c + 1); mma(2, c + 2); mma(3, c + 3);
+}
+
+// stage rows [m0, m0+32) x [k0, k0+kp) of A into LDS (row stride kp + 4), coalesced
+template <int NT>
+__device__ __forceinline__ void skinny2_stage(float *As, const float *__restrict__ A, int M, int K, int m0, int k0, int kp) {
+    const int f4row = kp / 4, total = 32 * f4row;
+    for (int idx = threadIdx.x; idx < total; idx += NT) {
+        const int row = idx / f4row, c4 = idx - row * f4row;
+        int ar = m0 + row; ar = ar < M ? ar : M - 1;
+        *(f32x4 *)&As[row * (kp + 4) + 4 * c4] = *(const f32x4 *)(A + (size_t)ar * K + k0 + 4 * c4);
+    }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256) void skinny2_gemm(
+    const float *__restrict__ A, const float *__restrict__ Wf, const float *__restrict__ bias,
+    float *__restrict__ C, int M, int N, int K, const float *__restrict__ pe, int T, int H, int dh) {
+    extern __shared__ __attribute__((aligned(16))) float As[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+    const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 128 + 32 * wave;
+    const bool live = n0 < N;
+    const int row = m0 + r;
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    f32x16 acc = MFMA32((h == 0 && live) ? bias[n0 + r] : 0.f, 1.0f, zero);
+    const int kpmax = K < 1024 ? K : 1024;
+    for (int k0 = 0; k0 < K; k0 += kpmax) {
+        const int kp = K - k0 < kpmax ? K - k0 : kpmax;
+        if (k0) __syncthreads();
+        skinny2_stage<256>(As, A, M, K, m0, k0, kp);
+        __syncthreads();
+        if (live)
+            skinny2_phase(acc, As + r * (kp + 4) + 4 * h, Wf + ((size_t)(n0 / 32) * (K / 8) + k0 / 8) * 256 + lane * 4, kp);
+    }
+    if (!live || row >= M) return;
+    int bb = 0, tt = 0;
+    if (EPI == EPI_PE || EPI == EPI_QKV) { bb = row / T; tt = row - bb * T; }
+    int which = 0, head = 0, e0 = 0;
+    if (EPI == EPI_QKV) { const int d = H * dh; which = n0 / d; const int c = n0 - which * d; head = c / dh; e0 = c - head * dh; }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int co = 8 * q + 4 * h;
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[4 * q + e];
+        if (EPI == EPI_RELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = relu1(v[e]);
+        }
+        if (EPI == EPI_PE) {
+            const f32x4 pv = *(const f32x4 *)(pe + (size_t)tt * N + n0 + co);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += pv[e];
+        }
+        if (EPI == EPI_QKV)
+            *(f32x4 *)(C + (size_t)which * M * (H * dh) + (((size_t)bb * H + head) * T + tt) * dh + e0 + co) = v;
+        else
+            *(f32x4 *)(C + (size_t)row * N + n0 + co) = v;
+    }
+}
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void skinny2_ln(
+    const float *__restrict__ A, const float *__restrict__ Wf, const float *__restrict__ bias,
+    const float *__restrict__ res, const float *__restrict__ gamma, const float *__restrict__ beta,
+    float *__restrict__ out, int M, int K,
+    const float *__restrict__ score_w, const float *__restrict__ score_b, int num_classes,
+    int sigmoid, float *__restrict__ scores) {
+    constexpr int N = 32 * NW;
+    extern __shared__ __attribute__((aligned(16))) float As[];
+    __shared__ float red[NW * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+    const int m0 = blockIdx.x * 32, n0 = 32 * wave;
+    const int row = m0 + r;
+    const bool row_ok = row < M;
+    const int arow = row_ok ? row : M - 1;
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 rv = *(const f32x4 *)(res + (size_t)arow * N + n0 + 8 * q + 4 * h);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[4 * q + e] = rv[e];
+    }
+    const int kpmax = K < 1024 ? K : 1024;
+    for (int k0 = 0; k0 < K; k0 += kpmax) {
+        const int kp = K - k0 < kpmax ? K - k0 : kpmax;
+        if (k0) __syncthreads();
+        skinny2_stage<64 * NW>(As, A, M, K, m0, k0, kp);
+        __syncthreads();
+        skinny2_phase(acc, As + r * (kp + 4) + 4 * h, Wf + ((size_t)wave * (K / 8) + k0 / 8) * 256 + lane * 4, kp);
+    }
+    auto row_total = [&](float v) __attribute__((always_inline)) {      // same tree as skinny_ln / gemm_ln_rows
+        __syncthreads();
+        red[wave * 64 + lane] = v;
+        __syncthreads();
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) t += red[w * 64 + lane];
+        return pair_sum(t);
+    };
+    float s1 = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 bv = *(const f32x4 *)(bias + n0 + 8 * q + 4 * h);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { acc[4 * q + e] += bv[e]; s1 += acc[4 * q + e]; }
+    }
+    const float mean = row_total(s1) * (1.0f / N);
+    float s2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) { const float c = acc[t] - mean; acc[t] = c; s2 += c * c; }
+    const float rstd = 1.0f / sqrtf(row_total(s2) * (1.0f / N) + 1e-5f);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int co = n0 + 8 * q + 4 * h;
+        const f32x4 gv = *(const f32x4 *)(gamma + co), bv = *(const f32x4 *)(beta + co);
+        f32x4 y;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { y[e] = acc[4 * q + e] * rstd * gv[e] + bv[e]; acc[4 * q + e] = y[e]; }
+        if (row_ok) *(f32x4 *)(out + (size_t)row * N + co) = y;
+    }
+    if (score_w != nullptr) {
+        for (int c = 0; c < num_classes; ++c) {
+            float dot = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 wv = *(const f32x4 *)(score_w + (size_t)c * N + n0 + 8 * q + 4 * h);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dot += acc[4 * q + e] * wv[e];
+            }
+            const float tot = row_total(dot);
+            if (wave == 0 && h == 0 && row_ok) {
+                float sc = tot + score_b[c];
+                if (sigmoid) sc = 1.0f / (1.0f + expf(-sc));
+                scores[(size_t)row * num_classes + c] = sc;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Attention: softmax(q k^T * scale + keymask) v without materialising [T,T].
 //   grid = (ceil(T/128), B*H); 4 waves, each owns 32 query rows and walks all key tiles.
 //   Both products keep the QUERY on the lane: S^T = K * Q^T  (A = K tile from LDS, B = Q in
@@ -1313,9 +1500,24 @@ static int skinny_max_rows() {
     return e ? atoi(e) : 4096;
 }
 
+// dynamic LDS of the packed skinny kernels: 32 activation rows x (min(K,1024) + 4) floats (up to 128.5 KiB)
+static size_t skinny2_lds(int K) { return (size_t)32 * ((K < 1024 ? K : 1024) + 4) * sizeof(float); }
+template <class F>
+static int allow_big_lds(F *kernel) {
+    return (int)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 32 * 1028 * 4);
+}
+
 template <int EPI>
-static int launch_gemm(const float *A, const float *W, const float *bias, float *C, int M, int N, int K,
+static int launch_gemm(const float *A, const float *W, const float *Wf, const float *bias, float *C, int M, int N, int K,
                        const float *pe, int T, int H, int dh, hipStream_t st) {
+    if (Wf != nullptr && M <= skinny_max_rows() && N % 32 == 0 && K % 128 == 0) {
+        static const int attr_rc = allow_big_lds(skinny2_gemm<EPI>);
+        if (attr_rc) return attr_rc;
+        dim3 grid((M + 31) / 32, (N + 127) / 128);
+        hipLaunchKernelGGL((skinny2_gemm<EPI>), grid, dim3(256), skinny2_lds(K), st, A, Wf, bias, C, M, N, K, pe, T, H, dh);
+        VSK_CHECK_LAUNCH();
+        return 0;
+    }
     if (M <= skinny_max_rows() && N % 32 == 0 && K % 128 == 0) {
         dim3 grid((M + 31) / 32, (N + 127) / 128);
         hipLaunchKernelGGL((skinny_gemm<EPI>), grid, dim3(256), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh);
@@ -1335,11 +1537,18 @@ static int launch_gemm(const float *A, const float *W, const float *bias, float 
     return 0;
 }
 
-int vsk_linear(const float *A, const float *W, const float *bias, float *C, int M, int N, int K,
+int vsk_linear(const float *A, const float *W, const float *Wf, const float *bias, float *C, int M, int N, int K,
                int relu, const float *pe, int T, hipStream_t st) {
-    if (pe != nullptr) return launch_gemm<EPI_PE>(A, W, bias, C, M, N, K, pe, T, 0, 0, st);
-    if (relu) return launch_gemm<EPI_RELU>(A, W, bias, C, M, N, K, nullptr, 1, 0, 0, st);
-    return launch_gemm<EPI_BIAS>(A, W, bias, C, M, N, K, nullptr, 1, 0, 0, st);
+    if (pe != nullptr) return launch_gemm<EPI_PE>(A, W, Wf, bias, C, M, N, K, pe, T, 0, 0, st);
+    if (relu) return launch_gemm<EPI_RELU>(A, W, Wf, bias, C, M, N, K, nullptr, 1, 0, 0, st);
+    return launch_gemm<EPI_BIAS>(A, W, Wf, bias, C, M, N, K, nullptr, 1, 0, 0, st);
+}
+
+int vsk_pack_fragments(const float *W, float *Wf, int N, int K, hipStream_t st) {
+    if (N % 32 || K % 8) return -1;
+    hipLaunchKernelGGL(pack_fragments, dim3(256), dim3(256), 0, st, W, Wf, N, K);
+    VSK_CHECK_LAUNCH();
+    return 0;
 }
 
 // diagnostic: the fc1-shaped GEMM with per-wave stamps (VS_DIAG_MODE 1..3, VS_DIAG_NWM 2|4); `grid` <= 0
@@ -1362,9 +1571,9 @@ int vsk_diag_gemm(const float *A, const float *W, const float *bias, float *C, i
     return 0;
 }
 
-int vsk_qkv(const float *h, const float *Wqkv, const float *bqkv, float *qkv, int B, int T, int d,
+int vsk_qkv(const float *h, const float *Wqkv, const float *Wf, const float *bqkv, float *qkv, int B, int T, int d,
             int H, hipStream_t st) {
-    return launch_gemm<EPI_QKV>(h, Wqkv, bqkv, qkv, B * T, 3 * d, d, nullptr, T, H, d / H, st);
+    return launch_gemm<EPI_QKV>(h, Wqkv, Wf, bqkv, qkv, B * T, 3 * d, d, nullptr, T, H, d / H, st);
 }
 
 int vsk_attention(const float *q, const float *k, const float *v, const uint8_t *mask, float *out,
@@ -1403,10 +1612,28 @@ int vsk_attention(const float *q, const float *k, const float *v, const uint8_t 
     return 0;
 }
 
-int vsk_linear_res_ln(const float *A, const float *W, const float *bias, const float *res,
+int vsk_linear_res_ln(const float *A, const float *W, const float *Wf, const float *bias, const float *res,
                       const float *gamma, const float *beta, float *out, int M, int N, int K,
                       const float *score_w, const float *score_b, int num_classes, int sigmoid,
                       float *scores, hipStream_t st) {
+    if (Wf != nullptr && M <= skinny_max_rows() && N <= 256 && N % 32 == 0 && K % 128 == 0) {
+        const int blocks = (M + 31) / 32;
+#define VSK_SLN2_CASE(NW_)                                                                                 \
+    case NW_: {                                                                                            \
+        static const int attr_rc = allow_big_lds(skinny2_ln<NW_>);                                         \
+        if (attr_rc) return attr_rc;                                                                       \
+        hipLaunchKernelGGL(skinny2_ln<NW_>, dim3(blocks), dim3(64 * NW_), skinny2_lds(K), st, A, Wf, bias, res, \
+                           gamma, beta, out, M, K, score_w, score_b, num_classes, sigmoid, scores);        \
+        break;                                                                                             \
+    }
+        switch (N / 32) {
+            VSK_SLN2_CASE(2) VSK_SLN2_CASE(4) VSK_SLN2_CASE(6) VSK_SLN2_CASE(8)
+            default: return -1;
+        }
+#undef VSK_SLN2_CASE
+        VSK_CHECK_LAUNCH();
+        return 0;
+    }
     if (M <= skinny_max_rows() && N <= 256 && N % 32 == 0 && K % 128 == 0) {
         const int blocks = (M + 31) / 32;
 #define VSK_SLN_CASE(NW_)                                                                          \

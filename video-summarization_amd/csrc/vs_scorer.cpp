@@ -73,6 +73,7 @@ struct StageScope {
 
 struct LayerOff {
     size_t wqkv, bqkv, wo, bo, ln1g, ln1b, w1, b1, w2, b2, ln2g, ln2b;
+    size_t f_wqkv, f_wo, f_w1, f_w2;        // fragment-major copies for the latency kernels
 };
 
 int check_desc(const vs_model_desc *d) {
@@ -98,7 +99,7 @@ struct vs_weights {
     vs_model_desc desc;
     float *blob = nullptr;        // one device allocation
     size_t blob_floats = 0;
-    size_t embed_w = 0, embed_b = 0, pe = 0, final_w = 0, final_b = 0;
+    size_t embed_w = 0, embed_b = 0, pe = 0, final_w = 0, final_b = 0, f_embed_w = 0;
     bool has_pe = false;
     std::vector<LayerOff> layers;
     const float *p(size_t off) const { return blob + off; }
@@ -141,6 +142,10 @@ int vs_weights_pack(const vs_model_desc *desc, const vs_model_params *params, vo
     }
     w->final_w = take(nc * d);
     w->final_b = take(nc);
+    w->f_embed_w = take(d * din);
+    for (auto &L : w->layers) {
+        L.f_wqkv = take(3 * d * d); L.f_wo = take(d * d); L.f_w1 = take(4 * d * d); L.f_w2 = take(4 * d * d);
+    }
     w->blob_floats = off;
     hipError_t e = hipMalloc((void **)&w->blob, off * sizeof(float));
     if (e != hipSuccess) { delete w; return fail(VS_ERR_HIP, "hipMalloc(%zu): %s", off * sizeof(float), hipGetErrorString(e)); }
@@ -180,6 +185,19 @@ int vs_weights_pack(const vs_model_desc *desc, const vs_model_params *params, vo
         delete w;
         return fail(VS_ERR_HIP, "parameter copy failed (NULL pointer or hipMemcpyAsync error: %s)",
                     hipGetErrorString(hipGetLastError()));
+    }
+    // fragment-major copies (stream-ordered after the copies above)
+    bool pk = vsk_pack_fragments(w->blob + w->embed_w, w->blob + w->f_embed_w, (int)d, (int)din, st) == 0;
+    for (const auto &L : w->layers) {
+        pk &= vsk_pack_fragments(w->blob + L.wqkv, w->blob + L.f_wqkv, (int)(3 * d), (int)d, st) == 0;
+        pk &= vsk_pack_fragments(w->blob + L.wo, w->blob + L.f_wo, (int)d, (int)d, st) == 0;
+        pk &= vsk_pack_fragments(w->blob + L.w1, w->blob + L.f_w1, (int)(4 * d), (int)d, st) == 0;
+        pk &= vsk_pack_fragments(w->blob + L.w2, w->blob + L.f_w2, (int)d, (int)(4 * d), st) == 0;
+    }
+    if (!pk) {
+        (void)hipFree(w->blob);
+        delete w;
+        return fail(VS_ERR_HIP, "weight fragment packing failed: %s", hipGetErrorString(hipGetLastError()));
     }
     *out = w;
     return VS_OK;
@@ -223,7 +241,7 @@ int vs_scorer_forward(const vs_weights *w, const float *x, const uint8_t *key_pa
     // Embedding + positional table (simnet.py:211, 237-238)
     {
         StageScope ps(VS_STAGE_EMBED, st);
-        VS_LAUNCH(vsk_linear(x, w->p(w->embed_w), w->p(w->embed_b), h0, M, d, D.in_features, 0,
+        VS_LAUNCH(vsk_linear(x, w->p(w->embed_w), w->p(w->f_embed_w), w->p(w->embed_b), h0, M, d, D.in_features, 0,
                              w->has_pe ? w->p(w->pe) : nullptr, T, st));
     }
     for (int l = 0; l < L; ++l) {
@@ -231,7 +249,7 @@ int vs_scorer_forward(const vs_weights *w, const float *x, const uint8_t *key_pa
         const bool last = l == L - 1;
         {
             StageScope ps(VS_STAGE_QKV, st);
-            VS_LAUNCH(vsk_qkv(h0, w->p(P.wqkv), w->p(P.bqkv), qkv, B, T, d, H, st));
+            VS_LAUNCH(vsk_qkv(h0, w->p(P.wqkv), w->p(P.f_wqkv), w->p(P.bqkv), qkv, B, T, d, H, st));
         }
         {
             StageScope ps(VS_STAGE_ATTENTION, st);
@@ -240,17 +258,17 @@ int vs_scorer_forward(const vs_weights *w, const float *x, const uint8_t *key_pa
         }
         {
             StageScope ps(VS_STAGE_OUTPROJ_LN, st);
-            VS_LAUNCH(vsk_linear_res_ln(att, w->p(P.wo), w->p(P.bo), h0, w->p(P.ln1g), w->p(P.ln1b), h1, M, d, d,
+            VS_LAUNCH(vsk_linear_res_ln(att, w->p(P.wo), w->p(P.f_wo), w->p(P.bo), h0, w->p(P.ln1g), w->p(P.ln1b), h1, M, d, d,
                                         nullptr, nullptr, 0, 0, nullptr, st));
         }
         {
             StageScope ps(VS_STAGE_FC1, st);
-            VS_LAUNCH(vsk_linear(h1, w->p(P.w1), w->p(P.b1), ffn, M, 4 * d, d, 1, nullptr, 1, st));
+            VS_LAUNCH(vsk_linear(h1, w->p(P.w1), w->p(P.f_w1), w->p(P.b1), ffn, M, 4 * d, d, 1, nullptr, 1, st));
         }
         float *dst = (last && hidden) ? hidden : h0;
         {
             StageScope ps(VS_STAGE_FC2_LN, st);
-            VS_LAUNCH(vsk_linear_res_ln(ffn, w->p(P.w2), w->p(P.b2), h1, w->p(P.ln2g), w->p(P.ln2b), dst, M, d,
+            VS_LAUNCH(vsk_linear_res_ln(ffn, w->p(P.w2), w->p(P.f_w2), w->p(P.b2), h1, w->p(P.ln2g), w->p(P.ln2b), dst, M, d,
                                         4 * d, last ? w->p(w->final_w) : nullptr,
                                         last ? w->p(w->final_b) : nullptr, D.num_classes, sig,
                                         last ? scores : nullptr, st));
@@ -302,7 +320,7 @@ int vs_linear_f32(const float *A, const float *W, const float *bias, float *C, i
     if (M <= 0 || N <= 0 || N % 32 || K <= 0 || K % 32)
         return fail(VS_ERR_INVALID, "M=%d N=%d K=%d unsupported (N, K multiples of 32)", M, N, K);
     if (pe && (T <= 0 || relu)) return fail(VS_ERR_INVALID, "pe needs T > 0 and relu == 0");
-    VS_LAUNCH(vsk_linear(A, W, bias, C, M, N, K, relu, pe, T > 0 ? T : 1, (hipStream_t)stream));
+    VS_LAUNCH(vsk_linear(A, W, nullptr, bias, C, M, N, K, relu, pe, T > 0 ? T : 1, (hipStream_t)stream));
     return VS_OK;
 }
 
@@ -311,7 +329,7 @@ int vs_qkv_proj_f32(const float *h, const float *Wqkv, const float *bqkv, float 
     if (!h || !Wqkv || !bqkv || !qkv) return fail(VS_ERR_INVALID, "NULL pointer");
     if (B <= 0 || T <= 0 || d <= 0 || d % 32 || H <= 0 || d % H || (d / H) % 32)
         return fail(VS_ERR_INVALID, "B=%d T=%d d=%d H=%d unsupported", B, T, d, H);
-    VS_LAUNCH(vsk_qkv(h, Wqkv, bqkv, qkv, B, T, d, H, (hipStream_t)stream));
+    VS_LAUNCH(vsk_qkv(h, Wqkv, nullptr, bqkv, qkv, B, T, d, H, (hipStream_t)stream));
     return VS_OK;
 }
 
@@ -334,7 +352,7 @@ int vs_linear_residual_layernorm_f32(const float *A, const float *W, const float
         return fail(VS_ERR_INVALID, "M=%d N=%d K=%d unsupported (N multiple of 64 <= 512, K multiple of 16)", M, N, K);
     if (score_w && (!score_b || !scores || num_classes <= 0))
         return fail(VS_ERR_INVALID, "score head needs score_b, scores and num_classes > 0");
-    VS_LAUNCH(vsk_linear_res_ln(A, W, bias, residual, gamma, beta, out, M, N, K, score_w, score_b, num_classes,
+    VS_LAUNCH(vsk_linear_res_ln(A, W, nullptr, bias, residual, gamma, beta, out, M, N, K, score_w, score_b, num_classes,
                                 sigmoid, scores, (hipStream_t)stream));
     return VS_OK;
 }
