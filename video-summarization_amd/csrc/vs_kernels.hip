@@ -269,58 +269,58 @@ __global__ __launch_bounds__(128 * NWM, 2) void gemm_nt_128(
                 for (int jj = 0; jj < 2; ++jj) asm volatile("" ::"v"(acc[i][jj]));
             continue;
         }
-        // ---- epilogue: a lane owns 2 rows x 2x16 columns, 4 consecutive columns per register quad ->
-        // 16-byte row-contiguous stores (store ISSUE, not bytes, is what costs); no loads except the
-        // positional table (EPI_PE), which precede every store of the tile
+        // ---- epilogue.  A lane owns output ROWS (4 consecutive columns per register quad), so a direct
+        // store instruction would write 32 B into 32 different cache lines (measured: ~460 cycles per
+        // store, 7.4 K cycles per tile).  Instead each 32x32 sub-tile is transposed through a wave-private
+        // corner of the LDS staging buffer that is idle right now (its k-tile was just consumed; the other
+        // buffer already holds the next tile's first k-tile): write as owned (ds_write_b128), read back with
+        // 8 lanes per row, and every store instruction writes 8 full 128-byte lines.  No block barrier is
+        // needed for the transposition itself (one wave, in-order LDS), only one afterwards, before any
+        // wave restages that buffer.
         const int m0 = cu_m0, n0 = cu_n0;
+        float *tp = smem + (fpar ^ 1) * (BM + BN) * LD + wave * (32 * LD);     // 32 x 36 floats per wave
+        const int trow = lane >> 3, tc4 = (lane & 7) * 4;                       // read-back map: rows trow + 8p
         int b0 = 0, t0 = 0;                       // (video, frame) of row m0, for EPI_PE / EPI_QKV
         if (EPI == EPI_PE || EPI == EPI_QKV) { b0 = m0 / T; t0 = m0 - b0 * T; }
-        int row[2], bb[2], tt[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            row[i] = m0 + 64 * wr + 32 * i + r;
-            bb[i] = b0; tt[i] = t0 + 64 * wr + 32 * i + r;
-            if (EPI == EPI_PE || EPI == EPI_QKV) { while (tt[i] >= T) { tt[i] -= T; ++bb[i]; } }
-        }
-        if (EPI == EPI_PE) {
 #pragma unroll
-            for (int jj = 0; jj < 2; ++jj)
+            for (int jj = 0; jj < 2; ++jj) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const int col = n0 + 64 * wc + 32 * jj + 4 * h + 8 * q;
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        const f32x4 pv = *(const f32x4 *)(pe + (size_t)tt[i] * N + (col < N ? col : 0));
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) acc[i][jj][4 * q + e] += pv[e];
-                    }
-                }
-        }
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
-            const int c32 = n0 + 64 * wc + 32 * jj;               // a 32-column block never straddles a head
-            int which = 0, head = 0, e0 = 0;
-            if (EPI == EPI_QKV) { const int d = H * dh; which = c32 / d; const int c = c32 - which * d; head = c / dh; e0 = c - head * dh; }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int co = 8 * q + 4 * h;
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
                     f32x4 v;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         v[e] = acc[i][jj][4 * q + e];
                         if (EPI == EPI_RELU) v[e] = relu1(v[e]);
                     }
-                    if (row[i] < M && c32 + co < N) {
+                    *(f32x4 *)&tp[r * LD + 8 * q + 4 * h] = v;
+                }
+                const int c32 = n0 + 64 * wc + 32 * jj;               // a 32-column block never straddles a head
+                int which = 0, head = 0, e0 = 0;
+                if (EPI == EPI_QKV) { const int d = H * dh; which = c32 / d; const int c = c32 - which * d; head = c / dh; e0 = c - head * dh; }
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const int ro = 64 * wr + 32 * i + trow + 8 * p;
+                    f32x4 v = *(const f32x4 *)&tp[(trow + 8 * p) * LD + tc4];
+                    const int row = m0 + ro;
+                    int bb = b0, tt = t0 + ro;
+                    if (EPI == EPI_PE || EPI == EPI_QKV) { while (tt >= T) { tt -= T; ++bb; } }
+                    if (row < M && c32 < N) {
+                        if (EPI == EPI_PE) {
+                            const f32x4 pv = *(const f32x4 *)(pe + (size_t)tt * N + c32 + tc4);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] += pv[e];
+                        }
                         if (EPI == EPI_QKV)
-                            *(f32x4 *)(C + (size_t)which * M * (H * dh) + (((size_t)bb[i] * H + head) * T + tt[i]) * dh + e0 + co) = v;
+                            *(f32x4 *)(C + (size_t)which * M * (H * dh) + (((size_t)bb * H + head) * T + tt) * dh + e0 + tc4) = v;
                         else
-                            *(f32x4 *)(C + (size_t)row[i] * N + c32 + co) = v;
+                            *(f32x4 *)(C + (size_t)row * N + c32 + tc4) = v;
                     }
                 }
             }
         }
+        __syncthreads();
     }
     if (DIAG >= 2) { ts0 = stamp(); dsum[4] = __builtin_amdgcn_s_memrealtime(); }
     if (DIAG != 0 && diag != nullptr && lane == 0) {
@@ -639,9 +639,12 @@ __global__ __launch_bounds__(256, 2) void gemm_ln_rows(
         }
         sq = pair_sum(sq);
         const float rstd = 1.0f / sqrtf(sq * (1.0f / N) + 1e-5f);
-        float *op = out + (size_t)row * N + 4 * h;
+        // stores: each 32x32 block is transposed through a wave-private corner of the (now idle) staging
+        // buffers so that a store instruction writes 8 full 128-byte lines instead of 32 B into 32 lines
+        float *tp = smem + wave * (32 * 36);
+        const int trow = lane >> 3, tc4 = (lane & 7) * 4;
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
+        for (int j = 0; j < NT; ++j) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const f32x4 gv = *(const f32x4 *)&gam_s[32 * j + 8 * q + 4 * h];
@@ -649,8 +652,15 @@ __global__ __launch_bounds__(256, 2) void gemm_ln_rows(
                 f32x4 y;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { y[e] = acc[j][4 * q + e] * rstd * gv[e] + bv[e]; acc[j][4 * q + e] = y[e]; }
-                if (row_ok) *(f32x4 *)(op + 32 * j + 8 * q) = y;
+                *(f32x4 *)&tp[r * 36 + 8 * q + 4 * h] = y;
             }
+#pragma unroll
+            for (int pq = 0; pq < 4; ++pq) {
+                const f32x4 v = *(const f32x4 *)&tp[(trow + 8 * pq) * 36 + tc4];
+                const int orow = m0 + 32 * wave + trow + 8 * pq;
+                if (orow < M) *(f32x4 *)(out + (size_t)orow * N + 32 * j + tc4) = v;
+            }
+        }
         if (score_w != nullptr) {
             for (int c = 0; c < num_classes; ++c) {
                 __syncthreads();
@@ -1236,17 +1246,29 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_pipe(
     const float NEG_INF = -__builtin_inff();
     const int ntiles = (T + KT - 1) / KT;
 
+    // Q fragment (B operand), scaled by scale*log2(e).  A lane needs 16 B of ITS query row per 8 k - as a
+    // direct load that is 32 B into 32 different lines per instruction (slow to issue) - so the wave's 32
+    // rows are loaded coalesced (DH*128 contiguous bytes), parked in a wave-private LDS corner (the K/V
+    // buffers are not in use yet) and read back as fragments.
     float qreg[4 * NJ];
+    static_assert(4 * TILE >= NW * 32 * LD || NW == 8, "LDS corner per wave");
+    float *wtp = smem + wave * (32 * LD);            // 32 x (DH+4) floats per wave (NW*32*LD <= 4*TILE for NW <= 8)
     {
-        int qr = q0 + r; qr = qr < T ? qr : T - 1;
-        const float *qp = Q + base + (size_t)qr * DH + 4 * h;
+#pragma unroll
+        for (int i = 0; i < DH / 8; ++i) {           // 32 rows x DH floats = DH/8 wave loads of 1 KiB
+            const int idx = lane + 64 * i;
+            const int row = idx / (DH / 4), c4 = (idx % (DH / 4)) * 4;
+            int qr = q0 + row; qr = qr < T ? qr : T - 1;
+            *(f32x4 *)&wtp[row * LD + c4] = *(const f32x4 *)(Q + base + (size_t)qr * DH + c4);
+        }
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            const f32x4 v = *(const f32x4 *)(qp + 8 * j);
+            const f32x4 v = *(const f32x4 *)&wtp[r * LD + 8 * j + 4 * h];
 #pragma unroll
             for (int s = 0; s < 4; ++s) qreg[4 * j + s] = v[s] * scale_log2e;
         }
     }
+    __syncthreads();                                 // Q corners are read; K/V staging may overwrite them
     f32x16 o[ND];
 #pragma unroll
     for (int d = 0; d < ND; ++d)
@@ -1447,10 +1469,11 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_pipe(
     if (HAS_MASK || (T % KT) != 0) tile_step(ntiles - 1, std::true_type{}, std::true_type{});
     else                           tile_step(ntiles - 1, std::false_type{}, std::true_type{});
 
-    const int q = q0 + r;
-    if (q < T) {
+    // ---- epilogue: O^T[d][q] / l -> out[b, q, head*DH + d], through the wave-private LDS corner so that
+    // every store instruction writes whole 128-byte lines (DH/4 lanes per row) ----
+    __syncthreads();                                 // every wave is done reading K/V tiles
+    {
         const float inv = 1.0f / l_run;
-        float *op = out + ((size_t)b * T + q) * (H * DH) + head * DH;
 #pragma unroll
         for (int d = 0; d < ND; ++d)
 #pragma unroll
@@ -1458,8 +1481,16 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_pipe(
                 f32x4 v;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = o[d][4 * g + e] * inv;
-                *(f32x4 *)(op + 32 * d + 8 * g + 4 * h) = v;
+                *(f32x4 *)&wtp[r * LD + 32 * d + 8 * g + 4 * h] = v;
             }
+        constexpr int LPR = DH / 4, RPI = 64 / LPR;       // lanes per row, rows per store instruction
+        const int orow = lane / LPR, oc4 = (lane % LPR) * 4;
+#pragma unroll
+        for (int p = 0; p < 32 / RPI; ++p) {
+            const int rr = orow + RPI * p, q = q0 + rr;
+            const f32x4 v = *(const f32x4 *)&wtp[rr * LD + oc4];
+            if (q < T) *(f32x4 *)(out + ((size_t)b * T + q) * (H * DH) + head * DH + oc4) = v;
+        }
     }
 }
 
