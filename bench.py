@@ -30,7 +30,7 @@ sys.path.insert(0, ROOT)
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
 # HBM bytes per launch per kernel come from separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; see
 # tools/collect_traffic.sh), committed under profiles/: counters cannot be read from inside the timed run.
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_v3_hbm_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_v4_hbm_traffic.json")
 STAGE_KERNEL = {"attention": "attn_fwd_pipe", "embed_pe": "gemm_nt_128<2", "qkv_proj": "gemm_nt_128<3",
                 "fc1_relu": "gemm_nt_128<1", "outproj_ln": "gemm_ln_rows", "fc2_ln_score": "gemm_ln_rows"}
 
