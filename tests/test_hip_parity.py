@@ -329,3 +329,62 @@ def test_long_video_shape_beyond_reference_envelope(vsa):
         rl, rh = oracle_forward(sd, x, None, 4)
     assert (logits.cpu() - rl).abs().max().item() < TOL
     assert (hidden.cpu() - rh).abs().max().item() < TOL
+
+
+@pytest.mark.parametrize("T", [1, 2, 31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 257])
+def test_awkward_lengths_match_oracle(vsa, T, kernel_path):
+    """Every tile/tail boundary of the kernels (32-row MFMA blocks, 64-key tiles, 128/256-row blocks), with
+    a ragged padding mask and an odd batch size, through both kernel families."""
+    synth = vsa.synth
+    sd = synth.make_state_dict(256, 2, 70 + T)
+    lens = [T, max(1, T // 2), max(1, T - 1)]
+    x = synth.make_features(3, T, 71 + T, "randn", lens)
+    mask = synth.padding_mask(x)
+    m = _model(vsa, dict(H=4, d=256, L=2), sd)
+    with torch.no_grad():
+        logits, hidden = m(x.to(_dev()), mask.to(_dev()))
+        nomask, _ = m(x[:1].to(_dev()))
+        rl, rh = oracle_forward(sd, x, mask, 4)
+        rn, _ = oracle_forward(sd, x[:1], None, 4)
+    valid = ~mask
+    assert (logits.cpu() - rl)[valid].abs().max().item() < TOL
+    assert (hidden.cpu() - rh)[valid].abs().max().item() < TOL
+    assert (nomask.cpu() - rn).abs().max().item() < TOL
+
+
+def test_fully_masked_video_yields_nan_like_the_reference(vsa):
+    """softmax over an all-masked key row is NaN in the reference; same here (no crash, no hang)."""
+    synth = vsa.synth
+    sd = synth.make_state_dict(256, 1, 5)
+    x = synth.make_features(2, 40, 6)
+    mask = torch.zeros(2, 40, dtype=torch.bool)
+    mask[1] = True
+    m = _model(vsa, dict(H=4, d=256, L=1), sd)
+    with torch.no_grad():
+        logits, _ = m(x.to(_dev()), mask.to(_dev()))
+        rl, _ = oracle_forward(sd, x, mask, 4)
+    assert torch.isnan(rl[1]).all() and torch.isnan(logits[1].cpu()).all()
+    assert (logits[0].cpu() - rl[0]).abs().max().item() < TOL
+
+
+def test_two_streams_and_two_models_do_not_interfere(vsa):
+    """Weights handles and workspaces are per call/module: two models on two streams give the same scores as alone."""
+    synth = vsa.synth
+    sd1, sd2 = synth.make_state_dict(256, 2, 91), synth.make_state_dict(256, 2, 92)
+    m1, m2 = _model(vsa, dict(H=4, d=256, L=2), sd1), _model(vsa, dict(H=4, d=256, L=2), sd2)
+    x = synth.make_features(4, 300, 93).to(_dev())
+    with torch.no_grad():
+        a1, _ = m1(x)
+        a2, _ = m2(x)
+        torch.cuda.synchronize()
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        outs = []
+        for _ in range(3):
+            with torch.cuda.stream(s1):
+                b1, _ = m1(x)
+            with torch.cuda.stream(s2):
+                b2, _ = m2(x)
+            outs.append((b1, b2))
+        torch.cuda.synchronize()
+    for b1, b2 in outs:
+        assert torch.equal(a1, b1) and torch.equal(a2, b2)
