@@ -148,6 +148,9 @@ def main():
     out = None
     if rank == 0:
         fl = stage_flops(B, T, Din, d, H, L)
+        if stages.get("fc1_relu", (0, 0))[1] == 0 and stages.get("fc2_ln_score", (0, 0))[1] > 0:
+            # d_model 256: fc1 + ReLU + fc2 + LayerNorm run as one fused kernel, recorded under the fc2 stage
+            fl["fc2_ln_score"] += fl["fc1_relu"]
         table = {}
         for name, (ms, n) in stages.items():
             if n:

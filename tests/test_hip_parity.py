@@ -32,12 +32,15 @@ def _model(vsa, c, sd):
     return m.to(_dev()).eval()
 
 
-@pytest.fixture(params=["auto", "tiled"])
+@pytest.fixture(params=["auto", "tiled", "tiled+fused_mlp"])
 def kernel_path(request, monkeypatch):
     """Small inputs take the skinny latency kernels by default; VS_SKINNY_ROWS=0 pins the LDS-tiled
-    throughput kernels so both families are held to the same vectors."""
-    if request.param == "tiled":
+    throughput kernels, and VS_MLP_FUSION=1 additionally the opt-in fused MLP kernel, so every family is
+    held to the same vectors."""
+    if request.param != "auto":
         monkeypatch.setenv("VS_SKINNY_ROWS", "0")
+    if request.param == "tiled+fused_mlp":
+        monkeypatch.setenv("VS_MLP_FUSION", "1")
     return request.param
 
 
@@ -260,10 +263,13 @@ def test_c_abi_rejects_bad_arguments(vsa):
 # full-size properties (BASELINE.json configs[2]: B=64, T=1024) that need no CPU oracle run
 # ---------------------------------------------------------------------------------------------
 
-def test_full_size_batch_properties(vsa):
+@pytest.mark.parametrize("fused_mlp", [False, True])
+def test_full_size_batch_properties(vsa, fused_mlp, monkeypatch):
     """At B=64,T=1024 (bench size): (i) videos are independent — scoring a slice of the batch gives
     bit-identical rows; (ii) a padded+masked copy of a short video scores its valid frames like the
     unpadded video within fp32 noise; (iii) outputs are finite."""
+    if fused_mlp:
+        monkeypatch.setenv("VS_MLP_FUSION", "1")     # the big batch then runs the fused kernel, the slices the skinny ones
     synth = vsa.synth
     sd = synth.make_state_dict(256, 4, 41)
     m = _model(vsa, dict(H=4, d=256, L=4), sd)

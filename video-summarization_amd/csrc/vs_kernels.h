@@ -18,3 +18,8 @@ int vsk_linear_res_ln(const float *A, const float *W, const float *Wf, const flo
                       float *scores, hipStream_t st);
 int vsk_diag_gemm(const float *A, const float *W, const float *bias, float *C, int M, int N, int K,
                   int grid, unsigned long long *diag, hipStream_t st);
+// fc1 + ReLU + fc2 + residual + LayerNorm (+ score head) in one kernel; d_model == 256 only (-1 otherwise)
+int vsk_mlp_fused(const float *H1, const float *W1, const float *b1, const float *W2, const float *b2,
+                  const float *gamma, const float *beta, float *out, int M, int d,
+                  const float *score_w, const float *score_b, int num_classes, int sigmoid, float *scores,
+                  hipStream_t st);

@@ -690,6 +690,245 @@ __global__ __launch_bounds__(256, 2) void gemm_ln_rows(
 }
 
 // ------------------------------------------------------------------------------------------
+// Fused MLP block (d_model = 256, hidden = 1024):
+//     out = LN2( relu(h1 * W1^T + b1) * W2^T + b2 + h1 ) * gamma + beta      (+ score head)
+// (reference simnet.py:109-110,180-183,42) in ONE kernel, activations never leaving registers:
+//   * a wave owns 32 rows; X = its h1 rows as MFMA B-operand fragments (128 registers: lane (r,h) holds
+//     row r, columns 32j + 8q + 4h + e in X[j][4q+e]);
+//   * per 128-column chunk of the hidden layer: U = W1[chunk] * X^T  (X registers are the B operands),
+//     ReLU in place, then Y += W2[:, chunk] * U^T  (the U accumulators are the B operands, the same
+//     k permutation);  Y starts at X (the residual) and ends in the LayerNorm epilogue of gemm_ln_rows.
+//   Only the WEIGHT tiles stream through LDS (double buffer, one barrier per 32-k tile); LDS reads per
+//   MFMA are half those of the tiled GEMMs, the [M,1024] hidden tensor (256 MiB write + read at M=65536)
+//   never exists, and three launches become two.  One block (4 waves, 128 rows, ~380 registers per
+//   lane) per CU.  Summation orders equal those of gemm_nt_128 / gemm_ln_rows / the skinny kernels, so the
+//   result is bit-identical to the unfused path.
+// ------------------------------------------------------------------------------------------
+template <int ABL>      // diagnostic ablation (timing only): 1 no weight loads/LDS writes, 2 no barriers in the step loop
+__global__ __launch_bounds__(256, 1) void mlp_fused_256(
+    const float *__restrict__ H1, const float *__restrict__ W1, const float *__restrict__ b1,
+    const float *__restrict__ W2, const float *__restrict__ b2, const float *__restrict__ gamma,
+    const float *__restrict__ beta, float *__restrict__ out, int M,
+    const float *__restrict__ score_w, const float *__restrict__ score_b, int num_classes,
+    int sigmoid, float *__restrict__ scores) {
+    constexpr int D = 256, HID = 1024, CH = 128, BK = 32, LD = BK + 4, NT = 8;
+    constexpr int BUF = 256 * LD;                                   // floats per staging buffer
+    __shared__ __attribute__((aligned(16))) float smem[2 * BUF + 4 * D];
+    float *gam_s = smem + 2 * BUF, *bet_s = gam_s + D, *sw_s = bet_s + D, *bias_s = sw_s + D;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    for (int i = tid; i < D; i += 256) { gam_s[i] = gamma[i]; bet_s[i] = beta[i]; bias_s[i] = b2[i]; }
+
+    // Weight tiles, 128 MFMAs per wave each, 8 float4 per thread:
+    //   fc1 tile (chunk c, k-tile kt of 64): W1 rows 128c + .., columns 64kt + ..  -> LDS [128][68]
+    //   fc2 tile (chunk c, k-tile kt of 32): W2 rows 0..255, columns 128c + 32kt + .. -> LDS [256][36]
+    constexpr int LD1 = 68, LD2 = 36;
+    const int r1 = tid >> 4, c1 = (tid & 15) * 4;          // fc1 tile: rows r1 + 16*i
+    const int r2 = tid >> 3, c2 = (tid & 7) * 4;           // fc2 tile: rows r2 + 32*i
+    f32x4 pa[8];
+    auto load_w1 = [&](int c, int kt) __attribute__((always_inline)) {
+        const float *p = W1 + (size_t)(CH * c + r1) * D + 64 * kt + c1;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) pa[i] = *(const f32x4 *)(p + (size_t)16 * i * D);
+    };
+    auto load_w2 = [&](int c, int kt) __attribute__((always_inline)) {
+        const float *p = W2 + (size_t)r2 * HID + CH * c + BK * kt + c2;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) pa[i] = *(const f32x4 *)(p + (size_t)32 * i * HID);
+    };
+    auto stage_w1 = [&](int buf) __attribute__((always_inline)) {
+        float *Ws = smem + buf * BUF;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) *(f32x4 *)&Ws[(r1 + 16 * i) * LD1 + c1] = pa[i];
+    };
+    auto stage_w2 = [&](int buf) __attribute__((always_inline)) {
+        float *Ws = smem + buf * BUF;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) *(f32x4 *)&Ws[(r2 + 32 * i) * LD2 + c2] = pa[i];
+    };
+    // one step's schedule: 8 global loads among the first 32 MFMAs, 8 LDS writes among the last 32
+    auto step_schedule = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 64, 0);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        }
+    };
+
+    f32x16 X[NT], Y[NT], U[4];
+    const int ntiles = (M + 127) / 128;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int m0 = tile * 128 + 32 * wave;
+        // ---- X: this wave's 32 rows of h1, loaded coalesced and transposed through a wave-private LDS corner
+        // (two column halves of 128; 4 waves x 32 x 132 floats = 66 KiB of the idle staging area) ----
+        __syncthreads();
+        {
+            float *tp = smem + wave * (32 * 132);
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {                                  // 32 rows x 128 floats = 16 wave loads
+                    const int idx = lane + 64 * i, row = idx >> 5, c4 = (idx & 31) * 4;
+                    int gr = m0 + row; gr = gr < M ? gr : M - 1;
+                    *(f32x4 *)&tp[row * 132 + c4] = *(const f32x4 *)(H1 + (size_t)gr * D + 128 * half + c4);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 v = *(const f32x4 *)&tp[r * 132 + 32 * j + 8 * q + 4 * h];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) X[4 * half + j][4 * q + e] = v[e];
+                    }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) Y[j] = X[j];                               // residual (simnet.py:110)
+        __syncthreads();
+        load_w1(0, 0);
+        stage_w1(0);
+        __syncthreads();
+
+        int fpar = 0;
+        for (int c = 0; c < HID / CH; ++c) {
+            // U = b1[chunk] (bias x ones MFMA, C = 0)
+            {
+                const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) U[jj] = MFMA32(h == 0 ? b1[CH * c + 32 * jj + r] : 0.f, 1.0f, zero);
+            }
+            // ---- fc1: 4 k-tiles of 64, B operand = X[2kt], X[2kt+1] ----
+            static_for<4>([&](auto ktc) {
+                constexpr int kt = decltype(ktc)::value;
+                const float *Ws = smem + fpar * BUF + r * LD1 + 4 * h;
+                if constexpr (!(ABL & 1)) { if constexpr (kt < 3) load_w1(c, kt + 1); else load_w2(c, 0); }
+                {   // weight fragment double-buffered by hand: the next ds_read is in flight under 4 MFMAs
+                    f32x4 wn = *(const f32x4 *)Ws;
+#pragma unroll
+                    for (int i = 0; i < 32; ++i) {
+                        const int g = i >> 2, jj = i & 3;                       // g: 8 groups of 8 k
+                        const f32x4 w = wn;
+                        if (i + 1 < 32) wn = *(const f32x4 *)(Ws + 32 * ((i + 1) & 3) * LD1 + 8 * ((i + 1) >> 2));
+#pragma unroll
+                        for (int st = 0; st < 4; ++st) U[jj] = MFMA32(w[st], X[2 * kt + (g >> 2)][4 * (g & 3) + st], U[jj]);
+                    }
+                }
+                if constexpr (!(ABL & 1)) { if constexpr (kt < 3) stage_w1(fpar ^ 1); else stage_w2(fpar ^ 1); }
+                step_schedule();
+                if constexpr (!(ABL & 2)) __syncthreads();
+                fpar ^= 1;
+            });
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                for (int t = 0; t < 16; ++t) U[jj][t] = relu1(U[jj][t]);
+            // ---- fc2 partial: 4 k-tiles of 32 of this chunk, B operand = relu(U)[kt] ----
+            static_for<4>([&](auto ktc) {
+                constexpr int kt = decltype(ktc)::value;
+                const float *Ws = smem + fpar * BUF + r * LD2 + 4 * h;
+                const int cn = c + 1 < HID / CH ? c + 1 : c;                    // after the last chunk: harmless reload
+                if constexpr (!(ABL & 1)) { if constexpr (kt < 3) load_w2(c, kt + 1); else load_w1(cn, 0); }
+                {
+                    f32x4 wn = *(const f32x4 *)Ws;
+#pragma unroll
+                    for (int i = 0; i < 32; ++i) {
+                        const int g = i >> 3, j = i & 7;
+                        const f32x4 w = wn;
+                        if (i + 1 < 32) wn = *(const f32x4 *)(Ws + 32 * ((i + 1) & 7) * LD2 + 8 * ((i + 1) >> 3));
+#pragma unroll
+                        for (int st = 0; st < 4; ++st) Y[j] = MFMA32(w[st], U[kt][4 * g + st], Y[j]);
+                    }
+                }
+                if constexpr (!(ABL & 1)) { if constexpr (kt < 3) stage_w2(fpar ^ 1); else stage_w1(fpar ^ 1); }
+                step_schedule();
+                if constexpr (!(ABL & 2)) __syncthreads();
+                fpar ^= 1;
+            });
+        }
+
+        // ---- epilogue: + b2, LayerNorm (same reduction trees as gemm_ln_rows), coalesced stores, score head ----
+        const int row = m0 + r;
+        const bool row_ok = row < M;
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            float pj = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 bv = *(const f32x4 *)&bias_s[32 * j + 8 * q + 4 * h];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { Y[j][4 * q + e] += bv[e]; pj += Y[j][4 * q + e]; }
+            }
+            sum += pj;
+        }
+        sum = pair_sum(sum);
+        const float mean = sum * (1.0f / D);
+        float sq = 0.f;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            float pj = 0.f;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) { const float cv = Y[j][t] - mean; Y[j][t] = cv; pj += cv * cv; }
+            sq += pj;
+        }
+        sq = pair_sum(sq);
+        const float rstd = 1.0f / sqrtf(sq * (1.0f / D) + 1e-5f);
+        float *tp = smem + wave * (32 * 36);
+        const int trow = lane >> 3, tc4 = (lane & 7) * 4;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 gv = *(const f32x4 *)&gam_s[32 * j + 8 * q + 4 * h];
+                const f32x4 bv = *(const f32x4 *)&bet_s[32 * j + 8 * q + 4 * h];
+                f32x4 y;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { y[e] = Y[j][4 * q + e] * rstd * gv[e] + bv[e]; Y[j][4 * q + e] = y[e]; }
+                *(f32x4 *)&tp[r * 36 + 8 * q + 4 * h] = y;
+            }
+#pragma unroll
+            for (int pq = 0; pq < 4; ++pq) {
+                const f32x4 v = *(const f32x4 *)&tp[(trow + 8 * pq) * 36 + tc4];
+                const int orow = m0 + trow + 8 * pq;
+                if (orow < M) *(f32x4 *)(out + (size_t)orow * D + 32 * j + tc4) = v;
+            }
+        }
+        if (score_w != nullptr) {
+            for (int c = 0; c < num_classes; ++c) {
+                __syncthreads();
+                for (int i = tid; i < D; i += 256) sw_s[i] = score_w[(size_t)c * D + i];
+                __syncthreads();
+                float dot = 0.f;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    float pj = 0.f;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 wv = *(const f32x4 *)&sw_s[32 * j + 8 * q + 4 * h];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) pj += Y[j][4 * q + e] * wv[e];
+                    }
+                    dot += pj;
+                }
+                dot = pair_sum(dot);
+                if (h == 0 && row_ok) {
+                    float sc = dot + score_b[c];
+                    if (sigmoid) sc = 1.0f / (1.0f + expf(-sc));
+                    scores[(size_t)row * num_classes + c] = sc;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Skinny-M kernels (latency path, M <= a few thousand rows: single videos, small batches).
 // The tiled kernels above put a whole K loop on each of a handful of blocks when M is small (fc2 + LN
 // of one 320-frame video: 152 us on 3 blocks).  Here every WAVE owns one 32x32 output tile and streams
@@ -1573,6 +1812,23 @@ int vsk_linear(const float *A, const float *W, const float *Wf, const float *bia
     if (pe != nullptr) return launch_gemm<EPI_PE>(A, W, Wf, bias, C, M, N, K, pe, T, 0, 0, st);
     if (relu) return launch_gemm<EPI_RELU>(A, W, Wf, bias, C, M, N, K, nullptr, 1, 0, 0, st);
     return launch_gemm<EPI_BIAS>(A, W, Wf, bias, C, M, N, K, nullptr, 1, 0, 0, st);
+}
+
+int vsk_mlp_fused(const float *H1, const float *W1, const float *b1, const float *W2, const float *b2,
+                  const float *gamma, const float *beta, float *out, int M, int d,
+                  const float *score_w, const float *score_b, int num_classes, int sigmoid, float *scores,
+                  hipStream_t st) {
+    if (d != 256) return -1;
+    int blocks = persistent_blocks((M + 127) / 128, 1);
+    if (blocks < 0) return (int)hipErrorInvalidDevice;
+    if (blocks > (M + 127) / 128) blocks = (M + 127) / 128;
+    const char *ab = getenv("VS_MLP_ABL");
+    const int abl = ab ? atoi(ab) : 0;
+#define VSK_MLP(A_) hipLaunchKernelGGL(mlp_fused_256<A_>, dim3(blocks), dim3(256), 0, st, H1, W1, b1, W2, b2, gamma, beta, out, M, score_w, score_b, num_classes, sigmoid, scores)
+    if (abl == 1) VSK_MLP(1); else if (abl == 2) VSK_MLP(2); else if (abl == 3) VSK_MLP(3); else VSK_MLP(0);
+#undef VSK_MLP
+    VSK_CHECK_LAUNCH();
+    return 0;
 }
 
 int vsk_pack_fragments(const float *W, float *Wf, int N, int K, hipStream_t st) {

@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -261,11 +262,24 @@ int vs_scorer_forward(const vs_weights *w, const float *x, const uint8_t *key_pa
             VS_LAUNCH(vsk_linear_res_ln(att, w->p(P.wo), w->p(P.f_wo), w->p(P.bo), h0, w->p(P.ln1g), w->p(P.ln1b), h1, M, d, d,
                                         nullptr, nullptr, 0, 0, nullptr, st));
         }
+        float *dst = (last && hidden) ? hidden : h0;
+        // Opt-in alternative (VS_MLP_FUSION=1, d_model = 256): fc1 + ReLU + fc2 + residual + norm2 (+ score head)
+        // as ONE kernel with the activations kept in registers (reported under the fc2 stage).  Bit-identical
+        // to the two-kernel path but measured 6 % slower: its ~506 registers per lane allow one
+        // wave per SIMD only, so nothing covers the weight loads' issue stalls.
+        const char *fz = getenv("VS_MLP_FUSION"), *sk = getenv("VS_SKINNY_ROWS");
+        const bool fused = d == 256 && fz && atoi(fz) != 0 && M > (sk ? atoi(sk) : 4096);
+        if (fused) {
+            StageScope ps(VS_STAGE_FC2_LN, st);
+            VS_LAUNCH(vsk_mlp_fused(h1, w->p(P.w1), w->p(P.b1), w->p(P.w2), w->p(P.b2), w->p(P.ln2g), w->p(P.ln2b), dst, M, d,
+                                    last ? w->p(w->final_w) : nullptr, last ? w->p(w->final_b) : nullptr,
+                                    D.num_classes, sig, last ? scores : nullptr, st));
+            continue;
+        }
         {
             StageScope ps(VS_STAGE_FC1, st);
             VS_LAUNCH(vsk_linear(h1, w->p(P.w1), w->p(P.f_w1), w->p(P.b1), ffn, M, 4 * d, d, 1, nullptr, 1, st));
         }
-        float *dst = (last && hidden) ? hidden : h0;
         {
             StageScope ps(VS_STAGE_FC2_LN, st);
             VS_LAUNCH(vsk_linear_res_ln(ffn, w->p(P.w2), w->p(P.f_w2), w->p(P.b2), h1, w->p(P.ln2g), w->p(P.ln2b), dst, M, d,
