@@ -42,6 +42,16 @@ with torch.no_grad():
             dt = timed(lambda: m(x), it)
             F = 2 * 1024 * d + L * (24 * d * d + 4 * T * d) + 2 * d
             print("cfg M-%s B=%2d T=%4d: %8.3f ms/forward  %10.0f frames/s  %6.1f TFLOP/s" % (tag, B, T, dt * 1e3, B * T / dt, B * T / dt * F / 1e12))
+    # configs[4] shape in fp32: B=8 videos x T=8192 frames x 2048-d features (beyond the reference's envelope)
+    H, d, L = MODELS["A"]
+    m5 = pkg.SimNet(num_heads=H, d_model=d, num_layers=L, sparsity=0.0, dropout=0.3, in_features=2048, pe_len=8192)
+    m5.load_state_dict(pkg.synth.make_state_dict(d, L, 1234, in_features=2048, max_len=8192))
+    m5 = m5.to(dev).eval()
+    x5 = torch.randn(8, 8192, 2048, device=dev)
+    dt = timed(lambda: m5(x5), 5, 2)
+    F5 = 2 * 2048 * d + L * (24 * d * d + 4 * 8192 * d) + 2 * d
+    print("cfg5 shape (fp32) B=8 T=8192 D=2048: %8.3f ms/forward  %10.0f frames/s  %6.1f TFLOP/s" % (dt * 1e3, 8 * 8192 / dt, 8 * 8192 / dt * F5 / 1e12))
+    del m5, x5
     # configs[3] shape: 50 + 25 ragged videos, key masks on, one GPU
     m = model("A")
     g = torch.Generator().manual_seed(7)

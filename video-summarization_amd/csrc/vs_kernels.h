@@ -23,3 +23,4 @@ int vsk_mlp_fused(const float *H1, const float *W1, const float *b1, const float
                   const float *gamma, const float *beta, float *out, int M, int d,
                   const float *score_w, const float *score_b, int num_classes, int sigmoid, float *scores,
                   hipStream_t st);
+int vsk_skinny_max_rows();      // rows up to which the skinny (latency) kernels are used

@@ -1780,10 +1780,12 @@ static bool use_wide_tiles(int M, int N) {
 }
 
 // latency path: below this many rows the LDS-tiled kernels cannot fill the chip
-static int skinny_max_rows() {
+// measured hand-over (tools/sweep_skinny.py, T=1024, M-A): skinny wins through M = 16384, tiled from 32768
+int vsk_skinny_max_rows() {
     const char *e = getenv("VS_SKINNY_ROWS");      // read per call so tests can pin either path
-    return e ? atoi(e) : 4096;
+    return e ? atoi(e) : 16384;
 }
+static int skinny_max_rows() { return vsk_skinny_max_rows(); }
 
 // dynamic LDS of the packed skinny kernels: 32 activation rows x (min(K,1024) + 4) floats (up to 128.5 KiB)
 static size_t skinny2_lds(int K) { return (size_t)32 * ((K < 1024 ? K : 1024) + 4) * sizeof(float); }

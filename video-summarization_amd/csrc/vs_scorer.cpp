@@ -267,8 +267,8 @@ int vs_scorer_forward(const vs_weights *w, const float *x, const uint8_t *key_pa
         // as ONE kernel with the activations kept in registers (reported under the fc2 stage).  Bit-identical
         // to the two-kernel path but measured 6 % slower: its ~506 registers per lane allow one
         // wave per SIMD only, so nothing covers the weight loads' issue stalls.
-        const char *fz = getenv("VS_MLP_FUSION"), *sk = getenv("VS_SKINNY_ROWS");
-        const bool fused = d == 256 && fz && atoi(fz) != 0 && M > (sk ? atoi(sk) : 4096);
+        const char *fz = getenv("VS_MLP_FUSION");
+        const bool fused = d == 256 && fz && atoi(fz) != 0 && M > vsk_skinny_max_rows();
         if (fused) {
             StageScope ps(VS_STAGE_FC2_LN, st);
             VS_LAUNCH(vsk_mlp_fused(h1, w->p(P.w1), w->p(P.b1), w->p(P.w2), w->p(P.b2), w->p(P.ln2g), w->p(P.ln2b), dst, M, d,
