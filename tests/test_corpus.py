@@ -117,3 +117,48 @@ def test_two_rank_gather_equals_single_rank_bit_for_bit(vsa):
             assert torch.equal(results2[r][i], single2[i])
             assert torch.equal(results[r][i], results[1 - r][i])
             assert (results[r][i] - single[i]).abs().max().item() < 1e-5
+
+
+class _StubScorer:
+    """Frame-wise, batch-invariant stand-in for SimNet.score on CPU (the HIP scorer needs a GPU)."""
+    def eval(self):
+        return self
+
+    def score(self, x, mask=None):
+        return torch.sigmoid(x[..., 0] * 0.5 + x[..., 1])
+
+
+def _val_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    harness = importlib.import_module("video-summarization_amd.harness")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    feats, targets, users = importlib.import_module("eval_corpus").corpus(seed=3)
+    out = harness.val_step_batched(_StubScorer(), feats[:12], targets[:12], users[:12], None, rank, world, max_frames=2048)
+    q.put((rank, [float(v) for v in out]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_val_step_batched_two_ranks_equals_one_rank(vsa):
+    """Sharded scoring + gather + keyshot evaluation (world_size 2, gloo) returns exactly the 1-rank metrics."""
+    vsa._lib.build()
+    harness = importlib.import_module("video-summarization_amd.harness")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    feats, targets, users = importlib.import_module("eval_corpus").corpus(seed=3)
+    single = harness.val_step_batched(_StubScorer(), feats[:12], targets[:12], users[:12], None, max_frames=2048)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_val_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in (0, 1):
+        assert got[r] == [float(v) for v in single]

@@ -394,3 +394,31 @@ def test_two_streams_and_two_models_do_not_interfere(vsa):
         torch.cuda.synchronize()
     for b1, b2 in outs:
         assert torch.equal(a1, b1) and torch.equal(a2, b2)
+
+
+def test_val_step_end_to_end_matches_reference(vsa):
+    """BASELINE configs[0]/SURVEY §8(c): the reference's val_step (train.py:134-152) on synthetic TVSum-shaped
+    records of split 0 — reference model + reference evaluation produced the golden
+    (tests/golden/make_golden_valstep.py).  Here: HIP scorer + C++ evaluation, per video and batched."""
+    import importlib
+    import os
+    import sys
+    import numpy as np
+    from conftest import GOLDEN
+    sys.path.insert(0, GOLDEN)
+    mk = importlib.import_module("make_golden_valstep")
+    harness = importlib.import_module("video-summarization_amd.harness")
+    g = np.load(os.path.join(GOLDEN, "valstep_golden.npz"))
+    recs = mk.make_records()
+    sd = vsa.synth.make_state_dict(256, 4, mk.WSEED)
+    m = _model(vsa, dict(H=4, d=256, L=4), sd)
+    loader = [(f.unsqueeze(0), t.unsqueeze(0), u) for f, t, u in recs]
+    loss, f, k, s = harness.val_step(m, loader, _dev())
+    with torch.no_grad():
+        for feats, _, u in recs:
+            sc = torch.sigmoid(m(feats.unsqueeze(0).to(_dev()))[0].view(-1)).cpu().numpy()
+            assert np.abs(sc - g["scores_" + u.name]).max() < TOL
+    assert abs(loss - float(g["loss"])) < 1e-5
+    assert abs(f - g["metrics"][0]) < 1e-6 and abs(k - g["metrics"][1]) < 1e-4 and abs(s - g["metrics"][2]) < 1e-4
+    lb, fb, kb, sb = harness.val_step_batched(m, [r[0] for r in recs], [r[1] for r in recs], [r[2] for r in recs], _dev())
+    assert abs(lb - loss) < 1e-6 and fb == f and abs(kb - k) < 1e-12 and abs(sb - s) < 1e-12

@@ -1,0 +1,53 @@
+"""Evaluation harness: the counterpart of the reference's ``val_step`` (``src/train.py:134-152``).
+
+``val_step(model, loader, device)`` keeps the reference's contract: ``loader`` yields
+``(feature [1,T,1024], target [1,T], user)`` per video (reference ``collate_fn_test``,
+``data/dataset.py:164-168``), the model is called unchanged, ``sigmoid`` is applied by the caller and
+the per-video scores go to ``eval_metrics`` keyed by ``user.name``.  Returns
+``(mean MSE loss, f_score, kendall_tau, spearman_r)`` like the reference.
+
+``val_step_batched`` is the MI355X-friendly form of the same computation: the videos are scored in
+length-bucketed padded batches (optionally sharded over ranks, scores gathered with one all_gather) and the
+result is bit-identical per frame, because a video's scores do not depend on the batch it is scored in.
+"""
+from __future__ import annotations
+
+from typing import Iterable, Sequence
+
+import torch
+import torch.nn.functional as F
+
+from .corpus import score_corpus
+from .evaluation import eval_metrics
+
+
+@torch.no_grad()
+def val_step(model, loader: Iterable, device):
+    model.eval()
+    score_dict, user_dict = {}, {}
+    loss_sum, n = 0.0, 0
+    for feature, target, user in loader:
+        feature, target = feature.to(device), target.to(device)
+        pred, _ = model(feature)                                   # train.py:143
+        pred = torch.sigmoid(pred.view(1, -1))                     # train.py:144
+        loss_sum += F.mse_loss(pred, target).item()                # train.py:145-147
+        n += 1
+        score_dict[user.name] = pred.squeeze(0).detach().cpu().numpy()
+        user_dict[user.name] = user
+    f_score, ktau, spr = eval_metrics(score_dict, user_dict)       # train.py:150
+    return loss_sum / max(n, 1), f_score, ktau, spr
+
+
+@torch.no_grad()
+def val_step_batched(model, features: Sequence[torch.Tensor], targets: Sequence[torch.Tensor], users: Sequence,
+                     device, rank: int = 0, world: int = 1, group=None, max_frames: int = 16384):
+    """Same result as ``val_step`` over (features[i] [T_i,1024], targets[i] [T_i], users[i])."""
+    model.eval()
+    scores = score_corpus(lambda x, m: model.score(x, m), list(features), rank=rank, world=world, group=group,
+                          device=device, max_frames=max_frames)
+    score_dict = {u.name: scores[i].numpy() for i, u in enumerate(users)}
+    user_dict = {u.name: u for u in users}
+    loss = sum(F.mse_loss(scores[i].view(1, -1), targets[i].detach().float().cpu().view(1, -1)).item()
+               for i in range(len(users))) / max(len(users), 1)
+    f_score, ktau, spr = eval_metrics(score_dict, user_dict)
+    return loss, f_score, ktau, spr
