@@ -161,4 +161,5 @@ def test_val_step_batched_two_ranks_equals_one_rank(vsa):
         p.join(timeout=60)
         assert p.exitcode == 0
     for r in (0, 1):
-        assert got[r] == [float(v) for v in single]
+        assert got[r] == got[0]
+        assert all(abs(a - b) < 1e-12 for a, b in zip(got[r], single))      # sums regrouped per rank: last-bit only

@@ -421,4 +421,4 @@ def test_val_step_end_to_end_matches_reference(vsa):
     assert abs(loss - float(g["loss"])) < 1e-5
     assert abs(f - g["metrics"][0]) < 1e-6 and abs(k - g["metrics"][1]) < 1e-4 and abs(s - g["metrics"][2]) < 1e-4
     lb, fb, kb, sb = harness.val_step_batched(m, [r[0] for r in recs], [r[1] for r in recs], [r[2] for r in recs], _dev())
-    assert abs(lb - loss) < 1e-6 and fb == f and abs(kb - k) < 1e-12 and abs(sb - s) < 1e-12
+    assert abs(lb - loss) < 1e-6 and abs(fb - f) < 1e-9 and abs(kb - k) < 1e-12 and abs(sb - s) < 1e-12

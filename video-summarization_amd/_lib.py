@@ -71,7 +71,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB_PATH
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wno-unused-value", "-fno-slp-vectorize", "-I" + INCLUDE, "-I" + CSRC]
+           "-Wno-unused-value", "-fno-slp-vectorize", "-pthread", "-I" + INCLUDE, "-I" + CSRC]
     # -fno-slp-vectorize: packed f32 VALU (v_pk_mul/add_f32) beside MFMAs costs more than the scalar
     # forms it replaces (MI355X_MICROARCH.md, cycle constants); keep elementwise epilogue/softmax ops scalar
     cmd += [os.path.join(CSRC, s) for s in SOURCES]

@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdio>
 #include <numeric>
+#include <thread>
 #include <vector>
 
 #include "vs_scorer.h"
@@ -257,14 +258,29 @@ int vs_eval_fscore(const int8_t *summary, int32_t summary_len, const int8_t *use
 int vs_eval_rank_correlation(const float *frame_scores, int32_t n, const double *user_scores, int32_t n_users,
                              double *kendall, double *spearman) {
     if (!frame_scores || !user_scores || !kendall || !spearman || n < 2 || n_users < 1) return bad("rank_correlation: bad arguments");
-    std::vector<double> pr, ur;
+    std::vector<double> pr;
     rank_neg_average(frame_scores, n, pr);
-    double ksum = 0, ssum = 0;
-    for (int u = 0; u < n_users; ++u) {
-        rank_neg_average(user_scores + (size_t)u * n, n, ur);
-        ssum += pearson(pr, ur);                                              // compute_correlation.py:9-11
-        ksum += kendall_tau_b(pr, ur);                                        // :12-14
+    // users are independent: a few host threads, results summed in user order (deterministic)
+    std::vector<double> kt(n_users), sp(n_users);
+    auto work = [&](int u0, int u1) {
+        std::vector<double> ur;
+        for (int u = u0; u < u1; ++u) {
+            rank_neg_average(user_scores + (size_t)u * n, n, ur);
+            sp[u] = pearson(pr, ur);                                          // compute_correlation.py:9-11
+            kt[u] = kendall_tau_b(pr, ur);                                    // :12-14
+        }
+    };
+    const int hw = (int)std::thread::hardware_concurrency();
+    const int nth = std::max(1, std::min({n_users, hw > 0 ? hw : 1, 8}));
+    if (nth == 1 || (size_t)n * n_users < 20000) {
+        work(0, n_users);
+    } else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < nth; ++t) pool.emplace_back(work, (int)((long long)n_users * t / nth), (int)((long long)n_users * (t + 1) / nth));
+        for (auto &th : pool) th.join();
     }
+    double ksum = 0, ssum = 0;
+    for (int u = 0; u < n_users; ++u) { ksum += kt[u]; ssum += sp[u]; }
     *kendall = ksum / n_users;
     *spearman = ssum / n_users;
     return VS_OK;

@@ -17,7 +17,7 @@ from typing import Iterable, Sequence
 import torch
 import torch.nn.functional as F
 
-from .corpus import score_corpus
+from .corpus import plan_shards, score_corpus
 from .evaluation import eval_metrics
 
 
@@ -45,9 +45,23 @@ def val_step_batched(model, features: Sequence[torch.Tensor], targets: Sequence[
     model.eval()
     scores = score_corpus(lambda x, m: model.score(x, m), list(features), rank=rank, world=world, group=group,
                           device=device, max_frames=max_frames)
-    score_dict = {u.name: scores[i].numpy() for i, u in enumerate(users)}
-    user_dict = {u.name: u for u in users}
-    loss = sum(F.mse_loss(scores[i].view(1, -1), targets[i].detach().float().cpu().view(1, -1)).item()
-               for i in range(len(users))) / max(len(users), 1)
-    f_score, ktau, spr = eval_metrics(score_dict, user_dict)
-    return loss, f_score, ktau, spr
+    # every rank holds every video's scores; the (CPU) evaluation is sharded too: a rank evaluates the videos it
+    # scored and the four sums are all-reduced.  Sums run in a fixed per-rank order.
+    lengths = [int(f.shape[0]) for f in features]
+    mine = plan_shards(lengths, world)[rank] if world > 1 else list(range(len(users)))
+    sums = [0.0, 0.0, 0.0, 0.0]
+    for i in sorted(mine):
+        u = users[i]
+        f, k, s = eval_metrics({u.name: scores[i].numpy()}, {u.name: u})
+        sums[0] += F.mse_loss(scores[i].view(1, -1), targets[i].detach().float().cpu().view(1, -1)).item()
+        sums[1] += f
+        sums[2] += k
+        sums[3] += s
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor(sums, dtype=torch.float64,
+                         device=device if (device is not None and dist.get_backend(group) == "nccl") else "cpu")
+        dist.all_reduce(t, group=group)
+        sums = t.tolist()
+    n = max(len(users), 1)
+    return sums[0] / n, sums[1] / n, sums[2] / n, sums[3] / n
