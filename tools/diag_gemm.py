@@ -25,7 +25,8 @@ st = torch.cuda.current_stream().cuda_stream
 
 
 def run(grid, diag):
-    mode = int(os.environ.get("VS_DIAG_MODE", "1"))
+    mode = int(os.environ.get("VS_DIAG_MODE", "3"))
+    mode = 3 if mode == 1 else mode
     g = grid if grid > 0 else 512
     dbuf = torch.zeros(g * 4 * 8, dtype=torch.int64, device=dev)
     dp = dbuf.data_ptr() if mode in (2, 3) else None       # modes 2/3 time the diagnostic build itself

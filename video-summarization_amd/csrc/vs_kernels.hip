@@ -42,13 +42,6 @@ __device__ __forceinline__ void static_for(F &&f) {
     static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
-// Blocks b and b+8 share an XCD (round-robin dispatch): give each XCD a contiguous run of
-// logical tile ids so tiles that share an A row-panel hit the same L2.  Bijective for any n.
-__device__ __forceinline__ int xcd_remap(int bid, int n) {
-    const int q = n >> 3, r = n & 7, x = bid & 7;
-    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
-}
-
 // Attention block -> (video*head, query tile).  Blocks b and b+8 share an XCD and are dispatched in
 // order, so the nq query tiles of one (video, head) are given to nq CONSECUTIVE blocks of one XCD:
 // they run at the same time and that head's K/V is fetched from HBM/MALL into one L2 once instead
@@ -120,7 +113,7 @@ __device__ __forceinline__ unsigned long long stamp() {
 // SIMD unfairly: the older one finishes ~25 % earlier and the younger runs a lonely tail).
 // NJ = 32-column MFMA tiles per wave along N (2: block tile 64*NWM x 128; 4: 64*NWM x 256 - a third fewer
 // staging instructions and a quarter fewer fragment reads per MFMA, 128 accumulator registers).
-template <int EPI, int NWM = 2, int DIAG = 0, int NJ = 2>     // DIAG 1: phase stamps; 2: epilogue skipped (wrong output) + total cycles; 3: total cycles only
+template <int EPI, int NWM = 2, int DIAG = 0, int NJ = 2>     // DIAG (tools/diag_gemm.py only) 2: epilogue skipped (wrong output) + per-wave cycles/wall clock; 1, 3: the same with the epilogue
 __global__ __launch_bounds__(128 * NWM, 2) void gemm_nt_128(
     const float *__restrict__ A, const float *__restrict__ W, const float *__restrict__ bias,
     float *__restrict__ C, int M, int N, int K, const float *__restrict__ pe, int T, int H, int dh,
@@ -186,7 +179,7 @@ __global__ __launch_bounds__(128 * NWM, 2) void gemm_nt_128(
     // acc[i][jj][t] = C[m = 64wr + 32i + r][n = 64wc + 32jj + acc_row(t,h)]  (lane = output ROW:
     // the W fragment is the MFMA A operand, the activation fragment the B operand)
     f32x16 acc[2][NJ];
-    unsigned long long dsum[5] = {0, 0, 0, 0, 0}, ts0 = 0, ts1 = 0;
+    unsigned long long dsum[5] = {0, 0, 0, 0, 0}, ts0 = 0;
     int fpar = 0;                                   // LDS buffer holding the k-tile about to be consumed
 
     // One k-tile: 64 MFMAs from LDS buffer `fpar`, with the global loads of the NEXT k-tile (at
