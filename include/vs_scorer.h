@@ -32,6 +32,11 @@ extern "C" {
 #define VS_FLAG_SIGMOID 1u   /* scores = sigmoid(logits): the caller-side head of reference
                                 train.py:144 / generate_summary_image.py:68, fused.  Default
                                 (flag clear) returns raw logits like SimNet.forward (simnet.py:42). */
+#define VS_FLAG_BF16_ATTENTION 2u /* opt-in, long videos (BASELINE config 5): the two attention products
+                                run on the bf16 matrix pipe (q*scale, k, v, p rounded to bf16; fp32
+                                softmax and accumulation).  Head dim 32 or 64.  Scores then differ from
+                                the reference's fp32 path by ~1e-3 (tolerance stated in the tests);
+                                the default path stays exact fp32. */
 
 /* Model hyper-parameters: the ctor arguments of reference SimNet.__init__ (simnet.py:10-13)
  * that shape the eval forward. */
@@ -127,6 +132,11 @@ int vs_qkv_proj_f32(const float *h, const float *Wqkv, const float *bqkv, float 
 int vs_attention_f32(const float *q, const float *k, const float *v, const uint8_t *key_pad_mask,
                      float *out, int32_t B, int32_t H, int32_t T, int32_t dh, float scale,
                      void *stream);
+
+/* The same contract on the bf16 matrix pipe (see VS_FLAG_BF16_ATTENTION); dh in {32, 64}. */
+int vs_attention_bf16(const float *q, const float *k, const float *v, const uint8_t *key_pad_mask,
+                      float *out, int32_t B, int32_t H, int32_t T, int32_t dh, float scale,
+                      void *stream);
 
 /* out = LayerNorm(A*W^T + bias + residual) * gamma + beta, eps 1e-5 (simnet.py:107,110,163,182);
  * N = d_model.  If score_w != NULL also scores[row, c] = out[row,:].score_w[c,:] + score_b[c]

@@ -107,3 +107,14 @@ def test_positional_table_formula(vsa):
     pe = vsa.synth.positional_table(256, 2000)
     assert pe.shape == (1, 2000, 256) and pe[0, 0, 0] == 0 and pe[0, 0, 1] == 1
     assert abs(pe[0, 3, 0].item() - float(torch.sin(torch.tensor(3.0)))) < 1e-6
+
+
+def test_attention_dtype_is_validated(vsa):
+    m = vsa.SimNet(num_heads=4, d_model=256, num_layers=1)
+    assert m.attention_dtype == "fp32"
+    m.attention_dtype = "bf16"
+    with pytest.raises(ValueError):
+        m.attention_dtype = "fp16"
+    wide = vsa.SimNet(num_heads=4, d_model=512, num_layers=1)      # head_dim 128: fp32 kernels only
+    with pytest.raises(ValueError):
+        wide.attention_dtype = "bf16"

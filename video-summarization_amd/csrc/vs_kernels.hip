@@ -1451,6 +1451,206 @@ __global__ __launch_bounds__(256, 2) void attn_fwd(
 }
 
 // ------------------------------------------------------------------------------------------
+// Attention on the bf16 matrix pipe (opt-in, VS_FLAG_BF16_ATTENTION; long videos): the same
+// flash-style walk and operand trick as attn_fwd, but both products run as
+// v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA rate).  Q*scale, K, V and the probabilities P are
+// rounded to bf16 (round-to-nearest-even, v_cvt_pk_bf16_f32) on their way into the MFMA; scores,
+// softmax statistics and the output accumulate in fp32.  Inputs and output stay fp32 in HBM.
+//   S^T = K * Q^T : A = K[key r][d = 16s+8h+j] (one ds_read_b128 of the bf16 tile), B = Q in registers.
+//   O^T = V^T * P^T: B = registers 8s..8s+7 of the S^T accumulator packed pairwise — element j of
+//   lane half h is key 16s + 8(j>>2) + 4h + (j&3) — and A = V^T[d r][those keys], two ds_read_b64
+//   of the TRANSPOSED bf16 V tile, which the staging writes (4 keys of one d packed per b64 store).
+// NOT within the 1e-4 fp32 bar of the reference: tests/test_hip_parity.py states its tolerance.
+// ------------------------------------------------------------------------------------------
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+#define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+
+template <int DH>
+__global__ __launch_bounds__(256, 2) void attn_fwd_bf16(
+    const float *__restrict__ Q, const float *__restrict__ Kg, const float *__restrict__ Vg,
+    const uint8_t *__restrict__ mask, float *__restrict__ out, int H, int T, float scale_log2e, int BH) {
+    constexpr int KT = 64, NS = DH / 16, ND = DH / 32;
+    constexpr int LDK = DH + 8;                    // bf16 per K row: 36 (DH 64) / 20 (DH 32) dwords, b128 reads conflict-free
+    constexpr int LDV = KT + 4;                    // bf16 per V^T row: 34 dwords, b64 reads conflict-free
+    constexpr int KPT = DH / 16;                   // keys per thread in the staging (4 or 2), one float4 of d each
+    constexpr int D4 = DH / 4;                     // float4 per key row
+    typedef unsigned short bf16raw;
+    __shared__ __attribute__((aligned(16))) bf16raw Kb[KT * LDK];
+    __shared__ __attribute__((aligned(16))) bf16raw Vt[DH * LDV];
+    __shared__ float mb[KT];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    int bh, qt;
+    if (!attn_block_map((T + 127) / 128, BH, bh, qt)) return;
+    const int b = bh / H, head = bh - b * H;
+    const size_t base = (size_t)bh * T * DH;
+    const int q0 = qt * 128 + 32 * wave;
+    const float NEG_INF = -__builtin_inff();
+
+    // Q fragments (B operand): Q[q][16s + 8h + j] * scale*log2(e), bf16
+    bf16x8 qreg[NS];
+    {
+        int qr = q0 + r; qr = qr < T ? qr : T - 1;
+        const float *qp = Q + base + (size_t)qr * DH + 8 * h;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const f32x4 v0 = *(const f32x4 *)(qp + 16 * s), v1 = *(const f32x4 *)(qp + 16 * s + 4);
+            u32x4 u;
+            u[0] = pack_bf16(v0[0] * scale_log2e, v0[1] * scale_log2e);
+            u[1] = pack_bf16(v0[2] * scale_log2e, v0[3] * scale_log2e);
+            u[2] = pack_bf16(v1[0] * scale_log2e, v1[1] * scale_log2e);
+            u[3] = pack_bf16(v1[2] * scale_log2e, v1[3] * scale_log2e);
+            qreg[s] = __builtin_bit_cast(bf16x8, u);
+        }
+    }
+
+    f32x16 o[ND];
+#pragma unroll
+    for (int d = 0; d < ND; ++d)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) o[d][t] = 0.f;
+    float m_run = NEG_INF, l_run = 0.f;
+
+    // staging: thread (d4 = tid % D4, kq = tid / D4) owns keys KPT*kq .. +KPT-1 at d = 4*d4 .. +3
+    const int d4 = tid % D4, kq = tid / D4;
+    const int ntiles = (T + KT - 1) / KT;
+    f32x4 pk[KPT], pv[KPT];
+    auto prefetch = [&](int tile) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            int row = tile * KT + KPT * kq + i;
+            row = row < T ? row : T - 1;
+            const size_t off = base + (size_t)row * DH + 4 * d4;
+            pk[i] = *(const f32x4 *)(Kg + off);
+            pv[i] = *(const f32x4 *)(Vg + off);
+        }
+    };
+    prefetch(0);
+
+    for (int tile = 0; tile < ntiles; ++tile) {
+        const int k0 = tile * KT;
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            u32x2 u;
+            u[0] = pack_bf16(pk[i][0], pk[i][1]);
+            u[1] = pack_bf16(pk[i][2], pk[i][3]);
+            *(u32x2 *)&Kb[(KPT * kq + i) * LDK + 4 * d4] = u;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if constexpr (KPT == 4) {
+                u32x2 u;
+                u[0] = pack_bf16(pv[0][e], pv[1][e]);
+                u[1] = pack_bf16(pv[2][e], pv[3][e]);
+                *(u32x2 *)&Vt[(4 * d4 + e) * LDV + 4 * kq] = u;
+            } else {
+                *(unsigned *)&Vt[(4 * d4 + e) * LDV + 2 * kq] = pack_bf16(pv[0][e], pv[1][e]);
+            }
+        }
+        if (tid < KT) {
+            const int key = k0 + tid;
+            bool dead = key >= T;
+            if (!dead && mask != nullptr) dead = mask[(size_t)b * T + key] != 0;
+            mb[tid] = dead ? NEG_INF : 0.f;
+        }
+        __syncthreads();
+        if (tile + 1 < ntiles) prefetch(tile + 1);
+
+        // ---- S^T = K * Q^T ----
+        f32x16 s[2];
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) s[n][t] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < NS; ++ks)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const u32x4 ka = *(const u32x4 *)&Kb[(32 * n + r) * LDK + 16 * ks + 8 * h];
+                s[n] = MFMA_BF16(__builtin_bit_cast(bf16x8, ka), qreg[ks], s[n]);
+            }
+        if (mask != nullptr || k0 + KT > T) {
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int t = 0; t < 16; ++t) s[n][t] += mb[32 * n + acc_row(t, h)];
+        }
+        // ---- online softmax, one query per lane pair (l, l^32) ----
+        float mx = NEG_INF;
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) mx = fmaxf(mx, s[n][t]);
+        mx = pair_max(mx);
+        const float m_new = fmaxf(m_run, mx);
+        const float m_use = (m_new == NEG_INF) ? 0.f : m_new;
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
+        float psum = 0.f;
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const float p = __builtin_amdgcn_exp2f(s[n][t] - m_use);
+                s[n][t] = p;
+                psum += p;
+            }
+        psum = pair_sum(psum);
+        l_run = l_run * alpha + psum;
+        if (m_new != m_run) {                      // wave-uniform in practice after the first tiles
+#pragma unroll
+            for (int d = 0; d < ND; ++d)
+#pragma unroll
+                for (int t = 0; t < 16; ++t) o[d][t] *= alpha;
+        }
+        m_run = m_new;
+        // ---- O^T += V^T * P^T ----
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                u32x4 pu;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) pu[j] = pack_bf16(s[n][8 * ks + 2 * j], s[n][8 * ks + 2 * j + 1]);
+                const bf16x8 pf = __builtin_bit_cast(bf16x8, pu);
+#pragma unroll
+                for (int d = 0; d < ND; ++d) {
+                    const bf16raw *vp = &Vt[(32 * d + r) * LDV + 32 * n + 16 * ks + 4 * h];
+                    const u32x2 lo = *(const u32x2 *)vp, hi = *(const u32x2 *)(vp + 8);
+                    u32x4 vu;
+                    vu[0] = lo[0]; vu[1] = lo[1]; vu[2] = hi[0]; vu[3] = hi[1];
+                    o[d] = MFMA_BF16(__builtin_bit_cast(bf16x8, vu), pf, o[d]);
+                }
+            }
+        __syncthreads();
+    }
+
+    // ---- epilogue: O^T[d][q] / l -> out[b, q, head*DH + d]; 4 consecutive d per 16-B store ----
+    const int q = q0 + r;
+    if (q < T) {
+        const float inv = 1.0f / l_run;
+        float *op = out + ((size_t)b * T + q) * (H * DH) + head * DH;
+#pragma unroll
+        for (int d = 0; d < ND; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = o[d][4 * g + e] * inv;
+                *(f32x4 *)(op + 32 * d + 8 * g + 4 * h) = v;
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Attention, software-pipelined (head dim 32 / 64): same math and operand trick as attn_fwd.
 //
 // Measured on gfx950 (profiles/): the fp32 MFMA shares the SIMD's FP32 lanes with
@@ -1469,8 +1669,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd(
 // of tile t+1 ride in the MFMA stream of tile t.  NW waves per block (8: one block per CU, all
 // blocks take the same time; 4: for short videos).
 // ------------------------------------------------------------------------------------------
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
 template <int DH, bool HAS_MASK, int NW>
 __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_pipe(
     const float *__restrict__ Q, const float *__restrict__ Kg, const float *__restrict__ Vg,
@@ -1907,6 +2105,21 @@ int vsk_attention(const float *q, const float *k, const float *v, const uint8_t 
     }
     else if (dh == 128)
         hipLaunchKernelGGL((attn_fwd<128, 1>), grid, dim3(256), 0, st, q, k, v, mask, out, H, T, sl2, BH);
+    else
+        return -1;
+    VSK_CHECK_LAUNCH();
+    return 0;
+}
+
+int vsk_attention_bf16(const float *q, const float *k, const float *v, const uint8_t *mask, float *out,
+                       int B, int H, int T, int dh, float scale, hipStream_t st) {
+    const float sl2 = scale * 1.4426950408889634f;
+    const int BH = B * H;
+    dim3 grid(8 * ((BH + 7) / 8) * ((T + 127) / 128));
+    if (dh == 64)
+        hipLaunchKernelGGL((attn_fwd_bf16<64>), grid, dim3(256), 0, st, q, k, v, mask, out, H, T, sl2, BH);
+    else if (dh == 32)
+        hipLaunchKernelGGL((attn_fwd_bf16<32>), grid, dim3(256), 0, st, q, k, v, mask, out, H, T, sl2, BH);
     else
         return -1;
     VSK_CHECK_LAUNCH();

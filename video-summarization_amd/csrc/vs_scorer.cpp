@@ -225,6 +225,8 @@ int vs_scorer_forward(const vs_weights *w, const float *x, const uint8_t *key_pa
     if (w->has_pe && T > D.max_len)
         return fail(VS_ERR_INVALID, "T=%d exceeds the positional table (max_len=%d)", T, D.max_len);
     if ((long long)B * T > (1ll << 30)) return fail(VS_ERR_INVALID, "B*T too large");
+    if ((flags & VS_FLAG_BF16_ATTENTION) && D.d_model / D.num_heads != 32 && D.d_model / D.num_heads != 64)
+        return fail(VS_ERR_INVALID, "VS_FLAG_BF16_ATTENTION needs head_dim 32 or 64 (got %d)", D.d_model / D.num_heads);
     const size_t need = vs_scorer_workspace_bytes(w, B, T);
     if (!workspace || workspace_bytes < need)
         return fail(VS_ERR_WORKSPACE, "workspace %zu bytes < %zu needed", workspace_bytes, need);
@@ -254,8 +256,12 @@ int vs_scorer_forward(const vs_weights *w, const float *x, const uint8_t *key_pa
         }
         {
             StageScope ps(VS_STAGE_ATTENTION, st);
-            VS_LAUNCH(vsk_attention(qkv, qkv + (size_t)M * d, qkv + 2 * (size_t)M * d, key_pad_mask, att, B, H,
-                                    T, d / H, scale, st));
+            if (flags & VS_FLAG_BF16_ATTENTION)
+                VS_LAUNCH(vsk_attention_bf16(qkv, qkv + (size_t)M * d, qkv + 2 * (size_t)M * d, key_pad_mask, att,
+                                             B, H, T, d / H, scale, st));
+            else
+                VS_LAUNCH(vsk_attention(qkv, qkv + (size_t)M * d, qkv + 2 * (size_t)M * d, key_pad_mask, att, B, H,
+                                        T, d / H, scale, st));
         }
         {
             StageScope ps(VS_STAGE_OUTPROJ_LN, st);
@@ -353,6 +359,15 @@ int vs_attention_f32(const float *q, const float *k, const float *v, const uint8
     if (B <= 0 || H <= 0 || T <= 0) return fail(VS_ERR_INVALID, "B=%d H=%d T=%d", B, H, T);
     if (dh != 32 && dh != 64 && dh != 128) return fail(VS_ERR_INVALID, "head_dim=%d unsupported", dh);
     VS_LAUNCH(vsk_attention(q, k, v, key_pad_mask, out, B, H, T, dh, scale, (hipStream_t)stream));
+    return VS_OK;
+}
+
+int vs_attention_bf16(const float *q, const float *k, const float *v, const uint8_t *key_pad_mask,
+                      float *out, int32_t B, int32_t H, int32_t T, int32_t dh, float scale, void *stream) {
+    if (!q || !k || !v || !out) return fail(VS_ERR_INVALID, "NULL pointer");
+    if (B <= 0 || H <= 0 || T <= 0) return fail(VS_ERR_INVALID, "B=%d H=%d T=%d", B, H, T);
+    if (dh != 32 && dh != 64) return fail(VS_ERR_INVALID, "head_dim=%d unsupported on the bf16 path", dh);
+    VS_LAUNCH(vsk_attention_bf16(q, k, v, key_pad_mask, out, B, H, T, dh, scale, (hipStream_t)stream));
     return VS_OK;
 }
 

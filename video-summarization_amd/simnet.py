@@ -139,6 +139,10 @@ class SimNet(nn.Module):
                             module_score=nn.ModuleList())                        # stays empty: SURVEY Q2
         self.final_layer = nn.Linear(d_model, num_classes)
         self.fused_sigmoid = False        # opt-in: fold the callers' torch.sigmoid (train.py:144) into the kernel
+        # opt-in, long videos (BASELINE config 5): "bf16" runs the two attention products on the bf16 matrix
+        # pipe (fp32 softmax/accumulation); scores then differ from the fp32 reference by ~1e-3, so the
+        # default "fp32" is the only mode the 1e-4 parity bar applies to.
+        self._attention_dtype = "fp32"
         self._packed: Optional[_Packed] = None
         self._packed_key = None
 
@@ -222,7 +226,7 @@ class SimNet(nn.Module):
         if not x.is_cuda:
             raise RuntimeError("SimNet scoring runs on the MI355X HIP kernels only: move the module and its "
                                "input to a HIP device (there is no CPU path for the scorer)")
-        flags = _lib.VS_FLAG_SIGMOID if self.fused_sigmoid else 0
+        flags = (_lib.VS_FLAG_SIGMOID if self.fused_sigmoid else 0) | self._attention_flag()
         x32 = x if x.dtype == torch.float32 else x.float()
         packed = self._packed_weights(x.device)
         scores, hidden = torch.ops.vs_amd.score_frames(x32, mask, packed.handle, self.d_model,
@@ -238,8 +242,23 @@ class SimNet(nn.Module):
         x32 = x if x.dtype == torch.float32 else x.float()
         packed = self._packed_weights(x.device)
         scores, _ = torch.ops.vs_amd.score_frames(x32, mask, packed.handle, self.d_model, 1,
-                                                  _lib.VS_FLAG_SIGMOID, False)
+                                                  _lib.VS_FLAG_SIGMOID | self._attention_flag(), False)
         return scores.squeeze(-1)
+
+    @property
+    def attention_dtype(self) -> str:
+        return self._attention_dtype
+
+    @attention_dtype.setter
+    def attention_dtype(self, value: str) -> None:
+        if value not in ("fp32", "bf16"):
+            raise ValueError("attention_dtype must be 'fp32' or 'bf16', got %r" % (value,))
+        if value == "bf16" and self.d_model // self.num_heads not in (32, 64):
+            raise ValueError("bf16 attention needs head_dim 32 or 64, got %d" % (self.d_model // self.num_heads))
+        self._attention_dtype = value
+
+    def _attention_flag(self) -> int:
+        return _lib.VS_FLAG_BF16_ATTENTION if self._attention_dtype == "bf16" else 0
 
     # ---- autograd-capable path for train.py / pretrain.py (dropout, backward, autocast) -----
     def _forward_autograd(self, x: Tensor, mask: Optional[Tensor]):
