@@ -37,6 +37,11 @@ extern "C" {
                                 softmax and accumulation).  Head dim 32 or 64.  Scores then differ from
                                 the reference's fp32 path by ~1e-3 (tolerance stated in the tests);
                                 the default path stays exact fp32. */
+#define VS_FLAG_BF16_LINEAR 4u /* opt-in: every Linear (embed, q/k/v, feature_projection, fc1, fc2) multiplies
+                                bf16-rounded operands on the bf16 matrix pipe; tensors stay fp32 in HBM, and
+                                bias, accumulation, residual, LayerNorm and the score head stay fp32.
+                                d_model <= 256.  Same tolerance caveat as VS_FLAG_BF16_ATTENTION. */
+#define VS_FLAG_BF16 (VS_FLAG_BF16_ATTENTION | VS_FLAG_BF16_LINEAR)
 
 /* Model hyper-parameters: the ctor arguments of reference SimNet.__init__ (simnet.py:10-13)
  * that shape the eval forward. */
@@ -123,6 +128,11 @@ int vs_linear_f32(const float *A, const float *W, const float *bias, float *C,
                   int32_t M, int32_t N, int32_t K, int32_t relu,
                   const float *pe, int32_t T, void *stream);
 
+/* vs_linear_f32 on the bf16 matrix pipe (see VS_FLAG_BF16_LINEAR). */
+int vs_linear_bf16(const float *A, const float *W, const float *bias, float *C,
+                   int32_t M, int32_t N, int32_t K, int32_t relu,
+                   const float *pe, int32_t T, void *stream);
+
 /* qkv = h * Wqkv^T + b, scattered head-major: out[3][B][H][T][dh]  (simnet.py:148-153). */
 int vs_qkv_proj_f32(const float *h, const float *Wqkv, const float *bqkv, float *qkv,
                     int32_t B, int32_t T, int32_t d, int32_t H, void *stream);
@@ -146,6 +156,13 @@ int vs_linear_residual_layernorm_f32(const float *A, const float *W, const float
                                      float *out, int32_t M, int32_t N, int32_t K,
                                      const float *score_w, const float *score_b, int32_t num_classes,
                                      int32_t sigmoid, float *scores, void *stream);
+
+/* The same on the bf16 matrix pipe (see VS_FLAG_BF16_LINEAR); N <= 256. */
+int vs_linear_residual_layernorm_bf16(const float *A, const float *W, const float *bias,
+                                      const float *residual, const float *gamma, const float *beta,
+                                      float *out, int32_t M, int32_t N, int32_t K,
+                                      const float *score_w, const float *score_b, int32_t num_classes,
+                                      int32_t sigmoid, float *scores, void *stream);
 
 #ifdef __cplusplus
 }

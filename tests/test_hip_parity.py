@@ -564,3 +564,110 @@ def test_bf16_attention_long_video(vsa):
 
 
 
+
+
+# ---- opt-in bf16 Linear kernels (VS_FLAG_BF16_LINEAR) ---------------------------------------------------
+# The checker multiplies the SAME bf16-rounded operands in fp64, so what is left is fp32 accumulation order:
+# 1e-4 absolute on O(1) outputs.  Against unrounded operands the error is the bf16 rounding itself.
+def _rb(t):
+    return t.to(torch.bfloat16).double()
+
+
+@pytest.mark.parametrize("M,N,K,relu,T", [(300, 256, 1024, 0, 0), (129, 1024, 256, 1, 0), (64, 768, 256, 0, 0),
+                                          (1000, 256, 1024, 0, 250), (37, 512, 2048, 0, 37), (2048, 2048, 512, 1, 0),
+                                          (1, 32, 32, 0, 0)])
+def test_linear_bf16_kernel(vsa, M, N, K, relu, T):
+    lib = vsa._lib.load()
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g)
+    pe = torch.randn(T, N, generator=g) if T else None
+    ref = _rb(A) @ _rb(W).t() + b.double()
+    if relu:
+        ref = F.relu(ref)
+    if T:
+        ref = ref + pe.double().repeat(M // T, 1)
+    dA, dW, db = A.to(_dev()), W.to(_dev()), b.to(_dev())
+    dpe = pe.to(_dev()) if T else None
+    out = torch.full((M, N), float("nan"), device=_dev())
+    vsa._lib.check(lib.vs_linear_bf16(dA.data_ptr(), dW.data_ptr(), db.data_ptr(), out.data_ptr(), M, N, K, relu,
+                                      dpe.data_ptr() if T else None, T, _stream()))
+    torch.cuda.synchronize()
+    assert (out.cpu().double() - ref).abs().max().item() < 1e-4
+
+
+@pytest.mark.parametrize("M,N,K,nc,sig", [(300, 256, 256, 0, 0), (100, 256, 1024, 1, 0), (64, 128, 512, 3, 0),
+                                          (1000, 192, 320, 2, 1), (33, 64, 256, 1, 0)])
+def test_linear_residual_layernorm_bf16_kernel(vsa, M, N, K, nc, sig):
+    lib = vsa._lib.load()
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b, res = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    gam, bet = 1 + 0.1 * torch.randn(N, generator=g), 0.1 * torch.randn(N, generator=g)
+    sw, sb = torch.randn(max(nc, 1), N, generator=g) / math.sqrt(N), torch.randn(max(nc, 1), generator=g)
+    y = F.layer_norm(_rb(A) @ _rb(W).t() + b.double() + res.double(), (N,), gam.double(), bet.double(), 1e-5)
+    sc = F.linear(y, sw.double(), sb.double())
+    if sig:
+        sc = torch.sigmoid(sc)
+    d = [t.to(_dev()) for t in (A, W, b, res, gam, bet, sw, sb)]
+    out = torch.full((M, N), float("nan"), device=_dev())
+    scores = torch.full((M, max(nc, 1)), float("nan"), device=_dev())
+    vsa._lib.check(lib.vs_linear_residual_layernorm_bf16(
+        d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), d[4].data_ptr(), d[5].data_ptr(),
+        out.data_ptr(), M, N, K, d[6].data_ptr() if nc else None, d[7].data_ptr() if nc else None, nc, sig,
+        scores.data_ptr() if nc else None, _stream()))
+    torch.cuda.synchronize()
+    assert (out.cpu().double() - y).abs().max().item() < 1e-4
+    if nc:
+        assert (scores.cpu().double() - sc).abs().max().item() < 1e-4
+
+
+BF16_FULL_LOGIT_TOL = 3e-2     # all products on the bf16 pipe; set from the measured errors printed below
+BF16_FULL_SCORE_TOL = 8e-3
+
+
+@pytest.mark.parametrize("cfg", ["M-A", "M-B8"])
+def test_bf16_compute_mode_end_to_end(vsa, cfg):
+    """SimNet.set_compute_dtype('bf16'): every matrix product on the bf16 pipe, against the fp32 oracle."""
+    synth = vsa.synth
+    d, H, L = (256, 4, 4) if cfg == "M-A" else (256, 8, 6)
+    sd = synth.make_state_dict(d, L, 71, trained_like=True)
+    lengths = [400, 333, 64, 1]
+    x = synth.make_features(4, 400, 72, "pool5", lengths=lengths)
+    mask = synth.padding_mask(x)
+    m = vsa.SimNet(num_heads=H, d_model=d, num_layers=L, sparsity=0.0, dropout=0.3)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(_dev()).eval().set_compute_dtype("bf16")
+    with torch.no_grad():
+        logits, hidden = m(x.to(_dev()), mask.to(_dev()))
+        s = m.score(x.to(_dev()), mask.to(_dev()))
+        rl, rh = oracle_forward(sd, x, mask, H)
+    valid = ~mask
+    err = (logits.cpu() - rl).abs().squeeze(-1)[valid].max().item()
+    serr = (s.cpu() - torch.sigmoid(rl).squeeze(-1)).abs()[valid].max().item()
+    herr = (hidden.cpu() - rh).abs()[valid].max().item()
+    print("bf16 compute %s: logit err %.3e score err %.3e hidden err %.3e" % (cfg, err, serr, herr))
+    assert err < BF16_FULL_LOGIT_TOL and serr < BF16_FULL_SCORE_TOL
+    m.set_compute_dtype("fp32")
+    with torch.no_grad():
+        l32, _ = m(x.to(_dev()), mask.to(_dev()))
+    assert (l32.cpu() - rl).abs().squeeze(-1)[valid].max().item() < TOL     # and back: the exact path is untouched
+
+
+def test_bf16_compute_long_video(vsa):
+    """BASELINE configs[4]: T=8192, 2048-d features, all products bf16 (oracle: fp32 restatement)."""
+    synth = vsa.synth
+    sd = synth.make_state_dict(256, 2, 61, in_features=2048, max_len=8192)
+    x = synth.make_features(1, 8192, 62, "randn", in_features=2048)
+    m = vsa.SimNet(num_heads=4, d_model=256, num_layers=2, sparsity=0.0, dropout=0.3, in_features=2048, pe_len=8192)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(_dev()).eval().set_compute_dtype("bf16")
+    with torch.no_grad():
+        logits, hidden = m(x.to(_dev()))
+        torch.set_num_threads(16)
+        rl, rh = oracle_forward(sd, x, None, 4)
+    err = (logits.cpu() - rl).abs().max().item()
+    print("bf16 compute T=8192: logit err %.3e" % err)
+    assert err < BF16_FULL_LOGIT_TOL

@@ -24,8 +24,12 @@ F = 2 * D * d + L * (24 * d * d + 4 * T * d) + 2 * d
 lib = _lib.load()
 with torch.no_grad():
     outs = {}
-    for mode in ("fp32", "bf16"):
-        m.attention_dtype = mode
+    for mode in ("fp32", "bf16-attn", "bf16"):
+        m.set_compute_dtype("fp32")
+        if mode == "bf16-attn":
+            m.attention_dtype = "bf16"
+        elif mode == "bf16":
+            m.set_compute_dtype("bf16")
         for _ in range(3):
             m.score(x)
         torch.cuda.synchronize()
@@ -44,7 +48,8 @@ with torch.no_grad():
         ms = {k: v[0] for k, v in prof.items()}
         stages = ", ".join("%s %.3f" % (k, v / iters) for k, v in ms.items())
         att_fl = L * 4.0 * T * d * B * T
-        print("attention %s  B=%d T=%d D=%d: %8.3f ms/forward  %10.0f frames/s  %6.1f TFLOP/s(model)  attention %.1f TFLOP/s"
+        print("mode %-9s  B=%d T=%d D=%d: %8.3f ms/forward  %10.0f frames/s  %6.1f TFLOP/s(model)  attention %.1f TFLOP/s"
               % (mode, B, T, D, dt * 1e3, B * T / dt, B * T / dt * F / 1e12, att_fl / (ms["attention"] / iters * 1e-3) / 1e12))
         print("   stages (ms/forward): " + stages)
-    print("max |score_bf16 - score_fp32| = %.3e" % (outs["bf16"] - outs["fp32"]).abs().max().item())
+    for k in ("bf16-attn", "bf16"):
+        print("max |score_%s - score_fp32| = %.3e" % (k, (outs[k] - outs["fp32"]).abs().max().item()))

@@ -4,12 +4,13 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// bf16 != 0: operands rounded to bf16 for the matrix pipe (opt-in; fp32 storage, bias, accumulation, LayerNorm)
 // Wf: the weight in fragment-major order (vsk_pack_fragments) or nullptr; enables the packed latency kernels
 int vsk_linear(const float *A, const float *W, const float *Wf, const float *bias, float *C, int M, int N, int K,
-               int relu, const float *pe, int T, hipStream_t st);
+               int relu, const float *pe, int T, int bf16, hipStream_t st);
 int vsk_pack_fragments(const float *W, float *Wf, int N, int K, hipStream_t st);
 int vsk_qkv(const float *h, const float *Wqkv, const float *Wf, const float *bqkv, float *qkv, int B, int T, int d,
-            int H, hipStream_t st);
+            int H, int bf16, hipStream_t st);
 int vsk_attention(const float *q, const float *k, const float *v, const uint8_t *mask, float *out,
                   int B, int H, int T, int dh, float scale, hipStream_t st);
 int vsk_attention_bf16(const float *q, const float *k, const float *v, const uint8_t *mask, float *out,
@@ -17,7 +18,7 @@ int vsk_attention_bf16(const float *q, const float *k, const float *v, const uin
 int vsk_linear_res_ln(const float *A, const float *W, const float *Wf, const float *bias, const float *res,
                       const float *gamma, const float *beta, float *out, int M, int N, int K,
                       const float *score_w, const float *score_b, int num_classes, int sigmoid,
-                      float *scores, hipStream_t st);
+                      float *scores, int bf16, hipStream_t st);
 int vsk_diag_gemm(const float *A, const float *W, const float *bias, float *C, int M, int N, int K,
                   int grid, unsigned long long *diag, hipStream_t st);
 // fc1 + ReLU + fc2 + residual + LayerNorm (+ score head) in one kernel; d_model == 256 only (-1 otherwise)

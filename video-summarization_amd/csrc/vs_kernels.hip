@@ -66,6 +66,18 @@ __device__ __forceinline__ float pair_sum(float x) {
     return __builtin_bit_cast(float, (unsigned)pr[0]) + __builtin_bit_cast(float, (unsigned)pr[1]);
 }
 
+// ---- bf16 matrix pipe (opt-in paths) ----
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+#define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+
 // max(x, 0) as ONE instruction (fmaxf first canonicalises its MFMA-produced input with a second v_max)
 __device__ __forceinline__ float relu1(float x) {
     float y;
@@ -113,7 +125,10 @@ __device__ __forceinline__ unsigned long long stamp() {
 // SIMD unfairly: the older one finishes ~25 % earlier and the younger runs a lonely tail).
 // NJ = 32-column MFMA tiles per wave along N (2: block tile 64*NWM x 128; 4: 64*NWM x 256 - a third fewer
 // staging instructions and a quarter fewer fragment reads per MFMA, 128 accumulator registers).
-template <int EPI, int NWM = 2, int DIAG = 0, int NJ = 2>     // DIAG (tools/diag_gemm.py only) 2: epilogue skipped (wrong output) + per-wave cycles/wall clock; 1, 3: the same with the epilogue
+// BF (opt-in, VS_FLAG_BF16_LINEAR): the product runs as v_mfma_f32_32x32x16_bf16.  Operands stay fp32 in HBM and
+// are rounded to bf16 once, on their way into LDS (rows of 32 k = 64 B, padded to 80 B: conflict-free b128
+// fragment reads); bias, accumulation and the epilogue are the fp32 ones.
+template <int EPI, int NWM = 2, int DIAG = 0, int NJ = 2, bool BF = false>     // DIAG (tools/diag_gemm.py only) 2: epilogue skipped (wrong output) + per-wave cycles/wall clock; 1, 3: the same with the epilogue
 __global__ __launch_bounds__(128 * NWM, 2) void gemm_nt_128(
     const float *__restrict__ A, const float *__restrict__ W, const float *__restrict__ bias,
     float *__restrict__ C, int M, int N, int K, const float *__restrict__ pe, int T, int H, int dh,
@@ -168,12 +183,26 @@ __global__ __launch_bounds__(128 * NWM, 2) void gemm_nt_128(
         }
     };
     f32x4 pa[LA], pw[LW];
+    constexpr int LDB = 20;                             // BF: LDS row stride in floats (80 B = 32 bf16 + pad)
     auto stage = [&](int buf) __attribute__((always_inline)) {
         float *As = smem + buf * (BM + BN) * LD, *Ws = As + BM * LD;
+        if constexpr (BF) {
 #pragma unroll
-        for (int i = 0; i < LA; ++i) *(f32x4 *)&As[(lrow + RS * i) * LD + lc4] = pa[i];
+            for (int i = 0; i < LA; ++i) {
+                u32x2 u; u[0] = pack_bf16(pa[i][0], pa[i][1]); u[1] = pack_bf16(pa[i][2], pa[i][3]);
+                *(u32x2 *)&As[(lrow + RS * i) * LDB + lc4 / 2] = u;
+            }
 #pragma unroll
-        for (int i = 0; i < LW; ++i) *(f32x4 *)&Ws[(lrow + RS * i) * LD + lc4] = pw[i];
+            for (int i = 0; i < LW; ++i) {
+                u32x2 u; u[0] = pack_bf16(pw[i][0], pw[i][1]); u[1] = pack_bf16(pw[i][2], pw[i][3]);
+                *(u32x2 *)&Ws[(lrow + RS * i) * LDB + lc4 / 2] = u;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < LA; ++i) *(f32x4 *)&As[(lrow + RS * i) * LD + lc4] = pa[i];
+#pragma unroll
+            for (int i = 0; i < LW; ++i) *(f32x4 *)&Ws[(lrow + RS * i) * LD + lc4] = pw[i];
+        }
     };
 
     // acc[i][jj][t] = C[m = 64wr + 32i + r][n = 64wc + 32jj + acc_row(t,h)]  (lane = output ROW:
@@ -186,6 +215,32 @@ __global__ __launch_bounds__(128 * NWM, 2) void gemm_nt_128(
     // aptr/wptr + koff) in the first half of the MFMA stream and their LDS writes in the last quarter.
     auto ktile = [&](int koff) __attribute__((always_inline)) {
         const float *As = smem + fpar * (BM + BN) * LD, *Ws = As + BM * LD;
+        if constexpr (BF) {
+            // 2 k-steps of 16: lane (r,h) supplies k = 16ks + 8h .. +7 (one b128 of the bf16 row)
+            const float *ap = As + (64 * wr + r) * LDB + 4 * h;
+            const float *wp = Ws + (32 * NJ * wc + r) * LDB + 4 * h;
+#pragma unroll
+            for (int i = 0; i < LA; ++i) pa[i] = *(const f32x4 *)(aptr[i] + koff);
+#pragma unroll
+            for (int i = 0; i < LW; ++i) pw[i] = *(const f32x4 *)(wptr[i] + koff);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 fa[2], fw[NJ];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) fa[i] = __builtin_bit_cast(bf16x8, *(const u32x4 *)(ap + 32 * i * LDB + 8 * ks));
+#pragma unroll
+                for (int jj = 0; jj < NJ; ++jj) fw[jj] = __builtin_bit_cast(bf16x8, *(const u32x4 *)(wp + 32 * jj * LDB + 8 * ks));
+#pragma unroll
+                for (int jj = 0; jj < NJ; ++jj) {
+                    acc[0][jj] = MFMA_BF16(fw[jj], fa[0], acc[0][jj]);
+                    acc[1][jj] = MFMA_BF16(fw[jj], fa[1], acc[1][jj]);
+                }
+            }
+            stage(fpar ^ 1);
+            __syncthreads();
+            fpar ^= 1;
+            return;
+        }
         const float *ap = As + (64 * wr + r) * LD + 4 * h;
         const float *wp = Ws + (32 * NJ * wc + r) * LD + 4 * h;
         f32x4 fa[2][2], fw[2][NJ];
@@ -513,7 +568,7 @@ __global__ __launch_bounds__(256) void gemm_res_ln(
 //   epilogue issues no loads from HBM at all; gamma/beta/score_w sit in LDS.
 //   Block = 4 waves = 128 rows, BK = 16 (LDS rows padded to 20 floats), 2 blocks per CU.
 // ------------------------------------------------------------------------------------------
-template <int NT>
+template <int NT, bool BF = false>     // BF: bf16 MFMA operands (see gemm_nt_128), LDS rows of 16 bf16 padded to 48 B
 __global__ __launch_bounds__(256, 2) void gemm_ln_rows(
     const float *__restrict__ A, const float *__restrict__ W, const float *__restrict__ bias,
     const float *__restrict__ res, const float *__restrict__ gamma, const float *__restrict__ beta,
@@ -541,13 +596,28 @@ __global__ __launch_bounds__(256, 2) void gemm_ln_rows(
         int wrow = lrow + 64 * i; wrow = wrow < N ? wrow : N - 1;
         wptr[i] = W + (size_t)wrow * K + lc4;
     }
-    auto stage = [&](int buf) {
+    constexpr int LDB = 12;                            // BF: LDS row stride in floats (48 B: conflict-free b128)
+    auto stage = [&](int buf) __attribute__((always_inline)) {
         float *As = smem + buf * (BM + N) * LD, *Ws = As + BM * LD;
+        if constexpr (BF) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) *(f32x4 *)&As[(lrow + 64 * i) * LD + lc4] = pa[i];
+            for (int i = 0; i < 2; ++i) {
+                u32x2 u; u[0] = pack_bf16(pa[i][0], pa[i][1]); u[1] = pack_bf16(pa[i][2], pa[i][3]);
+                *(u32x2 *)&As[(lrow + 64 * i) * LDB + lc4 / 2] = u;
+            }
 #pragma unroll
-        for (int i = 0; i < WL; ++i)
-            if (lrow + 64 * i < N) *(f32x4 *)&Ws[(lrow + 64 * i) * LD + lc4] = pw[i];
+            for (int i = 0; i < WL; ++i)
+                if (lrow + 64 * i < N) {
+                    u32x2 u; u[0] = pack_bf16(pw[i][0], pw[i][1]); u[1] = pack_bf16(pw[i][2], pw[i][3]);
+                    *(u32x2 *)&Ws[(lrow + 64 * i) * LDB + lc4 / 2] = u;
+                }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) *(f32x4 *)&As[(lrow + 64 * i) * LD + lc4] = pa[i];
+#pragma unroll
+            for (int i = 0; i < WL; ++i)
+                if (lrow + 64 * i < N) *(f32x4 *)&Ws[(lrow + 64 * i) * LD + lc4] = pw[i];
+        }
     };
 
     f32x16 acc[NT];
@@ -583,6 +653,22 @@ __global__ __launch_bounds__(256, 2) void gemm_ln_rows(
         for (int kt = 0; kt < nk; ++kt) {
             const int kn = kt + 1 < nk ? kt + 1 : kt;         // last step reloads a duplicate: branch-free stream
             const float *As = smem + (kt & 1) * (BM + N) * LD, *Ws = As + BM * LD;
+            if constexpr (BF) {
+                // one k-step of 16: lane (r,h) supplies k = 8h .. 8h+7
+                const bf16x8 fa = __builtin_bit_cast(bf16x8, *(const u32x4 *)(As + (32 * wave + r) * LDB + 4 * h));
+#pragma unroll
+                for (int i = 0; i < 2; ++i) pa[i] = *(const f32x4 *)(aptr[i] + kn * BK);
+#pragma unroll
+                for (int i = 0; i < WL; ++i) pw[i] = *(const f32x4 *)(wptr[i] + kn * BK);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const bf16x8 fw = __builtin_bit_cast(bf16x8, *(const u32x4 *)(Ws + (32 * j + r) * LDB + 4 * h));
+                    acc[j] = MFMA_BF16(fw, fa, acc[j]);
+                }
+                stage((kt + 1) & 1);
+                __syncthreads();
+                continue;
+            }
             const float *ap = As + (32 * wave + r) * LD + 4 * h;
             const float *wp = Ws + r * LD + 4 * h;
 #pragma unroll
@@ -1462,17 +1548,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd(
 //   of the TRANSPOSED bf16 V tile, which the staging writes (4 keys of one d packed per b64 store).
 // NOT within the 1e-4 fp32 bar of the reference: tests/test_hip_parity.py states its tolerance.
 // ------------------------------------------------------------------------------------------
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-#define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
-
-__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
-    unsigned r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-    return r;
-}
-
 template <int DH>
 __global__ __launch_bounds__(256, 2) void attn_fwd_bf16(
     const float *__restrict__ Q, const float *__restrict__ Kg, const float *__restrict__ Vg,
@@ -1987,7 +2062,20 @@ static int allow_big_lds(F *kernel) {
 
 template <int EPI>
 static int launch_gemm(const float *A, const float *W, const float *Wf, const float *bias, float *C, int M, int N, int K,
-                       const float *pe, int T, int H, int dh, hipStream_t st) {
+                       const float *pe, int T, int H, int dh, int bf16, hipStream_t st) {
+    if (bf16) {          // bf16 matrix pipe (opt-in): always the LDS-tiled kernels
+        if (N % 256 == 0 && M > 128) {
+            const int blocks = persistent_blocks(((M + 255) / 256) * (N / 256), 1);
+            if (blocks < 0) return (int)hipErrorInvalidDevice;
+            hipLaunchKernelGGL((gemm_nt_128<EPI, 4, 0, 4, true>), dim3(blocks), dim3(512), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr);
+        } else {
+            const int blocks = persistent_blocks(((M + 127) / 128) * ((N + 127) / 128), 2);
+            if (blocks < 0) return (int)hipErrorInvalidDevice;
+            hipLaunchKernelGGL((gemm_nt_128<EPI, 2, 0, 2, true>), dim3(blocks), dim3(256), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr);
+        }
+        VSK_CHECK_LAUNCH();
+        return 0;
+    }
     if (Wf != nullptr && M <= skinny_max_rows() && N % 32 == 0 && K % 128 == 0) {
         static const int attr_rc = allow_big_lds(skinny2_gemm<EPI>);
         if (attr_rc) return attr_rc;
@@ -2005,25 +2093,25 @@ static int launch_gemm(const float *A, const float *W, const float *Wf, const fl
     if (use_wide_tiles(M, N) && N % 256 == 0 && !getenv("VS_GEMM_NJ2")) {
         const int blocks = persistent_blocks(((M + 255) / 256) * (N / 256), 1);
         if (blocks < 0) return (int)hipErrorInvalidDevice;
-        hipLaunchKernelGGL((gemm_nt_128<EPI, 4, 0, 4>), dim3(blocks), dim3(512), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr);
+        hipLaunchKernelGGL((gemm_nt_128<EPI, 4, 0, 4, false>), dim3(blocks), dim3(512), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr);
     } else if (use_wide_tiles(M, N)) {
         const int blocks = persistent_blocks(((M + 255) / 256) * ((N + 127) / 128), 1);
         if (blocks < 0) return (int)hipErrorInvalidDevice;
-        hipLaunchKernelGGL((gemm_nt_128<EPI, 4, 0, 2>), dim3(blocks), dim3(512), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr);
+        hipLaunchKernelGGL((gemm_nt_128<EPI, 4, 0, 2, false>), dim3(blocks), dim3(512), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr);
     } else {
         const int blocks = persistent_blocks(((M + 127) / 128) * ((N + 127) / 128), 2);
         if (blocks < 0) return (int)hipErrorInvalidDevice;
-        hipLaunchKernelGGL((gemm_nt_128<EPI, 2, 0, 2>), dim3(blocks), dim3(256), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr);
+        hipLaunchKernelGGL((gemm_nt_128<EPI, 2, 0, 2, false>), dim3(blocks), dim3(256), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr);
     }
     VSK_CHECK_LAUNCH();
     return 0;
 }
 
 int vsk_linear(const float *A, const float *W, const float *Wf, const float *bias, float *C, int M, int N, int K,
-               int relu, const float *pe, int T, hipStream_t st) {
-    if (pe != nullptr) return launch_gemm<EPI_PE>(A, W, Wf, bias, C, M, N, K, pe, T, 0, 0, st);
-    if (relu) return launch_gemm<EPI_RELU>(A, W, Wf, bias, C, M, N, K, nullptr, 1, 0, 0, st);
-    return launch_gemm<EPI_BIAS>(A, W, Wf, bias, C, M, N, K, nullptr, 1, 0, 0, st);
+               int relu, const float *pe, int T, int bf16, hipStream_t st) {
+    if (pe != nullptr) return launch_gemm<EPI_PE>(A, W, Wf, bias, C, M, N, K, pe, T, 0, 0, bf16, st);
+    if (relu) return launch_gemm<EPI_RELU>(A, W, Wf, bias, C, M, N, K, nullptr, 1, 0, 0, bf16, st);
+    return launch_gemm<EPI_BIAS>(A, W, Wf, bias, C, M, N, K, nullptr, 1, 0, 0, bf16, st);
 }
 
 int vsk_mlp_fused(const float *H1, const float *W1, const float *b1, const float *W2, const float *b2,
@@ -2071,8 +2159,8 @@ int vsk_diag_gemm(const float *A, const float *W, const float *bias, float *C, i
 }
 
 int vsk_qkv(const float *h, const float *Wqkv, const float *Wf, const float *bqkv, float *qkv, int B, int T, int d,
-            int H, hipStream_t st) {
-    return launch_gemm<EPI_QKV>(h, Wqkv, Wf, bqkv, qkv, B * T, 3 * d, d, nullptr, T, H, d / H, st);
+            int H, int bf16, hipStream_t st) {
+    return launch_gemm<EPI_QKV>(h, Wqkv, Wf, bqkv, qkv, B * T, 3 * d, d, nullptr, T, H, d / H, bf16, st);
 }
 
 int vsk_attention(const float *q, const float *k, const float *v, const uint8_t *mask, float *out,
@@ -2129,7 +2217,25 @@ int vsk_attention_bf16(const float *q, const float *k, const float *v, const uin
 int vsk_linear_res_ln(const float *A, const float *W, const float *Wf, const float *bias, const float *res,
                       const float *gamma, const float *beta, float *out, int M, int N, int K,
                       const float *score_w, const float *score_b, int num_classes, int sigmoid,
-                      float *scores, hipStream_t st) {
+                      float *scores, int bf16, hipStream_t st) {
+    if (bf16) {          // bf16 matrix pipe (opt-in): d_model <= 256 only
+        if (N > 256 || N % 32) return -1;
+        int blocks = persistent_blocks((M + 127) / 128);
+        if (blocks < 0) return (int)hipErrorInvalidDevice;
+        if (blocks > (M + 127) / 128) blocks = (M + 127) / 128;
+#define VSK_LNB_CASE(NT_)                                                                                   \
+    case NT_:                                                                                               \
+        hipLaunchKernelGGL((gemm_ln_rows<NT_, true>), dim3(blocks), dim3(256), 0, st, A, W, bias, res, gamma, \
+                           beta, out, M, K, score_w, score_b, num_classes, sigmoid, scores);                \
+        break;
+        switch (N / 32) {
+            VSK_LNB_CASE(2) VSK_LNB_CASE(4) VSK_LNB_CASE(6) VSK_LNB_CASE(8)
+            default: return -1;
+        }
+#undef VSK_LNB_CASE
+        VSK_CHECK_LAUNCH();
+        return 0;
+    }
     if (Wf != nullptr && M <= skinny_max_rows() && N <= 256 && N % 32 == 0 && K % 128 == 0) {
         const int blocks = (M + 31) / 32;
 #define VSK_SLN2_CASE(NW_)                                                                                 \
@@ -2169,7 +2275,7 @@ int vsk_linear_res_ln(const float *A, const float *W, const float *Wf, const flo
         if (blocks > (M + 127) / 128) blocks = (M + 127) / 128;
 #define VSK_LNR_CASE(NT_)                                                                             \
     case NT_:                                                                                         \
-        hipLaunchKernelGGL(gemm_ln_rows<NT_>, dim3(blocks), dim3(256), 0, st, A, W, bias, res, gamma, \
+        hipLaunchKernelGGL((gemm_ln_rows<NT_, false>), dim3(blocks), dim3(256), 0, st, A, W, bias, res, gamma, \
                            beta, out, M, K, score_w, score_b, num_classes, sigmoid, scores);          \
         break;
         switch (N / 32) {

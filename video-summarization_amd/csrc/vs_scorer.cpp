@@ -225,6 +225,8 @@ int vs_scorer_forward(const vs_weights *w, const float *x, const uint8_t *key_pa
     if (w->has_pe && T > D.max_len)
         return fail(VS_ERR_INVALID, "T=%d exceeds the positional table (max_len=%d)", T, D.max_len);
     if ((long long)B * T > (1ll << 30)) return fail(VS_ERR_INVALID, "B*T too large");
+    if ((flags & VS_FLAG_BF16_LINEAR) && D.d_model > 256)
+        return fail(VS_ERR_INVALID, "VS_FLAG_BF16_LINEAR needs d_model <= 256 (got %d)", D.d_model);
     if ((flags & VS_FLAG_BF16_ATTENTION) && D.d_model / D.num_heads != 32 && D.d_model / D.num_heads != 64)
         return fail(VS_ERR_INVALID, "VS_FLAG_BF16_ATTENTION needs head_dim 32 or 64 (got %d)", D.d_model / D.num_heads);
     const size_t need = vs_scorer_workspace_bytes(w, B, T);
@@ -240,19 +242,20 @@ int vs_scorer_forward(const vs_weights *w, const float *x, const uint8_t *key_pa
     float *h0 = ws, *h1 = ws + md, *qkv = ws + 2 * md, *att = ws + 5 * md, *ffn = ws + 6 * md;
     const float scale = 1.0f / sqrtf((float)d);        // reference simnet.py:126: d_model ** -0.5
     const int sig = (flags & VS_FLAG_SIGMOID) ? 1 : 0;
+    const int lbf = (flags & VS_FLAG_BF16_LINEAR) ? 1 : 0;
 
     // Embedding + positional table (simnet.py:211, 237-238)
     {
         StageScope ps(VS_STAGE_EMBED, st);
         VS_LAUNCH(vsk_linear(x, w->p(w->embed_w), w->p(w->f_embed_w), w->p(w->embed_b), h0, M, d, D.in_features, 0,
-                             w->has_pe ? w->p(w->pe) : nullptr, T, st));
+                             w->has_pe ? w->p(w->pe) : nullptr, T, lbf, st));
     }
     for (int l = 0; l < L; ++l) {
         const LayerOff &P = w->layers[l];
         const bool last = l == L - 1;
         {
             StageScope ps(VS_STAGE_QKV, st);
-            VS_LAUNCH(vsk_qkv(h0, w->p(P.wqkv), w->p(P.f_wqkv), w->p(P.bqkv), qkv, B, T, d, H, st));
+            VS_LAUNCH(vsk_qkv(h0, w->p(P.wqkv), w->p(P.f_wqkv), w->p(P.bqkv), qkv, B, T, d, H, lbf, st));
         }
         {
             StageScope ps(VS_STAGE_ATTENTION, st);
@@ -266,7 +269,7 @@ int vs_scorer_forward(const vs_weights *w, const float *x, const uint8_t *key_pa
         {
             StageScope ps(VS_STAGE_OUTPROJ_LN, st);
             VS_LAUNCH(vsk_linear_res_ln(att, w->p(P.wo), w->p(P.f_wo), w->p(P.bo), h0, w->p(P.ln1g), w->p(P.ln1b), h1, M, d, d,
-                                        nullptr, nullptr, 0, 0, nullptr, st));
+                                        nullptr, nullptr, 0, 0, nullptr, lbf, st));
         }
         float *dst = (last && hidden) ? hidden : h0;
         // Opt-in alternative (VS_MLP_FUSION=1, d_model = 256): fc1 + ReLU + fc2 + residual + norm2 (+ score head)
@@ -274,7 +277,7 @@ int vs_scorer_forward(const vs_weights *w, const float *x, const uint8_t *key_pa
         // to the two-kernel path but measured 6 % slower: its ~506 registers per lane allow one
         // wave per SIMD only, so nothing covers the weight loads' issue stalls.
         const char *fz = getenv("VS_MLP_FUSION");
-        const bool fused = d == 256 && fz && atoi(fz) != 0 && M > vsk_skinny_max_rows();
+        const bool fused = d == 256 && fz && atoi(fz) != 0 && M > vsk_skinny_max_rows() && !lbf;
         if (fused) {
             StageScope ps(VS_STAGE_FC2_LN, st);
             VS_LAUNCH(vsk_mlp_fused(h1, w->p(P.w1), w->p(P.b1), w->p(P.w2), w->p(P.b2), w->p(P.ln2g), w->p(P.ln2b), dst, M, d,
@@ -284,14 +287,14 @@ int vs_scorer_forward(const vs_weights *w, const float *x, const uint8_t *key_pa
         }
         {
             StageScope ps(VS_STAGE_FC1, st);
-            VS_LAUNCH(vsk_linear(h1, w->p(P.w1), w->p(P.f_w1), w->p(P.b1), ffn, M, 4 * d, d, 1, nullptr, 1, st));
+            VS_LAUNCH(vsk_linear(h1, w->p(P.w1), w->p(P.f_w1), w->p(P.b1), ffn, M, 4 * d, d, 1, nullptr, 1, lbf, st));
         }
         {
             StageScope ps(VS_STAGE_FC2_LN, st);
             VS_LAUNCH(vsk_linear_res_ln(ffn, w->p(P.w2), w->p(P.f_w2), w->p(P.b2), h1, w->p(P.ln2g), w->p(P.ln2b), dst, M, d,
                                         4 * d, last ? w->p(w->final_w) : nullptr,
                                         last ? w->p(w->final_b) : nullptr, D.num_classes, sig,
-                                        last ? scores : nullptr, st));
+                                        last ? scores : nullptr, lbf, st));
         }
     }
     return VS_OK;
@@ -334,14 +337,24 @@ int vs_diag_gemm(const float *A, const float *W, const float *bias, float *C, in
     return VS_OK;
 }
 
-int vs_linear_f32(const float *A, const float *W, const float *bias, float *C, int32_t M, int32_t N,
-                  int32_t K, int32_t relu, const float *pe, int32_t T, void *stream) {
+static int linear_entry(const float *A, const float *W, const float *bias, float *C, int32_t M, int32_t N,
+                        int32_t K, int32_t relu, const float *pe, int32_t T, int bf16, void *stream) {
     if (!A || !W || !bias || !C) return fail(VS_ERR_INVALID, "NULL pointer");
     if (M <= 0 || N <= 0 || N % 32 || K <= 0 || K % 32)
         return fail(VS_ERR_INVALID, "M=%d N=%d K=%d unsupported (N, K multiples of 32)", M, N, K);
     if (pe && (T <= 0 || relu)) return fail(VS_ERR_INVALID, "pe needs T > 0 and relu == 0");
-    VS_LAUNCH(vsk_linear(A, W, nullptr, bias, C, M, N, K, relu, pe, T > 0 ? T : 1, (hipStream_t)stream));
+    VS_LAUNCH(vsk_linear(A, W, nullptr, bias, C, M, N, K, relu, pe, T > 0 ? T : 1, bf16, (hipStream_t)stream));
     return VS_OK;
+}
+
+int vs_linear_f32(const float *A, const float *W, const float *bias, float *C, int32_t M, int32_t N,
+                  int32_t K, int32_t relu, const float *pe, int32_t T, void *stream) {
+    return linear_entry(A, W, bias, C, M, N, K, relu, pe, T, 0, stream);
+}
+
+int vs_linear_bf16(const float *A, const float *W, const float *bias, float *C, int32_t M, int32_t N,
+                   int32_t K, int32_t relu, const float *pe, int32_t T, void *stream) {
+    return linear_entry(A, W, bias, C, M, N, K, relu, pe, T, 1, stream);
 }
 
 int vs_qkv_proj_f32(const float *h, const float *Wqkv, const float *bqkv, float *qkv, int32_t B,
@@ -349,7 +362,7 @@ int vs_qkv_proj_f32(const float *h, const float *Wqkv, const float *bqkv, float 
     if (!h || !Wqkv || !bqkv || !qkv) return fail(VS_ERR_INVALID, "NULL pointer");
     if (B <= 0 || T <= 0 || d <= 0 || d % 32 || H <= 0 || d % H || (d / H) % 32)
         return fail(VS_ERR_INVALID, "B=%d T=%d d=%d H=%d unsupported", B, T, d, H);
-    VS_LAUNCH(vsk_qkv(h, Wqkv, nullptr, bqkv, qkv, B, T, d, H, (hipStream_t)stream));
+    VS_LAUNCH(vsk_qkv(h, Wqkv, nullptr, bqkv, qkv, B, T, d, H, 0, (hipStream_t)stream));
     return VS_OK;
 }
 
@@ -371,19 +384,38 @@ int vs_attention_bf16(const float *q, const float *k, const float *v, const uint
     return VS_OK;
 }
 
-int vs_linear_residual_layernorm_f32(const float *A, const float *W, const float *bias,
-                                     const float *residual, const float *gamma, const float *beta,
-                                     float *out, int32_t M, int32_t N, int32_t K, const float *score_w,
-                                     const float *score_b, int32_t num_classes, int32_t sigmoid,
-                                     float *scores, void *stream) {
+static int linear_ln_entry(const float *A, const float *W, const float *bias,
+                           const float *residual, const float *gamma, const float *beta,
+                           float *out, int32_t M, int32_t N, int32_t K, const float *score_w,
+                           const float *score_b, int32_t num_classes, int32_t sigmoid,
+                           float *scores, int bf16, void *stream) {
     if (!A || !W || !bias || !residual || !gamma || !beta || !out) return fail(VS_ERR_INVALID, "NULL pointer");
     if (M <= 0 || N <= 0 || N % 64 || N > 512 || K <= 0 || K % 16)
         return fail(VS_ERR_INVALID, "M=%d N=%d K=%d unsupported (N multiple of 64 <= 512, K multiple of 16)", M, N, K);
     if (score_w && (!score_b || !scores || num_classes <= 0))
         return fail(VS_ERR_INVALID, "score head needs score_b, scores and num_classes > 0");
+    if (bf16 && N > 256) return fail(VS_ERR_INVALID, "N=%d unsupported on the bf16 path (N <= 256)", N);
     VS_LAUNCH(vsk_linear_res_ln(A, W, nullptr, bias, residual, gamma, beta, out, M, N, K, score_w, score_b, num_classes,
-                                sigmoid, scores, (hipStream_t)stream));
+                                sigmoid, scores, bf16, (hipStream_t)stream));
     return VS_OK;
+}
+
+int vs_linear_residual_layernorm_f32(const float *A, const float *W, const float *bias,
+                                     const float *residual, const float *gamma, const float *beta,
+                                     float *out, int32_t M, int32_t N, int32_t K, const float *score_w,
+                                     const float *score_b, int32_t num_classes, int32_t sigmoid,
+                                     float *scores, void *stream) {
+    return linear_ln_entry(A, W, bias, residual, gamma, beta, out, M, N, K, score_w, score_b, num_classes, sigmoid,
+                           scores, 0, stream);
+}
+
+int vs_linear_residual_layernorm_bf16(const float *A, const float *W, const float *bias,
+                                      const float *residual, const float *gamma, const float *beta,
+                                      float *out, int32_t M, int32_t N, int32_t K, const float *score_w,
+                                      const float *score_b, int32_t num_classes, int32_t sigmoid,
+                                      float *scores, void *stream) {
+    return linear_ln_entry(A, W, bias, residual, gamma, beta, out, M, N, K, score_w, score_b, num_classes, sigmoid,
+                           scores, 1, stream);
 }
 
 }  // extern "C"

@@ -143,6 +143,7 @@ class SimNet(nn.Module):
         # pipe (fp32 softmax/accumulation); scores then differ from the fp32 reference by ~1e-3, so the
         # default "fp32" is the only mode the 1e-4 parity bar applies to.
         self._attention_dtype = "fp32"
+        self._linear_dtype = "fp32"       # "bf16": every Linear multiplies bf16-rounded operands (fp32 storage/accumulate)
         self._packed: Optional[_Packed] = None
         self._packed_key = None
 
@@ -257,8 +258,28 @@ class SimNet(nn.Module):
             raise ValueError("bf16 attention needs head_dim 32 or 64, got %d" % (self.d_model // self.num_heads))
         self._attention_dtype = value
 
+    @property
+    def linear_dtype(self) -> str:
+        return self._linear_dtype
+
+    @linear_dtype.setter
+    def linear_dtype(self, value: str) -> None:
+        if value not in ("fp32", "bf16"):
+            raise ValueError("linear_dtype must be 'fp32' or 'bf16', got %r" % (value,))
+        if value == "bf16" and self.d_model > 256:
+            raise ValueError("bf16 Linear kernels need d_model <= 256, got %d" % self.d_model)
+        self._linear_dtype = value
+
+    def set_compute_dtype(self, value: str) -> "SimNet":
+        """'fp32' (default, the 1e-4 parity path) or 'bf16' (BASELINE config 5: all matrix products on the bf16
+        pipe with fp32 accumulation; tensors, softmax, LayerNorm and the score head stay fp32)."""
+        self.attention_dtype = value
+        self.linear_dtype = value
+        return self
+
     def _attention_flag(self) -> int:
-        return _lib.VS_FLAG_BF16_ATTENTION if self._attention_dtype == "bf16" else 0
+        return ((_lib.VS_FLAG_BF16_ATTENTION if self._attention_dtype == "bf16" else 0)
+                | (_lib.VS_FLAG_BF16_LINEAR if self._linear_dtype == "bf16" else 0))
 
     # ---- autograd-capable path for train.py / pretrain.py (dropout, backward, autocast) -----
     def _forward_autograd(self, x: Tensor, mask: Optional[Tensor]):
