@@ -624,8 +624,8 @@ def test_linear_residual_layernorm_bf16_kernel(vsa, M, N, K, nc, sig):
         assert (scores.cpu().double() - sc).abs().max().item() < 1e-4
 
 
-BF16_FULL_LOGIT_TOL = 3e-2     # all products on the bf16 pipe; set from the measured errors printed below
-BF16_FULL_SCORE_TOL = 8e-3
+BF16_FULL_LOGIT_TOL = 1.5e-2   # all products on the bf16 pipe (measured on trained-like weights: 4.3e-3 logits, 1.0e-3 scores)
+BF16_FULL_SCORE_TOL = 4e-3
 
 
 @pytest.mark.parametrize("cfg", ["M-A", "M-B8"])

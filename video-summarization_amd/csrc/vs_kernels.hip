@@ -72,10 +72,14 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 #define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
 
+// two floats -> packed bf16 pair (round to nearest even): lowers to one v_cvt_pk_bf16_f32.  NOT inline asm:
+// the hazard recogniser must see this instruction - it needs a wait state after a v_exp_f32 (trans unit)
+// producing its input, and an asm statement does not get one (measured: wrong products).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
-    unsigned r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-    return r;
+    const f32x2 f = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16x2));
 }
 
 // max(x, 0) as ONE instruction (fmaxf first canonicalises its MFMA-produced input with a second v_max)
@@ -1546,29 +1550,39 @@ __global__ __launch_bounds__(256, 2) void attn_fwd(
 //   O^T = V^T * P^T: B = registers 8s..8s+7 of the S^T accumulator packed pairwise — element j of
 //   lane half h is key 16s + 8(j>>2) + 4h + (j&3) — and A = V^T[d r][those keys], two ds_read_b64
 //   of the TRANSPOSED bf16 V tile, which the staging writes (4 keys of one d packed per b64 store).
+// The row sums l are a third "V" block of ones (the matrix pipe has slack, the VALU does not); the running
+// max is deferred (raised only on a jump > 2^8, so the O/l rescale almost never runs); K/V tiles arrive by
+// buffer loads with scalar offsets, are rounded once into a double-buffered LDS tile, one barrier per tile.
+// Measured (T=8192, B=8, M-A): 750 TFLOP/s; per 64-key tile and wave 20 MFMAs (640 cycles) + 32 v_exp_f32
+// (quarter rate, 512 cycles) + ~100 VALU - and the SIMD issues them one after the other, so the exp2 of the
+// softmax, not the matrix pipe, bounds this kernel at head dim 64.
 // NOT within the 1e-4 fp32 bar of the reference: tests/test_hip_parity.py states its tolerance.
 // ------------------------------------------------------------------------------------------
-template <int DH>
-__global__ __launch_bounds__(256, 2) void attn_fwd_bf16(
+template <int DH, int NW>       // NW waves per block, 32 query rows each
+__global__ __launch_bounds__(64 * NW, 2) void attn_fwd_bf16(
     const float *__restrict__ Q, const float *__restrict__ Kg, const float *__restrict__ Vg,
     const uint8_t *__restrict__ mask, float *__restrict__ out, int H, int T, float scale_log2e, int BH) {
-    constexpr int KT = 64, NS = DH / 16, ND = DH / 32;
+    constexpr int KT = 64, NS = DH / 16, ND = DH / 32, NT = 64 * NW, QB = 32 * NW;
     constexpr int LDK = DH + 8;                    // bf16 per K row: 36 (DH 64) / 20 (DH 32) dwords, b128 reads conflict-free
     constexpr int LDV = KT + 4;                    // bf16 per V^T row: 34 dwords, b64 reads conflict-free
-    constexpr int KPT = DH / 16;                   // keys per thread in the staging (4 or 2), one float4 of d each
     constexpr int D4 = DH / 4;                     // float4 per key row
+    constexpr int KPT = KT * D4 / NT;              // keys per thread in the staging, one float4 of d each
+    static_assert(KPT == 2 || KPT == 4, "staging packs 2 or 4 keys per V^T store");
+    constexpr float THR = 8.0f;                    // deferred max: the applied max is raised only on a jump > 2^8
     typedef unsigned short bf16raw;
-    __shared__ __attribute__((aligned(16))) bf16raw Kb[KT * LDK];
-    __shared__ __attribute__((aligned(16))) bf16raw Vt[DH * LDV];
-    __shared__ float mb[KT];
+    // K tile, V^T tile and key-mask bias, double-buffered: tile t+1 is written while tile t is consumed,
+    // one block barrier per tile
+    __shared__ __attribute__((aligned(16))) bf16raw Kb[2][KT * LDK];
+    __shared__ __attribute__((aligned(16))) bf16raw Vt[2][DH * LDV];
+    __shared__ __attribute__((aligned(16))) float mb[2][KT];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     int bh, qt;
-    if (!attn_block_map((T + 127) / 128, BH, bh, qt)) return;
+    if (!attn_block_map((T + QB - 1) / QB, BH, bh, qt)) return;
     const int b = bh / H, head = bh - b * H;
     const size_t base = (size_t)bh * T * DH;
-    const int q0 = qt * 128 + 32 * wave;
+    const int q0 = qt * QB + 32 * wave;
     const float NEG_INF = -__builtin_inff();
 
     // Q fragments (B operand): Q[q][16s + 8h + j] * scale*log2(e), bf16
@@ -1587,38 +1601,48 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16(
             qreg[s] = __builtin_bit_cast(bf16x8, u);
         }
     }
-
-    f32x16 o[ND];
+    // o[0..ND-1] = O^T blocks; o[ND] = the row sums l, as the product of P with a block of ones
+    // (the matrix pipe has slack, the VALU does not; and l then sums exactly the rounded P the output uses)
+    f32x16 o[ND + 1];
 #pragma unroll
-    for (int d = 0; d < ND; ++d)
+    for (int d = 0; d <= ND; ++d)
 #pragma unroll
         for (int t = 0; t < 16; ++t) o[d][t] = 0.f;
-    float m_run = NEG_INF, l_run = 0.f;
+    float m_run = NEG_INF;                         // the max actually applied to O and l (log2 units)
+    const u32x4 ones_u = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+    const bf16x8 ones_f = __builtin_bit_cast(bf16x8, ones_u);
 
-    // staging: thread (d4 = tid % D4, kq = tid / D4) owns keys KPT*kq .. +KPT-1 at d = 4*d4 .. +3
+    // staging: thread (d4 = tid % D4, kq = tid / D4) owns keys KPT*kq .. +KPT-1 at d = 4*d4 .. +3.
+    // Buffer loads: the per-tile offset is a scalar, rows beyond T read as zero (and are masked below).
     const int d4 = tid % D4, kq = tid / D4;
     const int ntiles = (T + KT - 1) / KT;
+    const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Kg + base), 0, T * DH * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Vg + base), 0, T * DH * 4, 0x00020000);
+    int voff[KPT];
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) voff[i] = ((KPT * kq + i) * DH + 4 * d4) * 4;
     f32x4 pk[KPT], pv[KPT];
-    auto prefetch = [&](int tile) __attribute__((always_inline)) {
+    float pm = 0.f;
+    auto gload = [&](int tile) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < KPT; ++i) {
-            int row = tile * KT + KPT * kq + i;
-            row = row < T ? row : T - 1;
-            const size_t off = base + (size_t)row * DH + 4 * d4;
-            pk[i] = *(const f32x4 *)(Kg + off);
-            pv[i] = *(const f32x4 *)(Vg + off);
+            pk[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(krs, voff[i], tile * (KT * DH * 4), 0));
+            pv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(vrs, voff[i], tile * (KT * DH * 4), 0));
+        }
+        if (tid < KT) {                             // key-mask bias of key tile*KT + tid: 0 or -inf (also beyond T)
+            const int key = tile * KT + tid;
+            float pmv = key >= T ? NEG_INF : 0.f;
+            if (mask != nullptr) pmv = mask[(size_t)b * T + (key < T ? key : T - 1)] != 0 ? NEG_INF : pmv;
+            pm = pmv;
         }
     };
-    prefetch(0);
-
-    for (int tile = 0; tile < ntiles; ++tile) {
-        const int k0 = tile * KT;
+    auto stage = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < KPT; ++i) {
             u32x2 u;
             u[0] = pack_bf16(pk[i][0], pk[i][1]);
             u[1] = pack_bf16(pk[i][2], pk[i][3]);
-            *(u32x2 *)&Kb[(KPT * kq + i) * LDK + 4 * d4] = u;
+            *(u32x2 *)&Kb[buf][(KPT * kq + i) * LDK + 4 * d4] = u;
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -1626,20 +1650,38 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16(
                 u32x2 u;
                 u[0] = pack_bf16(pv[0][e], pv[1][e]);
                 u[1] = pack_bf16(pv[2][e], pv[3][e]);
-                *(u32x2 *)&Vt[(4 * d4 + e) * LDV + 4 * kq] = u;
+                *(u32x2 *)&Vt[buf][(4 * d4 + e) * LDV + 4 * kq] = u;
             } else {
-                *(unsigned *)&Vt[(4 * d4 + e) * LDV + 2 * kq] = pack_bf16(pv[0][e], pv[1][e]);
+                *(unsigned *)&Vt[buf][(4 * d4 + e) * LDV + 2 * kq] = pack_bf16(pv[0][e], pv[1][e]);
             }
         }
-        if (tid < KT) {
-            const int key = k0 + tid;
-            bool dead = key >= T;
-            if (!dead && mask != nullptr) dead = mask[(size_t)b * T + key] != 0;
-            mb[tid] = dead ? NEG_INF : 0.f;
-        }
-        __syncthreads();
-        if (tile + 1 < ntiles) prefetch(tile + 1);
+        if (tid < KT) mb[buf][tid] = pm;
+    };
+    gload(0);
+    stage(0);
+    if (ntiles > 1) gload(1);
+    __syncthreads();
 
+    for (int tile = 0; tile < ntiles; ++tile) {
+        const int cur = tile & 1;
+        const bool masked_tile = mask != nullptr || (tile + 1) * KT > T;
+        // ---- operand fragments of this tile: K (A of S^T) and V^T (A of O^T), all reads in flight at once ----
+        u32x4 ka[NS][2];
+#pragma unroll
+        for (int ks = 0; ks < NS; ++ks)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) ka[ks][n] = *(const u32x4 *)&Kb[cur][(32 * n + r) * LDK + 16 * ks + 8 * h];
+        u32x4 va[2][2][ND];
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int d = 0; d < ND; ++d) {
+                    const bf16raw *vp = &Vt[cur][(32 * d + r) * LDV + 32 * n + 16 * ks + 4 * h];
+                    const u32x2 lo = *(const u32x2 *)vp, hi = *(const u32x2 *)(vp + 8);
+                    va[n][ks][d][0] = lo[0]; va[n][ks][d][1] = lo[1]; va[n][ks][d][2] = hi[0]; va[n][ks][d][3] = hi[1];
+                }
         // ---- S^T = K * Q^T ----
         f32x16 s[2];
 #pragma unroll
@@ -1649,61 +1691,58 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16(
 #pragma unroll
         for (int ks = 0; ks < NS; ++ks)
 #pragma unroll
-            for (int n = 0; n < 2; ++n) {
-                const u32x4 ka = *(const u32x4 *)&Kb[(32 * n + r) * LDK + 16 * ks + 8 * h];
-                s[n] = MFMA_BF16(__builtin_bit_cast(bf16x8, ka), qreg[ks], s[n]);
-            }
-        if (mask != nullptr || k0 + KT > T) {
+            for (int n = 0; n < 2; ++n) s[n] = MFMA_BF16(__builtin_bit_cast(bf16x8, ka[ks][n]), qreg[ks], s[n]);
+        // ---- tile t+1 into the other LDS buffer, tile t+2 into registers (under the MFMAs / softmax) ----
+        if (tile + 1 < ntiles) stage(cur ^ 1);
+        if (tile + 2 < ntiles) gload(tile + 2);
+        if (masked_tile) {
 #pragma unroll
             for (int n = 0; n < 2; ++n)
 #pragma unroll
-                for (int t = 0; t < 16; ++t) s[n][t] += mb[32 * n + acc_row(t, h)];
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 bv = *(const f32x4 *)&mb[cur][32 * n + 8 * g + 4 * h];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) s[n][4 * g + e] += bv[e];
+                }
         }
-        // ---- online softmax, one query per lane pair (l, l^32) ----
-        float mx = NEG_INF;
+        // ---- online softmax with a deferred max, one query per lane pair (l, l^32) ----
+        float mx = __builtin_fmaxf(__builtin_fmaxf(s[0][0], s[0][1]), s[1][0]);
+        mx = __builtin_fmaxf(mx, s[1][1]);
 #pragma unroll
-        for (int n = 0; n < 2; ++n)
-#pragma unroll
-            for (int t = 0; t < 16; ++t) mx = fmaxf(mx, s[n][t]);
+        for (int t = 2; t < 16; t += 2) {
+            mx = __builtin_fmaxf(__builtin_fmaxf(mx, s[0][t]), s[0][t + 1]);
+            mx = __builtin_fmaxf(__builtin_fmaxf(mx, s[1][t]), s[1][t + 1]);
+        }
         mx = pair_max(mx);
-        const float m_new = fmaxf(m_run, mx);
-        const float m_use = (m_new == NEG_INF) ? 0.f : m_new;
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
-        float psum = 0.f;
+        const bool raise = mx > m_run + THR || (m_run == NEG_INF && mx != NEG_INF);
+        if (__builtin_expect(__any(raise), 0)) {   // first live tile, or a jump > 2^THR: rare, wave-uniform branch
+            const float m_new = raise ? mx : m_run;
+            const float u_new = (m_new == NEG_INF) ? 0.f : m_new;
+            const float alpha = __builtin_amdgcn_exp2f(m_run - u_new);    // 1 for lanes that keep their max; 0 from -inf
 #pragma unroll
-        for (int n = 0; n < 2; ++n)
-#pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                const float p = __builtin_amdgcn_exp2f(s[n][t] - m_use);
-                s[n][t] = p;
-                psum += p;
-            }
-        psum = pair_sum(psum);
-        l_run = l_run * alpha + psum;
-        if (m_new != m_run) {                      // wave-uniform in practice after the first tiles
-#pragma unroll
-            for (int d = 0; d < ND; ++d)
+            for (int d = 0; d <= ND; ++d)
 #pragma unroll
                 for (int t = 0; t < 16; ++t) o[d][t] *= alpha;
+            m_run = m_new;
         }
-        m_run = m_new;
-        // ---- O^T += V^T * P^T ----
+        const float m_use = (m_run == NEG_INF) ? 0.f : m_run;           // p = exp2(s - m_use) <= 2^THR
+        const f32x2 mm = {m_use, m_use};
+        // ---- O^T += V^T * P^T, l += 1 * P^T ----
 #pragma unroll
         for (int n = 0; n < 2; ++n)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 u32x4 pu;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) pu[j] = pack_bf16(s[n][8 * ks + 2 * j], s[n][8 * ks + 2 * j + 1]);
+                for (int j = 0; j < 4; ++j) {
+                    const f32x2 sv = {s[n][8 * ks + 2 * j], s[n][8 * ks + 2 * j + 1]};
+                    const f32x2 dv = sv - mm;
+                    pu[j] = pack_bf16(__builtin_amdgcn_exp2f(dv[0]), __builtin_amdgcn_exp2f(dv[1]));
+                }
                 const bf16x8 pf = __builtin_bit_cast(bf16x8, pu);
 #pragma unroll
-                for (int d = 0; d < ND; ++d) {
-                    const bf16raw *vp = &Vt[(32 * d + r) * LDV + 32 * n + 16 * ks + 4 * h];
-                    const u32x2 lo = *(const u32x2 *)vp, hi = *(const u32x2 *)(vp + 8);
-                    u32x4 vu;
-                    vu[0] = lo[0]; vu[1] = lo[1]; vu[2] = hi[0]; vu[3] = hi[1];
-                    o[d] = MFMA_BF16(__builtin_bit_cast(bf16x8, vu), pf, o[d]);
-                }
+                for (int d = 0; d < ND; ++d) o[d] = MFMA_BF16(__builtin_bit_cast(bf16x8, va[n][ks][d]), pf, o[d]);
+                o[ND] = MFMA_BF16(ones_f, pf, o[ND]);
             }
         __syncthreads();
     }
@@ -1711,7 +1750,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16(
     // ---- epilogue: O^T[d][q] / l -> out[b, q, head*DH + d]; 4 consecutive d per 16-B store ----
     const int q = q0 + r;
     if (q < T) {
-        const float inv = 1.0f / l_run;
+        const float inv = 1.0f / o[ND][0];
         float *op = out + ((size_t)b * T + q) * (H * DH) + head * DH;
 #pragma unroll
         for (int d = 0; d < ND; ++d)
@@ -2203,11 +2242,16 @@ int vsk_attention_bf16(const float *q, const float *k, const float *v, const uin
                        int B, int H, int T, int dh, float scale, hipStream_t st) {
     const float sl2 = scale * 1.4426950408889634f;
     const int BH = B * H;
-    dim3 grid(8 * ((BH + 7) / 8) * ((T + 127) / 128));
-    if (dh == 64)
-        hipLaunchKernelGGL((attn_fwd_bf16<64>), grid, dim3(256), 0, st, q, k, v, mask, out, H, T, sl2, BH);
+    // 8-wave blocks (256 query rows share one staged K/V tile) unless the ragged tail would waste too many rows
+    const int r8 = (T + 255) / 256 * 256, r4 = (T + 127) / 128 * 128;
+    const bool wide = dh == 64 && !getenv("VS_ATTN_NW4") && r8 * 100 <= r4 * 105;
+    dim3 grid(8 * ((BH + 7) / 8) * (wide ? r8 / 256 : r4 / 128));
+    if (dh == 64 && wide)
+        hipLaunchKernelGGL((attn_fwd_bf16<64, 8>), grid, dim3(512), 0, st, q, k, v, mask, out, H, T, sl2, BH);
+    else if (dh == 64)
+        hipLaunchKernelGGL((attn_fwd_bf16<64, 4>), grid, dim3(256), 0, st, q, k, v, mask, out, H, T, sl2, BH);
     else if (dh == 32)
-        hipLaunchKernelGGL((attn_fwd_bf16<32>), grid, dim3(256), 0, st, q, k, v, mask, out, H, T, sl2, BH);
+        hipLaunchKernelGGL((attn_fwd_bf16<32, 4>), grid, dim3(256), 0, st, q, k, v, mask, out, H, T, sl2, BH);
     else
         return -1;
     VSK_CHECK_LAUNCH();
