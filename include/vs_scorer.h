@@ -42,6 +42,18 @@ extern "C" {
                                 bias, accumulation, residual, LayerNorm and the score head stay fp32.
                                 d_model <= 256.  Same tolerance caveat as VS_FLAG_BF16_ATTENTION. */
 #define VS_FLAG_BF16 (VS_FLAG_BF16_ATTENTION | VS_FLAG_BF16_LINEAR)
+#define VS_FLAG_F16X3_ATTENTION 16u /* opt-in: the two attention products emulated on the f16 pipe the same way
+                                (q*scale, k, v, p split into hi + lo halves, three MFMAs per product, fp32
+                                softmax and accumulation).  Head dim 32 or 64.  Exclusive with
+                                VS_FLAG_BF16_ATTENTION.  See VS_FLAG_F16X3_LINEAR. */
+#define VS_FLAG_F16X3 (VS_FLAG_F16X3_ATTENTION | 8u)
+#define VS_FLAG_F16X3_LINEAR 8u /* opt-in: every Linear EMULATES the fp32 product on the f16 matrix pipe: each
+                                operand x is split as f16(x) + f16(x - f16(x)) (22 significant bits) and
+                                a*b ~ a_hi*b_hi + a_hi*b_lo + a_lo*b_hi, fp32 accumulate - three f16 MFMAs
+                                (96 cycles) instead of eight fp32 MFMAs (512 cycles) per 16 k.  Per-product
+                                error ~3e-6 relative: results stay inside the 1e-4 bar (tests).  Operand
+                                magnitudes must be < 65504 (f16 range).  d_model <= 256.  Exclusive with
+                                VS_FLAG_BF16_LINEAR. */
 
 /* Model hyper-parameters: the ctor arguments of reference SimNet.__init__ (simnet.py:10-13)
  * that shape the eval forward. */
@@ -133,6 +145,11 @@ int vs_linear_bf16(const float *A, const float *W, const float *bias, float *C,
                    int32_t M, int32_t N, int32_t K, int32_t relu,
                    const float *pe, int32_t T, void *stream);
 
+/* vs_linear_f32 emulated on the f16 matrix pipe (see VS_FLAG_F16X3_LINEAR). */
+int vs_linear_f16x3(const float *A, const float *W, const float *bias, float *C,
+                    int32_t M, int32_t N, int32_t K, int32_t relu,
+                    const float *pe, int32_t T, void *stream);
+
 /* qkv = h * Wqkv^T + b, scattered head-major: out[3][B][H][T][dh]  (simnet.py:148-153). */
 int vs_qkv_proj_f32(const float *h, const float *Wqkv, const float *bqkv, float *qkv,
                     int32_t B, int32_t T, int32_t d, int32_t H, void *stream);
@@ -147,6 +164,11 @@ int vs_attention_f32(const float *q, const float *k, const float *v, const uint8
 int vs_attention_bf16(const float *q, const float *k, const float *v, const uint8_t *key_pad_mask,
                       float *out, int32_t B, int32_t H, int32_t T, int32_t dh, float scale,
                       void *stream);
+
+/* The same contract emulated on the f16 matrix pipe (see VS_FLAG_F16X3_ATTENTION); dh in {32, 64}. */
+int vs_attention_f16x3(const float *q, const float *k, const float *v, const uint8_t *key_pad_mask,
+                       float *out, int32_t B, int32_t H, int32_t T, int32_t dh, float scale,
+                       void *stream);
 
 /* out = LayerNorm(A*W^T + bias + residual) * gamma + beta, eps 1e-5 (simnet.py:107,110,163,182);
  * N = d_model.  If score_w != NULL also scores[row, c] = out[row,:].score_w[c,:] + score_b[c]
@@ -163,6 +185,13 @@ int vs_linear_residual_layernorm_bf16(const float *A, const float *W, const floa
                                       float *out, int32_t M, int32_t N, int32_t K,
                                       const float *score_w, const float *score_b, int32_t num_classes,
                                       int32_t sigmoid, float *scores, void *stream);
+
+/* The same emulated on the f16 matrix pipe (see VS_FLAG_F16X3_LINEAR); N <= 256. */
+int vs_linear_residual_layernorm_f16x3(const float *A, const float *W, const float *bias,
+                                       const float *residual, const float *gamma, const float *beta,
+                                       float *out, int32_t M, int32_t N, int32_t K,
+                                       const float *score_w, const float *score_b, int32_t num_classes,
+                                       int32_t sigmoid, float *scores, void *stream);
 
 #ifdef __cplusplus
 }

@@ -671,3 +671,169 @@ def test_bf16_compute_long_video(vsa):
     err = (logits.cpu() - rl).abs().max().item()
     print("bf16 compute T=8192: logit err %.3e" % err)
     assert err < BF16_FULL_LOGIT_TOL
+
+
+# ---- opt-in fp32 emulation on the f16 matrix pipe (VS_FLAG_F16X3_LINEAR, "fp16x3") ------------------------
+# Operands are split into two f16 halves (22 bits) and three products are accumulated in fp32, so the checker is
+# the plain fp64 product of the UNROUNDED operands, and the bar is the fp32 path's own 1e-4 (per-kernel 5e-5).
+@pytest.mark.parametrize("M,N,K,relu,T", [(300, 256, 1024, 0, 0), (129, 1024, 256, 1, 0), (64, 768, 256, 0, 0),
+                                          (1000, 256, 1024, 0, 250), (37, 512, 2048, 0, 37), (2048, 2048, 512, 1, 0),
+                                          (1, 32, 32, 0, 0)])
+def test_linear_f16x3_kernel(vsa, M, N, K, relu, T):
+    lib = vsa._lib.load()
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g)
+    pe = torch.randn(T, N, generator=g) if T else None
+    ref = F.linear(A.double(), W.double(), b.double())
+    if relu:
+        ref = F.relu(ref)
+    if T:
+        ref = ref + pe.double().repeat(M // T, 1)
+    dA, dW, db = A.to(_dev()), W.to(_dev()), b.to(_dev())
+    dpe = pe.to(_dev()) if T else None
+    out = torch.full((M, N), float("nan"), device=_dev())
+    vsa._lib.check(lib.vs_linear_f16x3(dA.data_ptr(), dW.data_ptr(), db.data_ptr(), out.data_ptr(), M, N, K, relu,
+                                       dpe.data_ptr() if T else None, T, _stream()))
+    torch.cuda.synchronize()
+    err = (out.cpu().double() - ref).abs().max().item()
+    print("f16x3 linear M=%d N=%d K=%d: err %.2e" % (M, N, K, err))
+    assert err < 5e-5
+
+
+@pytest.mark.parametrize("M,N,K,nc,sig", [(300, 256, 256, 0, 0), (100, 256, 1024, 1, 0), (64, 128, 512, 3, 0),
+                                          (1000, 192, 320, 2, 1), (33, 64, 256, 1, 0)])
+def test_linear_residual_layernorm_f16x3_kernel(vsa, M, N, K, nc, sig):
+    lib = vsa._lib.load()
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b, res = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    gam, bet = 1 + 0.1 * torch.randn(N, generator=g), 0.1 * torch.randn(N, generator=g)
+    sw, sb = torch.randn(max(nc, 1), N, generator=g) / math.sqrt(N), torch.randn(max(nc, 1), generator=g)
+    y = F.layer_norm(F.linear(A.double(), W.double(), b.double()) + res.double(), (N,), gam.double(), bet.double(), 1e-5)
+    sc = F.linear(y, sw.double(), sb.double())
+    if sig:
+        sc = torch.sigmoid(sc)
+    d = [t.to(_dev()) for t in (A, W, b, res, gam, bet, sw, sb)]
+    out = torch.full((M, N), float("nan"), device=_dev())
+    scores = torch.full((M, max(nc, 1)), float("nan"), device=_dev())
+    vsa._lib.check(lib.vs_linear_residual_layernorm_f16x3(
+        d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), d[4].data_ptr(), d[5].data_ptr(),
+        out.data_ptr(), M, N, K, d[6].data_ptr() if nc else None, d[7].data_ptr() if nc else None, nc, sig,
+        scores.data_ptr() if nc else None, _stream()))
+    torch.cuda.synchronize()
+    assert (out.cpu().double() - y).abs().max().item() < 5e-5
+    if nc:
+        assert (scores.cpu().double() - sc).abs().max().item() < 5e-5
+
+
+@pytest.mark.parametrize("case", golden_cases(), ids=lambda c: c["name"])
+def test_f16x3_linear_mode_matches_reference_golden(vsa, case):
+    """linear_dtype='fp16x3' against the reference-generated goldens, at the fp32 path's own 1e-4 bar."""
+    if case["d"] > 256:
+        pytest.skip("f16x3 Linear kernels: d_model <= 256")
+    g = load_golden(case["name"])
+    sd, x, mask = build_case(vsa.synth, case)
+    m = _model(vsa, case, sd)
+    m.linear_dtype = "fp16x3"
+    with torch.no_grad():
+        logits, hidden = m(x.to(_dev()), None if mask is None else mask.to(_dev()))
+    valid = torch.ones(x.shape[:2], dtype=torch.bool) if mask is None else ~mask
+    dl = (logits.cpu() - g["logits"])[valid].abs().max().item()
+    dh = (hidden.cpu()[:, g["rows"]] - g["hidden"])[valid[:, g["rows"]]].abs().max().item()
+    print("f16x3 linear %s: logits %.2e hidden %.2e" % (case["name"], dl, dh))
+    assert dl < TOL and dh < TOL, (dl, dh)
+
+
+def _run_attn_f16x3(vsa, q, k, v, mask, scale):
+    lib = vsa._lib.load()
+    B, H, T, dh = q.shape
+    dq, dk, dv = q.to(_dev()), k.to(_dev()), v.to(_dev())
+    dm = mask.to(_dev()) if mask is not None else None
+    out = torch.full((B, T, H * dh), float("nan"), device=_dev())
+    vsa._lib.check(lib.vs_attention_f16x3(dq.data_ptr(), dk.data_ptr(), dv.data_ptr(),
+                                          dm.data_ptr() if dm is not None else None, out.data_ptr(), B, H, T, dh,
+                                          scale, _stream()))
+    torch.cuda.synchronize()
+    return out.cpu()
+
+
+@pytest.mark.parametrize("B,H,T,dh,masked", [(2, 4, 320, 64, False), (1, 4, 1024, 64, False), (2, 4, 200, 64, True),
+                                             (1, 8, 65, 32, True), (1, 4, 31, 64, False), (3, 8, 257, 32, False),
+                                             (1, 1, 1, 64, False)])
+def test_attention_f16x3_kernel(vsa, B, H, T, dh, masked):
+    """fp32 attention emulated on the f16 pipe, against the fp64 reference at the fp32 kernel's own tolerance."""
+    g = torch.Generator().manual_seed(T + dh)
+    q, k, v = (torch.randn(B, H, T, dh, generator=g) * 2.0 for _ in range(3))
+    mask = vsa.synth.random_mask(B, T, 3) if masked else None
+    scale = (H * dh) ** -0.5
+    ref = _attn_ref(q, k, v, mask, scale)
+    out = _run_attn_f16x3(vsa, q, k, v, mask, scale)
+    err = (out.double() - ref).abs().max().item()
+    print("f16x3 attention T=%d dh=%d: err %.2e" % (T, dh, err))
+    assert err < 2e-5
+
+
+@pytest.mark.parametrize("T,dh", [(64, 64), (200, 64), (513, 64), (300, 32)])
+def test_attention_f16x3_operand_layout_is_exact_on_a_permutation(vsa, T, dh):
+    B, H = 2, 2
+    g = torch.Generator().manual_seed(T)
+    k = (torch.randint(0, 2, (B, H, T, dh), generator=g) * 2 - 1).float()
+    idx = torch.arange(T)
+    k[..., :12] = ((idx[:, None] >> torch.arange(12)[None, :]) & 1).float() * 2 - 1
+    perm = torch.stack([torch.randperm(T, generator=g) for _ in range(B * H)]).view(B, H, T)
+    q = torch.gather(k, 2, perm[..., None].expand(-1, -1, -1, dh))
+    v = torch.randint(-8, 9, (B, H, T, dh), generator=g).float() + 0.001        # needs the lo half too
+    out = _run_attn_f16x3(vsa, q * 16.0, k, v, None, 1.0)
+    want = torch.gather(v, 2, perm[..., None].expand(-1, -1, -1, dh)).permute(0, 2, 1, 3).reshape(B, T, H * dh)
+    assert (out - want).abs().max().item() < 2e-6
+
+
+def test_attention_f16x3_rescale_branch(vsa):
+    B, H, T, dh = 1, 4, 512, 64
+    g = torch.Generator().manual_seed(99)
+    q, k, v = (torch.randn(B, H, T, dh, generator=g) for _ in range(3))
+    k[:, :, 300] = q.mean(dim=2) * 50.0 + 20.0
+    k[:, :, 77] = -k[:, :, 300]
+    ref = _attn_ref(q, k, v, None, 1.0)
+    out = _run_attn_f16x3(vsa, q, k, v, None, 1.0)
+    err = (out.double() - ref).abs().max().item()
+    print("f16x3 attention rescale: err %.2e" % err)
+    assert err < 5e-4          # scores of several hundred: 2^-22 of them is ~1e-4 in the exponent
+
+
+@pytest.mark.parametrize("case", golden_cases(), ids=lambda c: c["name"])
+def test_f16x3_compute_mode_matches_reference_golden(vsa, case):
+    """set_compute_dtype('fp16x3') (every product emulated on the f16 pipe) against the reference-generated
+    goldens, at the fp32 path's own 1e-4 bar."""
+    if case["d"] > 256 or case["d"] // case["H"] not in (32, 64):
+        pytest.skip("f16x3 kernels: d_model <= 256, head dim 32/64")
+    g = load_golden(case["name"])
+    sd, x, mask = build_case(vsa.synth, case)
+    m = _model(vsa, case, sd).set_compute_dtype("fp16x3")
+    with torch.no_grad():
+        logits, hidden = m(x.to(_dev()), None if mask is None else mask.to(_dev()))
+    valid = torch.ones(x.shape[:2], dtype=torch.bool) if mask is None else ~mask
+    dl = (logits.cpu() - g["logits"])[valid].abs().max().item()
+    dh = (hidden.cpu()[:, g["rows"]] - g["hidden"])[valid[:, g["rows"]]].abs().max().item()
+    print("f16x3 %s: logits %.2e hidden %.2e" % (case["name"], dl, dh))
+    assert dl < TOL and dh < TOL, (dl, dh)
+
+
+def test_f16x3_full_size_batch_against_exact_path(vsa):
+    """BASELINE configs[2] size (B=64, T=1024): the emulated path against the exact fp32 MFMA path."""
+    synth = vsa.synth
+    sd = synth.make_state_dict(256, 4, 1234)
+    m = vsa.SimNet(num_heads=4, d_model=256, num_layers=4, sparsity=0.0, dropout=0.3)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(_dev()).eval()
+    x = torch.randn(64, 1024, 1024, generator=torch.Generator().manual_seed(5)).to(_dev())
+    with torch.no_grad():
+        l32, h32 = m(x)
+        m.set_compute_dtype("fp16x3")
+        l16, h16 = m(x)
+    dl, dh = (l16 - l32).abs().max().item(), (h16 - h32).abs().max().item()
+    print("f16x3 vs exact at B=64 T=1024: logits %.2e hidden %.2e" % (dl, dh))
+    assert dl < TOL and dh < TOL

@@ -22,12 +22,15 @@ VS_OK, VS_ERR_INVALID, VS_ERR_WORKSPACE, VS_ERR_HIP = 0, 1, 2, 3
 VS_FLAG_SIGMOID = 1
 VS_FLAG_BF16_ATTENTION = 2
 VS_FLAG_BF16_LINEAR = 4
+VS_FLAG_F16X3_LINEAR = 8
+VS_FLAG_F16X3_ATTENTION = 16
 
 # every symbol include/vs_scorer.h declares
 EXPORTS = ("vs_abi_version", "vs_last_error", "vs_weights_pack", "vs_weights_free",
            "vs_scorer_workspace_bytes", "vs_scorer_forward", "vs_linear_f32", "vs_qkv_proj_f32",
-           "vs_attention_f32", "vs_attention_bf16", "vs_linear_residual_layernorm_f32",
-           "vs_linear_bf16", "vs_linear_residual_layernorm_bf16",
+           "vs_attention_f32", "vs_attention_bf16", "vs_attention_f16x3", "vs_linear_residual_layernorm_f32",
+           "vs_linear_bf16", "vs_linear_residual_layernorm_bf16", "vs_linear_f16x3",
+           "vs_linear_residual_layernorm_f16x3",
            "vs_profile_enable", "vs_profile_collect", "vs_stage_name")
 # include/vs_eval.h
 EVAL_EXPORTS = ("vs_eval_upsample", "vs_eval_knapsack", "vs_eval_generate_summary", "vs_eval_fscore",
@@ -133,6 +136,8 @@ def load() -> C.CDLL:
         lib.vs_attention_f32.argtypes = [C.c_void_p] * 5 + [C.c_int32] * 4 + [C.c_float, C.c_void_p]
         lib.vs_attention_bf16.restype = C.c_int
         lib.vs_attention_bf16.argtypes = lib.vs_attention_f32.argtypes
+        lib.vs_attention_f16x3.restype = C.c_int
+        lib.vs_attention_f16x3.argtypes = lib.vs_attention_f32.argtypes
         lib.vs_linear_residual_layernorm_f32.restype = C.c_int
         lib.vs_linear_residual_layernorm_f32.argtypes = ([C.c_void_p] * 7 + [C.c_int32] * 3 + [C.c_void_p] * 2
                                                          + [C.c_int32] * 2 + [C.c_void_p] * 2)
@@ -140,6 +145,10 @@ def load() -> C.CDLL:
         lib.vs_linear_bf16.argtypes = lib.vs_linear_f32.argtypes
         lib.vs_linear_residual_layernorm_bf16.restype = C.c_int
         lib.vs_linear_residual_layernorm_bf16.argtypes = lib.vs_linear_residual_layernorm_f32.argtypes
+        lib.vs_linear_f16x3.restype = C.c_int
+        lib.vs_linear_f16x3.argtypes = lib.vs_linear_f32.argtypes
+        lib.vs_linear_residual_layernorm_f16x3.restype = C.c_int
+        lib.vs_linear_residual_layernorm_f16x3.argtypes = lib.vs_linear_residual_layernorm_f32.argtypes
         for name in EVAL_EXPORTS:
             getattr(lib, name).restype = C.c_int
         lib.vs_eval_upsample.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]

@@ -13,8 +13,9 @@ int vsk_qkv(const float *h, const float *Wqkv, const float *Wf, const float *bqk
             int H, int bf16, hipStream_t st);
 int vsk_attention(const float *q, const float *k, const float *v, const uint8_t *mask, float *out,
                   int B, int H, int T, int dh, float scale, hipStream_t st);
+// prec 1: bf16 operands; 2: fp32 emulated with f16 hi+lo operand halves ("fp16x3")
 int vsk_attention_bf16(const float *q, const float *k, const float *v, const uint8_t *mask, float *out,
-                  int B, int H, int T, int dh, float scale, hipStream_t st);
+                       int B, int H, int T, int dh, float scale, int prec, hipStream_t st);
 int vsk_linear_res_ln(const float *A, const float *W, const float *Wf, const float *bias, const float *res,
                       const float *gamma, const float *beta, float *out, int M, int N, int K,
                       const float *score_w, const float *score_b, int num_classes, int sigmoid,

@@ -82,11 +82,39 @@ __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16x2));
 }
 
-// max(x, 0) as ONE instruction (fmaxf first canonicalises its MFMA-produced input with a second v_max)
+// ---- f16 matrix pipe used to EMULATE fp32 (opt-in "fp16x3"): x ~= hi + lo with hi = f16(x), lo = f16(x - hi)
+// (22 significant bits), and a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi accumulated in fp32 (the dropped
+// a_lo*b_lo is ~2^-22 of the product).  Three 32x32x16 f16 MFMAs (96 cycles) replace eight 32x32x2 fp32 MFMAs
+// (512 cycles).  Operand magnitudes must stay below the f16 range (65504).
+// Weights are multiplied by F16X3_WS = 2^10 on their way into the split (exact), so that the lo half of a typical
+// weight (|w| ~ 0.03, lo ~ 2^-12 |w|) is a normal f16 number instead of a subnormal with 2^-24 absolute steps;
+// the accumulators then hold 2^10 times the result and the epilogue multiplies by 2^-10 (exact) - or, in the
+// LayerNorm kernel, scales residual, bias and eps instead (LayerNorm is scale-invariant).  |w| must be < 63.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+constexpr float F16X3_WS = 1024.0f;
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+#define MFMA_F16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+__device__ __forceinline__ void split_f16(float x0, float x1, unsigned &hi, unsigned &lo) {
+    const f32x2 x = {x0, x1};
+    const f16x2 hv = __builtin_convertvector(x, f16x2);
+    const f32x2 rem = x - __builtin_convertvector(hv, f32x2);
+    hi = __builtin_bit_cast(unsigned, hv);
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(rem, f16x2));
+}
+__device__ __forceinline__ void split_f16x4(const float *v, u32x2 &hi, u32x2 &lo) {   // 4 floats -> 2+2 dwords
+    unsigned h0, l0, h1, l1;
+    split_f16(v[0], v[1], h0, l0);
+    split_f16(v[2], v[3], h1, l1);
+    hi[0] = h0; hi[1] = h1; lo[0] = l0; lo[1] = l1;
+}
+
+// max(x, 0) as ONE instruction: integer max on the bit pattern (negative floats are negative integers).
+// fmaxf would first canonicalise its MFMA-produced input with a second v_max; and NOT inline asm: an asm
+// statement reading an MFMA result gets no hazard wait states from the compiler (measured: wrong values when
+// the scheduler placed it right behind the MFMA).
 __device__ __forceinline__ float relu1(float x) {
-    float y;
-    asm("v_max_f32 %0, 0, %1" : "=v"(y) : "v"(x));
-    return y;
+    const int b = __builtin_bit_cast(int, x);
+    return __builtin_bit_cast(float, b > 0 ? b : 0);
 }
 
 __device__ __forceinline__ float half_sum(float v) {   // sum over the 32 lanes of a half-wave
@@ -129,10 +157,12 @@ __device__ __forceinline__ unsigned long long stamp() {
 // SIMD unfairly: the older one finishes ~25 % earlier and the younger runs a lonely tail).
 // NJ = 32-column MFMA tiles per wave along N (2: block tile 64*NWM x 128; 4: 64*NWM x 256 - a third fewer
 // staging instructions and a quarter fewer fragment reads per MFMA, 128 accumulator registers).
-// BF (opt-in, VS_FLAG_BF16_LINEAR): the product runs as v_mfma_f32_32x32x16_bf16.  Operands stay fp32 in HBM and
+// PREC 1 (opt-in, VS_FLAG_BF16_LINEAR): the product runs as v_mfma_f32_32x32x16_bf16.  Operands stay fp32 in HBM and
 // are rounded to bf16 once, on their way into LDS (rows of 32 k = 64 B, padded to 80 B: conflict-free b128
 // fragment reads); bias, accumulation and the epilogue are the fp32 ones.
-template <int EPI, int NWM = 2, int DIAG = 0, int NJ = 2, bool BF = false>     // DIAG (tools/diag_gemm.py only) 2: epilogue skipped (wrong output) + per-wave cycles/wall clock; 1, 3: the same with the epilogue
+// PREC 2 (opt-in, VS_FLAG_F16X3_LINEAR): fp32 emulated on the f16 pipe (split_f16): an LDS row holds the 32 hi
+// halves then the 32 lo halves (128 B + 16 B pad = the fp32 row stride), three MFMAs per fragment pair.
+template <int EPI, int NWM = 2, int DIAG = 0, int NJ = 2, int PREC = 0>     // DIAG (tools/diag_gemm.py only) 2: epilogue skipped (wrong output) + per-wave cycles/wall clock; 1, 3: the same with the epilogue
 __global__ __launch_bounds__(128 * NWM, 2) void gemm_nt_128(
     const float *__restrict__ A, const float *__restrict__ W, const float *__restrict__ bias,
     float *__restrict__ C, int M, int N, int K, const float *__restrict__ pe, int T, int H, int dh,
@@ -190,7 +220,23 @@ __global__ __launch_bounds__(128 * NWM, 2) void gemm_nt_128(
     constexpr int LDB = 20;                             // BF: LDS row stride in floats (80 B = 32 bf16 + pad)
     auto stage = [&](int buf) __attribute__((always_inline)) {
         float *As = smem + buf * (BM + BN) * LD, *Ws = As + BM * LD;
-        if constexpr (BF) {
+        if constexpr (PREC == 2) {
+#pragma unroll
+            for (int i = 0; i < LA; ++i) {
+                u32x2 hi, lo;
+                split_f16x4((const float *)&pa[i], hi, lo);
+                *(u32x2 *)&As[(lrow + RS * i) * LD + lc4 / 2] = hi;
+                *(u32x2 *)&As[(lrow + RS * i) * LD + 16 + lc4 / 2] = lo;
+            }
+#pragma unroll
+            for (int i = 0; i < LW; ++i) {
+                u32x2 hi, lo;
+                const f32x4 ws = pw[i] * F16X3_WS;
+                split_f16x4((const float *)&ws, hi, lo);
+                *(u32x2 *)&Ws[(lrow + RS * i) * LD + lc4 / 2] = hi;
+                *(u32x2 *)&Ws[(lrow + RS * i) * LD + 16 + lc4 / 2] = lo;
+            }
+        } else if constexpr (PREC == 1) {
 #pragma unroll
             for (int i = 0; i < LA; ++i) {
                 u32x2 u; u[0] = pack_bf16(pa[i][0], pa[i][1]); u[1] = pack_bf16(pa[i][2], pa[i][3]);
@@ -219,7 +265,40 @@ __global__ __launch_bounds__(128 * NWM, 2) void gemm_nt_128(
     // aptr/wptr + koff) in the first half of the MFMA stream and their LDS writes in the last quarter.
     auto ktile = [&](int koff) __attribute__((always_inline)) {
         const float *As = smem + fpar * (BM + BN) * LD, *Ws = As + BM * LD;
-        if constexpr (BF) {
+        if constexpr (PREC == 2) {
+            // 2 k-steps of 16: lane (r,h) supplies k = 16ks + 8h .. +7 of the hi half-row and of the lo half-row
+            const float *ap = As + (64 * wr + r) * LD + 4 * h;
+            const float *wp = Ws + (32 * NJ * wc + r) * LD + 4 * h;
+#pragma unroll
+            for (int i = 0; i < LA; ++i) pa[i] = *(const f32x4 *)(aptr[i] + koff);
+#pragma unroll
+            for (int i = 0; i < LW; ++i) pw[i] = *(const f32x4 *)(wptr[i] + koff);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                f16x8 ah[2], al[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    ah[i] = __builtin_bit_cast(f16x8, *(const u32x4 *)(ap + 32 * i * LD + 8 * ks));
+                    al[i] = __builtin_bit_cast(f16x8, *(const u32x4 *)(ap + 32 * i * LD + 16 + 8 * ks));
+                }
+#pragma unroll
+                for (int jj = 0; jj < NJ; ++jj) {
+                    const f16x8 wh = __builtin_bit_cast(f16x8, *(const u32x4 *)(wp + 32 * jj * LD + 8 * ks));
+                    const f16x8 wl = __builtin_bit_cast(f16x8, *(const u32x4 *)(wp + 32 * jj * LD + 16 + 8 * ks));
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        acc[i][jj] = MFMA_F16(wl, ah[i], acc[i][jj]);
+                        acc[i][jj] = MFMA_F16(wh, al[i], acc[i][jj]);
+                        acc[i][jj] = MFMA_F16(wh, ah[i], acc[i][jj]);
+                    }
+                }
+            }
+            stage(fpar ^ 1);
+            __syncthreads();
+            fpar ^= 1;
+            return;
+        }
+        if constexpr (PREC == 1) {
             // 2 k-steps of 16: lane (r,h) supplies k = 16ks + 8h .. +7 (one b128 of the bf16 row)
             const float *ap = As + (64 * wr + r) * LDB + 4 * h;
             const float *wp = Ws + (32 * NJ * wc + r) * LDB + 4 * h;
@@ -315,7 +394,7 @@ __global__ __launch_bounds__(128 * NWM, 2) void gemm_nt_128(
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int jj = 0; jj < NJ; ++jj) acc[i][jj] = MFMA32(cu_bias[jj], 1.0f, zero);
+                for (int jj = 0; jj < NJ; ++jj) acc[i][jj] = MFMA32(cu_bias[jj], PREC == 2 ? F16X3_WS : 1.0f, zero);
         }
         for (int kt = 0; kt + 1 < nk; ++kt) ktile((kt + 1) * BK);
         // last k-tile of this output tile: prefetch the first k-tile of the next one (or a harmless
@@ -370,6 +449,7 @@ __global__ __launch_bounds__(128 * NWM, 2) void gemm_nt_128(
                 for (int p = 0; p < 4; ++p) {
                     const int ro = 64 * wr + 32 * i + trow + 8 * p;
                     f32x4 v = *(const f32x4 *)&tp[(trow + 8 * p) * LD + tc4];
+                    if constexpr (PREC == 2) v *= 1.0f / F16X3_WS;
                     const int row = m0 + ro;
                     int bb = b0, tt = t0 + ro;
                     if (EPI == EPI_PE || EPI == EPI_QKV) { while (tt >= T) { tt -= T; ++bb; } }
@@ -572,7 +652,7 @@ __global__ __launch_bounds__(256) void gemm_res_ln(
 //   epilogue issues no loads from HBM at all; gamma/beta/score_w sit in LDS.
 //   Block = 4 waves = 128 rows, BK = 16 (LDS rows padded to 20 floats), 2 blocks per CU.
 // ------------------------------------------------------------------------------------------
-template <int NT, bool BF = false>     // BF: bf16 MFMA operands (see gemm_nt_128), LDS rows of 16 bf16 padded to 48 B
+template <int NT, int PREC = 0>     // PREC 1: bf16 MFMA operands (see gemm_nt_128), LDS rows of 16 bf16 padded to 48 B; 2: f16 hi|lo rows (80 B)
 __global__ __launch_bounds__(256, 2) void gemm_ln_rows(
     const float *__restrict__ A, const float *__restrict__ W, const float *__restrict__ bias,
     const float *__restrict__ res, const float *__restrict__ gamma, const float *__restrict__ beta,
@@ -589,7 +669,8 @@ __global__ __launch_bounds__(256, 2) void gemm_ln_rows(
     const int ntiles = (M + BM - 1) / BM;
     const int nk = K / BK;
 
-    for (int i = tid; i < N; i += 256) { gam_s[i] = gamma[i]; bet_s[i] = beta[i]; bias_s[i] = bias[i]; }
+    constexpr float SC = PREC == 2 ? F16X3_WS : 1.0f;      // scale of the accumulators (see F16X3_WS)
+    for (int i = tid; i < N; i += 256) { gam_s[i] = gamma[i]; bet_s[i] = beta[i]; bias_s[i] = bias[i] * SC; }
 
     // staging map: A 128 rows x 4 float4 (2 per thread), W N rows x 4 float4 (WL per thread)
     const int lrow = tid >> 2, lc4 = (tid & 3) * 4;
@@ -603,7 +684,24 @@ __global__ __launch_bounds__(256, 2) void gemm_ln_rows(
     constexpr int LDB = 12;                            // BF: LDS row stride in floats (48 B: conflict-free b128)
     auto stage = [&](int buf) __attribute__((always_inline)) {
         float *As = smem + buf * (BM + N) * LD, *Ws = As + BM * LD;
-        if constexpr (BF) {
+        if constexpr (PREC == 2) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                u32x2 hi, lo;
+                split_f16x4((const float *)&pa[i], hi, lo);
+                *(u32x2 *)&As[(lrow + 64 * i) * LD + lc4 / 2] = hi;
+                *(u32x2 *)&As[(lrow + 64 * i) * LD + 8 + lc4 / 2] = lo;
+            }
+#pragma unroll
+            for (int i = 0; i < WL; ++i)
+                if (lrow + 64 * i < N) {
+                    u32x2 hi, lo;
+                    const f32x4 ws = pw[i] * F16X3_WS;
+                    split_f16x4((const float *)&ws, hi, lo);
+                    *(u32x2 *)&Ws[(lrow + 64 * i) * LD + lc4 / 2] = hi;
+                    *(u32x2 *)&Ws[(lrow + 64 * i) * LD + 8 + lc4 / 2] = lo;
+                }
+        } else if constexpr (PREC == 1) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 u32x2 u; u[0] = pack_bf16(pa[i][0], pa[i][1]); u[1] = pack_bf16(pa[i][2], pa[i][3]);
@@ -645,7 +743,8 @@ __global__ __launch_bounds__(256, 2) void gemm_ln_rows(
             for (int j = 0; j < NT; ++j)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const f32x4 rv = *(const f32x4 *)(rp + 32 * j + 8 * q);
+                    f32x4 rv = *(const f32x4 *)(rp + 32 * j + 8 * q);
+                    if constexpr (PREC == 2) rv *= SC;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) acc[j][4 * q + e] = rv[e];
                 }
@@ -657,7 +756,28 @@ __global__ __launch_bounds__(256, 2) void gemm_ln_rows(
         for (int kt = 0; kt < nk; ++kt) {
             const int kn = kt + 1 < nk ? kt + 1 : kt;         // last step reloads a duplicate: branch-free stream
             const float *As = smem + (kt & 1) * (BM + N) * LD, *Ws = As + BM * LD;
-            if constexpr (BF) {
+            if constexpr (PREC == 2) {
+                const float *arow = As + (32 * wave + r) * LD + 4 * h;
+                const f16x8 ah = __builtin_bit_cast(f16x8, *(const u32x4 *)arow);
+                const f16x8 al = __builtin_bit_cast(f16x8, *(const u32x4 *)(arow + 8));
+#pragma unroll
+                for (int i = 0; i < 2; ++i) pa[i] = *(const f32x4 *)(aptr[i] + kn * BK);
+#pragma unroll
+                for (int i = 0; i < WL; ++i) pw[i] = *(const f32x4 *)(wptr[i] + kn * BK);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const float *wrow = Ws + (32 * j + r) * LD + 4 * h;
+                    const f16x8 wh = __builtin_bit_cast(f16x8, *(const u32x4 *)wrow);
+                    const f16x8 wl = __builtin_bit_cast(f16x8, *(const u32x4 *)(wrow + 8));
+                    acc[j] = MFMA_F16(wl, ah, acc[j]);
+                    acc[j] = MFMA_F16(wh, al, acc[j]);
+                    acc[j] = MFMA_F16(wh, ah, acc[j]);
+                }
+                stage((kt + 1) & 1);
+                __syncthreads();
+                continue;
+            }
+            if constexpr (PREC == 1) {
                 // one k-step of 16: lane (r,h) supplies k = 8h .. 8h+7
                 const bf16x8 fa = __builtin_bit_cast(bf16x8, *(const u32x4 *)(As + (32 * wave + r) * LDB + 4 * h));
 #pragma unroll
@@ -736,7 +856,7 @@ __global__ __launch_bounds__(256, 2) void gemm_ln_rows(
             sq += pj;
         }
         sq = pair_sum(sq);
-        const float rstd = 1.0f / sqrtf(sq * (1.0f / N) + 1e-5f);
+        const float rstd = 1.0f / sqrtf(sq * (1.0f / N) + 1e-5f * (SC * SC));
         // stores: each 32x32 block is transposed through a wave-private corner of the (now idle) staging
         // buffers so that a store instruction writes 8 full 128-byte lines instead of 32 B into 32 lines
         float *tp = smem + wave * (32 * 36);
@@ -1558,22 +1678,27 @@ __global__ __launch_bounds__(256, 2) void attn_fwd(
 // softmax, not the matrix pipe, bounds this kernel at head dim 64.
 // NOT within the 1e-4 fp32 bar of the reference: tests/test_hip_parity.py states its tolerance.
 // ------------------------------------------------------------------------------------------
-template <int DH, int NW>       // NW waves per block, 32 query rows each
-__global__ __launch_bounds__(64 * NW, 2) void attn_fwd_bf16(
+// PREC 2 ("fp16x3", VS_FLAG_F16X3_ATTENTION) EMULATES the fp32 products on the f16 pipe instead: every operand
+// (q*scale, k, v, p) is split into f16 hi + lo halves (split_f16) kept in two LDS planes / register sets, and
+// each product is three MFMAs (lo*hi, hi*lo, hi*hi; fp32 accumulate) - 56 MFMAs of 32 cycles per 64-key tile
+// where the fp32 kernel needs 132 of 64 cycles - with results inside the fp32 path's own 1e-4 bar.
+template <int DH, int NW, int PREC>       // NW waves per block, 32 query rows each; PREC 1: bf16, 2: f16 hi+lo
+__global__ __launch_bounds__(64 * NW, 2) void attn_fwd_lp(
     const float *__restrict__ Q, const float *__restrict__ Kg, const float *__restrict__ Vg,
     const uint8_t *__restrict__ mask, float *__restrict__ out, int H, int T, float scale_log2e, int BH) {
     constexpr int KT = 64, NS = DH / 16, ND = DH / 32, NT = 64 * NW, QB = 32 * NW;
-    constexpr int LDK = DH + 8;                    // bf16 per K row: 36 (DH 64) / 20 (DH 32) dwords, b128 reads conflict-free
-    constexpr int LDV = KT + 4;                    // bf16 per V^T row: 34 dwords, b64 reads conflict-free
+    constexpr int NP = PREC == 2 ? 2 : 1;          // operand planes (hi, lo)
+    constexpr int LDK = DH + 8;                    // 16-bit elements per K row: 36 (DH 64) / 20 (DH 32) dwords, b128 reads conflict-free
+    constexpr int LDV = KT + 4;                    // 16-bit elements per V^T row: 34 dwords, b64 reads conflict-free
     constexpr int D4 = DH / 4;                     // float4 per key row
     constexpr int KPT = KT * D4 / NT;              // keys per thread in the staging, one float4 of d each
     static_assert(KPT == 2 || KPT == 4, "staging packs 2 or 4 keys per V^T store");
     constexpr float THR = 8.0f;                    // deferred max: the applied max is raised only on a jump > 2^8
-    typedef unsigned short bf16raw;
+    typedef unsigned short h16;
     // K tile, V^T tile and key-mask bias, double-buffered: tile t+1 is written while tile t is consumed,
     // one block barrier per tile
-    __shared__ __attribute__((aligned(16))) bf16raw Kb[2][KT * LDK];
-    __shared__ __attribute__((aligned(16))) bf16raw Vt[2][DH * LDV];
+    __shared__ __attribute__((aligned(16))) h16 Kb[2][NP][KT * LDK];
+    __shared__ __attribute__((aligned(16))) h16 Vt[2][NP][DH * LDV];
     __shared__ __attribute__((aligned(16))) float mb[2][KT];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1585,20 +1710,41 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_bf16(
     const int q0 = qt * QB + 32 * wave;
     const float NEG_INF = -__builtin_inff();
 
-    // Q fragments (B operand): Q[q][16s + 8h + j] * scale*log2(e), bf16
-    bf16x8 qreg[NS];
+    // two floats -> one packed pair per plane
+    auto pack = [&](float x0, float x1, unsigned (&pl)[NP]) __attribute__((always_inline)) {
+        if constexpr (PREC == 2) split_f16(x0, x1, pl[0], pl[1]);
+        else pl[0] = pack_bf16(x0, x1);
+    };
+    auto mma = [&](const u32x4 &a, const u32x4 &bq, const f32x16 &c) __attribute__((always_inline)) -> f32x16 {
+        if constexpr (PREC == 2) return MFMA_F16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, bq), c);
+        else return MFMA_BF16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, bq), c);
+    };
+    // acc += A * B over the planes: hi*hi (+ lo*hi + hi*lo, small terms first)
+    auto mma_planes = [&](const u32x4 (&a)[NP], const u32x4 (&bq)[NP], f32x16 &c) __attribute__((always_inline)) {
+        if constexpr (PREC == 2) {
+            c = mma(a[1], bq[0], c);
+            c = mma(a[0], bq[1], c);
+        }
+        c = mma(a[0], bq[0], c);
+    };
+
+    // Q fragments (B operand): Q[q][16s + 8h + j] * scale*log2(e)
+    u32x4 qreg[NS][NP];
     {
         int qr = q0 + r; qr = qr < T ? qr : T - 1;
         const float *qp = Q + base + (size_t)qr * DH + 8 * h;
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             const f32x4 v0 = *(const f32x4 *)(qp + 16 * s), v1 = *(const f32x4 *)(qp + 16 * s + 4);
-            u32x4 u;
-            u[0] = pack_bf16(v0[0] * scale_log2e, v0[1] * scale_log2e);
-            u[1] = pack_bf16(v0[2] * scale_log2e, v0[3] * scale_log2e);
-            u[2] = pack_bf16(v1[0] * scale_log2e, v1[1] * scale_log2e);
-            u[3] = pack_bf16(v1[2] * scale_log2e, v1[3] * scale_log2e);
-            qreg[s] = __builtin_bit_cast(bf16x8, u);
+            unsigned pl[4][NP];
+            pack(v0[0] * scale_log2e, v0[1] * scale_log2e, pl[0]);
+            pack(v0[2] * scale_log2e, v0[3] * scale_log2e, pl[1]);
+            pack(v1[0] * scale_log2e, v1[1] * scale_log2e, pl[2]);
+            pack(v1[2] * scale_log2e, v1[3] * scale_log2e, pl[3]);
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) qreg[s][p][e] = pl[e][p];
         }
     }
     // o[0..ND-1] = O^T blocks; o[ND] = the row sums l, as the product of P with a block of ones
@@ -1609,8 +1755,8 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_bf16(
 #pragma unroll
         for (int t = 0; t < 16; ++t) o[d][t] = 0.f;
     float m_run = NEG_INF;                         // the max actually applied to O and l (log2 units)
-    const u32x4 ones_u = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
-    const bf16x8 ones_f = __builtin_bit_cast(bf16x8, ones_u);
+    constexpr unsigned ONE2 = PREC == 2 ? 0x3C003C00u : 0x3F803F80u;        // (1.0, 1.0) in f16 / bf16
+    const u32x4 ones_u = {ONE2, ONE2, ONE2, ONE2};
 
     // staging: thread (d4 = tid % D4, kq = tid / D4) owns keys KPT*kq .. +KPT-1 at d = 4*d4 .. +3.
     // Buffer loads: the per-tile offset is a scalar, rows beyond T read as zero (and are masked below).
@@ -1639,20 +1785,31 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_bf16(
     auto stage = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < KPT; ++i) {
-            u32x2 u;
-            u[0] = pack_bf16(pk[i][0], pk[i][1]);
-            u[1] = pack_bf16(pk[i][2], pk[i][3]);
-            *(u32x2 *)&Kb[buf][(KPT * kq + i) * LDK + 4 * d4] = u;
+            unsigned p0[NP], p1[NP];
+            pack(pk[i][0], pk[i][1], p0);
+            pack(pk[i][2], pk[i][3], p1);
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                u32x2 u; u[0] = p0[p]; u[1] = p1[p];
+                *(u32x2 *)&Kb[buf][p][(KPT * kq + i) * LDK + 4 * d4] = u;
+            }
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             if constexpr (KPT == 4) {
-                u32x2 u;
-                u[0] = pack_bf16(pv[0][e], pv[1][e]);
-                u[1] = pack_bf16(pv[2][e], pv[3][e]);
-                *(u32x2 *)&Vt[buf][(4 * d4 + e) * LDV + 4 * kq] = u;
+                unsigned p0[NP], p1[NP];
+                pack(pv[0][e], pv[1][e], p0);
+                pack(pv[2][e], pv[3][e], p1);
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    u32x2 u; u[0] = p0[p]; u[1] = p1[p];
+                    *(u32x2 *)&Vt[buf][p][(4 * d4 + e) * LDV + 4 * kq] = u;
+                }
             } else {
-                *(unsigned *)&Vt[buf][(4 * d4 + e) * LDV + 2 * kq] = pack_bf16(pv[0][e], pv[1][e]);
+                unsigned p0[NP];
+                pack(pv[0][e], pv[1][e], p0);
+#pragma unroll
+                for (int p = 0; p < NP; ++p) *(unsigned *)&Vt[buf][p][(4 * d4 + e) * LDV + 2 * kq] = p0[p];
             }
         }
         if (tid < KT) mb[buf][tid] = pm;
@@ -1665,23 +1822,6 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_bf16(
     for (int tile = 0; tile < ntiles; ++tile) {
         const int cur = tile & 1;
         const bool masked_tile = mask != nullptr || (tile + 1) * KT > T;
-        // ---- operand fragments of this tile: K (A of S^T) and V^T (A of O^T), all reads in flight at once ----
-        u32x4 ka[NS][2];
-#pragma unroll
-        for (int ks = 0; ks < NS; ++ks)
-#pragma unroll
-            for (int n = 0; n < 2; ++n) ka[ks][n] = *(const u32x4 *)&Kb[cur][(32 * n + r) * LDK + 16 * ks + 8 * h];
-        u32x4 va[2][2][ND];
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int d = 0; d < ND; ++d) {
-                    const bf16raw *vp = &Vt[cur][(32 * d + r) * LDV + 32 * n + 16 * ks + 4 * h];
-                    const u32x2 lo = *(const u32x2 *)vp, hi = *(const u32x2 *)(vp + 8);
-                    va[n][ks][d][0] = lo[0]; va[n][ks][d][1] = lo[1]; va[n][ks][d][2] = hi[0]; va[n][ks][d][3] = hi[1];
-                }
         // ---- S^T = K * Q^T ----
         f32x16 s[2];
 #pragma unroll
@@ -1691,7 +1831,26 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_bf16(
 #pragma unroll
         for (int ks = 0; ks < NS; ++ks)
 #pragma unroll
-            for (int n = 0; n < 2; ++n) s[n] = MFMA_BF16(__builtin_bit_cast(bf16x8, ka[ks][n]), qreg[ks], s[n]);
+            for (int n = 0; n < 2; ++n) {
+                u32x4 ka[NP];
+#pragma unroll
+                for (int p = 0; p < NP; ++p) ka[p] = *(const u32x4 *)&Kb[cur][p][(32 * n + r) * LDK + 16 * ks + 8 * h];
+                mma_planes(ka, qreg[ks], s[n]);
+            }
+        // ---- V^T fragments of this tile (A of O^T): reads in flight under the softmax ----
+        u32x4 va[2][2][ND][NP];
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int d = 0; d < ND; ++d)
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) {
+                        const h16 *vp = &Vt[cur][p][(32 * d + r) * LDV + 32 * n + 16 * ks + 4 * h];
+                        const u32x2 lo = *(const u32x2 *)vp, hi = *(const u32x2 *)(vp + 8);
+                        va[n][ks][d][p][0] = lo[0]; va[n][ks][d][p][1] = lo[1]; va[n][ks][d][p][2] = hi[0]; va[n][ks][d][p][3] = hi[1];
+                    }
         // ---- tile t+1 into the other LDS buffer, tile t+2 into registers (under the MFMAs / softmax) ----
         if (tile + 1 < ntiles) stage(cur ^ 1);
         if (tile + 2 < ntiles) gload(tile + 2);
@@ -1732,17 +1891,20 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_bf16(
         for (int n = 0; n < 2; ++n)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                u32x4 pu;
+                u32x4 pf[NP];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const f32x2 sv = {s[n][8 * ks + 2 * j], s[n][8 * ks + 2 * j + 1]};
                     const f32x2 dv = sv - mm;
-                    pu[j] = pack_bf16(__builtin_amdgcn_exp2f(dv[0]), __builtin_amdgcn_exp2f(dv[1]));
-                }
-                const bf16x8 pf = __builtin_bit_cast(bf16x8, pu);
+                    unsigned pl[NP];
+                    pack(__builtin_amdgcn_exp2f(dv[0]), __builtin_amdgcn_exp2f(dv[1]), pl);
 #pragma unroll
-                for (int d = 0; d < ND; ++d) o[d] = MFMA_BF16(__builtin_bit_cast(bf16x8, va[n][ks][d]), pf, o[d]);
-                o[ND] = MFMA_BF16(ones_f, pf, o[ND]);
+                    for (int p = 0; p < NP; ++p) pf[p][j] = pl[p];
+                }
+#pragma unroll
+                for (int d = 0; d < ND; ++d) mma_planes(va[n][ks][d], pf, o[d]);
+#pragma unroll
+                for (int p = NP - 1; p >= 0; --p) o[ND] = mma(ones_u, pf[p], o[ND]);
             }
         __syncthreads();
     }
@@ -2102,15 +2264,28 @@ static int allow_big_lds(F *kernel) {
 template <int EPI>
 static int launch_gemm(const float *A, const float *W, const float *Wf, const float *bias, float *C, int M, int N, int K,
                        const float *pe, int T, int H, int dh, int bf16, hipStream_t st) {
+    if (bf16 == 2) {     // fp32 emulated on the f16 pipe (opt-in): always the LDS-tiled kernels
+        if (N % 256 == 0 && M > 128) {
+            const int blocks = persistent_blocks(((M + 255) / 256) * (N / 256), 1);
+            if (blocks < 0) return (int)hipErrorInvalidDevice;
+            hipLaunchKernelGGL((gemm_nt_128<EPI, 4, 0, 4, 2>), dim3(blocks), dim3(512), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr);
+        } else {
+            const int blocks = persistent_blocks(((M + 127) / 128) * ((N + 127) / 128), 2);
+            if (blocks < 0) return (int)hipErrorInvalidDevice;
+            hipLaunchKernelGGL((gemm_nt_128<EPI, 2, 0, 2, 2>), dim3(blocks), dim3(256), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr);
+        }
+        VSK_CHECK_LAUNCH();
+        return 0;
+    }
     if (bf16) {          // bf16 matrix pipe (opt-in): always the LDS-tiled kernels
         if (N % 256 == 0 && M > 128) {
             const int blocks = persistent_blocks(((M + 255) / 256) * (N / 256), 1);
             if (blocks < 0) return (int)hipErrorInvalidDevice;
-            hipLaunchKernelGGL((gemm_nt_128<EPI, 4, 0, 4, true>), dim3(blocks), dim3(512), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr);
+            hipLaunchKernelGGL((gemm_nt_128<EPI, 4, 0, 4, 1>), dim3(blocks), dim3(512), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr);
         } else {
             const int blocks = persistent_blocks(((M + 127) / 128) * ((N + 127) / 128), 2);
             if (blocks < 0) return (int)hipErrorInvalidDevice;
-            hipLaunchKernelGGL((gemm_nt_128<EPI, 2, 0, 2, true>), dim3(blocks), dim3(256), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr);
+            hipLaunchKernelGGL((gemm_nt_128<EPI, 2, 0, 2, 1>), dim3(blocks), dim3(256), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr);
         }
         VSK_CHECK_LAUNCH();
         return 0;
@@ -2132,15 +2307,15 @@ static int launch_gemm(const float *A, const float *W, const float *Wf, const fl
     if (use_wide_tiles(M, N) && N % 256 == 0 && !getenv("VS_GEMM_NJ2")) {
         const int blocks = persistent_blocks(((M + 255) / 256) * (N / 256), 1);
         if (blocks < 0) return (int)hipErrorInvalidDevice;
-        hipLaunchKernelGGL((gemm_nt_128<EPI, 4, 0, 4, false>), dim3(blocks), dim3(512), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr);
+        hipLaunchKernelGGL((gemm_nt_128<EPI, 4, 0, 4, 0>), dim3(blocks), dim3(512), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr);
     } else if (use_wide_tiles(M, N)) {
         const int blocks = persistent_blocks(((M + 255) / 256) * ((N + 127) / 128), 1);
         if (blocks < 0) return (int)hipErrorInvalidDevice;
-        hipLaunchKernelGGL((gemm_nt_128<EPI, 4, 0, 2, false>), dim3(blocks), dim3(512), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr);
+        hipLaunchKernelGGL((gemm_nt_128<EPI, 4, 0, 2, 0>), dim3(blocks), dim3(512), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr);
     } else {
         const int blocks = persistent_blocks(((M + 127) / 128) * ((N + 127) / 128), 2);
         if (blocks < 0) return (int)hipErrorInvalidDevice;
-        hipLaunchKernelGGL((gemm_nt_128<EPI, 2, 0, 2, false>), dim3(blocks), dim3(256), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr);
+        hipLaunchKernelGGL((gemm_nt_128<EPI, 2, 0, 2, 0>), dim3(blocks), dim3(256), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr);
     }
     VSK_CHECK_LAUNCH();
     return 0;
@@ -2239,21 +2414,24 @@ int vsk_attention(const float *q, const float *k, const float *v, const uint8_t 
 }
 
 int vsk_attention_bf16(const float *q, const float *k, const float *v, const uint8_t *mask, float *out,
-                       int B, int H, int T, int dh, float scale, hipStream_t st) {
+                       int B, int H, int T, int dh, float scale, int prec, hipStream_t st) {
     const float sl2 = scale * 1.4426950408889634f;
     const int BH = B * H;
     // 8-wave blocks (256 query rows share one staged K/V tile) unless the ragged tail would waste too many rows
     const int r8 = (T + 255) / 256 * 256, r4 = (T + 127) / 128 * 128;
     const bool wide = dh == 64 && !getenv("VS_ATTN_NW4") && r8 * 100 <= r4 * 105;
     dim3 grid(8 * ((BH + 7) / 8) * (wide ? r8 / 256 : r4 / 128));
-    if (dh == 64 && wide)
-        hipLaunchKernelGGL((attn_fwd_bf16<64, 8>), grid, dim3(512), 0, st, q, k, v, mask, out, H, T, sl2, BH);
-    else if (dh == 64)
-        hipLaunchKernelGGL((attn_fwd_bf16<64, 4>), grid, dim3(256), 0, st, q, k, v, mask, out, H, T, sl2, BH);
-    else if (dh == 32)
-        hipLaunchKernelGGL((attn_fwd_bf16<32, 4>), grid, dim3(256), 0, st, q, k, v, mask, out, H, T, sl2, BH);
-    else
+#define VSK_ATTN_LP(P_)                                                                                                  \
+    if (dh == 64 && wide)                                                                                                \
+        hipLaunchKernelGGL((attn_fwd_lp<64, 8, P_>), grid, dim3(512), 0, st, q, k, v, mask, out, H, T, sl2, BH);         \
+    else if (dh == 64)                                                                                                   \
+        hipLaunchKernelGGL((attn_fwd_lp<64, 4, P_>), grid, dim3(256), 0, st, q, k, v, mask, out, H, T, sl2, BH);         \
+    else if (dh == 32)                                                                                                   \
+        hipLaunchKernelGGL((attn_fwd_lp<32, 4, P_>), grid, dim3(256), 0, st, q, k, v, mask, out, H, T, sl2, BH);         \
+    else                                                                                                                 \
         return -1;
+    if (prec == 2) { VSK_ATTN_LP(2) } else { VSK_ATTN_LP(1) }
+#undef VSK_ATTN_LP
     VSK_CHECK_LAUNCH();
     return 0;
 }
@@ -2269,8 +2447,12 @@ int vsk_linear_res_ln(const float *A, const float *W, const float *Wf, const flo
         if (blocks > (M + 127) / 128) blocks = (M + 127) / 128;
 #define VSK_LNB_CASE(NT_)                                                                                   \
     case NT_:                                                                                               \
-        hipLaunchKernelGGL((gemm_ln_rows<NT_, true>), dim3(blocks), dim3(256), 0, st, A, W, bias, res, gamma, \
-                           beta, out, M, K, score_w, score_b, num_classes, sigmoid, scores);                \
+        if (bf16 == 2)                                                                                      \
+            hipLaunchKernelGGL((gemm_ln_rows<NT_, 2>), dim3(blocks), dim3(256), 0, st, A, W, bias, res, gamma, \
+                               beta, out, M, K, score_w, score_b, num_classes, sigmoid, scores);            \
+        else                                                                                                \
+            hipLaunchKernelGGL((gemm_ln_rows<NT_, 1>), dim3(blocks), dim3(256), 0, st, A, W, bias, res, gamma, \
+                               beta, out, M, K, score_w, score_b, num_classes, sigmoid, scores);            \
         break;
         switch (N / 32) {
             VSK_LNB_CASE(2) VSK_LNB_CASE(4) VSK_LNB_CASE(6) VSK_LNB_CASE(8)
@@ -2319,7 +2501,7 @@ int vsk_linear_res_ln(const float *A, const float *W, const float *Wf, const flo
         if (blocks > (M + 127) / 128) blocks = (M + 127) / 128;
 #define VSK_LNR_CASE(NT_)                                                                             \
     case NT_:                                                                                         \
-        hipLaunchKernelGGL((gemm_ln_rows<NT_, false>), dim3(blocks), dim3(256), 0, st, A, W, bias, res, gamma, \
+        hipLaunchKernelGGL((gemm_ln_rows<NT_, 0>), dim3(blocks), dim3(256), 0, st, A, W, bias, res, gamma, \
                            beta, out, M, K, score_w, score_b, num_classes, sigmoid, scores);          \
         break;
         switch (N / 32) {

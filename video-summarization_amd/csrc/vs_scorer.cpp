@@ -225,10 +225,14 @@ int vs_scorer_forward(const vs_weights *w, const float *x, const uint8_t *key_pa
     if (w->has_pe && T > D.max_len)
         return fail(VS_ERR_INVALID, "T=%d exceeds the positional table (max_len=%d)", T, D.max_len);
     if ((long long)B * T > (1ll << 30)) return fail(VS_ERR_INVALID, "B*T too large");
-    if ((flags & VS_FLAG_BF16_LINEAR) && D.d_model > 256)
-        return fail(VS_ERR_INVALID, "VS_FLAG_BF16_LINEAR needs d_model <= 256 (got %d)", D.d_model);
-    if ((flags & VS_FLAG_BF16_ATTENTION) && D.d_model / D.num_heads != 32 && D.d_model / D.num_heads != 64)
-        return fail(VS_ERR_INVALID, "VS_FLAG_BF16_ATTENTION needs head_dim 32 or 64 (got %d)", D.d_model / D.num_heads);
+    if ((flags & (VS_FLAG_BF16_LINEAR | VS_FLAG_F16X3_LINEAR)) && D.d_model > 256)
+        return fail(VS_ERR_INVALID, "VS_FLAG_BF16_LINEAR / VS_FLAG_F16X3_LINEAR need d_model <= 256 (got %d)", D.d_model);
+    if ((flags & VS_FLAG_BF16_LINEAR) && (flags & VS_FLAG_F16X3_LINEAR))
+        return fail(VS_ERR_INVALID, "VS_FLAG_BF16_LINEAR and VS_FLAG_F16X3_LINEAR are exclusive");
+    if ((flags & (VS_FLAG_BF16_ATTENTION | VS_FLAG_F16X3_ATTENTION)) && D.d_model / D.num_heads != 32 && D.d_model / D.num_heads != 64)
+        return fail(VS_ERR_INVALID, "VS_FLAG_BF16_ATTENTION / VS_FLAG_F16X3_ATTENTION need head_dim 32 or 64 (got %d)", D.d_model / D.num_heads);
+    if ((flags & VS_FLAG_BF16_ATTENTION) && (flags & VS_FLAG_F16X3_ATTENTION))
+        return fail(VS_ERR_INVALID, "VS_FLAG_BF16_ATTENTION and VS_FLAG_F16X3_ATTENTION are exclusive");
     const size_t need = vs_scorer_workspace_bytes(w, B, T);
     if (!workspace || workspace_bytes < need)
         return fail(VS_ERR_WORKSPACE, "workspace %zu bytes < %zu needed", workspace_bytes, need);
@@ -242,7 +246,7 @@ int vs_scorer_forward(const vs_weights *w, const float *x, const uint8_t *key_pa
     float *h0 = ws, *h1 = ws + md, *qkv = ws + 2 * md, *att = ws + 5 * md, *ffn = ws + 6 * md;
     const float scale = 1.0f / sqrtf((float)d);        // reference simnet.py:126: d_model ** -0.5
     const int sig = (flags & VS_FLAG_SIGMOID) ? 1 : 0;
-    const int lbf = (flags & VS_FLAG_BF16_LINEAR) ? 1 : 0;
+    const int lbf = (flags & VS_FLAG_F16X3_LINEAR) ? 2 : (flags & VS_FLAG_BF16_LINEAR) ? 1 : 0;
 
     // Embedding + positional table (simnet.py:211, 237-238)
     {
@@ -259,9 +263,9 @@ int vs_scorer_forward(const vs_weights *w, const float *x, const uint8_t *key_pa
         }
         {
             StageScope ps(VS_STAGE_ATTENTION, st);
-            if (flags & VS_FLAG_BF16_ATTENTION)
+            if (flags & (VS_FLAG_BF16_ATTENTION | VS_FLAG_F16X3_ATTENTION))
                 VS_LAUNCH(vsk_attention_bf16(qkv, qkv + (size_t)M * d, qkv + 2 * (size_t)M * d, key_pad_mask, att,
-                                             B, H, T, d / H, scale, st));
+                                             B, H, T, d / H, scale, (flags & VS_FLAG_F16X3_ATTENTION) ? 2 : 1, st));
             else
                 VS_LAUNCH(vsk_attention(qkv, qkv + (size_t)M * d, qkv + 2 * (size_t)M * d, key_pad_mask, att, B, H,
                                         T, d / H, scale, st));
@@ -357,6 +361,11 @@ int vs_linear_bf16(const float *A, const float *W, const float *bias, float *C, 
     return linear_entry(A, W, bias, C, M, N, K, relu, pe, T, 1, stream);
 }
 
+int vs_linear_f16x3(const float *A, const float *W, const float *bias, float *C, int32_t M, int32_t N,
+                    int32_t K, int32_t relu, const float *pe, int32_t T, void *stream) {
+    return linear_entry(A, W, bias, C, M, N, K, relu, pe, T, 2, stream);
+}
+
 int vs_qkv_proj_f32(const float *h, const float *Wqkv, const float *bqkv, float *qkv, int32_t B,
                     int32_t T, int32_t d, int32_t H, void *stream) {
     if (!h || !Wqkv || !bqkv || !qkv) return fail(VS_ERR_INVALID, "NULL pointer");
@@ -375,13 +384,23 @@ int vs_attention_f32(const float *q, const float *k, const float *v, const uint8
     return VS_OK;
 }
 
-int vs_attention_bf16(const float *q, const float *k, const float *v, const uint8_t *key_pad_mask,
-                      float *out, int32_t B, int32_t H, int32_t T, int32_t dh, float scale, void *stream) {
+static int attention_lp_entry(const float *q, const float *k, const float *v, const uint8_t *key_pad_mask,
+                              float *out, int32_t B, int32_t H, int32_t T, int32_t dh, float scale, int prec, void *stream) {
     if (!q || !k || !v || !out) return fail(VS_ERR_INVALID, "NULL pointer");
     if (B <= 0 || H <= 0 || T <= 0) return fail(VS_ERR_INVALID, "B=%d H=%d T=%d", B, H, T);
-    if (dh != 32 && dh != 64) return fail(VS_ERR_INVALID, "head_dim=%d unsupported on the bf16 path", dh);
-    VS_LAUNCH(vsk_attention_bf16(q, k, v, key_pad_mask, out, B, H, T, dh, scale, (hipStream_t)stream));
+    if (dh != 32 && dh != 64) return fail(VS_ERR_INVALID, "head_dim=%d unsupported on the bf16 / f16x3 path", dh);
+    VS_LAUNCH(vsk_attention_bf16(q, k, v, key_pad_mask, out, B, H, T, dh, scale, prec, (hipStream_t)stream));
     return VS_OK;
+}
+
+int vs_attention_bf16(const float *q, const float *k, const float *v, const uint8_t *key_pad_mask,
+                      float *out, int32_t B, int32_t H, int32_t T, int32_t dh, float scale, void *stream) {
+    return attention_lp_entry(q, k, v, key_pad_mask, out, B, H, T, dh, scale, 1, stream);
+}
+
+int vs_attention_f16x3(const float *q, const float *k, const float *v, const uint8_t *key_pad_mask,
+                       float *out, int32_t B, int32_t H, int32_t T, int32_t dh, float scale, void *stream) {
+    return attention_lp_entry(q, k, v, key_pad_mask, out, B, H, T, dh, scale, 2, stream);
 }
 
 static int linear_ln_entry(const float *A, const float *W, const float *bias,
@@ -416,6 +435,15 @@ int vs_linear_residual_layernorm_bf16(const float *A, const float *W, const floa
                                       float *scores, void *stream) {
     return linear_ln_entry(A, W, bias, residual, gamma, beta, out, M, N, K, score_w, score_b, num_classes, sigmoid,
                            scores, 1, stream);
+}
+
+int vs_linear_residual_layernorm_f16x3(const float *A, const float *W, const float *bias,
+                                       const float *residual, const float *gamma, const float *beta,
+                                       float *out, int32_t M, int32_t N, int32_t K, const float *score_w,
+                                       const float *score_b, int32_t num_classes, int32_t sigmoid,
+                                       float *scores, void *stream) {
+    return linear_ln_entry(A, W, bias, residual, gamma, beta, out, M, N, K, score_w, score_b, num_classes, sigmoid,
+                           scores, 2, stream);
 }
 
 }  // extern "C"

@@ -252,10 +252,10 @@ class SimNet(nn.Module):
 
     @attention_dtype.setter
     def attention_dtype(self, value: str) -> None:
-        if value not in ("fp32", "bf16"):
-            raise ValueError("attention_dtype must be 'fp32' or 'bf16', got %r" % (value,))
-        if value == "bf16" and self.d_model // self.num_heads not in (32, 64):
-            raise ValueError("bf16 attention needs head_dim 32 or 64, got %d" % (self.d_model // self.num_heads))
+        if value not in ("fp32", "bf16", "fp16x3"):
+            raise ValueError("attention_dtype must be 'fp32', 'bf16' or 'fp16x3', got %r" % (value,))
+        if value != "fp32" and self.d_model // self.num_heads not in (32, 64):
+            raise ValueError("%s attention needs head_dim 32 or 64, got %d" % (value, self.d_model // self.num_heads))
         self._attention_dtype = value
 
     @property
@@ -264,22 +264,26 @@ class SimNet(nn.Module):
 
     @linear_dtype.setter
     def linear_dtype(self, value: str) -> None:
-        if value not in ("fp32", "bf16"):
-            raise ValueError("linear_dtype must be 'fp32' or 'bf16', got %r" % (value,))
-        if value == "bf16" and self.d_model > 256:
-            raise ValueError("bf16 Linear kernels need d_model <= 256, got %d" % self.d_model)
+        if value not in ("fp32", "bf16", "fp16x3"):
+            raise ValueError("linear_dtype must be 'fp32', 'bf16' or 'fp16x3', got %r" % (value,))
+        if value != "fp32" and self.d_model > 256:
+            raise ValueError("%s Linear kernels need d_model <= 256, got %d" % (value, self.d_model))
         self._linear_dtype = value
 
     def set_compute_dtype(self, value: str) -> "SimNet":
-        """'fp32' (default, the 1e-4 parity path) or 'bf16' (BASELINE config 5: all matrix products on the bf16
-        pipe with fp32 accumulation; tensors, softmax, LayerNorm and the score head stay fp32)."""
+        """'fp32' (default: exact fp32 MFMA), 'fp16x3' (fp32 EMULATED on the f16 matrix pipe: operands split into
+        hi + lo halves, three products, fp32 accumulate - same 1e-4 parity, ~2x faster; operands < 65504) or 'bf16'
+        (BASELINE config 5: operands rounded to bf16, logits move by ~4e-3).  Tensors, softmax, LayerNorm and the
+        score head stay fp32 in every mode."""
         self.attention_dtype = value
         self.linear_dtype = value
         return self
 
     def _attention_flag(self) -> int:
         return ((_lib.VS_FLAG_BF16_ATTENTION if self._attention_dtype == "bf16" else 0)
-                | (_lib.VS_FLAG_BF16_LINEAR if self._linear_dtype == "bf16" else 0))
+                | (_lib.VS_FLAG_F16X3_ATTENTION if self._attention_dtype == "fp16x3" else 0)
+                | (_lib.VS_FLAG_BF16_LINEAR if self._linear_dtype == "bf16" else 0)
+                | (_lib.VS_FLAG_F16X3_LINEAR if self._linear_dtype == "fp16x3" else 0))
 
     # ---- autograd-capable path for train.py / pretrain.py (dropout, backward, autocast) -----
     def _forward_autograd(self, x: Tensor, mask: Optional[Tensor]):
