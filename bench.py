@@ -14,6 +14,9 @@ score matrices (one async all_gather per step, overlapped with the next step's k
 Prints ONE JSON line on rank 0 with the contract fields plus
   roofline      the dominant kernel, from HIP events recorded around every launch of the timed region
   cpu_baseline  the oracle (CPU restatement of the reference, "port") timed on this box's host cores
+  emulated_f32  the same K steps again with every product EMULATED on the f16 matrix pipe ("fp16x3": operands split
+                into f16 hi + lo halves, three products, fp32 accumulate; same 1e-4 parity in the tests) - reported
+                beside `value`, never as `value`: the headline is the exact-fp32 MFMA path (--compute to change).
 """
 import argparse
 import importlib
@@ -28,6 +31,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
+PEAK_F16_MFMA_TFLOPS = 2500.0     # dense f16 / bf16 matrix peak; an fp16x3 product costs 3 f16 products
 # HBM bytes per launch per kernel come from separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; see
 # tools/collect_traffic.sh), committed under profiles/: counters cannot be read from inside the timed run.
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_v4_hbm_traffic.json")
@@ -69,6 +73,9 @@ def main():
     ap.add_argument("--frames", type=int, default=1024)
     ap.add_argument("--model", default="A", choices=["A", "B"], help="A: H4 d256 L4 (run scripts); B: H4 d512 L3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--compute", default="fp32", choices=["fp32", "fp16x3", "bf16"],
+                    help="matrix-product arithmetic of the timed path (default: exact fp32 MFMA)")
+    ap.add_argument("--no-emulated", action="store_true", help="skip the secondary fp16x3 measurement")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline sample length")
     args = ap.parse_args()
 
@@ -96,7 +103,7 @@ def main():
     sd = pkg.synth.make_state_dict(d, L, seed=1234)
     model = pkg.SimNet(num_heads=H, d_model=d, num_layers=L, sparsity=0.0, dropout=0.3)
     model.load_state_dict(sd, strict=True)
-    model = model.to(dev).eval()
+    model = model.to(dev).eval().set_compute_dtype(args.compute)
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)       # disjoint videos per rank
     x_host = torch.randn(B, T, Din, generator=g).pin_memory()
     x = x_host.to(dev)
@@ -130,6 +137,27 @@ def main():
         stages = pkg._lib.profile_collect()
         lib.vs_profile_enable(0)
 
+        # secondary: the same K steps with fp32 emulated on the f16 pipe (never `value`)
+        emu = None
+        if args.compute == "fp32" and not args.no_emulated and d <= 256 and d // H in (32, 64):
+            exact_logits = model(x)[0].clone()
+            model.set_compute_dtype("fp16x3")
+            for _ in range(max(2, args.warmup // 2)):
+                w = step()
+                if w is not None:
+                    w.wait()
+            fence()
+            t2 = time.perf_counter()
+            works = [step() for _ in range(args.steps)]
+            for w in works:
+                if w is not None:
+                    w.wait()
+            fence()
+            dt_emu = time.perf_counter() - t2
+            diff = (model(x)[0] - exact_logits).abs().max().item()
+            model.set_compute_dtype("fp32")
+            emu = (dt_emu, diff)
+
         # PCIe-inclusive rate (never `value`): pinned host batch -> device -> forward, same stream
         fence()
         t1 = time.perf_counter()
@@ -139,9 +167,11 @@ def main():
         pcie_fps = 3 * B * T / (time.perf_counter() - t1)
 
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt, emu[0] if emu else 0.0, emu[1] if emu else 0.0], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
+        dt = t[0].item()
+        if emu:
+            emu = (t[1].item(), t[2].item())
     frames = B * T * world * args.steps
     value = frames / dt
 
@@ -162,12 +192,14 @@ def main():
             v["share"] = round(v["avg_ms"] * v["launches"] / tot, 3)
         dom = max(table, key=lambda k: table[k]["share"])
         flops_per_frame = 2 * Din * d + L * (24 * d * d + 4 * T * d) + 2 * d
-        roofline = {"bound": "mfma", "kernel": dom, "achieved": table[dom]["tflops"], "peak": PEAK_F32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(table[dom]["tflops"] / PEAK_F32_MFMA_TFLOPS, 4),
-                    "traffic": measured_traffic(dom) if (B, T, args.model) == (64, 1024, "A") else None,
+        # peak of the arithmetic the timed path used: fp32 MFMA, or f16 MFMA / 3 products (fp16x3), or bf16 MFMA
+        peak = {"fp32": PEAK_F32_MFMA_TFLOPS, "fp16x3": PEAK_F16_MFMA_TFLOPS / 3, "bf16": PEAK_F16_MFMA_TFLOPS}[args.compute]
+        roofline = {"bound": "mfma", "kernel": dom, "achieved": table[dom]["tflops"], "peak": round(peak, 1),
+                    "unit": "TFLOP/s", "frac": round(table[dom]["tflops"] / peak, 4),
+                    "traffic": measured_traffic(dom) if (B, T, args.model, args.compute) == (64, 1024, "A", "fp32") else None,
                     "whole_forward": {"flop_per_frame": flops_per_frame,
                                       "achieved": round(value / world * flops_per_frame / 1e12, 2),
-                                      "frac": round(value / world * flops_per_frame / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)},
+                                      "frac": round(value / world * flops_per_frame / 1e12 / peak, 4)},
                     "stages": table}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
@@ -179,7 +211,10 @@ def main():
             "metric": "frames/sec scored (whole node), synthetic [B,T=1024,D=1024]",
             "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": {"fp32": "f32", "fp16x3": "f32 emulated as 3 x f16 MFMA (hi+lo operand split), f32 accumulate",
+                      "bf16": "bf16 MFMA operands, f32 accumulate"}[args.compute],
+            "data": "synthetic",
             "config": {"workload": "configs[2]: B=%d videos x T=%d frames x D=%d per GPU, scorer cfg M-%s "
                                    "(heads %d, d_model %d, layers %d), logits + hidden state" % (B, T, Din, args.model, H, d, L),
                        "global_batch": B * world, "frames_per_step": B * T * world,
@@ -187,6 +222,14 @@ def main():
             "pcie_inclusive_value": round(pcie_fps * world, 1),
             "roofline": roofline, "cpu_baseline": cpu,
         }
+        if emu:
+            ev = frames / emu[0]
+            out["emulated_f32"] = {
+                "mode": "fp16x3: every product as 3 f16 MFMAs over hi+lo operand halves, f32 accumulate (opt-in "
+                        "SimNet.set_compute_dtype('fp16x3'); parity tests hold it to the same 1e-4 goldens)",
+                "value": round(ev, 1), "unit": "frames/s", "ms_per_step": round(emu[0] / args.steps * 1e3, 4),
+                "speedup_vs_value": round(ev / value, 3), "max_abs_logit_diff_vs_exact": emu[1],
+                "f32_equivalent_tflops": round(ev / world * flops_per_frame / 1e12, 2)}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
