@@ -1927,6 +1927,316 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_lp(
 }
 
 // ------------------------------------------------------------------------------------------
+// attn_fwd_lp, software-pipelined (the default for the bf16 / fp16x3 modes): attn_fwd_lp keeps every wave in
+// the same phase (the per-tile barrier aligns them), so the matrix pipe idles during the softmax and the VALU
+// during the products.  Here K runs one tile ahead of V: iteration t issues the MFMAs of S(t+1) = K(t+1) Q^T
+// with the softmax of tile t (max3 chain, deferred-max check, exp2, hi/lo split) sliced between them, then the
+// MFMAs of O += V(t)^T P(t)^T (+ row sums) with the staging of K(t+2) / V(t+1) (split, LDS writes) and the
+// buffer loads of K(t+3) / V(t+2) between them.  One barrier per tile; K and V double-buffered in LDS, the
+// key-mask bias triple-buffered (it is read two iterations after it is written).
+// ------------------------------------------------------------------------------------------
+template <int DH, int NW, int PREC>
+__global__ __launch_bounds__(64 * NW, 2) void attn_fwd_lp_pipe(
+    const float *__restrict__ Q, const float *__restrict__ Kg, const float *__restrict__ Vg,
+    const uint8_t *__restrict__ mask, float *__restrict__ out, int H, int T, float scale_log2e, int BH) {
+    constexpr int KT = 64, NS = DH / 16, ND = DH / 32, NT = 64 * NW, QB = 32 * NW;
+    constexpr int NP = PREC == 2 ? 2 : 1, NPROD = PREC == 2 ? 3 : 1;
+    constexpr int LDK = DH + 8, LDV = KT + 4, D4 = DH / 4;
+    constexpr int KPT = KT * D4 / NT;
+    static_assert(KPT == 2 || KPT == 4, "staging packs 2 or 4 keys per V^T store");
+    constexpr float THR = 8.0f;
+    typedef unsigned short h16;
+    __shared__ __attribute__((aligned(16))) h16 Kb[2][NP][KT * LDK];
+    __shared__ __attribute__((aligned(16))) h16 Vt[2][NP][DH * LDV];
+    __shared__ __attribute__((aligned(16))) float mb[3][KT];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    int bh, qt;
+    if (!attn_block_map((T + QB - 1) / QB, BH, bh, qt)) return;
+    const int b = bh / H, head = bh - b * H;
+    const size_t base = (size_t)bh * T * DH;
+    const int q0 = qt * QB + 32 * wave;
+    const float NEG_INF = -__builtin_inff();
+
+    auto pack = [&](float x0, float x1, unsigned (&pl)[NP]) __attribute__((always_inline)) {
+        if constexpr (PREC == 2) split_f16(x0, x1, pl[0], pl[1]);
+        else pl[0] = pack_bf16(x0, x1);
+    };
+    auto mma = [&](const u32x4 &a, const u32x4 &bq, const f32x16 &c) __attribute__((always_inline)) -> f32x16 {
+        if constexpr (PREC == 2) return MFMA_F16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, bq), c);
+        else return MFMA_BF16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, bq), c);
+    };
+    // product `pr` of the plane expansion, small terms first: (lo,hi), (hi,lo), (hi,hi); bf16: (hi,hi) only
+    auto mma_prod = [&](auto prc, const u32x4 (&a)[NP], const u32x4 (&bq)[NP], f32x16 &c) __attribute__((always_inline)) {
+        constexpr int pr = decltype(prc)::value;
+        if constexpr (PREC == 2 && pr == 0) c = mma(a[1], bq[0], c);
+        else if constexpr (PREC == 2 && pr == 1) c = mma(a[0], bq[1], c);
+        else c = mma(a[0], bq[0], c);
+    };
+
+    u32x4 qreg[NS][NP];
+    {
+        int qr = q0 + r; qr = qr < T ? qr : T - 1;
+        const float *qp = Q + base + (size_t)qr * DH + 8 * h;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const f32x4 v0 = *(const f32x4 *)(qp + 16 * s), v1 = *(const f32x4 *)(qp + 16 * s + 4);
+            unsigned pl[4][NP];
+            pack(v0[0] * scale_log2e, v0[1] * scale_log2e, pl[0]);
+            pack(v0[2] * scale_log2e, v0[3] * scale_log2e, pl[1]);
+            pack(v1[0] * scale_log2e, v1[1] * scale_log2e, pl[2]);
+            pack(v1[2] * scale_log2e, v1[3] * scale_log2e, pl[3]);
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) qreg[s][p][e] = pl[e][p];
+        }
+    }
+    f32x16 o[ND + 1];                               // O^T blocks + the row sums (block of ones)
+#pragma unroll
+    for (int d = 0; d <= ND; ++d)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) o[d][t] = 0.f;
+    float m_run = NEG_INF;
+    constexpr unsigned ONE2 = PREC == 2 ? 0x3C003C00u : 0x3F803F80u;
+    const u32x4 ones_u = {ONE2, ONE2, ONE2, ONE2};
+
+    const int d4 = tid % D4, kq = tid / D4;
+    const int ntiles = (T + KT - 1) / KT;
+    const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Kg + base), 0, T * DH * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Vg + base), 0, T * DH * 4, 0x00020000);
+    int voff[KPT];
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) voff[i] = ((KPT * kq + i) * DH + 4 * d4) * 4;
+    f32x4 pk[KPT], pv[KPT];
+    float pm = 0.f;
+    // the pipeline runs up to three tiles past the end: those loads re-read the last tile (their products are
+    // never consumed); rows beyond T inside the last tile read as zeros (buffer bounds check) and are masked
+    auto gload_k = [&](int tile) __attribute__((always_inline)) {
+        tile = tile < ntiles ? tile : ntiles - 1;
+#pragma unroll
+        for (int i = 0; i < KPT; ++i)
+            pk[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(krs, voff[i], tile * (KT * DH * 4), 0));
+    };
+    auto gload_v = [&](int tile) __attribute__((always_inline)) {
+        tile = tile < ntiles ? tile : ntiles - 1;
+#pragma unroll
+        for (int i = 0; i < KPT; ++i)
+            pv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(vrs, voff[i], tile * (KT * DH * 4), 0));
+    };
+    auto gload_m = [&](int tile) __attribute__((always_inline)) {
+        if (tid < KT) {
+            const int key = tile * KT + tid;
+            float pmv = key >= T ? NEG_INF : 0.f;
+            if (mask != nullptr) pmv = mask[(size_t)b * T + (key < T ? key : T - 1)] != 0 ? NEG_INF : pmv;
+            pm = pmv;
+        }
+    };
+    auto stage_k1 = [&](int i, int buf) __attribute__((always_inline)) {
+        unsigned p0[NP], p1[NP];
+        pack(pk[i][0], pk[i][1], p0);
+        pack(pk[i][2], pk[i][3], p1);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            u32x2 u; u[0] = p0[p]; u[1] = p1[p];
+            *(u32x2 *)&Kb[buf][p][(KPT * kq + i) * LDK + 4 * d4] = u;
+        }
+    };
+    auto stage_v1 = [&](int e, int buf) __attribute__((always_inline)) {
+        if constexpr (KPT == 4) {
+            unsigned p0[NP], p1[NP];
+            pack(pv[0][e], pv[1][e], p0);
+            pack(pv[2][e], pv[3][e], p1);
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                u32x2 u; u[0] = p0[p]; u[1] = p1[p];
+                *(u32x2 *)&Vt[buf][p][(4 * d4 + e) * LDV + 4 * kq] = u;
+            }
+        } else {
+            unsigned p0[NP];
+            pack(pv[0][e], pv[1][e], p0);
+#pragma unroll
+            for (int p = 0; p < NP; ++p) *(unsigned *)&Vt[buf][p][(4 * d4 + e) * LDV + 2 * kq] = p0[p];
+        }
+    };
+    auto stage_m = [&](int mbuf) __attribute__((always_inline)) { if (tid < KT) mb[mbuf][tid] = pm; };
+    auto k_frag = [&](int buf, int ks, int n, u32x4 (&ka)[NP]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) ka[p] = *(const u32x4 *)&Kb[buf][p][(32 * n + r) * LDK + 16 * ks + 8 * h];
+    };
+    auto v_frag = [&](int buf, int n, int ks, int d, u32x4 (&va)[NP]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const h16 *vp = &Vt[buf][p][(32 * d + r) * LDV + 32 * n + 16 * ks + 4 * h];
+            const u32x2 lo = *(const u32x2 *)vp, hi = *(const u32x2 *)(vp + 8);
+            va[p][0] = lo[0]; va[p][1] = lo[1]; va[p][2] = hi[0]; va[p][3] = hi[1];
+        }
+    };
+
+    // ---- prologue: K(0), V(0), K(1) in LDS; K(2), V(1) in registers; S(0) computed ----
+    gload_k(0); gload_v(0); gload_m(0);
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) stage_k1(i, 0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) stage_v1(e, 0);
+    stage_m(0);
+    gload_k(1); gload_m(1);
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) stage_k1(i, 1);
+    stage_m(1);
+    gload_k(2); gload_m(2); gload_v(1);
+    __syncthreads();
+    f32x16 sa[2], sb[2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) { sa[n][t] = 0.f; sb[n][t] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < NS; ++ks)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            u32x4 ka[NP];
+            k_frag(0, ks, n, ka);
+            static_for<NPROD>([&](auto prc) { mma_prod(prc, ka, qreg[ks], sa[n]); });
+        }
+
+    // softmax state of the tile in flight
+    float sm_mx = 0.f;
+    f32x2 sm_mm = {0.f, 0.f};
+    u32x4 pf[2][2][NP];
+    // one unit of softmax(t) work on s_in: 0..3 max3 chain, 4 deferred-max check (+ rare rescale), 5..20 one
+    // (n, ks, j) pair each: subtract, exp2, pack / split into the P fragments
+    auto sm_unit = [&](auto uc, f32x16 (&sv)[2]) __attribute__((always_inline)) {
+        constexpr int U = decltype(uc)::value;
+        if constexpr (U == 0) {
+            sm_mx = __builtin_fmaxf(__builtin_fmaxf(sv[0][0], sv[0][1]), sv[1][0]);
+            sm_mx = __builtin_fmaxf(sm_mx, sv[1][1]);
+        }
+        if constexpr (U < 4) {
+            constexpr int t0 = U == 0 ? 2 : 4 * U;
+#pragma unroll
+            for (int t = t0; t < 4 * U + 4; t += 2) {
+                sm_mx = __builtin_fmaxf(__builtin_fmaxf(sm_mx, sv[0][t]), sv[0][t + 1]);
+                sm_mx = __builtin_fmaxf(__builtin_fmaxf(sm_mx, sv[1][t]), sv[1][t + 1]);
+            }
+        }
+        if constexpr (U == 4) {
+            const float mx = pair_max(sm_mx);
+            const bool raise = mx > m_run + THR || (m_run == NEG_INF && mx != NEG_INF);
+            if (__builtin_expect(__any(raise), 0)) {
+                const float m_new = raise ? mx : m_run;
+                const float u_new = (m_new == NEG_INF) ? 0.f : m_new;
+                const float alpha = __builtin_amdgcn_exp2f(m_run - u_new);
+#pragma unroll
+                for (int d = 0; d <= ND; ++d)
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) o[d][t] *= alpha;
+                m_run = m_new;
+            }
+            const float m_use = (m_run == NEG_INF) ? 0.f : m_run;
+            sm_mm[0] = m_use; sm_mm[1] = m_use;
+        }
+        if constexpr (U >= 5 && U < 21) {
+            constexpr int k = U - 5, n = k / 8, ks = (k / 4) % 2, j = k % 4;
+            const f32x2 sx = {sv[n][8 * ks + 2 * j], sv[n][8 * ks + 2 * j + 1]};
+            const f32x2 dv = sx - sm_mm;
+            unsigned pl[NP];
+            pack(__builtin_amdgcn_exp2f(dv[0]), __builtin_amdgcn_exp2f(dv[1]), pl);
+#pragma unroll
+            for (int p = 0; p < NP; ++p) pf[n][ks][p][j] = pl[p];
+        }
+    };
+    constexpr int NU = 21;
+    constexpr int NSLOT_A = NS * 2 * NPROD, RA = (NU + NSLOT_A - 1) / NSLOT_A;
+    constexpr int NSLOT_B = 4 * (ND * NPROD + NP);
+    constexpr int NITEM = KPT + 4 + 2, SB = NSLOT_B / NITEM > 0 ? NSLOT_B / NITEM : 1;    // staging items, slot stride
+
+    // one iteration: s_in = S(t) (complete), s_out <- S(t+1)
+    auto iteration = [&](int t, f32x16 (&s_in)[2], f32x16 (&s_out)[2]) __attribute__((always_inline)) {
+        const int cur = t & 1, nxt = cur ^ 1;
+        if (mask != nullptr || (t + 1) * KT > T) {       // masked / ragged tile: key-mask bias first (rare)
+            const float *mp = mb[t % 3];
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 bv = *(const f32x4 *)&mp[32 * n + 8 * g + 4 * h];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) s_in[n][4 * g + e] += bv[e];
+                }
+        }
+        // ---- phase A: S(t+1) MFMAs, softmax(t) between them ----
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int x = 0; x < 16; ++x) s_out[n][x] = 0.f;
+        u32x4 ka[2][NP];
+        k_frag(nxt, 0, 0, ka[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<NSLOT_A>([&](auto ic) {
+            constexpr int i = decltype(ic)::value, g = i / NPROD, pr = i % NPROD, ks = g / 2, n = g % 2;
+            if constexpr (pr == 0 && g + 1 < NS * 2) k_frag(nxt, (g + 1) / 2, (g + 1) % 2, ka[(g + 1) & 1]);
+            mma_prod(std::integral_constant<int, pr>{}, ka[g & 1], qreg[ks], s_out[n]);
+            static_for<RA>([&](auto rc) {
+                constexpr int U = i * RA + decltype(rc)::value;
+                if constexpr (U < NU) sm_unit(std::integral_constant<int, U>{}, s_in);
+            });
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        // ---- phase B: O += V(t)^T P(t)^T and the row sums; staging of K(t+2), V(t+1), loads of K(t+3), V(t+2) ----
+        u32x4 va[2][NP];
+        v_frag(cur, 0, 0, 0, va[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<NSLOT_B>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            constexpr int PER = ND * NPROD + NP;                 // MFMAs per (n, ks): products per d block, then row sums
+            constexpr int g = i / PER, w = i % PER, n = g / 2, ks = g % 2;
+            if constexpr (w < ND * NPROD) {
+                constexpr int d = w / NPROD, pr = w % NPROD, f = g * ND + d;       // fragment index
+                if constexpr (pr == 0 && f + 1 < 4 * ND)
+                    v_frag(cur, (f + 1) / ND / 2, ((f + 1) / ND) % 2, (f + 1) % ND, va[(f + 1) & 1]);
+                mma_prod(std::integral_constant<int, pr>{}, va[f & 1], pf[n][ks], o[d]);
+            } else {
+                constexpr int p = NP - 1 - (w - ND * NPROD);     // lo plane first
+                o[ND] = mma(ones_u, pf[n][ks][p], o[ND]);
+            }
+            if constexpr (i % SB == SB - 1 && i / SB < NITEM) {
+                constexpr int item = i / SB;
+                if constexpr (item < KPT) stage_k1(item, cur);
+                else if constexpr (item < KPT + 4) stage_v1(item - KPT, nxt);
+                else if constexpr (item == KPT + 4) { stage_m((t + 2) % 3); }
+                else { gload_k(t + 3); gload_m(t + 3); gload_v(t + 2); }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        __syncthreads();
+    };
+
+    int t = 0;
+    for (; t + 1 < ntiles; t += 2) {
+        iteration(t, sa, sb);
+        iteration(t + 1, sb, sa);
+    }
+    if (t < ntiles) iteration(t, sa, sb);
+
+    const int q = q0 + r;
+    if (q < T) {
+        const float inv = 1.0f / o[ND][0];
+        float *op = out + ((size_t)b * T + q) * (H * DH) + head * DH;
+#pragma unroll
+        for (int d = 0; d < ND; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = o[d][4 * g + e] * inv;
+                *(f32x4 *)(op + 32 * d + 8 * g + 4 * h) = v;
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Attention, software-pipelined (head dim 32 / 64): same math and operand trick as attn_fwd.
 //
 // Measured on gfx950 (profiles/): the fp32 MFMA shares the SIMD's FP32 lanes with
@@ -2421,16 +2731,18 @@ int vsk_attention_bf16(const float *q, const float *k, const float *v, const uin
     const int r8 = (T + 255) / 256 * 256, r4 = (T + 127) / 128 * 128;
     const bool wide = dh == 64 && !getenv("VS_ATTN_NW4") && r8 * 100 <= r4 * 105;
     dim3 grid(8 * ((BH + 7) / 8) * (wide ? r8 / 256 : r4 / 128));
-#define VSK_ATTN_LP(P_)                                                                                                  \
+    static const bool simple = getenv("VS_ATTN_LP_SIMPLE") != nullptr;      // A/B switch for tools/, not a fallback
+#define VSK_ATTN_LP(KERN_, P_)                                                                                           \
     if (dh == 64 && wide)                                                                                                \
-        hipLaunchKernelGGL((attn_fwd_lp<64, 8, P_>), grid, dim3(512), 0, st, q, k, v, mask, out, H, T, sl2, BH);         \
+        hipLaunchKernelGGL((KERN_<64, 8, P_>), grid, dim3(512), 0, st, q, k, v, mask, out, H, T, sl2, BH);               \
     else if (dh == 64)                                                                                                   \
-        hipLaunchKernelGGL((attn_fwd_lp<64, 4, P_>), grid, dim3(256), 0, st, q, k, v, mask, out, H, T, sl2, BH);         \
+        hipLaunchKernelGGL((KERN_<64, 4, P_>), grid, dim3(256), 0, st, q, k, v, mask, out, H, T, sl2, BH);               \
     else if (dh == 32)                                                                                                   \
-        hipLaunchKernelGGL((attn_fwd_lp<32, 4, P_>), grid, dim3(256), 0, st, q, k, v, mask, out, H, T, sl2, BH);         \
+        hipLaunchKernelGGL((KERN_<32, 4, P_>), grid, dim3(256), 0, st, q, k, v, mask, out, H, T, sl2, BH);               \
     else                                                                                                                 \
         return -1;
-    if (prec == 2) { VSK_ATTN_LP(2) } else { VSK_ATTN_LP(1) }
+    if (simple) { if (prec == 2) { VSK_ATTN_LP(attn_fwd_lp, 2) } else { VSK_ATTN_LP(attn_fwd_lp, 1) } }
+    else        { if (prec == 2) { VSK_ATTN_LP(attn_fwd_lp_pipe, 2) } else { VSK_ATTN_LP(attn_fwd_lp_pipe, 1) } }
 #undef VSK_ATTN_LP
     VSK_CHECK_LAUNCH();
     return 0;
