@@ -2672,6 +2672,15 @@ int vsk_diag_gemm(const float *A, const float *W, const float *bias, float *C, i
                           : persistent_blocks(((M + 127) / 128) * ((N + 127) / 128), 2);
     if (blocks < 0) return (int)hipErrorInvalidDevice;
     if (grid > 0) blocks = grid;
+    if (getenv("VS_DIAG_PREC")) {         // the fp16x3 instantiation (256x256 tiles): 2 = without, else with the epilogue
+        blocks = grid > 0 ? grid : persistent_blocks(((M + 255) / 256) * (N / 256), 1);
+        if (m == 2)
+            hipLaunchKernelGGL((gemm_nt_128<EPI_RELU, 4, 2, 4, 2>), dim3(blocks), dim3(512), 0, st, A, W, bias, C, M, N, K, nullptr, 1, 0, 0, diag);
+        else
+            hipLaunchKernelGGL((gemm_nt_128<EPI_RELU, 4, 3, 4, 2>), dim3(blocks), dim3(512), 0, st, A, W, bias, C, M, N, K, nullptr, 1, 0, 0, diag);
+        VSK_CHECK_LAUNCH();
+        return 0;
+    }
 #define VSK_DG(NWM_, D_) hipLaunchKernelGGL((gemm_nt_128<EPI_RELU, NWM_, D_, 2>), dim3(blocks), dim3(128 * NWM_), 0, st, A, W, bias, C, M, N, K, nullptr, 1, 0, 0, diag)
     if (diag == nullptr) { if (nwm == 4) VSK_DG(4, 0); else VSK_DG(2, 0); }
     else if (m == 1) { if (nwm == 4) VSK_DG(4, 1); else VSK_DG(2, 1); }
