@@ -837,3 +837,25 @@ def test_f16x3_full_size_batch_against_exact_path(vsa):
     dl, dh = (l16 - l32).abs().max().item(), (h16 - h32).abs().max().item()
     print("f16x3 vs exact at B=64 T=1024: logits %.2e hidden %.2e" % (dl, dh))
     assert dl < TOL and dh < TOL
+
+
+def test_f16x3_ragged_padded_batch_matches_oracle(vsa):
+    """fp16x3 on a right-padded batch large enough for the emulated Linear kernels (1600 rows): the 1000.0 padding
+    sentinel (collate_fn_train) must survive the f16 split, valid frames must meet the 1e-4 bar."""
+    synth = vsa.synth
+    sd = synth.make_state_dict(256, 4, 71, trained_like=True)
+    lengths = [400, 333, 64, 1]
+    x = synth.make_features(4, 400, 72, "pool5", lengths=lengths)
+    mask = synth.padding_mask(x)
+    m = vsa.SimNet(num_heads=4, d_model=256, num_layers=4, sparsity=0.0, dropout=0.3)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(_dev()).eval().set_compute_dtype("fp16x3")
+    with torch.no_grad():
+        logits, hidden = m(x.to(_dev()), mask.to(_dev()))
+        rl, rh = oracle_forward(sd, x, mask, 4)
+    valid = ~mask
+    assert torch.isfinite(logits.cpu()[valid]).all()
+    dl = (logits.cpu() - rl).abs().squeeze(-1)[valid].max().item()
+    dh = (hidden.cpu() - rh).abs()[valid].max().item()
+    print("f16x3 ragged padded: logits %.2e hidden %.2e" % (dl, dh))
+    assert dl < TOL and dh < TOL
