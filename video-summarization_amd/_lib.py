@@ -5,6 +5,7 @@ shared object is missing or a symbol is absent, ``load()`` raises — loudly —
 """
 from __future__ import annotations
 
+import concurrent.futures
 import ctypes as C
 import os
 import subprocess
@@ -15,7 +16,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(ROOT, "include")
 LIB_PATH = os.path.join(HERE, "libvsscore.so")
-SOURCES = ("vs_kernels.hip", "vs_scorer.cpp", "vs_eval.cpp")
+SOURCES = ("vs_kernels.hip", "vs_attention.hip", "vs_scorer.cpp", "vs_eval.cpp")
 ABI_VERSION = 1
 
 VS_OK, VS_ERR_INVALID, VS_ERR_WORKSPACE, VS_ERR_HIP = 0, 1, 2, 3
@@ -76,18 +77,36 @@ def build(force: bool = False, verbose: bool = False) -> str:
     (works without a GPU).  Returns the library path."""
     if not force and not needs_build():
         return LIB_PATH
-    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wno-unused-value", "-fno-slp-vectorize", "-pthread", "-I" + INCLUDE, "-I" + CSRC]
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-fno-slp-vectorize",
+             "-pthread", "-I" + INCLUDE, "-I" + CSRC]
     # -fno-slp-vectorize: packed f32 VALU (v_pk_mul/add_f32) beside MFMAs costs more than the scalar
     # forms it replaces (MI355X_MICROARCH.md, cycle constants); keep elementwise epilogue/softmax ops scalar
-    cmd += [os.path.join(CSRC, s) for s in SOURCES]
     tmp = LIB_PATH + ".tmp.%d" % os.getpid()
-    cmd += ["-o", tmp]
-    if verbose:
-        print(" ".join(cmd))
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    if r.returncode != 0:
-        raise RuntimeError("hipcc failed building libvsscore.so:\n" + r.stdout + r.stderr)
+    objs = [tmp + "." + os.path.splitext(src)[0] + ".o" for src in SOURCES]
+
+    def compile_one(pair):
+        src, obj = pair
+        cmd = [hipcc_path()] + flags + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        return subprocess.run(cmd, capture_output=True, text=True)
+
+    try:
+        # one hipcc per translation unit, side by side (the two kernel files dominate the build time)
+        with concurrent.futures.ThreadPoolExecutor(max_workers=len(SOURCES)) as pool:
+            for r in pool.map(compile_one, zip(SOURCES, objs)):
+                if r.returncode != 0:
+                    raise RuntimeError("hipcc failed building libvsscore.so:\n" + r.stdout + r.stderr)
+        cmd = [hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread"] + objs + ["-o", tmp]
+        if verbose:
+            print(" ".join(cmd))
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed linking libvsscore.so:\n" + r.stdout + r.stderr)
+    finally:
+        for o in objs:
+            if os.path.exists(o):
+                os.remove(o)
     os.replace(tmp, LIB_PATH)
     return LIB_PATH
 

@@ -1,0 +1,1100 @@
+// vs_attention.hip — gfx950 attention kernels of the frame-importance scorer (reference simnet.py:155-161):
+//   attn_fwd            exact fp32, head dim 128 (and the A/B baseline for 32/64)
+//   attn_fwd_pipe       exact fp32, software-pipelined, head dim 32/64 (the default path)
+//   attn_fwd_lp(_pipe)  opt-in low-precision matrix pipes: bf16 operands, or fp32 emulated with f16 hi+lo halves
+#include "vs_device.h"
+#include "vs_kernels.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// Attention: softmax(q k^T * scale + keymask) v without materialising [T,T].
+//   grid = (ceil(T/128), B*H); 4 waves, each owns 32 query rows and walks all key tiles.
+//   Both products keep the QUERY on the lane: S^T = K * Q^T  (A = K tile from LDS, B = Q in
+//   registers) leaves, for query r, 16 keys per register set; O^T = V^T * P^T then takes that
+//   accumulator register t directly as its B operand (keys (t&3)+8(t>>2)+4h — exactly the
+//   k-pair of MFMA step t) with A = V[key][d-column] read from LDS.  So the softmax row
+//   statistics (max, sum, rescale) are lane-local plus one exchange with lane^32, and P never
+//   leaves registers.
+// ------------------------------------------------------------------------------------------
+template <int DH, int NKB>   // NKB 32-key blocks per tile
+__global__ __launch_bounds__(256, 2) void attn_fwd(
+    const float *__restrict__ Q, const float *__restrict__ Kg, const float *__restrict__ Vg,
+    const uint8_t *__restrict__ mask, float *__restrict__ out, int H, int T, float scale_log2e, int BH) {
+    constexpr int KT = 32 * NKB, LD = DH + 4, NJ = DH / 8, ND = DH / 32;
+    constexpr int F4 = KT * DH / 4 / 256;          // float4 per thread per operand tile
+    __shared__ __attribute__((aligned(16))) float Ks[KT * LD];
+    __shared__ __attribute__((aligned(16))) float Vs[KT * LD];
+    __shared__ float mb[KT];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    int bh, qt;
+    if (!attn_block_map((T + 127) / 128, BH, bh, qt)) return;
+    const int b = bh / H, head = bh - b * H;
+    const size_t base = (size_t)bh * T * DH;
+    const int q0 = qt * 128 + 32 * wave;
+    const float NEG_INF = -__builtin_inff();
+
+    // Q fragment (B operand), pre-multiplied by scale*log2(e) so that p = exp2(s - m)
+    float qreg[4 * NJ];
+    {
+        int qr = q0 + r; qr = qr < T ? qr : T - 1;
+        const float *qp = Q + base + (size_t)qr * DH + 4 * h;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const f32x4 v = *(const f32x4 *)(qp + 8 * j);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) qreg[4 * j + s] = v[s] * scale_log2e;
+        }
+    }
+
+    f32x16 o[ND];
+#pragma unroll
+    for (int d = 0; d < ND; ++d)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) o[d][t] = 0.f;
+    float m_run = NEG_INF, l_run = 0.f;
+
+    const int ntiles = (T + KT - 1) / KT;
+    f32x4 pk[F4], pv[F4];
+    auto prefetch = [&](int tile) {
+#pragma unroll
+        for (int i = 0; i < F4; ++i) {
+            const int idx = tid + 256 * i;               // float4 index inside the tile
+            int row = tile * KT + idx / (DH / 4);
+            row = row < T ? row : T - 1;
+            const size_t off = base + (size_t)row * DH + (idx % (DH / 4)) * 4;
+            pk[i] = *(const f32x4 *)(Kg + off);
+            pv[i] = *(const f32x4 *)(Vg + off);
+        }
+    };
+    prefetch(0);
+
+    for (int tile = 0; tile < ntiles; ++tile) {
+        const int k0 = tile * KT;
+#pragma unroll
+        for (int i = 0; i < F4; ++i) {
+            const int idx = tid + 256 * i;
+            const int row = idx / (DH / 4), c = (idx % (DH / 4)) * 4;
+            *(f32x4 *)&Ks[row * LD + c] = pk[i];
+            *(f32x4 *)&Vs[row * LD + c] = pv[i];
+        }
+        if (tid < KT) {
+            const int key = k0 + tid;
+            bool dead = key >= T;
+            if (!dead && mask != nullptr) dead = mask[(size_t)b * T + key] != 0;
+            mb[tid] = dead ? NEG_INF : 0.f;
+        }
+        __syncthreads();
+        if (tile + 1 < ntiles) prefetch(tile + 1);
+
+        // ---- S^T = K * Q^T ----
+        f32x16 s[NKB];
+#pragma unroll
+        for (int n = 0; n < NKB; ++n)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) s[n][t] = 0.f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            f32x4 ka[NKB];
+#pragma unroll
+            for (int n = 0; n < NKB; ++n) ka[n] = *(const f32x4 *)&Ks[(32 * n + r) * LD + 8 * j + 4 * h];
+#pragma unroll
+            for (int st = 0; st < 4; ++st)
+#pragma unroll
+                for (int n = 0; n < NKB; ++n) s[n] = MFMA32(ka[n][st], qreg[4 * j + st], s[n]);
+        }
+        // ---- key mask (padding mask and the ragged tail) ----
+        if (mask != nullptr || k0 + KT > T) {
+#pragma unroll
+            for (int n = 0; n < NKB; ++n)
+#pragma unroll
+                for (int t = 0; t < 16; ++t) s[n][t] += mb[32 * n + acc_row(t, h)];
+        }
+        // ---- online softmax, one query per lane pair (l, l^32) ----
+        float mx = NEG_INF;
+#pragma unroll
+        for (int n = 0; n < NKB; ++n)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) mx = fmaxf(mx, s[n][t]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);
+        const float m_use = (m_new == NEG_INF) ? 0.f : m_new;
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
+        float psum = 0.f;
+#pragma unroll
+        for (int n = 0; n < NKB; ++n)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const float p = __builtin_amdgcn_exp2f(s[n][t] - m_use);
+                s[n][t] = p;
+                psum += p;
+            }
+        psum += __shfl_xor(psum, 32);
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int d = 0; d < ND; ++d)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) o[d][t] *= alpha;
+        // ---- O^T += V^T * P^T ----
+#pragma unroll
+        for (int d = 0; d < ND; ++d) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+#pragma unroll
+                for (int n = 0; n < NKB; ++n) {
+                    const float va = Vs[(32 * n + acc_row(t, h)) * LD + 32 * d + r];
+                    o[d] = MFMA32(va, s[n][t], o[d]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: O^T[d][q] / l -> out[b, q, head*DH + d]; 4 consecutive d per 16-B store ----
+    const int q = q0 + r;
+    if (q < T) {
+        const float inv = 1.0f / l_run;
+        float *op = out + ((size_t)b * T + q) * (H * DH) + head * DH;
+#pragma unroll
+        for (int d = 0; d < ND; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = o[d][4 * g + e] * inv;
+                *(f32x4 *)(op + 32 * d + 8 * g + 4 * h) = v;
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Attention on the bf16 matrix pipe (opt-in, VS_FLAG_BF16_ATTENTION; long videos): the same
+// flash-style walk and operand trick as attn_fwd, but both products run as
+// v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA rate).  Q*scale, K, V and the probabilities P are
+// rounded to bf16 (round-to-nearest-even, v_cvt_pk_bf16_f32) on their way into the MFMA; scores,
+// softmax statistics and the output accumulate in fp32.  Inputs and output stay fp32 in HBM.
+//   S^T = K * Q^T : A = K[key r][d = 16s+8h+j] (one ds_read_b128 of the bf16 tile), B = Q in registers.
+//   O^T = V^T * P^T: B = registers 8s..8s+7 of the S^T accumulator packed pairwise — element j of
+//   lane half h is key 16s + 8(j>>2) + 4h + (j&3) — and A = V^T[d r][those keys], two ds_read_b64
+//   of the TRANSPOSED bf16 V tile, which the staging writes (4 keys of one d packed per b64 store).
+// The row sums l are a third "V" block of ones (the matrix pipe has slack, the VALU does not); the running
+// max is deferred (raised only on a jump > 2^8, so the O/l rescale almost never runs); K/V tiles arrive by
+// buffer loads with scalar offsets, are rounded once into a double-buffered LDS tile, one barrier per tile.
+// Measured (T=8192, B=8, M-A): 750 TFLOP/s; per 64-key tile and wave 20 MFMAs (640 cycles) + 32 v_exp_f32
+// (quarter rate, 512 cycles) + ~100 VALU - and the SIMD issues them one after the other, so the exp2 of the
+// softmax, not the matrix pipe, bounds this kernel at head dim 64.
+// NOT within the 1e-4 fp32 bar of the reference: tests/test_hip_parity.py states its tolerance.
+// ------------------------------------------------------------------------------------------
+// PREC 2 ("fp16x3", VS_FLAG_F16X3_ATTENTION) EMULATES the fp32 products on the f16 pipe instead: every operand
+// (q*scale, k, v, p) is split into f16 hi + lo halves (split_f16) kept in two LDS planes / register sets, and
+// each product is three MFMAs (lo*hi, hi*lo, hi*hi; fp32 accumulate) - 56 MFMAs of 32 cycles per 64-key tile
+// where the fp32 kernel needs 132 of 64 cycles - with results inside the fp32 path's own 1e-4 bar.
+template <int DH, int NW, int PREC>       // NW waves per block, 32 query rows each; PREC 1: bf16, 2: f16 hi+lo
+__global__ __launch_bounds__(64 * NW, 2) void attn_fwd_lp(
+    const float *__restrict__ Q, const float *__restrict__ Kg, const float *__restrict__ Vg,
+    const uint8_t *__restrict__ mask, float *__restrict__ out, int H, int T, float scale_log2e, int BH) {
+    constexpr int KT = 64, NS = DH / 16, ND = DH / 32, NT = 64 * NW, QB = 32 * NW;
+    constexpr int NP = PREC == 2 ? 2 : 1;          // operand planes (hi, lo)
+    constexpr int LDK = DH + 8;                    // 16-bit elements per K row: 36 (DH 64) / 20 (DH 32) dwords, b128 reads conflict-free
+    constexpr int LDV = KT + 4;                    // 16-bit elements per V^T row: 34 dwords, b64 reads conflict-free
+    constexpr int D4 = DH / 4;                     // float4 per key row
+    constexpr int KPT = KT * D4 / NT;              // keys per thread in the staging, one float4 of d each
+    static_assert(KPT == 2 || KPT == 4, "staging packs 2 or 4 keys per V^T store");
+    constexpr float THR = 8.0f;                    // deferred max: the applied max is raised only on a jump > 2^8
+    typedef unsigned short h16;
+    // K tile, V^T tile and key-mask bias, double-buffered: tile t+1 is written while tile t is consumed,
+    // one block barrier per tile
+    __shared__ __attribute__((aligned(16))) h16 Kb[2][NP][KT * LDK];
+    __shared__ __attribute__((aligned(16))) h16 Vt[2][NP][DH * LDV];
+    __shared__ __attribute__((aligned(16))) float mb[2][KT];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    int bh, qt;
+    if (!attn_block_map((T + QB - 1) / QB, BH, bh, qt)) return;
+    const int b = bh / H, head = bh - b * H;
+    const size_t base = (size_t)bh * T * DH;
+    const int q0 = qt * QB + 32 * wave;
+    const float NEG_INF = -__builtin_inff();
+
+    // two floats -> one packed pair per plane
+    auto pack = [&](float x0, float x1, unsigned (&pl)[NP]) __attribute__((always_inline)) {
+        if constexpr (PREC == 2) split_f16(x0, x1, pl[0], pl[1]);
+        else pl[0] = pack_bf16(x0, x1);
+    };
+    auto mma = [&](const u32x4 &a, const u32x4 &bq, const f32x16 &c) __attribute__((always_inline)) -> f32x16 {
+        if constexpr (PREC == 2) return MFMA_F16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, bq), c);
+        else return MFMA_BF16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, bq), c);
+    };
+    // acc += A * B over the planes: hi*hi (+ lo*hi + hi*lo, small terms first)
+    auto mma_planes = [&](const u32x4 (&a)[NP], const u32x4 (&bq)[NP], f32x16 &c) __attribute__((always_inline)) {
+        if constexpr (PREC == 2) {
+            c = mma(a[1], bq[0], c);
+            c = mma(a[0], bq[1], c);
+        }
+        c = mma(a[0], bq[0], c);
+    };
+
+    // Q fragments (B operand): Q[q][16s + 8h + j] * scale*log2(e)
+    u32x4 qreg[NS][NP];
+    {
+        int qr = q0 + r; qr = qr < T ? qr : T - 1;
+        const float *qp = Q + base + (size_t)qr * DH + 8 * h;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const f32x4 v0 = *(const f32x4 *)(qp + 16 * s), v1 = *(const f32x4 *)(qp + 16 * s + 4);
+            unsigned pl[4][NP];
+            pack(v0[0] * scale_log2e, v0[1] * scale_log2e, pl[0]);
+            pack(v0[2] * scale_log2e, v0[3] * scale_log2e, pl[1]);
+            pack(v1[0] * scale_log2e, v1[1] * scale_log2e, pl[2]);
+            pack(v1[2] * scale_log2e, v1[3] * scale_log2e, pl[3]);
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) qreg[s][p][e] = pl[e][p];
+        }
+    }
+    // o[0..ND-1] = O^T blocks; o[ND] = the row sums l, as the product of P with a block of ones
+    // (the matrix pipe has slack, the VALU does not; and l then sums exactly the rounded P the output uses)
+    f32x16 o[ND + 1];
+#pragma unroll
+    for (int d = 0; d <= ND; ++d)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) o[d][t] = 0.f;
+    float m_run = NEG_INF;                         // the max actually applied to O and l (log2 units)
+    constexpr unsigned ONE2 = PREC == 2 ? 0x3C003C00u : 0x3F803F80u;        // (1.0, 1.0) in f16 / bf16
+    const u32x4 ones_u = {ONE2, ONE2, ONE2, ONE2};
+
+    // staging: thread (d4 = tid % D4, kq = tid / D4) owns keys KPT*kq .. +KPT-1 at d = 4*d4 .. +3.
+    // Buffer loads: the per-tile offset is a scalar, rows beyond T read as zero (and are masked below).
+    const int d4 = tid % D4, kq = tid / D4;
+    const int ntiles = (T + KT - 1) / KT;
+    const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Kg + base), 0, T * DH * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Vg + base), 0, T * DH * 4, 0x00020000);
+    int voff[KPT];
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) voff[i] = ((KPT * kq + i) * DH + 4 * d4) * 4;
+    f32x4 pk[KPT], pv[KPT];
+    float pm = 0.f;
+    auto gload = [&](int tile) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            pk[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(krs, voff[i], tile * (KT * DH * 4), 0));
+            pv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(vrs, voff[i], tile * (KT * DH * 4), 0));
+        }
+        if (tid < KT) {                             // key-mask bias of key tile*KT + tid: 0 or -inf (also beyond T)
+            const int key = tile * KT + tid;
+            float pmv = key >= T ? NEG_INF : 0.f;
+            if (mask != nullptr) pmv = mask[(size_t)b * T + (key < T ? key : T - 1)] != 0 ? NEG_INF : pmv;
+            pm = pmv;
+        }
+    };
+    auto stage = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            unsigned p0[NP], p1[NP];
+            pack(pk[i][0], pk[i][1], p0);
+            pack(pk[i][2], pk[i][3], p1);
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                u32x2 u; u[0] = p0[p]; u[1] = p1[p];
+                *(u32x2 *)&Kb[buf][p][(KPT * kq + i) * LDK + 4 * d4] = u;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if constexpr (KPT == 4) {
+                unsigned p0[NP], p1[NP];
+                pack(pv[0][e], pv[1][e], p0);
+                pack(pv[2][e], pv[3][e], p1);
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    u32x2 u; u[0] = p0[p]; u[1] = p1[p];
+                    *(u32x2 *)&Vt[buf][p][(4 * d4 + e) * LDV + 4 * kq] = u;
+                }
+            } else {
+                unsigned p0[NP];
+                pack(pv[0][e], pv[1][e], p0);
+#pragma unroll
+                for (int p = 0; p < NP; ++p) *(unsigned *)&Vt[buf][p][(4 * d4 + e) * LDV + 2 * kq] = p0[p];
+            }
+        }
+        if (tid < KT) mb[buf][tid] = pm;
+    };
+    gload(0);
+    stage(0);
+    if (ntiles > 1) gload(1);
+    __syncthreads();
+
+    for (int tile = 0; tile < ntiles; ++tile) {
+        const int cur = tile & 1;
+        const bool masked_tile = mask != nullptr || (tile + 1) * KT > T;
+        // ---- S^T = K * Q^T ----
+        f32x16 s[2];
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) s[n][t] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < NS; ++ks)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                u32x4 ka[NP];
+#pragma unroll
+                for (int p = 0; p < NP; ++p) ka[p] = *(const u32x4 *)&Kb[cur][p][(32 * n + r) * LDK + 16 * ks + 8 * h];
+                mma_planes(ka, qreg[ks], s[n]);
+            }
+        // ---- V^T fragments of this tile (A of O^T): reads in flight under the softmax ----
+        u32x4 va[2][2][ND][NP];
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int d = 0; d < ND; ++d)
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) {
+                        const h16 *vp = &Vt[cur][p][(32 * d + r) * LDV + 32 * n + 16 * ks + 4 * h];
+                        const u32x2 lo = *(const u32x2 *)vp, hi = *(const u32x2 *)(vp + 8);
+                        va[n][ks][d][p][0] = lo[0]; va[n][ks][d][p][1] = lo[1]; va[n][ks][d][p][2] = hi[0]; va[n][ks][d][p][3] = hi[1];
+                    }
+        // ---- tile t+1 into the other LDS buffer, tile t+2 into registers (under the MFMAs / softmax) ----
+        if (tile + 1 < ntiles) stage(cur ^ 1);
+        if (tile + 2 < ntiles) gload(tile + 2);
+        if (masked_tile) {
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 bv = *(const f32x4 *)&mb[cur][32 * n + 8 * g + 4 * h];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) s[n][4 * g + e] += bv[e];
+                }
+        }
+        // ---- online softmax with a deferred max, one query per lane pair (l, l^32) ----
+        float mx = __builtin_fmaxf(__builtin_fmaxf(s[0][0], s[0][1]), s[1][0]);
+        mx = __builtin_fmaxf(mx, s[1][1]);
+#pragma unroll
+        for (int t = 2; t < 16; t += 2) {
+            mx = __builtin_fmaxf(__builtin_fmaxf(mx, s[0][t]), s[0][t + 1]);
+            mx = __builtin_fmaxf(__builtin_fmaxf(mx, s[1][t]), s[1][t + 1]);
+        }
+        mx = pair_max(mx);
+        const bool raise = mx > m_run + THR || (m_run == NEG_INF && mx != NEG_INF);
+        if (__builtin_expect(__any(raise), 0)) {   // first live tile, or a jump > 2^THR: rare, wave-uniform branch
+            const float m_new = raise ? mx : m_run;
+            const float u_new = (m_new == NEG_INF) ? 0.f : m_new;
+            const float alpha = __builtin_amdgcn_exp2f(m_run - u_new);    // 1 for lanes that keep their max; 0 from -inf
+#pragma unroll
+            for (int d = 0; d <= ND; ++d)
+#pragma unroll
+                for (int t = 0; t < 16; ++t) o[d][t] *= alpha;
+            m_run = m_new;
+        }
+        const float m_use = (m_run == NEG_INF) ? 0.f : m_run;           // p = exp2(s - m_use) <= 2^THR
+        const f32x2 mm = {m_use, m_use};
+        // ---- O^T += V^T * P^T, l += 1 * P^T ----
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                u32x4 pf[NP];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x2 sv = {s[n][8 * ks + 2 * j], s[n][8 * ks + 2 * j + 1]};
+                    const f32x2 dv = sv - mm;
+                    unsigned pl[NP];
+                    pack(__builtin_amdgcn_exp2f(dv[0]), __builtin_amdgcn_exp2f(dv[1]), pl);
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) pf[p][j] = pl[p];
+                }
+#pragma unroll
+                for (int d = 0; d < ND; ++d) mma_planes(va[n][ks][d], pf, o[d]);
+#pragma unroll
+                for (int p = NP - 1; p >= 0; --p) o[ND] = mma(ones_u, pf[p], o[ND]);
+            }
+        __syncthreads();
+    }
+
+    // ---- epilogue: O^T[d][q] / l -> out[b, q, head*DH + d]; 4 consecutive d per 16-B store ----
+    const int q = q0 + r;
+    if (q < T) {
+        const float inv = 1.0f / o[ND][0];
+        float *op = out + ((size_t)b * T + q) * (H * DH) + head * DH;
+#pragma unroll
+        for (int d = 0; d < ND; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = o[d][4 * g + e] * inv;
+                *(f32x4 *)(op + 32 * d + 8 * g + 4 * h) = v;
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// attn_fwd_lp, software-pipelined (the default for the bf16 / fp16x3 modes): attn_fwd_lp keeps every wave in
+// the same phase (the per-tile barrier aligns them), so the matrix pipe idles during the softmax and the VALU
+// during the products.  Here K runs one tile ahead of V: iteration t issues the MFMAs of S(t+1) = K(t+1) Q^T
+// with the softmax of tile t (max3 chain, deferred-max check, exp2, hi/lo split) sliced between them, then the
+// MFMAs of O += V(t)^T P(t)^T (+ row sums) with the staging of K(t+2) / V(t+1) (split, LDS writes) and the
+// buffer loads of K(t+3) / V(t+2) between them.  One barrier per tile; K and V double-buffered in LDS, the
+// key-mask bias triple-buffered (it is read two iterations after it is written).
+// ------------------------------------------------------------------------------------------
+template <int DH, int NW, int PREC>
+__global__ __launch_bounds__(64 * NW, 2) void attn_fwd_lp_pipe(
+    const float *__restrict__ Q, const float *__restrict__ Kg, const float *__restrict__ Vg,
+    const uint8_t *__restrict__ mask, float *__restrict__ out, int H, int T, float scale_log2e, int BH) {
+    constexpr int KT = 64, NS = DH / 16, ND = DH / 32, NT = 64 * NW, QB = 32 * NW;
+    constexpr int NP = PREC == 2 ? 2 : 1, NPROD = PREC == 2 ? 3 : 1;
+    constexpr int LDK = DH + 8, LDV = KT + 4, D4 = DH / 4;
+    constexpr int KPT = KT * D4 / NT;
+    static_assert(KPT == 2 || KPT == 4, "staging packs 2 or 4 keys per V^T store");
+    constexpr float THR = 8.0f;
+    typedef unsigned short h16;
+    __shared__ __attribute__((aligned(16))) h16 Kb[2][NP][KT * LDK];
+    __shared__ __attribute__((aligned(16))) h16 Vt[2][NP][DH * LDV];
+    __shared__ __attribute__((aligned(16))) float mb[3][KT];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    int bh, qt;
+    if (!attn_block_map((T + QB - 1) / QB, BH, bh, qt)) return;
+    const int b = bh / H, head = bh - b * H;
+    const size_t base = (size_t)bh * T * DH;
+    const int q0 = qt * QB + 32 * wave;
+    const float NEG_INF = -__builtin_inff();
+
+    auto pack = [&](float x0, float x1, unsigned (&pl)[NP]) __attribute__((always_inline)) {
+        if constexpr (PREC == 2) split_f16(x0, x1, pl[0], pl[1]);
+        else pl[0] = pack_bf16(x0, x1);
+    };
+    auto mma = [&](const u32x4 &a, const u32x4 &bq, const f32x16 &c) __attribute__((always_inline)) -> f32x16 {
+        if constexpr (PREC == 2) return MFMA_F16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, bq), c);
+        else return MFMA_BF16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, bq), c);
+    };
+    // product `pr` of the plane expansion, small terms first: (lo,hi), (hi,lo), (hi,hi); bf16: (hi,hi) only
+    auto mma_prod = [&](auto prc, const u32x4 (&a)[NP], const u32x4 (&bq)[NP], f32x16 &c) __attribute__((always_inline)) {
+        constexpr int pr = decltype(prc)::value;
+        if constexpr (PREC == 2 && pr == 0) c = mma(a[1], bq[0], c);
+        else if constexpr (PREC == 2 && pr == 1) c = mma(a[0], bq[1], c);
+        else c = mma(a[0], bq[0], c);
+    };
+
+    u32x4 qreg[NS][NP];
+    {
+        int qr = q0 + r; qr = qr < T ? qr : T - 1;
+        const float *qp = Q + base + (size_t)qr * DH + 8 * h;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const f32x4 v0 = *(const f32x4 *)(qp + 16 * s), v1 = *(const f32x4 *)(qp + 16 * s + 4);
+            unsigned pl[4][NP];
+            pack(v0[0] * scale_log2e, v0[1] * scale_log2e, pl[0]);
+            pack(v0[2] * scale_log2e, v0[3] * scale_log2e, pl[1]);
+            pack(v1[0] * scale_log2e, v1[1] * scale_log2e, pl[2]);
+            pack(v1[2] * scale_log2e, v1[3] * scale_log2e, pl[3]);
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) qreg[s][p][e] = pl[e][p];
+        }
+    }
+    f32x16 o[ND + 1];                               // O^T blocks + the row sums (block of ones)
+#pragma unroll
+    for (int d = 0; d <= ND; ++d)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) o[d][t] = 0.f;
+    float m_run = NEG_INF;
+    constexpr unsigned ONE2 = PREC == 2 ? 0x3C003C00u : 0x3F803F80u;
+    const u32x4 ones_u = {ONE2, ONE2, ONE2, ONE2};
+
+    const int d4 = tid % D4, kq = tid / D4;
+    const int ntiles = (T + KT - 1) / KT;
+    const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Kg + base), 0, T * DH * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Vg + base), 0, T * DH * 4, 0x00020000);
+    int voff[KPT];
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) voff[i] = ((KPT * kq + i) * DH + 4 * d4) * 4;
+    f32x4 pk[KPT], pv[KPT];
+    float pm = 0.f;
+    // the pipeline runs up to three tiles past the end: those loads re-read the last tile (their products are
+    // never consumed); rows beyond T inside the last tile read as zeros (buffer bounds check) and are masked
+    auto gload_k = [&](int tile) __attribute__((always_inline)) {
+        tile = tile < ntiles ? tile : ntiles - 1;
+#pragma unroll
+        for (int i = 0; i < KPT; ++i)
+            pk[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(krs, voff[i], tile * (KT * DH * 4), 0));
+    };
+    auto gload_v = [&](int tile) __attribute__((always_inline)) {
+        tile = tile < ntiles ? tile : ntiles - 1;
+#pragma unroll
+        for (int i = 0; i < KPT; ++i)
+            pv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(vrs, voff[i], tile * (KT * DH * 4), 0));
+    };
+    auto gload_m = [&](int tile) __attribute__((always_inline)) {
+        if (tid < KT) {
+            const int key = tile * KT + tid;
+            float pmv = key >= T ? NEG_INF : 0.f;
+            if (mask != nullptr) pmv = mask[(size_t)b * T + (key < T ? key : T - 1)] != 0 ? NEG_INF : pmv;
+            pm = pmv;
+        }
+    };
+    auto stage_k1 = [&](int i, int buf) __attribute__((always_inline)) {
+        unsigned p0[NP], p1[NP];
+        pack(pk[i][0], pk[i][1], p0);
+        pack(pk[i][2], pk[i][3], p1);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            u32x2 u; u[0] = p0[p]; u[1] = p1[p];
+            *(u32x2 *)&Kb[buf][p][(KPT * kq + i) * LDK + 4 * d4] = u;
+        }
+    };
+    auto stage_v1 = [&](int e, int buf) __attribute__((always_inline)) {
+        if constexpr (KPT == 4) {
+            unsigned p0[NP], p1[NP];
+            pack(pv[0][e], pv[1][e], p0);
+            pack(pv[2][e], pv[3][e], p1);
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                u32x2 u; u[0] = p0[p]; u[1] = p1[p];
+                *(u32x2 *)&Vt[buf][p][(4 * d4 + e) * LDV + 4 * kq] = u;
+            }
+        } else {
+            unsigned p0[NP];
+            pack(pv[0][e], pv[1][e], p0);
+#pragma unroll
+            for (int p = 0; p < NP; ++p) *(unsigned *)&Vt[buf][p][(4 * d4 + e) * LDV + 2 * kq] = p0[p];
+        }
+    };
+    auto stage_m = [&](int mbuf) __attribute__((always_inline)) { if (tid < KT) mb[mbuf][tid] = pm; };
+    auto k_frag = [&](int buf, int ks, int n, u32x4 (&ka)[NP]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) ka[p] = *(const u32x4 *)&Kb[buf][p][(32 * n + r) * LDK + 16 * ks + 8 * h];
+    };
+    auto v_frag = [&](int buf, int n, int ks, int d, u32x4 (&va)[NP]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const h16 *vp = &Vt[buf][p][(32 * d + r) * LDV + 32 * n + 16 * ks + 4 * h];
+            const u32x2 lo = *(const u32x2 *)vp, hi = *(const u32x2 *)(vp + 8);
+            va[p][0] = lo[0]; va[p][1] = lo[1]; va[p][2] = hi[0]; va[p][3] = hi[1];
+        }
+    };
+
+    // ---- prologue: K(0), V(0), K(1) in LDS; K(2), V(1) in registers; S(0) computed ----
+    gload_k(0); gload_v(0); gload_m(0);
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) stage_k1(i, 0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) stage_v1(e, 0);
+    stage_m(0);
+    gload_k(1); gload_m(1);
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) stage_k1(i, 1);
+    stage_m(1);
+    gload_k(2); gload_m(2); gload_v(1);
+    __syncthreads();
+    f32x16 sa[2], sb[2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) { sa[n][t] = 0.f; sb[n][t] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < NS; ++ks)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            u32x4 ka[NP];
+            k_frag(0, ks, n, ka);
+            static_for<NPROD>([&](auto prc) { mma_prod(prc, ka, qreg[ks], sa[n]); });
+        }
+
+    // softmax state of the tile in flight
+    float sm_mx = 0.f;
+    f32x2 sm_mm = {0.f, 0.f};
+    u32x4 pf[2][2][NP];
+    // one unit of softmax(t) work on s_in: 0..3 max3 chain, 4 deferred-max check (+ rare rescale), 5..20 one
+    // (n, ks, j) pair each: subtract, exp2, pack / split into the P fragments
+    auto sm_unit = [&](auto uc, f32x16 (&sv)[2]) __attribute__((always_inline)) {
+        constexpr int U = decltype(uc)::value;
+        if constexpr (U == 0) {
+            sm_mx = __builtin_fmaxf(__builtin_fmaxf(sv[0][0], sv[0][1]), sv[1][0]);
+            sm_mx = __builtin_fmaxf(sm_mx, sv[1][1]);
+        }
+        if constexpr (U < 4) {
+            constexpr int t0 = U == 0 ? 2 : 4 * U;
+#pragma unroll
+            for (int t = t0; t < 4 * U + 4; t += 2) {
+                sm_mx = __builtin_fmaxf(__builtin_fmaxf(sm_mx, sv[0][t]), sv[0][t + 1]);
+                sm_mx = __builtin_fmaxf(__builtin_fmaxf(sm_mx, sv[1][t]), sv[1][t + 1]);
+            }
+        }
+        if constexpr (U == 4) {
+            const float mx = pair_max(sm_mx);
+            const bool raise = mx > m_run + THR || (m_run == NEG_INF && mx != NEG_INF);
+            if (__builtin_expect(__any(raise), 0)) {
+                const float m_new = raise ? mx : m_run;
+                const float u_new = (m_new == NEG_INF) ? 0.f : m_new;
+                const float alpha = __builtin_amdgcn_exp2f(m_run - u_new);
+#pragma unroll
+                for (int d = 0; d <= ND; ++d)
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) o[d][t] *= alpha;
+                m_run = m_new;
+            }
+            const float m_use = (m_run == NEG_INF) ? 0.f : m_run;
+            sm_mm[0] = m_use; sm_mm[1] = m_use;
+        }
+        if constexpr (U >= 5 && U < 21) {
+            constexpr int k = U - 5, n = k / 8, ks = (k / 4) % 2, j = k % 4;
+            const f32x2 sx = {sv[n][8 * ks + 2 * j], sv[n][8 * ks + 2 * j + 1]};
+            const f32x2 dv = sx - sm_mm;
+            unsigned pl[NP];
+            pack(__builtin_amdgcn_exp2f(dv[0]), __builtin_amdgcn_exp2f(dv[1]), pl);
+#pragma unroll
+            for (int p = 0; p < NP; ++p) pf[n][ks][p][j] = pl[p];
+        }
+    };
+    constexpr int NU = 21;
+    constexpr int NSLOT_A = NS * 2 * NPROD, RA = (NU + NSLOT_A - 1) / NSLOT_A;
+    constexpr int NSLOT_B = 4 * (ND * NPROD + NP);
+    constexpr int NITEM = KPT + 4 + 2, SB = NSLOT_B / NITEM > 0 ? NSLOT_B / NITEM : 1;    // staging items, slot stride
+
+    // one iteration: s_in = S(t) (complete), s_out <- S(t+1)
+    auto iteration = [&](int t, f32x16 (&s_in)[2], f32x16 (&s_out)[2]) __attribute__((always_inline)) {
+        const int cur = t & 1, nxt = cur ^ 1;
+        if (mask != nullptr || (t + 1) * KT > T) {       // masked / ragged tile: key-mask bias first (rare)
+            const float *mp = mb[t % 3];
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 bv = *(const f32x4 *)&mp[32 * n + 8 * g + 4 * h];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) s_in[n][4 * g + e] += bv[e];
+                }
+        }
+        // ---- phase A: S(t+1) MFMAs, softmax(t) between them ----
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int x = 0; x < 16; ++x) s_out[n][x] = 0.f;
+        u32x4 ka[2][NP];
+        k_frag(nxt, 0, 0, ka[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<NSLOT_A>([&](auto ic) {
+            constexpr int i = decltype(ic)::value, g = i / NPROD, pr = i % NPROD, ks = g / 2, n = g % 2;
+            if constexpr (pr == 0 && g + 1 < NS * 2) k_frag(nxt, (g + 1) / 2, (g + 1) % 2, ka[(g + 1) & 1]);
+            mma_prod(std::integral_constant<int, pr>{}, ka[g & 1], qreg[ks], s_out[n]);
+            static_for<RA>([&](auto rc) {
+                constexpr int U = i * RA + decltype(rc)::value;
+                if constexpr (U < NU) sm_unit(std::integral_constant<int, U>{}, s_in);
+            });
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        // ---- phase B: O += V(t)^T P(t)^T and the row sums; staging of K(t+2), V(t+1), loads of K(t+3), V(t+2) ----
+        u32x4 va[2][NP];
+        v_frag(cur, 0, 0, 0, va[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<NSLOT_B>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            constexpr int PER = ND * NPROD + NP;                 // MFMAs per (n, ks): products per d block, then row sums
+            constexpr int g = i / PER, w = i % PER, n = g / 2, ks = g % 2;
+            if constexpr (w < ND * NPROD) {
+                constexpr int d = w / NPROD, pr = w % NPROD, f = g * ND + d;       // fragment index
+                if constexpr (pr == 0 && f + 1 < 4 * ND)
+                    v_frag(cur, (f + 1) / ND / 2, ((f + 1) / ND) % 2, (f + 1) % ND, va[(f + 1) & 1]);
+                mma_prod(std::integral_constant<int, pr>{}, va[f & 1], pf[n][ks], o[d]);
+            } else {
+                constexpr int p = NP - 1 - (w - ND * NPROD);     // lo plane first
+                o[ND] = mma(ones_u, pf[n][ks][p], o[ND]);
+            }
+            if constexpr (i % SB == SB - 1 && i / SB < NITEM) {
+                constexpr int item = i / SB;
+                if constexpr (item < KPT) stage_k1(item, cur);
+                else if constexpr (item < KPT + 4) stage_v1(item - KPT, nxt);
+                else if constexpr (item == KPT + 4) { stage_m((t + 2) % 3); }
+                else { gload_k(t + 3); gload_m(t + 3); gload_v(t + 2); }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        __syncthreads();
+    };
+
+    int t = 0;
+    for (; t + 1 < ntiles; t += 2) {
+        iteration(t, sa, sb);
+        iteration(t + 1, sb, sa);
+    }
+    if (t < ntiles) iteration(t, sa, sb);
+
+    const int q = q0 + r;
+    if (q < T) {
+        const float inv = 1.0f / o[ND][0];
+        float *op = out + ((size_t)b * T + q) * (H * DH) + head * DH;
+#pragma unroll
+        for (int d = 0; d < ND; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = o[d][4 * g + e] * inv;
+                *(f32x4 *)(op + 32 * d + 8 * g + 4 * h) = v;
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Attention, software-pipelined (head dim 32 / 64): same math and operand trick as attn_fwd.
+//
+// Measured on gfx950 (profiles/): the fp32 MFMA shares the SIMD's FP32 lanes with
+// ordinary VALU work — every VALU instruction costs ~4 of the 64 cycles an MFMA owns, "in its shadow"
+// or not.  So this kernel is built to issue as few VALU instructions per MFMA as possible:
+//  * K/V tiles arrive through buffer loads whose per-tile offset is a scalar (no address VALU, and the
+//    hardware bounds check zero-fills the ragged tail);
+//  * the running row max m is folded into the product: S' = [K,1]*[Q,-m]^T costs one extra MFMA per
+//    32-key block and replaces the accumulator zero-init and the 16 subtracts before exp2;
+//  * deferred max: m is only raised (and O, l rescaled) when a block's max exceeds it by more than
+//    2^8 — exact in fp32 (p <= 256 instead of <= 1) and almost never taken after the first block;
+//  * the key-mask bias (0/-inf) is added only on tiles that have masked keys or the ragged tail.
+// Keys are consumed in 32-key blocks; block b+1's S' MFMAs issue while block b's softmax (max check,
+// exp2, row sum) runs between them; then O^T += V_b^T * P_b^T with the V operands prefetched into
+// registers.  K/V tiles of 64 keys are double-buffered in LDS; global loads of tile t+2 and LDS writes
+// of tile t+1 ride in the MFMA stream of tile t.  NW waves per block (8: one block per CU, all
+// blocks take the same time; 4: for short videos).
+// ------------------------------------------------------------------------------------------
+template <int DH, bool HAS_MASK, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void attn_fwd_pipe(
+    const float *__restrict__ Q, const float *__restrict__ Kg, const float *__restrict__ Vg,
+    const uint8_t *__restrict__ mask, float *__restrict__ out, int H, int T, float scale_log2e, int BH) {
+    constexpr int KT = 64, LD = DH + 4, NJ = DH / 8, ND = DH / 32;
+    constexpr int NT = 64 * NW;                     // threads per block
+    constexpr int F4 = KT * DH / 4 / NT;            // float4 per thread per operand tile
+    constexpr int TILE = KT * LD;                   // floats per K (or V) tile in LDS
+    constexpr float THR = 8.0f;                     // deferred-max threshold (log2 units)
+    __shared__ __attribute__((aligned(16))) float smem[4 * TILE + 2 * KT];   // [buf]{K,V} + mask bias
+    float *mbs = smem + 4 * TILE;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    int bh, qt;
+    if (!attn_block_map((T + 32 * NW - 1) / (32 * NW), BH, bh, qt)) return;
+    const int b = bh / H, head = bh - b * H;
+    const size_t base = (size_t)bh * T * DH;
+    const int q0 = qt * (32 * NW) + 32 * wave;
+    const float NEG_INF = -__builtin_inff();
+    const int ntiles = (T + KT - 1) / KT;
+
+    // Q fragment (B operand), scaled by scale*log2(e).  A lane needs 16 B of ITS query row per 8 k - as a
+    // direct load that is 32 B into 32 different lines per instruction (slow to issue) - so the wave's 32
+    // rows are loaded coalesced (DH*128 contiguous bytes), parked in a wave-private LDS corner (the K/V
+    // buffers are not in use yet) and read back as fragments.
+    float qreg[4 * NJ];
+    static_assert(4 * TILE >= NW * 32 * LD || NW == 8, "LDS corner per wave");
+    float *wtp = smem + wave * (32 * LD);            // 32 x (DH+4) floats per wave (NW*32*LD <= 4*TILE for NW <= 8)
+    {
+#pragma unroll
+        for (int i = 0; i < DH / 8; ++i) {           // 32 rows x DH floats = DH/8 wave loads of 1 KiB
+            const int idx = lane + 64 * i;
+            const int row = idx / (DH / 4), c4 = (idx % (DH / 4)) * 4;
+            int qr = q0 + row; qr = qr < T ? qr : T - 1;
+            *(f32x4 *)&wtp[row * LD + c4] = *(const f32x4 *)(Q + base + (size_t)qr * DH + c4);
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const f32x4 v = *(const f32x4 *)&wtp[r * LD + 8 * j + 4 * h];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) qreg[4 * j + s] = v[s] * scale_log2e;
+        }
+    }
+    __syncthreads();                                 // Q corners are read; K/V staging may overwrite them
+    f32x16 o[ND];
+#pragma unroll
+    for (int d = 0; d < ND; ++d)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) o[d][t] = 0.f;
+    // m_run: running max (log2 units) actually applied to O and l; -inf until the first live key.
+    // m_use(m) = m, or 0 while m is still -inf (keeps exp2 arguments finite-or--inf, never inf-inf).
+    float m_run = NEG_INF, l_run = 0.f;
+    const float ones_a = h == 0 ? 1.0f : 0.0f;      // A operand of the bias step: adds B[0][q] to every key row
+
+    // ---- staging: buffer loads (scalar per-tile offset, zero fill beyond T), then LDS writes ----
+    const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(Kg + base), 0, T * DH * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(Vg + base), 0, T * DH * 4, 0x00020000);
+    int voff[F4];
+#pragma unroll
+    for (int i = 0; i < F4; ++i) {
+        const int idx = tid + NT * i;
+        voff[i] = ((idx / (DH / 4)) * DH + (idx % (DH / 4)) * 4) * 4;
+    }
+    f32x4 pk[F4], pv[F4];
+    float pm = 0.f;
+    auto gload_k = [&](int i, int tile) __attribute__((always_inline)) { pk[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(krs, voff[i], tile * (KT * DH * 4), 0)); };
+    auto gload_v = [&](int i, int tile) __attribute__((always_inline)) { pv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(vrs, voff[i], tile * (KT * DH * 4), 0)); };
+    auto gload_m = [&](int tile) __attribute__((always_inline)) {      // key-mask bias of key (tid & 63): 0 or -inf (also for keys >= T)
+        const int key = tile * KT + (tid & (KT - 1));
+        float pmv = key >= T ? NEG_INF : 0.f;
+        if (HAS_MASK) pmv = mask[(size_t)b * T + (key < T ? key : T - 1)] != 0 ? NEG_INF : pmv;
+        pm = pmv;
+    };
+    auto stage_k = [&](int i, int buf) __attribute__((always_inline)) {
+        const int idx = tid + NT * i;
+        *(f32x4 *)&smem[buf * 2 * TILE + (idx / (DH / 4)) * LD + (idx % (DH / 4)) * 4] = pk[i];
+    };
+    auto stage_v = [&](int i, int buf) __attribute__((always_inline)) {
+        const int idx = tid + NT * i;
+        *(f32x4 *)&smem[buf * 2 * TILE + TILE + (idx / (DH / 4)) * LD + (idx % (DH / 4)) * 4] = pv[i];
+    };
+
+    // ---- softmax state of the block in flight ----
+    float sm_mx = 0.f, sm_psum = 0.f;
+    float vreg[16 * ND];
+    // Rare path (first live block, or a max jump > 2^THR, or a block whose bias is stale): bring the
+    // block's S' onto the (possibly raised) running max and rescale O, l.  Wave-uniform branch.
+    auto fixup = [&](f32x16 &sv, float m_bias, float raw_max) __attribute__((always_inline)) {
+        const float m_new = (raw_max > m_run + THR || m_run == NEG_INF) ? fmaxf(m_run, raw_max) : m_run;
+        const float u_new = (m_new == NEG_INF) ? 0.f : m_new;
+        const float shift = m_bias - u_new;                     // finite
+        const float alpha = __builtin_amdgcn_exp2f(m_run - u_new);   // m_run = -inf -> 0 (O = l = 0 then anyway)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) sv[t] += shift;
+#pragma unroll
+        for (int d = 0; d < ND; ++d)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) o[d][t] *= alpha;
+        l_run *= alpha;
+        m_run = m_new;
+    };
+    // One unit of block-b softmax work, issued between two MFMAs of block b+1's S'.  sv = S' of block b
+    // (biased by -m_bias), MASKED: add the key-mask bias first.
+    auto sm_unit = [&](auto uc, f32x16 &sv, float m_bias, const float *mb, auto masked_tag) __attribute__((always_inline)) {
+        constexpr int U = decltype(uc)::value;
+        constexpr bool MASKED = decltype(masked_tag)::value;
+        if constexpr (MASKED && U < 4) {
+            const f32x4 bv = *(const f32x4 *)(mb + 8 * U + 4 * h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sv[4 * U + e] += bv[e];
+        }
+        if constexpr (U == 4) {
+            sm_mx = fmaxf(fmaxf(sv[0], sv[1]), sv[2]);
+#pragma unroll
+            for (int t = 3; t < 15; t += 2) sm_mx = fmaxf(fmaxf(sm_mx, sv[t]), sv[t + 1]);
+            sm_mx = fmaxf(sm_mx, sv[15]);
+        }
+        if constexpr (U == 5) {
+            const float raw_max = pair_max(sm_mx) + m_bias;      // -inf if every key so far is masked
+            const float u_run = (m_run == NEG_INF) ? 0.f : m_run;
+            const bool fix = (m_bias != u_run) || (raw_max > m_run + THR) || (m_run == NEG_INF && raw_max != NEG_INF);
+            if (__builtin_expect(__any(fix), 0)) fixup(sv, m_bias, raw_max);
+            sm_psum = 0.f;
+        }
+        if constexpr (U >= 8 && U < 16) {
+            constexpr int k = U - 8;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const float pe_ = __builtin_amdgcn_exp2f(sv[2 * k + e]);
+                sv[2 * k + e] = pe_;
+                sm_psum += pe_;
+            }
+        }
+        if constexpr (U == 16) l_run += pair_sum(sm_psum);
+    };
+    // MFMA stream of one half-step:  s_out = [K_blk,1]*[Q,-m_bias]^T  (1 + 4*NJ MFMAs), with between
+    // consecutive MFMAs: one V operand of block (Vsrc,vblk) into vreg, one softmax unit of s_in, and
+    // (STAGE) the LDS writes of tile t+1 / buffer loads of tile t+2.
+    auto half_step = [&](const float *Ksrc, int blk, f32x16 &s_out, float m_bias_out, f32x16 &s_in, float m_bias_in,
+                         const float *mb, const float *Vsrc, int vblk, auto masked_tag, auto stage_tag, int nbuf, int ntile) __attribute__((always_inline)) {
+        constexpr bool STAGE = decltype(stage_tag)::value;
+        constexpr int NSLOT = 4 * NJ, R = 32 / NSLOT;      // softmax units per MFMA slot (DH=64: 1, DH=32: 2)
+        static_assert(NSLOT == 16 * ND, "one V operand per MFMA slot");
+        const float *kp = Ksrc + (32 * blk + r) * LD + 4 * h;
+        const float *vp = Vsrc + (32 * vblk + 4 * h) * LD + r;
+        f32x4 ka[2];
+        ka[0] = *(const f32x4 *)kp;
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        s_out = MFMA32(ones_a, -m_bias_out, zero);
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<NSLOT>([&](auto ic) {
+            constexpr int i = decltype(ic)::value, j = i / 4, st = i % 4;
+            if constexpr (st == 0 && j + 1 < NJ) ka[(j + 1) & 1] = *(const f32x4 *)(kp + 8 * (j + 1));
+            s_out = MFMA32(ka[j & 1][st], qreg[4 * j + st], s_out);
+            {
+                constexpr int t = i / ND, d = i % ND;
+                vreg[i] = vp[((t & 3) + 8 * (t >> 2)) * LD + 32 * d];
+            }
+            static_for<R>([&](auto rc) {
+                constexpr int U = i * R + decltype(rc)::value;
+                sm_unit(std::integral_constant<int, U>{}, s_in, m_bias_in, mb, masked_tag);
+                if constexpr (STAGE) {
+                    if constexpr (U < 2 * F4) { if constexpr (U % 2 == 0) stage_k(U / 2, nbuf); else stage_v(U / 2, nbuf); }
+                    if constexpr (U == 2 * F4) mbs[nbuf * KT + (tid & (KT - 1))] = pm;
+                    if constexpr (U >= 17 && U < 17 + 2 * F4) { if constexpr ((U - 17) % 2 == 0) gload_k((U - 17) / 2, ntile); else gload_v((U - 17) / 2, ntile); }
+                    if constexpr (U == 17 + 2 * F4) gload_m(ntile);
+                }
+            });
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+    // softmax alone (last block of the video: nothing left to overlap with)
+    auto softmax_only = [&](f32x16 &sv, float m_bias, const float *mb, const float *Vsrc, int vblk, auto masked_tag) __attribute__((always_inline)) {
+        const float *vp = Vsrc + (32 * vblk + 4 * h) * LD + r;
+#pragma unroll
+        for (int i = 0; i < 16 * ND; ++i) vreg[i] = vp[(((i / ND) & 3) + 8 * ((i / ND) >> 2)) * LD + 32 * (i % ND)];
+        static_for<32>([&](auto uc) { sm_unit(uc, sv, m_bias, mb, masked_tag); });
+    };
+    // O^T += V[32 keys]^T * P^T : 16*ND MFMAs, operands already in registers
+    auto pv_acc = [&](const f32x16 &p) __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+#pragma unroll
+            for (int d = 0; d < ND; ++d) o[d] = MFMA32(vreg[ND * t + d], p[t], o[d]);
+    };
+
+    // ---- prologue: tile 0 into LDS, tile 1 into registers, S' of block (0,0) with bias 0 ----
+#pragma unroll
+    for (int i = 0; i < F4; ++i) { gload_k(i, 0); gload_v(i, 0); }
+    gload_m(0);
+#pragma unroll
+    for (int i = 0; i < F4; ++i) { stage_k(i, 0); stage_v(i, 0); }
+    mbs[tid & (KT - 1)] = pm;
+    {
+        const int t1 = ntiles > 1 ? 1 : 0;
+#pragma unroll
+        for (int i = 0; i < F4; ++i) { gload_k(i, t1); gload_v(i, t1); }
+        gload_m(t1);
+    }
+    __syncthreads();
+    f32x16 s_cur, s_nxt;
+    float mb_cur = 0.f, mb_nxt = 0.f;            // bias each in-flight block was started with
+    {
+        const float *kp = smem + r * LD + 4 * h;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) s_cur[t] = 0.f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const f32x4 ka = *(const f32x4 *)(kp + 8 * j);
+#pragma unroll
+            for (int st = 0; st < 4; ++st) s_cur = MFMA32(ka[st], qreg[4 * j + st], s_cur);
+        }
+    }
+
+    // One 64-key tile.  LAST (the video's final tile) is peeled out of the loop so that the loop body has
+    // no branch besides the rare fix-up: a branch there costs 64 accumulator-register copies per tile.
+    auto tile_step = [&](int t, auto masked_tag, auto last_tag) __attribute__((always_inline)) {
+        constexpr bool LAST = decltype(last_tag)::value;
+        const int buf = t & 1;
+        const float *Ks = smem + buf * 2 * TILE, *Vs = Ks + TILE;
+        const float *Kn = smem + (buf ^ 1) * 2 * TILE;
+        __syncthreads();                       // everyone is done with buffer buf^1 (tile t-1)
+        // S' of block (t,1)  ||  softmax of block (t,0), LDS writes of tile t+1, loads of tile t+2
+        mb_nxt = (m_run == NEG_INF) ? 0.f : m_run;
+        half_step(Ks, 1, s_nxt, mb_nxt, s_cur, mb_cur, mbs + buf * KT, Vs, 0, masked_tag, std::integral_constant<bool, !LAST>{},
+                  buf ^ 1, t + 2 < ntiles ? t + 2 : ntiles - 1);
+        pv_acc(s_cur);
+        __syncthreads();                       // tile t+1 is visible in buffer buf^1
+        if constexpr (!LAST) {
+            // S' of block (t+1,0)  ||  softmax of block (t,1)
+            mb_cur = (m_run == NEG_INF) ? 0.f : m_run;
+            half_step(Kn, 0, s_cur, mb_cur, s_nxt, mb_nxt, mbs + buf * KT + 32, Vs, 1, masked_tag, std::false_type{}, 0, 0);
+        } else {
+            softmax_only(s_nxt, mb_nxt, mbs + buf * KT + 32, Vs, 1, masked_tag);
+        }
+        pv_acc(s_nxt);
+    };
+    // without a mask only the ragged last tile carries dead keys
+    for (int t = 0; t + 1 < ntiles; ++t) tile_step(t, std::integral_constant<bool, HAS_MASK>{}, std::false_type{});
+    if (HAS_MASK || (T % KT) != 0) tile_step(ntiles - 1, std::true_type{}, std::true_type{});
+    else                           tile_step(ntiles - 1, std::false_type{}, std::true_type{});
+
+    // ---- epilogue: O^T[d][q] / l -> out[b, q, head*DH + d], through the wave-private LDS corner so that
+    // every store instruction writes whole 128-byte lines (DH/4 lanes per row) ----
+    __syncthreads();                                 // every wave is done reading K/V tiles
+    {
+        const float inv = 1.0f / l_run;
+#pragma unroll
+        for (int d = 0; d < ND; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = o[d][4 * g + e] * inv;
+                *(f32x4 *)&wtp[r * LD + 32 * d + 8 * g + 4 * h] = v;
+            }
+        constexpr int LPR = DH / 4, RPI = 64 / LPR;       // lanes per row, rows per store instruction
+        const int orow = lane / LPR, oc4 = (lane % LPR) * 4;
+#pragma unroll
+        for (int p = 0; p < 32 / RPI; ++p) {
+            const int rr = orow + RPI * p, q = q0 + rr;
+            const f32x4 v = *(const f32x4 *)&wtp[rr * LD + oc4];
+            if (q < T) *(f32x4 *)(out + ((size_t)b * T + q) * (H * DH) + head * DH + oc4) = v;
+        }
+    }
+}
+
+}  // namespace
+
+int vsk_attention(const float *q, const float *k, const float *v, const uint8_t *mask, float *out,
+                  int B, int H, int T, int dh, float scale, hipStream_t st) {
+    const float sl2 = scale * 1.4426950408889634f;
+    const int BH = B * H;
+    dim3 grid(8 * ((BH + 7) / 8) * ((T + 127) / 128));
+    static const bool legacy = getenv("VS_ATTN_LEGACY") != nullptr;      // A/B switch for tools/, not a fallback
+    if (dh == 32 && legacy)
+        hipLaunchKernelGGL((attn_fwd<32, 2>), grid, dim3(256), 0, st, q, k, v, mask, out, H, T, sl2, BH);
+    else if (dh == 64 && legacy)
+        hipLaunchKernelGGL((attn_fwd<64, 2>), grid, dim3(256), 0, st, q, k, v, mask, out, H, T, sl2, BH);
+    else if (dh == 32 || dh == 64) {
+        // 8-wave blocks (one per CU, 256 query rows) unless the ragged tail would waste more rows than
+        // 4-wave blocks (two per CU, 128 query rows) do
+        const int r8 = (T + 255) / 256 * 256, r4 = (T + 127) / 128 * 128;
+        const bool wide = !getenv("VS_ATTN_NW4") && r8 * 100 <= r4 * 105;
+        const int nq = wide ? r8 / 256 : r4 / 128;
+        dim3 g(8 * ((BH + 7) / 8) * nq), blk(wide ? 512 : 256);
+#define VSK_ATTN(DH_, MASK_, NW_) \
+    hipLaunchKernelGGL((attn_fwd_pipe<DH_, MASK_, NW_>), g, blk, 0, st, q, k, v, mask, out, H, T, sl2, BH)
+        if (dh == 32) {
+            if (mask) { if (wide) VSK_ATTN(32, true, 8); else VSK_ATTN(32, true, 4); }
+            else      { if (wide) VSK_ATTN(32, false, 8); else VSK_ATTN(32, false, 4); }
+        } else {
+            if (mask) { if (wide) VSK_ATTN(64, true, 8); else VSK_ATTN(64, true, 4); }
+            else      { if (wide) VSK_ATTN(64, false, 8); else VSK_ATTN(64, false, 4); }
+        }
+#undef VSK_ATTN
+    }
+    else if (dh == 128)
+        hipLaunchKernelGGL((attn_fwd<128, 1>), grid, dim3(256), 0, st, q, k, v, mask, out, H, T, sl2, BH);
+    else
+        return -1;
+    VSK_CHECK_LAUNCH();
+    return 0;
+}
+
+int vsk_attention_bf16(const float *q, const float *k, const float *v, const uint8_t *mask, float *out,
+                       int B, int H, int T, int dh, float scale, int prec, hipStream_t st) {
+    const float sl2 = scale * 1.4426950408889634f;
+    const int BH = B * H;
+    // 8-wave blocks (256 query rows share one staged K/V tile) unless the ragged tail would waste too many rows
+    const int r8 = (T + 255) / 256 * 256, r4 = (T + 127) / 128 * 128;
+    const bool wide = dh == 64 && !getenv("VS_ATTN_NW4") && r8 * 100 <= r4 * 105;
+    dim3 grid(8 * ((BH + 7) / 8) * (wide ? r8 / 256 : r4 / 128));
+    static const bool simple = getenv("VS_ATTN_LP_SIMPLE") != nullptr;      // A/B switch for tools/, not a fallback
+#define VSK_ATTN_LP(KERN_, P_)                                                                                           \
+    if (dh == 64 && wide)                                                                                                \
+        hipLaunchKernelGGL((KERN_<64, 8, P_>), grid, dim3(512), 0, st, q, k, v, mask, out, H, T, sl2, BH);               \
+    else if (dh == 64)                                                                                                   \
+        hipLaunchKernelGGL((KERN_<64, 4, P_>), grid, dim3(256), 0, st, q, k, v, mask, out, H, T, sl2, BH);               \
+    else if (dh == 32)                                                                                                   \
+        hipLaunchKernelGGL((KERN_<32, 4, P_>), grid, dim3(256), 0, st, q, k, v, mask, out, H, T, sl2, BH);               \
+    else                                                                                                                 \
+        return -1;
+    if (simple) { if (prec == 2) { VSK_ATTN_LP(attn_fwd_lp, 2) } else { VSK_ATTN_LP(attn_fwd_lp, 1) } }
+    else        { if (prec == 2) { VSK_ATTN_LP(attn_fwd_lp_pipe, 2) } else { VSK_ATTN_LP(attn_fwd_lp_pipe, 1) } }
+#undef VSK_ATTN_LP
+    VSK_CHECK_LAUNCH();
+    return 0;
+}
+
