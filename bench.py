@@ -88,13 +88,21 @@ def main():
                      % (args.gpus, args.gpus))
         args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU path for the scorer)"
+    # VS_BENCH_REHEARSE=1: rehearsal of the N > 1 control flow on a ONE-GPU box (every rank on cuda:0, gloo instead
+    # of RCCL, which refuses two ranks on one device).  Its numbers mean nothing; it only proves the path runs.
+    rehearse = os.environ.get("VS_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     pkg = importlib.import_module("video-summarization_amd")
     lib = pkg._lib.load()
@@ -107,7 +115,7 @@ def main():
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)       # disjoint videos per rank
     x_host = torch.randn(B, T, Din, generator=g).pin_memory()
     x = x_host.to(dev)
-    gathered = torch.empty((world, B, T), dtype=torch.float32, device=dev) if world > 1 else None
+    gathered = torch.empty((world * B, T), dtype=torch.float32, device=dev) if world > 1 else None   # rank-major rows
 
     def step():
         logits, _hidden = model(x)
