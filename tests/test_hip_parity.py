@@ -421,7 +421,17 @@ def test_val_step_end_to_end_matches_reference(vsa):
     assert abs(loss - float(g["loss"])) < 1e-5
     assert abs(f - g["metrics"][0]) < 1e-6 and abs(k - g["metrics"][1]) < 1e-4 and abs(s - g["metrics"][2]) < 1e-4
     lb, fb, kb, sb = harness.val_step_batched(m, [r[0] for r in recs], [r[1] for r in recs], [r[2] for r in recs], _dev())
-    assert abs(lb - loss) < 1e-6 and abs(fb - f) < 1e-9 and abs(kb - k) < 1e-12 and abs(sb - s) < 1e-12# ---- opt-in bf16 attention (VS_FLAG_BF16_ATTENTION; BASELINE configs[4] names bf16) ----------------------
+    assert abs(lb - loss) < 1e-6 and abs(fb - f) < 1e-9 and abs(kb - k) < 1e-12 and abs(sb - s) < 1e-12
+
+
+@pytest.fixture
+def lp_linear_everywhere(monkeypatch):
+    """The forward keeps the exact fp32 latency kernels for batches of up to 8192 frames whatever the precision
+    flags say; VS_LP_MIN_ROWS=0 pins the low-precision Linear kernels so small test batches exercise them."""
+    monkeypatch.setenv("VS_LP_MIN_ROWS", "0")
+
+
+# ---- opt-in bf16 attention (VS_FLAG_BF16_ATTENTION; BASELINE configs[4] names bf16) ----------------------
 # Tolerances, stated: the bf16 path rounds q*scale, k, v and the probabilities to 8-bit mantissas (relative
 # 2^-9 each) before the two products and accumulates in fp32.  Per-kernel: |out - fp64 reference| <= 1.5e-2 of
 # the largest |reference| entry (4e-3 against a checker that shares the rounded operands).  End to end
@@ -629,7 +639,7 @@ BF16_FULL_SCORE_TOL = 4e-3
 
 
 @pytest.mark.parametrize("cfg", ["M-A", "M-B8"])
-def test_bf16_compute_mode_end_to_end(vsa, cfg):
+def test_bf16_compute_mode_end_to_end(vsa, lp_linear_everywhere, cfg):
     """SimNet.set_compute_dtype('bf16'): every matrix product on the bf16 pipe, against the fp32 oracle."""
     synth = vsa.synth
     d, H, L = (256, 4, 4) if cfg == "M-A" else (256, 8, 6)
@@ -656,7 +666,7 @@ def test_bf16_compute_mode_end_to_end(vsa, cfg):
     assert (l32.cpu() - rl).abs().squeeze(-1)[valid].max().item() < TOL     # and back: the exact path is untouched
 
 
-def test_bf16_compute_long_video(vsa):
+def test_bf16_compute_long_video(vsa, lp_linear_everywhere):
     """BASELINE configs[4]: T=8192, 2048-d features, all products bf16 (oracle: fp32 restatement)."""
     synth = vsa.synth
     sd = synth.make_state_dict(256, 2, 61, in_features=2048, max_len=8192)
@@ -730,7 +740,7 @@ def test_linear_residual_layernorm_f16x3_kernel(vsa, M, N, K, nc, sig):
 
 
 @pytest.mark.parametrize("case", golden_cases(), ids=lambda c: c["name"])
-def test_f16x3_linear_mode_matches_reference_golden(vsa, case):
+def test_f16x3_linear_mode_matches_reference_golden(vsa, lp_linear_everywhere, case):
     """linear_dtype='fp16x3' against the reference-generated goldens, at the fp32 path's own 1e-4 bar."""
     if case["d"] > 256:
         pytest.skip("f16x3 Linear kernels: d_model <= 256")
@@ -805,7 +815,7 @@ def test_attention_f16x3_rescale_branch(vsa):
 
 
 @pytest.mark.parametrize("case", golden_cases(), ids=lambda c: c["name"])
-def test_f16x3_compute_mode_matches_reference_golden(vsa, case):
+def test_f16x3_compute_mode_matches_reference_golden(vsa, lp_linear_everywhere, case):
     """set_compute_dtype('fp16x3') (every product emulated on the f16 pipe) against the reference-generated
     goldens, at the fp32 path's own 1e-4 bar."""
     if case["d"] > 256 or case["d"] // case["H"] not in (32, 64):
@@ -839,7 +849,7 @@ def test_f16x3_full_size_batch_against_exact_path(vsa):
     assert dl < TOL and dh < TOL
 
 
-def test_f16x3_ragged_padded_batch_matches_oracle(vsa):
+def test_f16x3_ragged_padded_batch_matches_oracle(vsa, lp_linear_everywhere):
     """fp16x3 on a right-padded batch large enough for the emulated Linear kernels (1600 rows): the 1000.0 padding
     sentinel (collate_fn_train) must survive the f16 split, valid frames must meet the 1e-4 bar."""
     synth = vsa.synth

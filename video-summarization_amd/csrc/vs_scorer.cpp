@@ -246,9 +246,12 @@ int vs_scorer_forward(const vs_weights *w, const float *x, const uint8_t *key_pa
     float *h0 = ws, *h1 = ws + md, *qkv = ws + 2 * md, *att = ws + 5 * md, *ffn = ws + 6 * md;
     const float scale = 1.0f / sqrtf((float)d);        // reference simnet.py:126: d_model ** -0.5
     const int sig = (flags & VS_FLAG_SIGMOID) ? 1 : 0;
-    // Low-precision Linear kernels exist as LDS-tiled throughput kernels only; up to 1024 rows the exact fp32
-    // latency kernels are faster (measured: one T=320 video 0.46 vs 0.78 ms) and are used whatever the flag says.
-    const int lbf = M <= 1024 ? 0 : (flags & VS_FLAG_F16X3_LINEAR) ? 2 : (flags & VS_FLAG_BF16_LINEAR) ? 1 : 0;
+    // Low-precision Linear kernels exist as LDS-tiled throughput kernels only; up to 8192 rows the exact fp32
+    // latency kernels are faster (measured crossover, M-A: 8192 rows 0.92 vs 0.96 ms, 12288 rows 1.31 vs 0.99 ms)
+    // and are used whatever the flag says.
+    const char *lpe = getenv("VS_LP_MIN_ROWS");          // tests / tools pin the low-precision kernels with 0
+    const int lp_min_rows = lpe ? atoi(lpe) : 8192;
+    const int lbf = M <= lp_min_rows ? 0 : (flags & VS_FLAG_F16X3_LINEAR) ? 2 : (flags & VS_FLAG_BF16_LINEAR) ? 1 : 0;
 
     // Embedding + positional table (simnet.py:211, 237-238)
     {
