@@ -41,7 +41,8 @@ extern "C" {
                                 bf16-rounded operands on the bf16 matrix pipe; tensors stay fp32 in HBM, and
                                 bias, accumulation, residual, LayerNorm and the score head stay fp32.
                                 d_model <= 256.  Same tolerance caveat as VS_FLAG_BF16_ATTENTION.  Batches of up
-                                to 8192 frames keep the (faster, exact) fp32 latency kernels. */
+                                to 8192 frames keep the (faster, exact) fp32 latency kernels (bf16 only:
+                                fp16x3 has latency kernels of its own). */
 #define VS_FLAG_BF16 (VS_FLAG_BF16_ATTENTION | VS_FLAG_BF16_LINEAR)
 #define VS_FLAG_F16X3_ATTENTION 16u /* opt-in: the two attention products emulated on the f16 pipe the same way
                                 (q*scale, k, v, p split into hi + lo halves, three MFMAs per product, fp32

@@ -817,9 +817,9 @@ def test_attention_f16x3_rescale_branch(vsa):
 
 
 @pytest.mark.parametrize("case", golden_cases(), ids=lambda c: c["name"])
-def test_f16x3_compute_mode_matches_reference_golden(vsa, lp_linear_everywhere, case):
+def test_f16x3_compute_mode_matches_reference_golden(vsa, case, kernel_path):
     """set_compute_dtype('fp16x3') (every product emulated on the f16 pipe) against the reference-generated
-    goldens, at the fp32 path's own 1e-4 bar."""
+    goldens, at the fp32 path's own 1e-4 bar - through its latency kernels ("auto") and its tiled kernels."""
     if case["d"] > 256 or case["d"] // case["H"] not in (32, 64):
         pytest.skip("f16x3 kernels: d_model <= 256, head dim 32/64")
     g = load_golden(case["name"])
@@ -849,6 +849,11 @@ def test_f16x3_full_size_batch_against_exact_path(vsa):
     dl, dh = (l16 - l32).abs().max().item(), (h16 - h32).abs().max().item()
     print("f16x3 vs exact at B=64 T=1024: logits %.2e hidden %.2e" % (dl, dh))
     assert dl < TOL and dh < TOL
+    # the emulated latency kernels (one video alone) multiply in the same order as the emulated tiled kernels
+    # (the video inside the batch of 64): bit-identical scores whatever the batch
+    with torch.no_grad():
+        l1, h1 = m(x[5:6])
+    assert torch.equal(l1[0], l16[5]) and torch.equal(h1[0], h16[5])
 
 
 def test_f16x3_ragged_padded_batch_matches_oracle(vsa, lp_linear_everywhere):

@@ -9,6 +9,8 @@
 int vsk_linear(const float *A, const float *W, const float *Wf, const float *bias, float *C, int M, int N, int K,
                int relu, const float *pe, int T, int bf16, hipStream_t st);
 int vsk_pack_fragments(const float *W, float *Wf, int N, int K, hipStream_t st);
+// the fp16x3 counterpart (hi|lo f16 halves of 2^10 * W, same size): pass it as `Wf` together with bf16 == 2
+int vsk_pack_fragments_f16x3(const float *W, float *Wh, int N, int K, hipStream_t st);
 int vsk_qkv(const float *h, const float *Wqkv, const float *Wf, const float *bqkv, float *qkv, int B, int T, int d,
             int H, int bf16, hipStream_t st);
 int vsk_attention(const float *q, const float *k, const float *v, const uint8_t *mask, float *out,

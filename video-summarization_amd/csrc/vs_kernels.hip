@@ -1264,7 +1264,86 @@ __device__ __forceinline__ void skinny2_stage(float *As, const float *__restrict
     }
 }
 
-template <int EPI>
+// ---- the same latency kernels with the fp32 product EMULATED on the f16 pipe (PREC 2, "fp16x3") ----
+// Packed weights: Wh[n/32][k/16][lane][hi 8 x f16 | lo 8 x f16] = split_f16(2^10 * W[32*(n/32) + (lane&31)]
+// [16*(k/16) + 8*(lane>>5) + j]): 32 B per lane and k-group, the same bytes as the fp32 fragment copy.
+// Activations are split once while they are staged into LDS: a row holds its kp hi halves, then its kp lo halves
+// (4*kp + 16 B: the fp32 row stride, same conflict-free reads).  Product order per 16 k: lo*hi, hi*lo, hi*hi -
+// the order of the tiled PREC 2 kernels, so a video's scores do not depend on the batch it is scored in.
+__global__ void pack_fragments_f16x3(const float *__restrict__ W, unsigned *__restrict__ Wh, int N, int K) {
+    const size_t total = (size_t)N * K / 8;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int lane = (int)(idx & 63);
+        const size_t gi = idx >> 6;
+        const int g = (int)(gi % (K / 16)), nb = (int)(gi / (K / 16));
+        const int row = 32 * nb + (lane & 31), col = 16 * g + 8 * (lane >> 5);
+        const f32x4 v0 = *(const f32x4 *)(W + (size_t)row * K + col) * F16X3_WS;
+        const f32x4 v1 = *(const f32x4 *)(W + (size_t)row * K + col + 4) * F16X3_WS;
+        u32x2 h0, l0, h1, l1;
+        split_f16x4((const float *)&v0, h0, l0);
+        split_f16x4((const float *)&v1, h1, l1);
+        u32x4 hi, lo;
+        hi[0] = h0[0]; hi[1] = h0[1]; hi[2] = h1[0]; hi[3] = h1[1];
+        lo[0] = l0[0]; lo[1] = l0[1]; lo[2] = l1[0]; lo[3] = l1[1];
+        *(u32x4 *)(Wh + idx * 8) = hi;
+        *(u32x4 *)(Wh + idx * 8 + 4) = lo;
+    }
+}
+
+// K loop of one wave over one K phase of kp: as_row = this lane's LDS row + 16*h bytes (hi half; lo half 2*kp
+// bytes further), wh = this lane's 8 dwords of the phase's first 16-k group (groups are 512 dwords apart).
+// 4 register sets of one 32-k chunk (2 groups) each, as skinny2_phase.
+__device__ __forceinline__ void skinny3_phase(f32x16 &acc, const unsigned char *__restrict__ as_row,
+                                              const unsigned *__restrict__ wh, int kp) {
+    u32x4 w[4][2][2];
+    auto load = [&](int set, int chunk) __attribute__((always_inline)) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            w[set][g][0] = *(const u32x4 *)(wh + (size_t)(2 * chunk + g) * 512);
+            w[set][g][1] = *(const u32x4 *)(wh + (size_t)(2 * chunk + g) * 512 + 4);
+        }
+    };
+    auto mma = [&](int set, int chunk) __attribute__((always_inline)) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const f16x8 ah = __builtin_bit_cast(f16x8, *(const u32x4 *)(as_row + 64 * chunk + 32 * g));
+            const f16x8 al = __builtin_bit_cast(f16x8, *(const u32x4 *)(as_row + 2 * kp + 64 * chunk + 32 * g));
+            const f16x8 wh8 = __builtin_bit_cast(f16x8, w[set][g][0]), wl8 = __builtin_bit_cast(f16x8, w[set][g][1]);
+            acc = MFMA_F16(wl8, ah, acc);
+            acc = MFMA_F16(wh8, al, acc);
+            acc = MFMA_F16(wh8, ah, acc);
+        }
+    };
+    const int nc = kp / 32;                         // multiple of 4
+    load(0, 0); load(1, 1); load(2, 2);
+    int c = 0;
+    for (; c < nc - 4; c += 4) {
+        load(3, c + 3); mma(0, c);
+        load(0, c + 4); mma(1, c + 1);
+        load(1, c + 5); mma(2, c + 2);
+        load(2, c + 6); mma(3, c + 3);
+    }
+    load(3, c + 3);
+    mma(0, c); mma(1, c + 1); mma(2, c + 2); mma(3, c + 3);
+}
+
+// stage rows [m0, m0+32) x [k0, k0+kp) of A into LDS as f16 hi | lo half-rows (row stride 4*kp + 16 bytes)
+template <int NT>
+__device__ __forceinline__ void skinny3_stage(unsigned char *As, const float *__restrict__ A, int M, int K, int m0, int k0, int kp) {
+    const int f4row = kp / 4, total = 32 * f4row;
+    for (int idx = threadIdx.x; idx < total; idx += NT) {
+        const int row = idx / f4row, c4 = idx - row * f4row;
+        int ar = m0 + row; ar = ar < M ? ar : M - 1;
+        const f32x4 v = *(const f32x4 *)(A + (size_t)ar * K + k0 + 4 * c4);
+        u32x2 hi, lo;
+        split_f16x4((const float *)&v, hi, lo);
+        unsigned char *rowp = As + (size_t)row * (4 * kp + 16);
+        *(u32x2 *)(rowp + 8 * c4) = hi;
+        *(u32x2 *)(rowp + 2 * kp + 8 * c4) = lo;
+    }
+}
+
+template <int EPI, int PREC = 0>       // PREC 2: Wf is the pack_fragments_f16x3 copy
 __global__ __launch_bounds__(256) void skinny2_gemm(
     const float *__restrict__ A, const float *__restrict__ Wf, const float *__restrict__ bias,
     float *__restrict__ C, int M, int N, int K, const float *__restrict__ pe, int T, int H, int dh) {
@@ -1274,15 +1353,21 @@ __global__ __launch_bounds__(256) void skinny2_gemm(
     const bool live = n0 < N;
     const int row = m0 + r;
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    f32x16 acc = MFMA32((h == 0 && live) ? bias[n0 + r] : 0.f, 1.0f, zero);
+    f32x16 acc = MFMA32((h == 0 && live) ? bias[n0 + r] : 0.f, PREC == 2 ? F16X3_WS : 1.0f, zero);
     const int kpmax = K < 1024 ? K : 1024;
     for (int k0 = 0; k0 < K; k0 += kpmax) {
         const int kp = K - k0 < kpmax ? K - k0 : kpmax;
         if (k0) __syncthreads();
-        skinny2_stage<256>(As, A, M, K, m0, k0, kp);
+        if constexpr (PREC == 2) skinny3_stage<256>((unsigned char *)As, A, M, K, m0, k0, kp);
+        else skinny2_stage<256>(As, A, M, K, m0, k0, kp);
         __syncthreads();
-        if (live)
-            skinny2_phase(acc, As + r * (kp + 4) + 4 * h, Wf + ((size_t)(n0 / 32) * (K / 8) + k0 / 8) * 256 + lane * 4, kp);
+        if (live) {
+            if constexpr (PREC == 2)
+                skinny3_phase(acc, (const unsigned char *)As + (size_t)r * (4 * kp + 16) + 16 * h,
+                              (const unsigned *)Wf + ((size_t)(n0 / 32) * (K / 16) + k0 / 16) * 512 + lane * 8, kp);
+            else
+                skinny2_phase(acc, As + r * (kp + 4) + 4 * h, Wf + ((size_t)(n0 / 32) * (K / 8) + k0 / 8) * 256 + lane * 4, kp);
+        }
     }
     if (!live || row >= M) return;
     int bb = 0, tt = 0;
@@ -1295,6 +1380,7 @@ __global__ __launch_bounds__(256) void skinny2_gemm(
         f32x4 v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = acc[4 * q + e];
+        if constexpr (PREC == 2) v *= 1.0f / F16X3_WS;
         if (EPI == EPI_RELU) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = relu1(v[e]);
@@ -1311,7 +1397,7 @@ __global__ __launch_bounds__(256) void skinny2_gemm(
     }
 }
 
-template <int NW>
+template <int NW, int PREC = 0>
 __global__ __launch_bounds__(64 * NW) void skinny2_ln(
     const float *__restrict__ A, const float *__restrict__ Wf, const float *__restrict__ bias,
     const float *__restrict__ res, const float *__restrict__ gamma, const float *__restrict__ beta,
@@ -1326,10 +1412,12 @@ __global__ __launch_bounds__(64 * NW) void skinny2_ln(
     const int row = m0 + r;
     const bool row_ok = row < M;
     const int arow = row_ok ? row : M - 1;
+    constexpr float SC = PREC == 2 ? F16X3_WS : 1.0f;      // scale of the accumulators (see F16X3_WS, gemm_ln_rows)
     f32x16 acc;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const f32x4 rv = *(const f32x4 *)(res + (size_t)arow * N + n0 + 8 * q + 4 * h);
+        f32x4 rv = *(const f32x4 *)(res + (size_t)arow * N + n0 + 8 * q + 4 * h);
+        if constexpr (PREC == 2) rv *= SC;
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[4 * q + e] = rv[e];
     }
@@ -1337,9 +1425,14 @@ __global__ __launch_bounds__(64 * NW) void skinny2_ln(
     for (int k0 = 0; k0 < K; k0 += kpmax) {
         const int kp = K - k0 < kpmax ? K - k0 : kpmax;
         if (k0) __syncthreads();
-        skinny2_stage<64 * NW>(As, A, M, K, m0, k0, kp);
+        if constexpr (PREC == 2) skinny3_stage<64 * NW>((unsigned char *)As, A, M, K, m0, k0, kp);
+        else skinny2_stage<64 * NW>(As, A, M, K, m0, k0, kp);
         __syncthreads();
-        skinny2_phase(acc, As + r * (kp + 4) + 4 * h, Wf + ((size_t)wave * (K / 8) + k0 / 8) * 256 + lane * 4, kp);
+        if constexpr (PREC == 2)
+            skinny3_phase(acc, (const unsigned char *)As + (size_t)r * (4 * kp + 16) + 16 * h,
+                          (const unsigned *)Wf + ((size_t)wave * (K / 16) + k0 / 16) * 512 + lane * 8, kp);
+        else
+            skinny2_phase(acc, As + r * (kp + 4) + 4 * h, Wf + ((size_t)wave * (K / 8) + k0 / 8) * 256 + lane * 4, kp);
     }
     auto row_total = [&](float v) __attribute__((always_inline)) {      // same tree as skinny_ln / gemm_ln_rows
         __syncthreads();
@@ -1353,7 +1446,8 @@ __global__ __launch_bounds__(64 * NW) void skinny2_ln(
     float s1 = 0.f;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const f32x4 bv = *(const f32x4 *)(bias + n0 + 8 * q + 4 * h);
+        f32x4 bv = *(const f32x4 *)(bias + n0 + 8 * q + 4 * h);
+        if constexpr (PREC == 2) bv *= SC;
 #pragma unroll
         for (int e = 0; e < 4; ++e) { acc[4 * q + e] += bv[e]; s1 += acc[4 * q + e]; }
     }
@@ -1361,7 +1455,7 @@ __global__ __launch_bounds__(64 * NW) void skinny2_ln(
     float s2 = 0.f;
 #pragma unroll
     for (int t = 0; t < 16; ++t) { const float c = acc[t] - mean; acc[t] = c; s2 += c * c; }
-    const float rstd = 1.0f / sqrtf(row_total(s2) * (1.0f / N) + 1e-5f);
+    const float rstd = 1.0f / sqrtf(row_total(s2) * (1.0f / N) + 1e-5f * (SC * SC));
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int co = n0 + 8 * q + 4 * h;
@@ -1438,7 +1532,16 @@ static int allow_big_lds(F *kernel) {
 template <int EPI>
 static int launch_gemm(const float *A, const float *W, const float *Wf, const float *bias, float *C, int M, int N, int K,
                        const float *pe, int T, int H, int dh, int bf16, hipStream_t st) {
-    if (bf16 == 2) {     // fp32 emulated on the f16 pipe (opt-in): always the LDS-tiled kernels
+    if (bf16 == 2 && Wf != nullptr && M <= skinny_max_rows() && N % 32 == 0 && K % 128 == 0) {
+        // fp16x3 latency kernels (Wf is then the pack_fragments_f16x3 copy)
+        static const int attr_rc = allow_big_lds(skinny2_gemm<EPI, 2>);
+        if (attr_rc) return attr_rc;
+        dim3 grid((M + 31) / 32, (N + 127) / 128);
+        hipLaunchKernelGGL((skinny2_gemm<EPI, 2>), grid, dim3(256), skinny2_lds(K), st, A, Wf, bias, C, M, N, K, pe, T, H, dh);
+        VSK_CHECK_LAUNCH();
+        return 0;
+    }
+    if (bf16 == 2) {     // fp32 emulated on the f16 pipe (opt-in): the LDS-tiled kernels
         if (N % 256 == 0 && M > 128) {
             const int blocks = persistent_blocks(((M + 255) / 256) * (N / 256), 1);
             if (blocks < 0) return (int)hipErrorInvalidDevice;
@@ -1465,10 +1568,10 @@ static int launch_gemm(const float *A, const float *W, const float *Wf, const fl
         return 0;
     }
     if (Wf != nullptr && M <= skinny_max_rows() && N % 32 == 0 && K % 128 == 0) {
-        static const int attr_rc = allow_big_lds(skinny2_gemm<EPI>);
+        static const int attr_rc = allow_big_lds(skinny2_gemm<EPI, 0>);
         if (attr_rc) return attr_rc;
         dim3 grid((M + 31) / 32, (N + 127) / 128);
-        hipLaunchKernelGGL((skinny2_gemm<EPI>), grid, dim3(256), skinny2_lds(K), st, A, Wf, bias, C, M, N, K, pe, T, H, dh);
+        hipLaunchKernelGGL((skinny2_gemm<EPI, 0>), grid, dim3(256), skinny2_lds(K), st, A, Wf, bias, C, M, N, K, pe, T, H, dh);
         VSK_CHECK_LAUNCH();
         return 0;
     }
@@ -1526,6 +1629,13 @@ int vsk_pack_fragments(const float *W, float *Wf, int N, int K, hipStream_t st) 
     return 0;
 }
 
+int vsk_pack_fragments_f16x3(const float *W, float *Wh, int N, int K, hipStream_t st) {
+    if (N % 32 || K % 16) return -1;
+    hipLaunchKernelGGL(pack_fragments_f16x3, dim3(256), dim3(256), 0, st, W, (unsigned *)Wh, N, K);
+    VSK_CHECK_LAUNCH();
+    return 0;
+}
+
 // diagnostic: the fc1-shaped GEMM with per-wave stamps (VS_DIAG_MODE 1..3, VS_DIAG_NWM 2|4); `grid` <= 0
 // selects the product grid.  diag == nullptr runs the product kernel.
 int vsk_diag_gemm(const float *A, const float *W, const float *bias, float *C, int M, int N, int K,
@@ -1564,6 +1674,24 @@ int vsk_linear_res_ln(const float *A, const float *W, const float *Wf, const flo
                       const float *gamma, const float *beta, float *out, int M, int N, int K,
                       const float *score_w, const float *score_b, int num_classes, int sigmoid,
                       float *scores, int bf16, hipStream_t st) {
+    if (bf16 == 2 && Wf != nullptr && M <= skinny_max_rows() && N <= 256 && N % 32 == 0 && K % 128 == 0) {
+        const int blocks = (M + 31) / 32;       // fp16x3 latency kernel (Wf: pack_fragments_f16x3 copy)
+#define VSK_SLN3_CASE(NW_)                                                                                 \
+    case NW_: {                                                                                            \
+        static const int attr_rc = allow_big_lds(skinny2_ln<NW_, 2>);                                      \
+        if (attr_rc) return attr_rc;                                                                       \
+        hipLaunchKernelGGL((skinny2_ln<NW_, 2>), dim3(blocks), dim3(64 * NW_), skinny2_lds(K), st, A, Wf, bias, res, \
+                           gamma, beta, out, M, K, score_w, score_b, num_classes, sigmoid, scores);        \
+        break;                                                                                             \
+    }
+        switch (N / 32) {
+            VSK_SLN3_CASE(2) VSK_SLN3_CASE(4) VSK_SLN3_CASE(6) VSK_SLN3_CASE(8)
+            default: return -1;
+        }
+#undef VSK_SLN3_CASE
+        VSK_CHECK_LAUNCH();
+        return 0;
+    }
     if (bf16) {          // bf16 matrix pipe (opt-in): d_model <= 256 only
         if (N > 256 || N % 32) return -1;
         int blocks = persistent_blocks((M + 127) / 128);
@@ -1590,9 +1718,9 @@ int vsk_linear_res_ln(const float *A, const float *W, const float *Wf, const flo
         const int blocks = (M + 31) / 32;
 #define VSK_SLN2_CASE(NW_)                                                                                 \
     case NW_: {                                                                                            \
-        static const int attr_rc = allow_big_lds(skinny2_ln<NW_>);                                         \
+        static const int attr_rc = allow_big_lds(skinny2_ln<NW_, 0>);                                      \
         if (attr_rc) return attr_rc;                                                                       \
-        hipLaunchKernelGGL(skinny2_ln<NW_>, dim3(blocks), dim3(64 * NW_), skinny2_lds(K), st, A, Wf, bias, res, \
+        hipLaunchKernelGGL((skinny2_ln<NW_, 0>), dim3(blocks), dim3(64 * NW_), skinny2_lds(K), st, A, Wf, bias, res, \
                            gamma, beta, out, M, K, score_w, score_b, num_classes, sigmoid, scores);        \
         break;                                                                                             \
     }

@@ -75,6 +75,7 @@ struct StageScope {
 struct LayerOff {
     size_t wqkv, bqkv, wo, bo, ln1g, ln1b, w1, b1, w2, b2, ln2g, ln2b;
     size_t f_wqkv, f_wo, f_w1, f_w2;        // fragment-major copies for the latency kernels
+    size_t h_wqkv, h_wo, h_w1, h_w2;        // their fp16x3 counterparts (hi|lo f16 halves, same size)
 };
 
 int check_desc(const vs_model_desc *d) {
@@ -100,7 +101,7 @@ struct vs_weights {
     vs_model_desc desc;
     float *blob = nullptr;        // one device allocation
     size_t blob_floats = 0;
-    size_t embed_w = 0, embed_b = 0, pe = 0, final_w = 0, final_b = 0, f_embed_w = 0;
+    size_t embed_w = 0, embed_b = 0, pe = 0, final_w = 0, final_b = 0, f_embed_w = 0, h_embed_w = 0;
     bool has_pe = false;
     std::vector<LayerOff> layers;
     const float *p(size_t off) const { return blob + off; }
@@ -146,6 +147,10 @@ int vs_weights_pack(const vs_model_desc *desc, const vs_model_params *params, vo
     w->f_embed_w = take(d * din);
     for (auto &L : w->layers) {
         L.f_wqkv = take(3 * d * d); L.f_wo = take(d * d); L.f_w1 = take(4 * d * d); L.f_w2 = take(4 * d * d);
+    }
+    w->h_embed_w = take(d * din);
+    for (auto &L : w->layers) {
+        L.h_wqkv = take(3 * d * d); L.h_wo = take(d * d); L.h_w1 = take(4 * d * d); L.h_w2 = take(4 * d * d);
     }
     w->blob_floats = off;
     hipError_t e = hipMalloc((void **)&w->blob, off * sizeof(float));
@@ -194,6 +199,13 @@ int vs_weights_pack(const vs_model_desc *desc, const vs_model_params *params, vo
         pk &= vsk_pack_fragments(w->blob + L.wo, w->blob + L.f_wo, (int)d, (int)d, st) == 0;
         pk &= vsk_pack_fragments(w->blob + L.w1, w->blob + L.f_w1, (int)(4 * d), (int)d, st) == 0;
         pk &= vsk_pack_fragments(w->blob + L.w2, w->blob + L.f_w2, (int)d, (int)(4 * d), st) == 0;
+    }
+    pk &= vsk_pack_fragments_f16x3(w->blob + w->embed_w, w->blob + w->h_embed_w, (int)d, (int)din, st) == 0;
+    for (const auto &L : w->layers) {
+        pk &= vsk_pack_fragments_f16x3(w->blob + L.wqkv, w->blob + L.h_wqkv, (int)(3 * d), (int)d, st) == 0;
+        pk &= vsk_pack_fragments_f16x3(w->blob + L.wo, w->blob + L.h_wo, (int)d, (int)d, st) == 0;
+        pk &= vsk_pack_fragments_f16x3(w->blob + L.w1, w->blob + L.h_w1, (int)(4 * d), (int)d, st) == 0;
+        pk &= vsk_pack_fragments_f16x3(w->blob + L.w2, w->blob + L.h_w2, (int)d, (int)(4 * d), st) == 0;
     }
     if (!pk) {
         (void)hipFree(w->blob);
@@ -246,17 +258,17 @@ int vs_scorer_forward(const vs_weights *w, const float *x, const uint8_t *key_pa
     float *h0 = ws, *h1 = ws + md, *qkv = ws + 2 * md, *att = ws + 5 * md, *ffn = ws + 6 * md;
     const float scale = 1.0f / sqrtf((float)d);        // reference simnet.py:126: d_model ** -0.5
     const int sig = (flags & VS_FLAG_SIGMOID) ? 1 : 0;
-    // Low-precision Linear kernels exist as LDS-tiled throughput kernels only; up to 8192 rows the exact fp32
-    // latency kernels are faster (measured crossover, M-A: 8192 rows 0.92 vs 0.96 ms, 12288 rows 1.31 vs 0.99 ms)
-    // and are used whatever the flag says.
-    const char *lpe = getenv("VS_LP_MIN_ROWS");          // tests / tools pin the low-precision kernels with 0
+    // bf16 Linear kernels exist as LDS-tiled throughput kernels only: up to 8192 rows (measured crossover) the exact
+    // fp32 latency kernels are faster and are used whatever that flag says.  fp16x3 has its own latency kernels
+    // (same product order as its tiled kernels: a video's scores do not depend on the batch it is scored in).
+    const char *lpe = getenv("VS_LP_MIN_ROWS");          // tests / tools pin the bf16 tiled kernels with 0
     const int lp_min_rows = lpe ? atoi(lpe) : 8192;
-    const int lbf = M <= lp_min_rows ? 0 : (flags & VS_FLAG_F16X3_LINEAR) ? 2 : (flags & VS_FLAG_BF16_LINEAR) ? 1 : 0;
+    const int lbf = (flags & VS_FLAG_F16X3_LINEAR) ? 2 : ((flags & VS_FLAG_BF16_LINEAR) && M > lp_min_rows) ? 1 : 0;
 
     // Embedding + positional table (simnet.py:211, 237-238)
     {
         StageScope ps(VS_STAGE_EMBED, st);
-        VS_LAUNCH(vsk_linear(x, w->p(w->embed_w), w->p(w->f_embed_w), w->p(w->embed_b), h0, M, d, D.in_features, 0,
+        VS_LAUNCH(vsk_linear(x, w->p(w->embed_w), w->p(lbf == 2 ? w->h_embed_w : w->f_embed_w), w->p(w->embed_b), h0, M, d, D.in_features, 0,
                              w->has_pe ? w->p(w->pe) : nullptr, T, lbf, st));
     }
     for (int l = 0; l < L; ++l) {
@@ -264,7 +276,7 @@ int vs_scorer_forward(const vs_weights *w, const float *x, const uint8_t *key_pa
         const bool last = l == L - 1;
         {
             StageScope ps(VS_STAGE_QKV, st);
-            VS_LAUNCH(vsk_qkv(h0, w->p(P.wqkv), w->p(P.f_wqkv), w->p(P.bqkv), qkv, B, T, d, H, lbf, st));
+            VS_LAUNCH(vsk_qkv(h0, w->p(P.wqkv), w->p(lbf == 2 ? P.h_wqkv : P.f_wqkv), w->p(P.bqkv), qkv, B, T, d, H, lbf, st));
         }
         {
             StageScope ps(VS_STAGE_ATTENTION, st);
@@ -277,7 +289,7 @@ int vs_scorer_forward(const vs_weights *w, const float *x, const uint8_t *key_pa
         }
         {
             StageScope ps(VS_STAGE_OUTPROJ_LN, st);
-            VS_LAUNCH(vsk_linear_res_ln(att, w->p(P.wo), w->p(P.f_wo), w->p(P.bo), h0, w->p(P.ln1g), w->p(P.ln1b), h1, M, d, d,
+            VS_LAUNCH(vsk_linear_res_ln(att, w->p(P.wo), w->p(lbf == 2 ? P.h_wo : P.f_wo), w->p(P.bo), h0, w->p(P.ln1g), w->p(P.ln1b), h1, M, d, d,
                                         nullptr, nullptr, 0, 0, nullptr, lbf, st));
         }
         float *dst = (last && hidden) ? hidden : h0;
@@ -296,11 +308,11 @@ int vs_scorer_forward(const vs_weights *w, const float *x, const uint8_t *key_pa
         }
         {
             StageScope ps(VS_STAGE_FC1, st);
-            VS_LAUNCH(vsk_linear(h1, w->p(P.w1), w->p(P.f_w1), w->p(P.b1), ffn, M, 4 * d, d, 1, nullptr, 1, lbf, st));
+            VS_LAUNCH(vsk_linear(h1, w->p(P.w1), w->p(lbf == 2 ? P.h_w1 : P.f_w1), w->p(P.b1), ffn, M, 4 * d, d, 1, nullptr, 1, lbf, st));
         }
         {
             StageScope ps(VS_STAGE_FC2_LN, st);
-            VS_LAUNCH(vsk_linear_res_ln(ffn, w->p(P.w2), w->p(P.f_w2), w->p(P.b2), h1, w->p(P.ln2g), w->p(P.ln2b), dst, M, d,
+            VS_LAUNCH(vsk_linear_res_ln(ffn, w->p(P.w2), w->p(lbf == 2 ? P.h_w2 : P.f_w2), w->p(P.b2), h1, w->p(P.ln2g), w->p(P.ln2b), dst, M, d,
                                         4 * d, last ? w->p(w->final_w) : nullptr,
                                         last ? w->p(w->final_b) : nullptr, D.num_classes, sig,
                                         last ? scores : nullptr, lbf, st));
