@@ -118,3 +118,20 @@ def test_attention_dtype_is_validated(vsa):
     wide = vsa.SimNet(num_heads=4, d_model=512, num_layers=1)      # head_dim 128: fp32 kernels only
     with pytest.raises(ValueError):
         wide.attention_dtype = "bf16"
+
+
+def test_compute_dtype_switches_are_validated(vsa):
+    m = vsa.SimNet(num_heads=4, d_model=256, num_layers=1)
+    for mode in ("fp16x3", "bf16", "fp32"):
+        assert m.set_compute_dtype(mode) is m
+        assert m.attention_dtype == mode and m.linear_dtype == mode
+    with pytest.raises(ValueError):
+        m.set_compute_dtype("fp8")
+    with pytest.raises(ValueError):
+        m.linear_dtype = "tf32"
+    wide = vsa.SimNet(num_heads=4, d_model=512, num_layers=1)          # M-B: exact fp32 kernels only
+    with pytest.raises(ValueError):
+        wide.set_compute_dtype("fp16x3")
+    assert wide.attention_dtype == "fp32" and wide.linear_dtype == "fp32"
+    flags = vsa._lib
+    assert flags.VS_FLAG_F16X3_LINEAR == 8 and flags.VS_FLAG_F16X3_ATTENTION == 16 and flags.VS_FLAG_BF16_LINEAR == 4
