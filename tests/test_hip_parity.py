@@ -876,3 +876,26 @@ def test_f16x3_ragged_padded_batch_matches_oracle(vsa, lp_linear_everywhere):
     dh = (hidden.cpu() - rh).abs()[valid].max().item()
     print("f16x3 ragged padded: logits %.2e hidden %.2e" % (dl, dh))
     assert dl < TOL and dh < TOL
+
+
+def test_overlapped_host_streaming_matches_direct_scoring(vsa):
+    """corpus.score_host_batches (H2D of batch i+1 under the kernels of batch i, two alternating device buffers):
+    same scores as scoring each batch directly, including ragged batches with masks."""
+    import importlib
+    corpus = importlib.import_module("video-summarization_amd.corpus")
+    synth = vsa.synth
+    sd = synth.make_state_dict(256, 2, 31)
+    m = vsa.SimNet(num_heads=4, d_model=256, num_layers=2, sparsity=0.0, dropout=0.3)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(_dev()).eval()
+    batches = []
+    for i in range(5):
+        lengths = [200 - 7 * i, 150, 33 + i]
+        x = synth.make_features(3, 200 - 7 * i, 40 + i, "pool5", lengths=lengths)
+        batches.append((x.pin_memory() if i % 2 == 0 else x, synth.padding_mask(x)))
+    with torch.no_grad():
+        outs = corpus.score_host_batches(lambda xx, mm: m.score(xx, mm), batches, _dev())
+        for (x, mask), o in zip(batches, outs):
+            want = m.score(x.to(_dev()), mask.to(_dev())).cpu()
+            valid = ~mask
+            assert torch.equal(o[valid], want[valid])

@@ -112,3 +112,50 @@ def score_corpus(score_fn: ScoreFn, videos: Sequence[torch.Tensor], rank: int = 
             if i >= 0:
                 out[i] = recv[r, slot, 1: 1 + lengths[i]].clone()
     return out
+
+
+def score_host_batches(score_fn: ScoreFn, batches, device) -> List[torch.Tensor]:
+    """Scores a sequence of HOST batches (x [B,T,D] pinned or pageable, mask or None) with the host-to-device
+    copy of batch i+1 overlapped with the kernels of batch i: copies run on a side HIP stream into two device
+    buffers that alternate, scores come back with an asynchronous D2H copy.  Returns the per-batch score tensors
+    (host, valid after the final synchronize this function performs).  This is the PCIe-inclusive use of the
+    scorer (features arrive from the loader's pinned host buffers, `train.py:140`): its steady-state rate is
+    max(copy time, compute time) per batch instead of their sum."""
+    compute = torch.cuda.current_stream(device)
+    copy = torch.cuda.Stream(device=device)
+    staged: List[Optional[tuple]] = [None, None]          # device (x, mask, ready-event) per slot
+    freed = [None, None]                                  # event: the slot's previous batch was consumed
+    outs: List[torch.Tensor] = []
+    batches = list(batches)
+
+    def upload(i: int) -> None:
+        slot = i & 1
+        x, mask = batches[i]
+        with torch.cuda.stream(copy):
+            if freed[slot] is not None:
+                copy.wait_event(freed[slot])              # do not overwrite a buffer the kernels still read
+            dx = x.to(device, non_blocking=True)
+            dm = mask.to(device, non_blocking=True) if mask is not None else None
+            ev = torch.cuda.Event()
+            ev.record(copy)
+        staged[slot] = (dx, dm, ev)
+
+    if batches:
+        upload(0)
+    for i in range(len(batches)):
+        if i + 1 < len(batches):
+            upload(i + 1)
+        dx, dm, ev = staged[i & 1]
+        compute.wait_event(ev)
+        dx.record_stream(compute)
+        if dm is not None:
+            dm.record_stream(compute)
+        sc = score_fn(dx, dm)
+        done = torch.cuda.Event()
+        done.record(compute)
+        freed[i & 1] = done
+        host = torch.empty(sc.shape, dtype=sc.dtype, pin_memory=True)
+        host.copy_(sc, non_blocking=True)
+        outs.append(host)
+    torch.cuda.synchronize(device)
+    return outs
