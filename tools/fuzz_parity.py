@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Randomised parity soak: random (architecture, batch, lengths, mask kind, compute mode) against the CPU oracle.
+usage: fuzz_parity.py [seconds] [seed]   (GPU box; prints a summary line, fails on the first violation).
+tests/test_hip_parity.py runs a short fixed-seed slice of it."""
+import importlib
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pkg = importlib.import_module("video-summarization_amd")
+from oracle.simnet_oracle import oracle_forward  # noqa: E402  (the checker)
+
+TOL = {"fp32": 1e-4, "fp16x3": 1e-4, "bf16": 3e-2}
+ARCH = [(4, 256, 4), (4, 256, 1), (8, 256, 2), (4, 128, 2), (2, 128, 3), (4, 512, 1), (8, 512, 2)]   # (H, d, L)
+LENGTHS = [1, 2, 17, 31, 32, 33, 63, 64, 65, 100, 127, 128, 129, 200, 255, 256, 257, 320, 511, 640, 777, 1024]
+
+
+def run(budget: float, seed: int, max_cases: int = 1 << 30, progress: bool = False):
+    """Returns (cases, worst error per mode); raises AssertionError on the first violation."""
+    dev = torch.device("cuda:0")
+    rng = np.random.Generator(np.random.PCG64(seed))
+    torch.set_num_threads(16)
+    t_end = time.time() + budget
+    n = 0
+    t_print = time.time() + 30
+    worst = {k: 0.0 for k in TOL}
+    saved = {k: os.environ.get(k) for k in ("VS_SKINNY_ROWS", "VS_LP_MIN_ROWS")}
+    try:
+        while time.time() < t_end and n < max_cases:
+            H, d, L = ARCH[rng.integers(len(ARCH))]
+            B = int(rng.integers(1, 6))
+            T = int(rng.choice(LENGTHS))
+            kind = rng.choice(["none", "suffix", "random"])
+            sd = pkg.synth.make_state_dict(d, L, int(rng.integers(1 << 30)), trained_like=bool(rng.integers(2)))
+            lengths = None
+            if kind == "suffix" and T > 1:
+                lengths = [int(rng.integers(1, T + 1)) for _ in range(B)]
+                lengths[int(rng.integers(B))] = T
+            x = pkg.synth.make_features(B, T, int(rng.integers(1 << 30)), "pool5" if rng.integers(2) else "randn", lengths=lengths)
+            mask = pkg.synth.padding_mask(x) if lengths is not None else (
+                pkg.synth.random_mask(B, T, int(rng.integers(1 << 30))) if kind == "random" else None)
+            m = pkg.SimNet(num_heads=H, d_model=d, num_layers=L, sparsity=0.0, dropout=0.3)
+            m.load_state_dict(sd, strict=True)
+            m = m.to(dev).eval()
+            modes = ["fp32"] + (["fp16x3", "bf16"] if d <= 256 and d // H in (32, 64) else [])
+            with torch.no_grad():
+                rl, rh = oracle_forward(sd, x, mask, H)
+                valid = torch.ones(B, T, dtype=torch.bool) if mask is None else ~mask
+                for mode in modes:
+                    for pin in ("0", None):                      # tiled kernels pinned, then the default dispatch
+                        for k in saved:
+                            if pin is None:
+                                os.environ.pop(k, None)
+                            else:
+                                os.environ[k] = pin
+                        m.set_compute_dtype(mode)
+                        l, hdn = m(x.to(dev), None if mask is None else mask.to(dev))
+                        err = max((l.cpu() - rl).abs().squeeze(-1)[valid].max().item(),
+                                  (hdn.cpu() - rh).abs()[valid].max().item())
+                        worst[mode] = max(worst[mode], err)
+                        assert err < TOL[mode], "mode=%s pin=%s H=%d d=%d L=%d B=%d T=%d kind=%s err=%.3e" % (
+                            mode, pin, H, d, L, B, T, kind, err)
+            n += 1
+            if progress and time.time() > t_print:       # a silent GPU job is taken for hung after a few minutes
+                print("  ... %d cases" % n, flush=True)
+                t_print = time.time() + 30
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    return n, worst
+
+
+if __name__ == "__main__":
+    n, worst = run(float(sys.argv[1]) if len(sys.argv) > 1 else 60.0, int(sys.argv[2]) if len(sys.argv) > 2 else 1, progress=True)
+    print("fuzz ok: %d random cases, worst |err| vs oracle: %s" % (n, ", ".join("%s %.2e" % kv for kv in worst.items())))
