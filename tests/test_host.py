@@ -129,9 +129,12 @@ def test_compute_dtype_switches_are_validated(vsa):
         m.set_compute_dtype("fp8")
     with pytest.raises(ValueError):
         m.linear_dtype = "tf32"
-    wide = vsa.SimNet(num_heads=4, d_model=512, num_layers=1)          # M-B: exact fp32 kernels only
+    wide = vsa.SimNet(num_heads=4, d_model=512, num_layers=1)          # M-B: head dim 128
+    wide.set_compute_dtype("fp16x3")                                   # plain projections emulated, the rest exact
+    assert wide.attention_dtype == "fp32" and wide.linear_dtype == "fp16x3"
     with pytest.raises(ValueError):
-        wide.set_compute_dtype("fp16x3")
-    assert wide.attention_dtype == "fp32" and wide.linear_dtype == "fp32"
+        wide.set_compute_dtype("bf16")
+    with pytest.raises(ValueError):
+        wide.attention_dtype = "fp16x3"
     flags = vsa._lib
     assert flags.VS_FLAG_F16X3_LINEAR == 8 and flags.VS_FLAG_F16X3_ATTENTION == 16 and flags.VS_FLAG_BF16_LINEAR == 4

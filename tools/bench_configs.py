@@ -39,9 +39,13 @@ with torch.no_grad():
         H, d, L = MODELS[tag]
         for B, T, it in ((1, 320, 200), (1, 1024, 200), (8, 1024, 50), (64, 1024, 20)):
             x = torch.randn(B, T, 1024, device=dev)
-            dt = timed(lambda: m(x), it)
             F = 2 * 1024 * d + L * (24 * d * d + 4 * T * d) + 2 * d
-            print("cfg M-%s B=%2d T=%4d: %8.3f ms/forward  %10.0f frames/s  %6.1f TFLOP/s" % (tag, B, T, dt * 1e3, B * T / dt, B * T / dt * F / 1e12))
+            for mode in ("fp32", "fp16x3"):
+                m.set_compute_dtype(mode)
+                dt = timed(lambda: m(x), it)
+                print("cfg M-%s %-6s B=%2d T=%4d: %8.3f ms/forward  %10.0f frames/s  %6.1f TFLOP/s(fp32-equivalent)" % (
+                    tag, mode, B, T, dt * 1e3, B * T / dt, B * T / dt * F / 1e12))
+            m.set_compute_dtype("fp32")
     # configs[4] shape in fp32: B=8 videos x T=8192 frames x 2048-d features (beyond the reference's envelope)
     H, d, L = MODELS["A"]
     m5 = pkg.SimNet(num_heads=H, d_model=d, num_layers=L, sparsity=0.0, dropout=0.3, in_features=2048, pe_len=8192)

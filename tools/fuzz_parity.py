@@ -47,7 +47,7 @@ def run(budget: float, seed: int, max_cases: int = 1 << 30, progress: bool = Fal
             m = pkg.SimNet(num_heads=H, d_model=d, num_layers=L, sparsity=0.0, dropout=0.3)
             m.load_state_dict(sd, strict=True)
             m = m.to(dev).eval()
-            modes = ["fp32"] + (["fp16x3", "bf16"] if d <= 256 and d // H in (32, 64) else [])
+            modes = ["fp32", "fp16x3"] + (["bf16"] if d <= 256 and d // H in (32, 64) else [])
             with torch.no_grad():
                 rl, rh = oracle_forward(sd, x, mask, H)
                 valid = torch.ones(B, T, dtype=torch.bool) if mask is None else ~mask

@@ -237,8 +237,8 @@ int vs_scorer_forward(const vs_weights *w, const float *x, const uint8_t *key_pa
     if (w->has_pe && T > D.max_len)
         return fail(VS_ERR_INVALID, "T=%d exceeds the positional table (max_len=%d)", T, D.max_len);
     if ((long long)B * T > (1ll << 30)) return fail(VS_ERR_INVALID, "B*T too large");
-    if ((flags & (VS_FLAG_BF16_LINEAR | VS_FLAG_F16X3_LINEAR)) && D.d_model > 256)
-        return fail(VS_ERR_INVALID, "VS_FLAG_BF16_LINEAR / VS_FLAG_F16X3_LINEAR need d_model <= 256 (got %d)", D.d_model);
+    if ((flags & VS_FLAG_BF16_LINEAR) && D.d_model > 256)
+        return fail(VS_ERR_INVALID, "VS_FLAG_BF16_LINEAR needs d_model <= 256 (got %d)", D.d_model);
     if ((flags & VS_FLAG_BF16_LINEAR) && (flags & VS_FLAG_F16X3_LINEAR))
         return fail(VS_ERR_INVALID, "VS_FLAG_BF16_LINEAR and VS_FLAG_F16X3_LINEAR are exclusive");
     if ((flags & (VS_FLAG_BF16_ATTENTION | VS_FLAG_F16X3_ATTENTION)) && D.d_model / D.num_heads != 32 && D.d_model / D.num_heads != 64)
@@ -264,6 +264,9 @@ int vs_scorer_forward(const vs_weights *w, const float *x, const uint8_t *key_pa
     const char *lpe = getenv("VS_LP_MIN_ROWS");          // tests / tools pin the bf16 tiled kernels with 0
     const int lp_min_rows = lpe ? atoi(lpe) : 8192;
     const int lbf = (flags & VS_FLAG_F16X3_LINEAR) ? 2 : ((flags & VS_FLAG_BF16_LINEAR) && M > lp_min_rows) ? 1 : 0;
+    // the Linear + LayerNorm kernels have low-precision variants up to d_model 256; wider models (M-B: 512) keep
+    // them exact and emulate the plain projections only (embed, q/k/v, fc1: 70 % of the Linear FLOPs)
+    const int lnbf = d <= 256 ? lbf : 0;
 
     // Embedding + positional table (simnet.py:211, 237-238)
     {
@@ -289,8 +292,8 @@ int vs_scorer_forward(const vs_weights *w, const float *x, const uint8_t *key_pa
         }
         {
             StageScope ps(VS_STAGE_OUTPROJ_LN, st);
-            VS_LAUNCH(vsk_linear_res_ln(att, w->p(P.wo), w->p(lbf == 2 ? P.h_wo : P.f_wo), w->p(P.bo), h0, w->p(P.ln1g), w->p(P.ln1b), h1, M, d, d,
-                                        nullptr, nullptr, 0, 0, nullptr, lbf, st));
+            VS_LAUNCH(vsk_linear_res_ln(att, w->p(P.wo), w->p(lnbf == 2 ? P.h_wo : P.f_wo), w->p(P.bo), h0, w->p(P.ln1g), w->p(P.ln1b), h1, M, d, d,
+                                        nullptr, nullptr, 0, 0, nullptr, lnbf, st));
         }
         float *dst = (last && hidden) ? hidden : h0;
         // Opt-in alternative (VS_MLP_FUSION=1, d_model = 256): fc1 + ReLU + fc2 + residual + norm2 (+ score head)
@@ -312,10 +315,10 @@ int vs_scorer_forward(const vs_weights *w, const float *x, const uint8_t *key_pa
         }
         {
             StageScope ps(VS_STAGE_FC2_LN, st);
-            VS_LAUNCH(vsk_linear_res_ln(ffn, w->p(P.w2), w->p(lbf == 2 ? P.h_w2 : P.f_w2), w->p(P.b2), h1, w->p(P.ln2g), w->p(P.ln2b), dst, M, d,
+            VS_LAUNCH(vsk_linear_res_ln(ffn, w->p(P.w2), w->p(lnbf == 2 ? P.h_w2 : P.f_w2), w->p(P.b2), h1, w->p(P.ln2g), w->p(P.ln2b), dst, M, d,
                                         4 * d, last ? w->p(w->final_w) : nullptr,
                                         last ? w->p(w->final_b) : nullptr, D.num_classes, sig,
-                                        last ? scores : nullptr, lbf, st));
+                                        last ? scores : nullptr, lnbf, st));
         }
     }
     return VS_OK;
