@@ -54,8 +54,7 @@ extern "C" {
                                 a*b ~ a_hi*b_hi + a_hi*b_lo + a_lo*b_hi, fp32 accumulate - three f16 MFMAs
                                 (96 cycles) instead of eight fp32 MFMAs (512 cycles) per 16 k.  Per-product
                                 error ~3e-6 relative: results stay inside the 1e-4 bar (tests).  Operand
-                                magnitudes must be < 65504 (f16 range).  With d_model > 256 only the plain
-                                projections are emulated (the Linear + LayerNorm kernels stay exact).
+                                magnitudes must be < 65504 (f16 range).  Any supported d_model.
                                 Exclusive with VS_FLAG_BF16_LINEAR. */
 
 /* Model hyper-parameters: the ctor arguments of reference SimNet.__init__ (simnet.py:10-13)

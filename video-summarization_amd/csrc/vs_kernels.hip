@@ -377,7 +377,7 @@ __global__ __launch_bounds__(128 * NWM, 2) void gemm_nt_128(
 //   4 waves as 2 (rows) x 2 (column halves); each wave 32 rows x 32*NB columns.
 //   BK = 16, LDS row pad 20 floats (20*r mod 64 = 4*(5r mod 16): conflict-free b128 reads).
 // ------------------------------------------------------------------------------------------
-template <int NB>
+template <int NB, int PREC = 0>      // PREC 2: fp32 emulated on the f16 pipe (rows hold 16 hi then 16 lo halves: the same 80 B)
 __global__ __launch_bounds__(256) void gemm_res_ln(
     const float *__restrict__ A, const float *__restrict__ W, const float *__restrict__ bias,
     const float *__restrict__ res, const float *__restrict__ gamma, const float *__restrict__ beta,
@@ -407,11 +407,22 @@ __global__ __launch_bounds__(256) void gemm_res_ln(
 #pragma unroll
         for (int t = 0; t < 16; ++t) acc[j][t] = 0.f;
 
+    auto put = [&](float *rowp, f32x4 v, float scale) __attribute__((always_inline)) {
+        if constexpr (PREC == 2) {
+            v *= scale;
+            u32x2 hi, lo;
+            split_f16x4((const float *)&v, hi, lo);
+            *(u32x2 *)&rowp[lc4 / 2] = hi;
+            *(u32x2 *)&rowp[8 + lc4 / 2] = lo;
+        } else {
+            *(f32x4 *)&rowp[lc4] = v;
+        }
+    };
     {
         float *As = smem, *Ws = smem + BM * LD;
-        *(f32x4 *)&As[lrow * LD + lc4] = pa;
+        put(&As[lrow * LD], pa, 1.0f);
 #pragma unroll
-        for (int i = 0; i < NB; ++i) *(f32x4 *)&Ws[(lrow + 64 * i) * LD + lc4] = pw[i];
+        for (int i = 0; i < NB; ++i) put(&Ws[(lrow + 64 * i) * LD], pw[i], F16X3_WS);
     }
     __syncthreads();
 
@@ -427,22 +438,35 @@ __global__ __launch_bounds__(256) void gemm_res_ln(
         }
         const float *ap = As + (32 * wr + r) * LD + 4 * h;
         const float *wp = Ws + (32 * NB * wc + r) * LD + 4 * h;
+        if constexpr (PREC == 2) {
+            // one k-step of 16: lane (r,h) supplies k = 8h .. 8h+7 of the hi half-row and of the lo half-row
+            const f16x8 ah = __builtin_bit_cast(f16x8, *(const u32x4 *)ap), al = __builtin_bit_cast(f16x8, *(const u32x4 *)(ap + 8));
 #pragma unroll
-        for (int g = 0; g < BK / 8; ++g) {
-            const f32x4 a = *(const f32x4 *)(ap + 8 * g);
-            f32x4 b[NB];
+            for (int j = 0; j < NB; ++j) {
+                const f16x8 bh = __builtin_bit_cast(f16x8, *(const u32x4 *)(wp + 32 * j * LD));
+                const f16x8 bl = __builtin_bit_cast(f16x8, *(const u32x4 *)(wp + 32 * j * LD + 8));
+                acc[j] = MFMA_F16(ah, bl, acc[j]);
+                acc[j] = MFMA_F16(al, bh, acc[j]);
+                acc[j] = MFMA_F16(ah, bh, acc[j]);
+            }
+        } else {
 #pragma unroll
-            for (int j = 0; j < NB; ++j) b[j] = *(const f32x4 *)(wp + 32 * j * LD + 8 * g);
+            for (int g = 0; g < BK / 8; ++g) {
+                const f32x4 a = *(const f32x4 *)(ap + 8 * g);
+                f32x4 b[NB];
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
+                for (int j = 0; j < NB; ++j) b[j] = *(const f32x4 *)(wp + 32 * j * LD + 8 * g);
 #pragma unroll
-                for (int j = 0; j < NB; ++j) acc[j] = MFMA32(a[s], b[j][s], acc[j]);
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) acc[j] = MFMA32(a[s], b[j][s], acc[j]);
+            }
         }
         if (more) {
             float *An = smem + (cur ^ 1) * (BM + N) * LD, *Wn = An + BM * LD;
-            *(f32x4 *)&An[lrow * LD + lc4] = pa;
+            put(&An[lrow * LD], pa, 1.0f);
 #pragma unroll
-            for (int i = 0; i < NB; ++i) *(f32x4 *)&Wn[(lrow + 64 * i) * LD + lc4] = pw[i];
+            for (int i = 0; i < NB; ++i) put(&Wn[(lrow + 64 * i) * LD], pw[i], F16X3_WS);
         }
         __syncthreads();
     }
@@ -461,7 +485,7 @@ __global__ __launch_bounds__(256) void gemm_res_ln(
         float s = 0.f;
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
-            const float v = acc[j][t] + bj[j] + res[(size_t)row * N + cbase + 32 * j];
+            const float v = (PREC == 2 ? acc[j][t] * (1.0f / F16X3_WS) : acc[j][t]) + bj[j] + res[(size_t)row * N + cbase + 32 * j];
             acc[j][t] = v;
             s += v;
         }
@@ -1692,8 +1716,9 @@ int vsk_linear_res_ln(const float *A, const float *W, const float *Wf, const flo
         VSK_CHECK_LAUNCH();
         return 0;
     }
-    if (bf16) {          // bf16 matrix pipe (opt-in): d_model <= 256 only
-        if (N > 256 || N % 32) return -1;
+    if (bf16 == 1 && (N > 256 || N % 32)) return -1;      // bf16: d_model <= 256 only
+    if (bf16 && N <= 256) {          // low-precision lane-owns-a-row kernels (wider fp16x3: gemm_res_ln<NB, 2> below)
+        if (N % 32) return -1;
         int blocks = persistent_blocks((M + 127) / 128);
         if (blocks < 0) return (int)hipErrorInvalidDevice;
         if (blocks > (M + 127) / 128) blocks = (M + 127) / 128;
@@ -1765,10 +1790,14 @@ int vsk_linear_res_ln(const float *A, const float *W, const float *Wf, const flo
         return 0;
     }
     const int blocks = (M + 63) / 64;
-#define VSK_LN_CASE(NB_)                                                                             \
-    case NB_:                                                                                        \
-        hipLaunchKernelGGL(gemm_res_ln<NB_>, dim3(blocks), dim3(256), 0, st, A, W, bias, res, gamma, \
-                           beta, out, M, K, score_w, score_b, num_classes, sigmoid, scores);         \
+#define VSK_LN_CASE(NB_)                                                                                  \
+    case NB_:                                                                                             \
+        if (bf16 == 2)                                                                                    \
+            hipLaunchKernelGGL((gemm_res_ln<NB_, 2>), dim3(blocks), dim3(256), 0, st, A, W, bias, res, gamma, \
+                               beta, out, M, K, score_w, score_b, num_classes, sigmoid, scores);          \
+        else                                                                                              \
+            hipLaunchKernelGGL((gemm_res_ln<NB_, 0>), dim3(blocks), dim3(256), 0, st, A, W, bias, res, gamma, \
+                               beta, out, M, K, score_w, score_b, num_classes, sigmoid, scores);          \
         break;
     switch (N / 64) {
         VSK_LN_CASE(1) VSK_LN_CASE(2) VSK_LN_CASE(3) VSK_LN_CASE(4)

@@ -264,9 +264,8 @@ int vs_scorer_forward(const vs_weights *w, const float *x, const uint8_t *key_pa
     const char *lpe = getenv("VS_LP_MIN_ROWS");          // tests / tools pin the bf16 tiled kernels with 0
     const int lp_min_rows = lpe ? atoi(lpe) : 8192;
     const int lbf = (flags & VS_FLAG_F16X3_LINEAR) ? 2 : ((flags & VS_FLAG_BF16_LINEAR) && M > lp_min_rows) ? 1 : 0;
-    // the Linear + LayerNorm kernels have low-precision variants up to d_model 256; wider models (M-B: 512) keep
-    // them exact and emulate the plain projections only (embed, q/k/v, fc1: 70 % of the Linear FLOPs)
-    const int lnbf = d <= 256 ? lbf : 0;
+    // the bf16 Linear + LayerNorm kernels stop at d_model 256 (validated above); fp16x3 has a wide variant too
+    const int lnbf = lbf;
 
     // Embedding + positional table (simnet.py:211, 237-238)
     {

@@ -268,7 +268,6 @@ class SimNet(nn.Module):
             raise ValueError("linear_dtype must be 'fp32', 'bf16' or 'fp16x3', got %r" % (value,))
         if value == "bf16" and self.d_model > 256:
             raise ValueError("bf16 Linear kernels need d_model <= 256, got %d" % self.d_model)
-        # fp16x3 with d_model > 256: the plain projections are emulated, the Linear + LayerNorm kernels stay exact
         self._linear_dtype = value
 
     def set_compute_dtype(self, value: str) -> "SimNet":
@@ -276,8 +275,7 @@ class SimNet(nn.Module):
         hi + lo halves, three products, fp32 accumulate - same 1e-4 parity, ~2x faster; operands < 65504) or 'bf16'
         (BASELINE config 5: operands rounded to bf16, logits move by ~4e-3).  Tensors, softmax, LayerNorm and the
         score head stay fp32 in every mode."""
-        # wider / longer-headed models take what exists for them: M-B (d 512, head dim 128) gets the emulated plain
-        # projections and keeps exact attention and Linear + LayerNorm kernels
+        # models with head dim 128 (M-B) take what exists for them: every Linear emulated, attention exact
         head_ok = self.d_model // self.num_heads in (32, 64)
         if value == "bf16" and not (head_ok and self.d_model <= 256):
             raise ValueError("bf16 mode needs d_model <= 256 and head_dim 32 or 64")
