@@ -213,10 +213,14 @@ def main():
         roofline = {"bound": "mfma", "kernel": dom, "achieved": table[dom]["tflops"], "peak": round(peak, 1),
                     "unit": "TFLOP/s", "frac": round(table[dom]["tflops"] / peak, 4),
                     "traffic": measured_traffic(dom) if (B, T, args.model, args.compute) == (64, 1024, "A", "fp32") else None,
+                    "hbm_gbps": None,
                     "whole_forward": {"flop_per_frame": flops_per_frame,
                                       "achieved": round(value / world * flops_per_frame / 1e12, 2),
                                       "frac": round(value / world * flops_per_frame / 1e12 / peak, 4)},
                     "stages": table}
+        if roofline["traffic"]:
+            # HBM GB/s of the dominant kernel: measured bytes per launch (PMC passes) / its live average duration
+            roofline["hbm_gbps"] = round(roofline["traffic"] / (table[dom]["avg_ms"] * 1e-3) / 1e9, 1)
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             from oracle.simnet_oracle import time_cpu_baseline      # the checker, timed as the CPU "port"
