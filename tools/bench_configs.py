@@ -61,6 +61,10 @@ with torch.no_grad():
     g = torch.Generator().manual_seed(7)
     lens = torch.randint(150, 650, (50,), generator=g).tolist() + torch.randint(100, 650, (25,), generator=g).tolist()
     vids = [torch.randn(t, 1024, generator=g).to(dev) for t in lens]
-    fn = lambda: corpus.score_corpus(lambda x, mk: m.score(x, mk), vids, device=dev, max_frames=16384)
-    dt = timed(fn, 10, 2)
-    print("corpus 75 ragged videos (%d frames): %.2f ms  %.0f frames/s (incl. host batching + D2H of scores)" % (sum(lens), dt * 1e3, sum(lens) / dt))
+    for mode in ("fp32", "fp16x3"):
+        m.set_compute_dtype(mode)
+        for mf in (16384, 65536):
+            fn = lambda: corpus.score_corpus(lambda x, mk: m.score(x, mk), vids, device=dev, max_frames=mf)
+            dt = timed(fn, 10, 2)
+            print("corpus 75 ragged videos (%d frames) %-6s max_frames=%5d: %.2f ms  %.0f frames/s (incl. host batching + D2H of scores)" % (
+                sum(lens), mode, mf, dt * 1e3, sum(lens) / dt))

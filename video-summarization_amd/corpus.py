@@ -57,19 +57,16 @@ def bucket_batches(indices: Sequence[int], lengths: Sequence[int], max_frames: i
 
 
 def pad_batch(videos: Sequence[torch.Tensor], device=None):
-    """[T_i, D] tensors -> (x [B, Tmax, D] right-padded with 1000.0, mask [B, Tmax] bool or None)."""
-    tmax = max(v.shape[0] for v in videos)
-    D = videos[0].shape[1]
-    x = torch.full((len(videos), tmax, D), PAD_VALUE, dtype=torch.float32, device=device)
-    ragged = False
-    for b, v in enumerate(videos):
-        x[b, : v.shape[0]] = v.to(device=device, dtype=torch.float32)
-        ragged |= v.shape[0] != tmax
+    """[T_i, D] tensors -> (x [B, Tmax, D] right-padded with 1000.0, mask [B, Tmax] bool or None).
+    A handful of launches whatever the number of videos: one pad_sequence, one comparison for the mask."""
+    lengths = [int(v.shape[0]) for v in videos]
+    tmax = max(lengths)
+    vs = [v.to(device=device, dtype=torch.float32) for v in videos]
+    x = torch.nn.utils.rnn.pad_sequence(vs, batch_first=True, padding_value=PAD_VALUE)
     mask = None
-    if ragged:
-        mask = torch.zeros((len(videos), tmax), dtype=torch.bool, device=device)
-        for b, v in enumerate(videos):
-            mask[b, v.shape[0]:] = True
+    if any(t != tmax for t in lengths):
+        lt = torch.tensor(lengths, device=x.device)
+        mask = torch.arange(tmax, device=x.device)[None, :] >= lt[:, None]
     return x, mask
 
 
@@ -84,11 +81,14 @@ def score_corpus(score_fn: ScoreFn, videos: Sequence[torch.Tensor], rank: int = 
     lengths = [int(v.shape[0]) for v in videos]
     mine = plan_shards(lengths, world)[rank]
     local: Dict[int, torch.Tensor] = {}
+    pending = []
     for batch in bucket_batches(mine, lengths, max_frames):
         x, mask = pad_batch([videos[i] for i in batch], device)
-        s = score_fn(x, mask)
+        pending.append((batch, score_fn(x, mask).detach().float()))     # stays on the device: no sync per batch
+    for batch, s in pending:                                            # one D2H per batch, after all launches
+        sh = s.cpu()
         for b, i in enumerate(batch):
-            local[i] = s[b, : lengths[i]].detach().float().cpu()
+            local[i] = sh[b, : lengths[i]].clone()
     if world == 1:
         return local
     import torch.distributed as dist
