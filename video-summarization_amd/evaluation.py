@@ -11,6 +11,8 @@ from __future__ import annotations
 
 import ctypes as C
 
+import concurrent.futures
+
 import numpy as np
 
 from . import _lib
@@ -86,16 +88,23 @@ def evaluate_scores(predicted_scores, user_scores):
 
 
 def eval_metrics(data, user_dict):
-    """compute_metrics.py:42-92 -> (mean F-score ['avg' protocol, :43], mean Kendall tau, mean Spearman rho)."""
+    """compute_metrics.py:42-92 -> (mean F-score ['avg' protocol, :43], mean Kendall tau, mean Spearman rho).
+    Videos are independent: they are evaluated on a few host threads (the C++ calls release the GIL) and the
+    means are taken in key order, so the result does not depend on the scheduling."""
     keys = list(data.keys())
-    users = [user_dict[k] for k in keys]
-    scores = [np.asarray(data[k]) for k in keys]
-    summaries = generate_summary([u.change_points for u in users], scores, [u.n_frames for u in users],
-                                 [u.picks for u in users])
-    f, kt, sp = [], [], []
-    for summary, sc, u in zip(summaries, scores, users):
-        f.append(evaluate_summary(summary, u.user_summary, "avg"))
-        k, s = evaluate_scores(upsample(sc, u.n_frames, u.picks), u.user_scores)
-        kt.append(k)
-        sp.append(s)
+
+    def one(k):
+        u = user_dict[k]
+        sc = np.asarray(data[k])
+        summary = generate_summary([u.change_points], [sc], [u.n_frames], [u.picks])[0]
+        f = evaluate_summary(summary, u.user_summary, "avg")
+        kt, sp = evaluate_scores(upsample(sc, u.n_frames, u.picks), u.user_scores)
+        return f, kt, sp
+
+    if len(keys) > 1:
+        with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, len(keys))) as pool:
+            res = list(pool.map(one, keys))
+    else:
+        res = [one(k) for k in keys]
+    f, kt, sp = zip(*res) if res else ((), (), ())
     return float(np.mean(f)), float(np.mean(kt)), float(np.mean(sp))

@@ -14,6 +14,8 @@ from __future__ import annotations
 
 from typing import Iterable, Sequence
 
+import concurrent.futures
+
 import torch
 import torch.nn.functional as F
 
@@ -49,14 +51,23 @@ def val_step_batched(model, features: Sequence[torch.Tensor], targets: Sequence[
     # scored and the four sums are all-reduced.  Sums run in a fixed per-rank order.
     lengths = [int(f.shape[0]) for f in features]
     mine = plan_shards(lengths, world)[rank] if world > 1 else list(range(len(users)))
-    sums = [0.0, 0.0, 0.0, 0.0]
-    for i in sorted(mine):
+    order = sorted(mine)
+
+    def one(i):
         u = users[i]
         f, k, s = eval_metrics({u.name: scores[i].numpy()}, {u.name: u})
-        sums[0] += F.mse_loss(scores[i].view(1, -1), targets[i].detach().float().cpu().view(1, -1)).item()
-        sums[1] += f
-        sums[2] += k
-        sums[3] += s
+        return F.mse_loss(scores[i].view(1, -1), targets[i].detach().float().cpu().view(1, -1)).item(), f, k, s
+
+    # videos are independent: a few host threads (the C++ evaluation releases the GIL), sums in index order
+    if len(order) > 1:
+        with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, len(order))) as pool:
+            res = list(pool.map(one, order))
+    else:
+        res = [one(i) for i in order]
+    sums = [0.0, 0.0, 0.0, 0.0]
+    for r in res:
+        for j in range(4):
+            sums[j] += r[j]
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor(sums, dtype=torch.float64,
