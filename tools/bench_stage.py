@@ -1,7 +1,6 @@
 #!/usr/bin/env python3
 """Times single stages of the scorer at bench shapes through the per-kernel C entry points.
 usage: bench_stage.py attention|fc1|qkv|outproj|fc2 [iters]"""
-import ctypes as C
 import importlib
 import os
 import sys
