@@ -912,3 +912,34 @@ def test_randomised_parity_slice(vsa):
     n, worst = mod.run(budget=60.0, seed=7, max_cases=40)
     print("fuzz slice: %d cases, worst %s" % (n, worst))
     assert n == 40
+
+
+@pytest.mark.parametrize("cfg", [(4, 256, 4), (8, 256, 2), (4, 128, 2)])
+def test_packed_ragged_batch_is_bit_identical_to_scoring_each_video_alone(vsa, cfg):
+    """SimNet.forward_packed (frames of all videos concatenated, no padding rows, no mask): every video's logits
+    and hidden state equal scoring that video alone bit for bit, and meet the oracle at 1e-4."""
+    H, d, L = cfg
+    synth = vsa.synth
+    sd = synth.make_state_dict(d, L, 17)
+    m = vsa.SimNet(num_heads=H, d_model=d, num_layers=L, sparsity=0.0, dropout=0.3)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(_dev()).eval()
+    lengths = [320, 1, 257, 64, 650, 33, 128, 129, 2000]
+    vids = [synth.make_features(1, t, 100 + i, "pool5")[0] for i, t in enumerate(lengths)]
+    x = torch.cat(vids, dim=0).to(_dev())
+    with torch.no_grad():
+        logits, hidden = m.forward_packed(x, lengths)
+        sc = m.score_packed(x, lengths)
+        row = 0
+        for i, (v, t) in enumerate(zip(vids, lengths)):
+            l1, h1 = m(v[None].to(_dev()))
+            assert torch.equal(logits[row:row + t], l1[0]) and torch.equal(hidden[row:row + t], h1[0]), i
+            assert (sc[row:row + t] - torch.sigmoid(l1[0, :, 0])).abs().max().item() < 1e-6
+            if i in (0, 4):
+                rl, rh = oracle_forward(sd, v[None], None, H)
+                assert (l1.cpu() - rl).abs().max().item() < TOL and (h1.cpu() - rh).abs().max().item() < TOL
+            row += t
+    with pytest.raises(RuntimeError):
+        m.forward_packed(x, lengths[:-1])                     # row count does not match
+    with pytest.raises(RuntimeError):
+        m.forward_packed(torch.cat([x, x[:1]]), lengths[:-1] + [2001])     # beyond the positional table

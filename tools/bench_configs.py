@@ -64,7 +64,9 @@ with torch.no_grad():
     for mode in ("fp32", "fp16x3"):
         m.set_compute_dtype(mode)
         for mf in (16384, 65536):
-            fn = lambda: corpus.score_corpus(lambda x, mk: m.score(x, mk), vids, device=dev, max_frames=mf)
-            dt = timed(fn, 10, 2)
-            print("corpus 75 ragged videos (%d frames) %-6s max_frames=%5d: %.2f ms  %.0f frames/s (incl. host batching + D2H of scores)" % (
-                sum(lens), mode, mf, dt * 1e3, sum(lens) / dt))
+            for packed in ((False, True) if mode == "fp32" else (False,)):
+                fn = lambda: corpus.score_corpus(lambda x, mk: m.score(x, mk), vids, device=dev, max_frames=mf,
+                                                 packed_fn=(lambda x, ln: m.score_packed(x, ln)) if packed else None)
+                dt = timed(fn, 10, 2)
+                print("corpus 75 ragged videos (%d frames) %-6s max_frames=%5d %-6s: %.2f ms  %.0f frames/s (incl. host batching + D2H of scores)" % (
+                    sum(lens), mode, mf, "packed" if packed else "padded", dt * 1e3, sum(lens) / dt))

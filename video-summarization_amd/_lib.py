@@ -28,7 +28,8 @@ VS_FLAG_F16X3_ATTENTION = 16
 
 # every symbol include/vs_scorer.h declares
 EXPORTS = ("vs_abi_version", "vs_last_error", "vs_weights_pack", "vs_weights_free",
-           "vs_scorer_workspace_bytes", "vs_scorer_forward", "vs_linear_f32", "vs_qkv_proj_f32",
+           "vs_scorer_workspace_bytes", "vs_scorer_forward", "vs_scorer_workspace_bytes_packed",
+           "vs_scorer_forward_packed", "vs_linear_f32", "vs_qkv_proj_f32",
            "vs_attention_f32", "vs_attention_bf16", "vs_attention_f16x3", "vs_linear_residual_layernorm_f32",
            "vs_linear_bf16", "vs_linear_residual_layernorm_bf16", "vs_linear_f16x3",
            "vs_linear_residual_layernorm_f16x3",
@@ -147,6 +148,11 @@ def load() -> C.CDLL:
         lib.vs_scorer_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                           C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                           C.c_void_p]
+        lib.vs_scorer_workspace_bytes_packed.restype = C.c_size_t
+        lib.vs_scorer_workspace_bytes_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+        lib.vs_scorer_forward_packed.restype = C.c_int
+        lib.vs_scorer_forward_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_uint32,
+                                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         lib.vs_linear_f32.restype = C.c_int
         lib.vs_linear_f32.argtypes = [C.c_void_p] * 4 + [C.c_int32] * 4 + [C.c_void_p, C.c_int32, C.c_void_p]
         lib.vs_qkv_proj_f32.restype = C.c_int

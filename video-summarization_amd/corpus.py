@@ -73,22 +73,36 @@ def pad_batch(videos: Sequence[torch.Tensor], device=None):
 ScoreFn = Callable[[torch.Tensor, Optional[torch.Tensor]], torch.Tensor]   # (x, mask) -> scores [B, T]
 
 
+PackedScoreFn = Callable[[torch.Tensor, List[int]], torch.Tensor]           # (x [sum T, D], lengths) -> scores [sum T]
+
+
 def score_corpus(score_fn: ScoreFn, videos: Sequence[torch.Tensor], rank: int = 0, world: int = 1,
-                 group=None, device=None, max_frames: int = 65536) -> Dict[int, torch.Tensor]:
+                 group=None, device=None, max_frames: int = 65536,
+                 packed_fn: Optional[PackedScoreFn] = None) -> Dict[int, torch.Tensor]:
     """Scores every video once across `world` ranks and returns {video index: scores [T_i]} on EVERY
     rank (CPU tensors).  `score_fn` is `SimNet.score` on a GPU box.  With world == 1 no
-    `torch.distributed` call is made."""
+    `torch.distributed` call is made.  With `packed_fn` (`SimNet.score_packed`) the batches are PACKED - the videos'
+    frames concatenated, no sentinel padding, no mask - instead of padded; the scores are the same bits."""
     lengths = [int(v.shape[0]) for v in videos]
     mine = plan_shards(lengths, world)[rank]
     local: Dict[int, torch.Tensor] = {}
     pending = []
     for batch in bucket_batches(mine, lengths, max_frames):
-        x, mask = pad_batch([videos[i] for i in batch], device)
-        pending.append((batch, score_fn(x, mask).detach().float()))     # stays on the device: no sync per batch
+        if packed_fn is not None:
+            x = torch.cat([videos[i].to(device=device, dtype=torch.float32) for i in batch], dim=0)
+            pending.append((batch, packed_fn(x, [lengths[i] for i in batch]).detach().float()))
+        else:
+            x, mask = pad_batch([videos[i] for i in batch], device)
+            pending.append((batch, score_fn(x, mask).detach().float()))  # stays on the device: no sync per batch
     for batch, s in pending:                                            # one D2H per batch, after all launches
         sh = s.cpu()
+        row = 0
         for b, i in enumerate(batch):
-            local[i] = sh[b, : lengths[i]].clone()
+            if packed_fn is not None:
+                local[i] = sh[row: row + lengths[i]].clone()
+                row += lengths[i]
+            else:
+                local[i] = sh[b, : lengths[i]].clone()
     if world == 1:
         return local
     import torch.distributed as dist

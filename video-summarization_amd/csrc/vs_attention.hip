@@ -765,10 +765,14 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_lp_pipe(
 // of tile t+1 ride in the MFMA stream of tile t.  NW waves per block (8: one block per CU, all
 // blocks take the same time; 4: for short videos).
 // ------------------------------------------------------------------------------------------
-template <int DH, bool HAS_MASK, int NW>
+// VARLEN (packed ragged batches, vs_scorer_forward_packed): the videos' frames are concatenated ([Mtot, .] rows,
+// video b = rows cu[b] .. cu[b+1]), q/k/v are head-major over the packed rows ([H][Mtot][DH]) and the grid is
+// (work items, heads) with work[w] = (video, query tile): T, the operand bases and the output rows are per block.
+template <int DH, bool HAS_MASK, int NW, bool VARLEN = false>
 __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_pipe(
     const float *__restrict__ Q, const float *__restrict__ Kg, const float *__restrict__ Vg,
-    const uint8_t *__restrict__ mask, float *__restrict__ out, int H, int T, float scale_log2e, int BH) {
+    const uint8_t *__restrict__ mask, float *__restrict__ out, int H, int T, float scale_log2e, int BH,
+    const int *__restrict__ cu = nullptr, const int2 *__restrict__ work = nullptr, int Mtot = 0) {
     constexpr int KT = 64, LD = DH + 4, NJ = DH / 8, ND = DH / 32;
     constexpr int NT = 64 * NW;                     // threads per block
     constexpr int F4 = KT * DH / 4 / NT;            // float4 per thread per operand tile
@@ -779,10 +783,22 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_pipe(
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    int bh, qt;
-    if (!attn_block_map((T + 32 * NW - 1) / (32 * NW), BH, bh, qt)) return;
-    const int b = bh / H, head = bh - b * H;
-    const size_t base = (size_t)bh * T * DH;
+    int b, head, qt;
+    size_t base, orow0;                              // operand base (floats), first output row of this video
+    if constexpr (VARLEN) {
+        const int2 wk = work[blockIdx.x];
+        b = wk.x; qt = wk.y; head = blockIdx.y;
+        const int c0 = cu[b];
+        T = cu[b + 1] - c0;
+        base = ((size_t)head * Mtot + c0) * DH;
+        orow0 = (size_t)c0;
+    } else {
+        int bh;
+        if (!attn_block_map((T + 32 * NW - 1) / (32 * NW), BH, bh, qt)) return;
+        b = bh / H; head = bh - b * H;
+        base = (size_t)bh * T * DH;
+        orow0 = (size_t)b * T;
+    }
     const int q0 = qt * (32 * NW) + 32 * wave;
     const float NEG_INF = -__builtin_inff();
     const int ntiles = (T + KT - 1) / KT;
@@ -1030,7 +1046,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_pipe(
         for (int p = 0; p < 32 / RPI; ++p) {
             const int rr = orow + RPI * p, q = q0 + rr;
             const f32x4 v = *(const f32x4 *)&wtp[rr * LD + oc4];
-            if (q < T) *(f32x4 *)(out + ((size_t)b * T + q) * (H * DH) + head * DH + oc4) = v;
+            if (q < T) *(f32x4 *)(out + (orow0 + q) * (H * DH) + head * DH + oc4) = v;
         }
     }
 }
@@ -1055,7 +1071,7 @@ int vsk_attention(const float *q, const float *k, const float *v, const uint8_t 
         const int nq = wide ? r8 / 256 : r4 / 128;
         dim3 g(8 * ((BH + 7) / 8) * nq), blk(wide ? 512 : 256);
 #define VSK_ATTN(DH_, MASK_, NW_) \
-    hipLaunchKernelGGL((attn_fwd_pipe<DH_, MASK_, NW_>), g, blk, 0, st, q, k, v, mask, out, H, T, sl2, BH)
+    hipLaunchKernelGGL((attn_fwd_pipe<DH_, MASK_, NW_, false>), g, blk, 0, st, q, k, v, mask, out, H, T, sl2, BH, nullptr, nullptr, 0)
         if (dh == 32) {
             if (mask) { if (wide) VSK_ATTN(32, true, 8); else VSK_ATTN(32, true, 4); }
             else      { if (wide) VSK_ATTN(32, false, 8); else VSK_ATTN(32, false, 4); }
@@ -1069,6 +1085,26 @@ int vsk_attention(const float *q, const float *k, const float *v, const uint8_t 
         hipLaunchKernelGGL((attn_fwd<128, 1>), grid, dim3(256), 0, st, q, k, v, mask, out, H, T, sl2, BH);
     else
         return -1;
+    VSK_CHECK_LAUNCH();
+    return 0;
+}
+
+// packed ragged batch: q/k/v [H][Mtot][dh] head-major over the packed rows, cu [B+1] row offsets, work[nwork] =
+// (video, query tile of 32*nw rows); exact fp32, head dim 32 / 64
+int vsk_attention_packed(const float *q, const float *k, const float *v, float *out, int H, int Mtot, int dh,
+                         float scale, const int *cu, const int *work, int nwork, int nw, hipStream_t st) {
+    const float sl2 = scale * 1.4426950408889634f;
+    if (nwork <= 0) return 0;
+    dim3 grid(nwork, H);
+    const int2 *wk = (const int2 *)work;
+#define VSK_ATTN_P(DH_, NW_) \
+    hipLaunchKernelGGL((attn_fwd_pipe<DH_, false, NW_, true>), grid, dim3(64 * NW_), 0, st, q, k, v, nullptr, out, H, 0, sl2, 0, cu, wk, Mtot)
+    if (dh == 64 && nw == 8) VSK_ATTN_P(64, 8);
+    else if (dh == 64 && nw == 4) VSK_ATTN_P(64, 4);
+    else if (dh == 32 && nw == 8) VSK_ATTN_P(32, 8);
+    else if (dh == 32 && nw == 4) VSK_ATTN_P(32, 4);
+    else return -1;
+#undef VSK_ATTN_P
     VSK_CHECK_LAUNCH();
     return 0;
 }

@@ -15,6 +15,8 @@ int vsk_qkv(const float *h, const float *Wqkv, const float *Wf, const float *bqk
             int H, int bf16, hipStream_t st);
 int vsk_attention(const float *q, const float *k, const float *v, const uint8_t *mask, float *out,
                   int B, int H, int T, int dh, float scale, hipStream_t st);
+int vsk_attention_packed(const float *q, const float *k, const float *v, float *out, int H, int Mtot, int dh,
+                         float scale, const int *cu, const int *work, int nwork, int nw, hipStream_t st);
 // prec 1: bf16 operands; 2: fp32 emulated with f16 hi+lo operand halves ("fp16x3")
 int vsk_attention_bf16(const float *q, const float *k, const float *v, const uint8_t *mask, float *out,
                        int B, int H, int T, int dh, float scale, int prec, hipStream_t st);
@@ -29,4 +31,8 @@ int vsk_mlp_fused(const float *H1, const float *W1, const float *b1, const float
                   const float *gamma, const float *beta, float *out, int M, int d,
                   const float *score_w, const float *score_b, int num_classes, int sigmoid, float *scores,
                   hipStream_t st);
+// packed ragged batches: row offsets cu[B+1] and the (video, query tile) work list from device lengths; gather of
+// the positional rows pe[t] of every frame into rows[Mtot, d]
+int vsk_plan_packed(const int *lengths_dev, int B, int qb, int *cu, int *work, hipStream_t st);
+int vsk_gather_rows(const float *pe, const int *cu, int B, int tmax, int d, float *rows, hipStream_t st);
 int vsk_skinny_max_rows();      // rows up to which the skinny (latency) kernels are used

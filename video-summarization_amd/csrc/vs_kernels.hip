@@ -1508,6 +1508,30 @@ __global__ __launch_bounds__(64 * NW) void skinny2_ln(
     }
 }
 
+// ---- packed ragged batches (vs_scorer_forward_packed) ----
+// one thread: B is a few hundred at most, and the launch is stream-ordered before its consumers
+__global__ void plan_packed(const int *__restrict__ lengths, int B, int qb, int *__restrict__ cu, int *__restrict__ work) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int row = 0, n = 0;
+    for (int b = 0; b < B; ++b) {
+        cu[b] = row;
+        const int t = lengths[b];
+        for (int q = 0; q < (t + qb - 1) / qb; ++q) { work[2 * n] = b; work[2 * n + 1] = q; ++n; }
+        row += t;
+    }
+    cu[B] = row;
+}
+
+// rows[cu[b] + t, :] = pe[t, :]  (grid: 64-frame chunks x videos)
+__global__ __launch_bounds__(256) void gather_rows(const float *__restrict__ pe, const int *__restrict__ cu, int d,
+                                                    float *__restrict__ rows) {
+    const int b = blockIdx.y, c0 = cu[b], len = cu[b + 1] - c0, f4 = d / 4;
+    for (int idx = threadIdx.x; idx < 64 * f4; idx += 256) {
+        const int t = blockIdx.x * 64 + idx / f4, c = (idx % f4) * 4;
+        if (t < len) *(f32x4 *)(rows + (size_t)(c0 + t) * d + c) = *(const f32x4 *)(pe + (size_t)t * d + c);
+    }
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------
@@ -1540,6 +1564,18 @@ static bool use_wide_tiles(int M, int N) {
 
 // latency path: below this many rows the LDS-tiled kernels cannot fill the chip
 // measured hand-over (tools/sweep_skinny.py, T=1024, M-A): skinny wins through M = 16384, tiled from 32768
+int vsk_plan_packed(const int *lengths_dev, int B, int qb, int *cu, int *work, hipStream_t st) {
+    hipLaunchKernelGGL(plan_packed, dim3(1), dim3(64), 0, st, lengths_dev, B, qb, cu, work);
+    VSK_CHECK_LAUNCH();
+    return 0;
+}
+
+int vsk_gather_rows(const float *pe, const int *cu, int B, int tmax, int d, float *rows, hipStream_t st) {
+    hipLaunchKernelGGL(gather_rows, dim3((tmax + 63) / 64, B), dim3(256), 0, st, pe, cu, d, rows);
+    VSK_CHECK_LAUNCH();
+    return 0;
+}
+
 int vsk_skinny_max_rows() {
     const char *e = getenv("VS_SKINNY_ROWS");      // read per call so tests can pin either path
     return e ? atoi(e) : 16384;

@@ -228,13 +228,25 @@ size_t vs_scorer_workspace_bytes(const vs_weights *w, int32_t B, int32_t T) {
     return 10 * md;     // h0, h1, q, k, v, att, ffn(4)
 }
 
-int vs_scorer_forward(const vs_weights *w, const float *x, const uint8_t *key_pad_mask, int32_t B,
-                      int32_t T, uint32_t flags, float *scores, float *hidden, void *workspace,
-                      size_t workspace_bytes, void *stream) {
+}  // extern "C"
+
+namespace {
+// packed ragged batch (vs_scorer_forward_packed): the frames of all videos concatenated as ONE "video" of Mtot rows
+// for every row-wise kernel; only the positional rows and the attention know about the video boundaries
+struct PackedInfo {
+    const float *pe_rows;    // [Mtot, d] positional rows gathered per frame (or nullptr without a positional table)
+    const int *cu;           // device [B+1] row offsets
+    const int *work;         // device [nwork][2] (video, query tile)
+    int nwork, nw;           // query tile = 32*nw rows
+};
+
+int forward_core(const vs_weights *w, const float *x, const uint8_t *key_pad_mask, int32_t B,
+                 int32_t T, uint32_t flags, float *scores, float *hidden, void *workspace,
+                 size_t workspace_bytes, void *stream, const PackedInfo *pk) {
     if (!w || !x || !scores) return fail(VS_ERR_INVALID, "weights/x/scores is NULL");
     if (B <= 0 || T <= 0) return fail(VS_ERR_INVALID, "B=%d T=%d", B, T);
     const vs_model_desc &D = w->desc;
-    if (w->has_pe && T > D.max_len)
+    if (!pk && w->has_pe && T > D.max_len)
         return fail(VS_ERR_INVALID, "T=%d exceeds the positional table (max_len=%d)", T, D.max_len);
     if ((long long)B * T > (1ll << 30)) return fail(VS_ERR_INVALID, "B*T too large");
     if ((flags & VS_FLAG_BF16_LINEAR) && D.d_model > 256)
@@ -271,7 +283,7 @@ int vs_scorer_forward(const vs_weights *w, const float *x, const uint8_t *key_pa
     {
         StageScope ps(VS_STAGE_EMBED, st);
         VS_LAUNCH(vsk_linear(x, w->p(w->embed_w), w->p(lbf == 2 ? w->h_embed_w : w->f_embed_w), w->p(w->embed_b), h0, M, d, D.in_features, 0,
-                             w->has_pe ? w->p(w->pe) : nullptr, T, lbf, st));
+                             pk ? pk->pe_rows : (w->has_pe ? w->p(w->pe) : nullptr), T, lbf, st));
     }
     for (int l = 0; l < L; ++l) {
         const LayerOff &P = w->layers[l];
@@ -282,7 +294,10 @@ int vs_scorer_forward(const vs_weights *w, const float *x, const uint8_t *key_pa
         }
         {
             StageScope ps(VS_STAGE_ATTENTION, st);
-            if (flags & (VS_FLAG_BF16_ATTENTION | VS_FLAG_F16X3_ATTENTION))
+            if (pk)
+                VS_LAUNCH(vsk_attention_packed(qkv, qkv + (size_t)M * d, qkv + 2 * (size_t)M * d, att, H, M, d / H, scale,
+                                               pk->cu, pk->work, pk->nwork, pk->nw, st));
+            else if (flags & (VS_FLAG_BF16_ATTENTION | VS_FLAG_F16X3_ATTENTION))
                 VS_LAUNCH(vsk_attention_bf16(qkv, qkv + (size_t)M * d, qkv + 2 * (size_t)M * d, key_pad_mask, att,
                                              B, H, T, d / H, scale, (flags & VS_FLAG_F16X3_ATTENTION) ? 2 : 1, st));
             else
@@ -321,6 +336,80 @@ int vs_scorer_forward(const vs_weights *w, const float *x, const uint8_t *key_pa
         }
     }
     return VS_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int vs_scorer_forward(const vs_weights *w, const float *x, const uint8_t *key_pad_mask, int32_t B,
+                      int32_t T, uint32_t flags, float *scores, float *hidden, void *workspace,
+                      size_t workspace_bytes, void *stream) {
+    return forward_core(w, x, key_pad_mask, B, T, flags, scores, hidden, workspace, workspace_bytes, stream, nullptr);
+}
+
+// ---- packed ragged batches ----
+static int packed_plan(const vs_weights *w, const int32_t *lengths, int32_t B, std::vector<int> &cu,
+                       std::vector<int> &work, int &nw) {
+    if (!w || !lengths || B <= 0) return fail(VS_ERR_INVALID, "weights/lengths is NULL or B=%d", B);
+    const vs_model_desc &D = w->desc;
+    const int dh = D.d_model / D.num_heads;
+    if (dh != 32 && dh != 64) return fail(VS_ERR_INVALID, "packed batches need head_dim 32 or 64 (got %d)", dh);
+    cu.assign(B + 1, 0);
+    long long r8 = 0, r4 = 0;
+    for (int b = 0; b < B; ++b) {
+        const int t = lengths[b];
+        if (t <= 0) return fail(VS_ERR_INVALID, "lengths[%d]=%d", b, t);
+        if (w->has_pe && t > D.max_len)
+            return fail(VS_ERR_INVALID, "T=%d exceeds the positional table (max_len=%d)", t, D.max_len);
+        if ((long long)cu[b] + t > (1ll << 30)) return fail(VS_ERR_INVALID, "too many frames");
+        cu[b + 1] = cu[b] + t;
+        r8 += (t + 255) / 256 * 256;
+        r4 += (t + 127) / 128 * 128;
+    }
+    nw = r8 * 100 <= r4 * 105 ? 8 : 4;            // 256-row query tiles unless the ragged tails waste too much
+    const int qb = 32 * nw;
+    work.clear();
+    for (int b = 0; b < B; ++b)
+        for (int q = 0; q < (lengths[b] + qb - 1) / qb; ++q) { work.push_back(b); work.push_back(q); }
+    return VS_OK;
+}
+
+size_t vs_scorer_workspace_bytes_packed(const vs_weights *w, const int32_t *lengths, int32_t B) {
+    std::vector<int> cu, work;
+    int nw = 0;
+    if (packed_plan(w, lengths, B, cu, work, nw) != VS_OK) return 0;
+    const size_t md = align_up((size_t)cu[B] * w->desc.d_model * sizeof(float), 256);
+    return 11 * md + align_up((cu.size() + work.size()) * sizeof(int), 256);      // + gathered positional rows, plan
+}
+
+int vs_scorer_forward_packed(const vs_weights *w, const float *x, const int32_t *lengths, const int32_t *lengths_dev,
+                             int32_t B, uint32_t flags, float *scores, float *hidden, void *workspace,
+                             size_t workspace_bytes, void *stream) {
+    if (!lengths_dev) return fail(VS_ERR_INVALID, "lengths_dev is NULL");
+    if (flags & ~VS_FLAG_SIGMOID) return fail(VS_ERR_INVALID, "packed batches run the exact fp32 kernels only (flags=%u)", flags);
+    std::vector<int> cu, work;
+    int nw = 0;
+    if (int rc = packed_plan(w, lengths, B, cu, work, nw)) return rc;
+    const size_t need = vs_scorer_workspace_bytes_packed(w, lengths, B);
+    if (!workspace || workspace_bytes < need)
+        return fail(VS_ERR_WORKSPACE, "workspace %zu bytes < %zu needed", workspace_bytes, need);
+    if ((uintptr_t)workspace & 255) return fail(VS_ERR_INVALID, "workspace must be 256-byte aligned");
+    const int M = cu[B], d = w->desc.d_model;
+    const size_t md = align_up((size_t)M * d * sizeof(float), 256);
+    hipStream_t st = (hipStream_t)stream;
+    float *pe_rows = (float *)((char *)workspace + 10 * md);
+    int *plan = (int *)((char *)workspace + 11 * md);
+    // the device builds its own copy of the plan from the device lengths (no host memory is read after return,
+    // no synchronisation); the host copy above only sized the launch
+    VS_LAUNCH(vsk_plan_packed(lengths_dev, B, 32 * nw, plan, plan + cu.size(), st));
+    PackedInfo pk{nullptr, plan, plan + cu.size(), (int)(work.size() / 2), nw};
+    if (w->has_pe) {
+        int tmax = 0;
+        for (int b = 0; b < B; ++b) tmax = lengths[b] > tmax ? lengths[b] : tmax;
+        VS_LAUNCH(vsk_gather_rows(w->p(w->pe), pk.cu, B, tmax, d, pe_rows, st));
+        pk.pe_rows = pe_rows;
+    }
+    return forward_core(w, x, nullptr, 1, M, flags, scores, hidden, workspace, 10 * md, stream, &pk);
 }
 
 int vs_profile_enable(int32_t on) {

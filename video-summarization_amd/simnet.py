@@ -80,6 +80,33 @@ def _(x, mask, handle, d_model, num_classes, flags, want_hidden):
             x.new_empty((B, T, d_model) if want_hidden else (0,), dtype=torch.float32))
 
 
+def score_frames_packed(x: Tensor, lengths, handle: int, d_model: int, num_classes: int, flags: int,
+                        want_hidden: bool) -> Tuple[Tensor, Tensor]:
+    """Packed ragged batch: x [sum(lengths), Din] fp32 (HIP device) = the frames of len(lengths) videos concatenated.
+    Returns (scores [Mtot, num_classes], hidden [Mtot, d_model] or an empty tensor).  No padding, no mask."""
+    lib = _lib.load()
+    lengths = [int(t) for t in lengths]
+    if x.dim() != 2 or x.size(0) != sum(lengths):
+        raise RuntimeError("expected x of shape [sum(lengths)=%d, D], got %s" % (sum(lengths), tuple(x.shape)))
+    x = x.contiguous()
+    M, B = x.size(0), len(lengths)
+    host = (C.c_int32 * B)(*lengths)
+    scores = torch.empty((M, num_classes), dtype=torch.float32, device=x.device)
+    hidden = torch.empty((M, d_model) if want_hidden else (0,), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        dev_len = torch.tensor(lengths, dtype=torch.int32, device=x.device)
+        need = lib.vs_scorer_workspace_bytes_packed(handle, host, B)
+        if need == 0:
+            _lib.check(lib.vs_scorer_forward_packed(handle, x.data_ptr(), host, dev_len.data_ptr(), B, flags,
+                                                    scores.data_ptr(), None, None, 0, None))   # raises with the reason
+        ws = torch.empty((need,), dtype=torch.uint8, device=x.device)
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        _lib.check(lib.vs_scorer_forward_packed(handle, x.data_ptr(), host, dev_len.data_ptr(), B, flags,
+                                                scores.data_ptr(), hidden.data_ptr() if want_hidden else None,
+                                                ws.data_ptr(), ws.numel(), stream))
+    return scores, hidden
+
+
 # --------------------------------------------------------------------------------------------
 # parameter containers: only there to give the state_dict its reference key names
 # --------------------------------------------------------------------------------------------
@@ -284,6 +311,31 @@ class SimNet(nn.Module):
         self.attention_dtype = value if (head_ok or value == "fp32") else "fp32"
         self.linear_dtype = value
         return self
+
+    @torch.no_grad()
+    def forward_packed(self, x: Tensor, lengths, want_hidden: bool = True):
+        """Scores a RAGGED batch without padding: x [sum(lengths), in_features] = the videos' frames concatenated.
+        Returns (logits [Mtot, num_classes], hidden [Mtot, d_model]); video i = rows sum(lengths[:i]) ...  The reference
+        pads with the 1000.0 sentinel and masks (dataset.py:157-161); here no padded row is computed, and each video's
+        result is bit-identical to scoring it alone.  Exact fp32 kernels (head dim 32 / 64)."""
+        if not x.is_cuda:
+            raise RuntimeError("SimNet scoring runs on the MI355X HIP kernels only (no CPU path for the scorer)")
+        if self.use_pos and max(int(t) for t in lengths) > self.pe_len:
+            raise RuntimeError("T=%d exceeds the positional table (%d rows)" % (max(lengths), self.pe_len))
+        packed = self._packed_weights(x.device)
+        x32 = x if x.dtype == torch.float32 else x.float()
+        flags = _lib.VS_FLAG_SIGMOID if self.fused_sigmoid else 0
+        return score_frames_packed(x32, lengths, packed.handle, self.d_model, self.num_classes, flags, want_hidden)
+
+    @torch.no_grad()
+    def score_packed(self, x: Tensor, lengths) -> Tensor:
+        """Sigmoid importance scores [Mtot] of a packed ragged batch (see forward_packed)."""
+        if self.num_classes != 1:
+            raise RuntimeError("score_packed() needs num_classes == 1")
+        packed = self._packed_weights(x.device)
+        x32 = x if x.dtype == torch.float32 else x.float()
+        s, _ = score_frames_packed(x32, lengths, packed.handle, self.d_model, 1, _lib.VS_FLAG_SIGMOID, False)
+        return s.squeeze(-1)
 
     def _attention_flag(self) -> int:
         return ((_lib.VS_FLAG_BF16_ATTENTION if self._attention_dtype == "bf16" else 0)
