@@ -914,8 +914,9 @@ def test_randomised_parity_slice(vsa):
     assert n == 40
 
 
+@pytest.mark.parametrize("compute", ["fp32", "fp16x3"])
 @pytest.mark.parametrize("cfg", [(4, 256, 4), (8, 256, 2), (4, 128, 2)])
-def test_packed_ragged_batch_is_bit_identical_to_scoring_each_video_alone(vsa, cfg):
+def test_packed_ragged_batch_is_bit_identical_to_scoring_each_video_alone(vsa, cfg, compute):
     """SimNet.forward_packed (frames of all videos concatenated, no padding rows, no mask): every video's logits
     and hidden state equal scoring that video alone bit for bit, and meet the oracle at 1e-4."""
     H, d, L = cfg
@@ -923,7 +924,7 @@ def test_packed_ragged_batch_is_bit_identical_to_scoring_each_video_alone(vsa, c
     sd = synth.make_state_dict(d, L, 17)
     m = vsa.SimNet(num_heads=H, d_model=d, num_layers=L, sparsity=0.0, dropout=0.3)
     m.load_state_dict(sd, strict=True)
-    m = m.to(_dev()).eval()
+    m = m.to(_dev()).eval().set_compute_dtype(compute)
     lengths = [320, 1, 257, 64, 650, 33, 128, 129, 2000]
     vids = [synth.make_features(1, t, 100 + i, "pool5")[0] for i, t in enumerate(lengths)]
     x = torch.cat(vids, dim=0).to(_dev())

@@ -64,7 +64,7 @@ with torch.no_grad():
     for mode in ("fp32", "fp16x3"):
         m.set_compute_dtype(mode)
         for mf in (16384, 65536):
-            for packed in ((False, True) if mode == "fp32" else (False,)):
+            for packed in (False, True):
                 fn = lambda: corpus.score_corpus(lambda x, mk: m.score(x, mk), vids, device=dev, max_frames=mf,
                                                  packed_fn=(lambda x, ln: m.score_packed(x, ln)) if packed else None)
                 dt = timed(fn, 10, 2)

@@ -445,10 +445,11 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_lp(
 // buffer loads of K(t+3) / V(t+2) between them.  One barrier per tile; K and V double-buffered in LDS, the
 // key-mask bias triple-buffered (it is read two iterations after it is written).
 // ------------------------------------------------------------------------------------------
-template <int DH, int NW, int PREC>
+template <int DH, int NW, int PREC, bool VARLEN = false>       // VARLEN: packed ragged batches, see attn_fwd_pipe
 __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_lp_pipe(
     const float *__restrict__ Q, const float *__restrict__ Kg, const float *__restrict__ Vg,
-    const uint8_t *__restrict__ mask, float *__restrict__ out, int H, int T, float scale_log2e, int BH) {
+    const uint8_t *__restrict__ mask, float *__restrict__ out, int H, int T, float scale_log2e, int BH,
+    const int *__restrict__ cu = nullptr, const int2 *__restrict__ work = nullptr, int Mtot = 0) {
     constexpr int KT = 64, NS = DH / 16, ND = DH / 32, NT = 64 * NW, QB = 32 * NW;
     constexpr int NP = PREC == 2 ? 2 : 1, NPROD = PREC == 2 ? 3 : 1;
     constexpr int LDK = DH + 8, LDV = KT + 4, D4 = DH / 4;
@@ -462,10 +463,22 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_lp_pipe(
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    int bh, qt;
-    if (!attn_block_map((T + QB - 1) / QB, BH, bh, qt)) return;
-    const int b = bh / H, head = bh - b * H;
-    const size_t base = (size_t)bh * T * DH;
+    int b, head, qt;
+    size_t base, orow0;
+    if constexpr (VARLEN) {
+        const int2 wk = work[blockIdx.x];
+        b = wk.x; qt = wk.y; head = blockIdx.y;
+        const int c0 = cu[b];
+        T = cu[b + 1] - c0;
+        base = ((size_t)head * Mtot + c0) * DH;
+        orow0 = (size_t)c0;
+    } else {
+        int bh;
+        if (!attn_block_map((T + QB - 1) / QB, BH, bh, qt)) return;
+        b = bh / H; head = bh - b * H;
+        base = (size_t)bh * T * DH;
+        orow0 = (size_t)b * T;
+    }
     const int q0 = qt * QB + 32 * wave;
     const float NEG_INF = -__builtin_inff();
 
@@ -733,7 +746,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_lp_pipe(
     const int q = q0 + r;
     if (q < T) {
         const float inv = 1.0f / o[ND][0];
-        float *op = out + ((size_t)b * T + q) * (H * DH) + head * DH;
+        float *op = out + (orow0 + q) * (H * DH) + head * DH;
 #pragma unroll
         for (int d = 0; d < ND; ++d)
 #pragma unroll
@@ -1092,19 +1105,29 @@ int vsk_attention(const float *q, const float *k, const float *v, const uint8_t 
 // packed ragged batch: q/k/v [H][Mtot][dh] head-major over the packed rows, cu [B+1] row offsets, work[nwork] =
 // (video, query tile of 32*nw rows); exact fp32, head dim 32 / 64
 int vsk_attention_packed(const float *q, const float *k, const float *v, float *out, int H, int Mtot, int dh,
-                         float scale, const int *cu, const int *work, int nwork, int nw, hipStream_t st) {
+                         float scale, const int *cu, const int *work, int nwork, int nw, int prec, hipStream_t st) {
     const float sl2 = scale * 1.4426950408889634f;
     if (nwork <= 0) return 0;
     dim3 grid(nwork, H);
     const int2 *wk = (const int2 *)work;
-#define VSK_ATTN_P(DH_, NW_) \
+#define VSK_ATTN_PX(DH_, NW_) \
     hipLaunchKernelGGL((attn_fwd_pipe<DH_, false, NW_, true>), grid, dim3(64 * NW_), 0, st, q, k, v, nullptr, out, H, 0, sl2, 0, cu, wk, Mtot)
-    if (dh == 64 && nw == 8) VSK_ATTN_P(64, 8);
-    else if (dh == 64 && nw == 4) VSK_ATTN_P(64, 4);
-    else if (dh == 32 && nw == 8) VSK_ATTN_P(32, 8);
-    else if (dh == 32 && nw == 4) VSK_ATTN_P(32, 4);
-    else return -1;
-#undef VSK_ATTN_P
+#define VSK_ATTN_PE(DH_, NW_) \
+    hipLaunchKernelGGL((attn_fwd_lp_pipe<DH_, NW_, 2, true>), grid, dim3(64 * NW_), 0, st, q, k, v, nullptr, out, H, 0, sl2, 0, cu, wk, Mtot)
+    if (prec == 2) {
+        if (dh == 64 && nw == 8) VSK_ATTN_PE(64, 8);
+        else if (dh == 64 && nw == 4) VSK_ATTN_PE(64, 4);
+        else if (dh == 32 && nw == 4) VSK_ATTN_PE(32, 4);
+        else return -1;
+    } else {
+        if (dh == 64 && nw == 8) VSK_ATTN_PX(64, 8);
+        else if (dh == 64 && nw == 4) VSK_ATTN_PX(64, 4);
+        else if (dh == 32 && nw == 8) VSK_ATTN_PX(32, 8);
+        else if (dh == 32 && nw == 4) VSK_ATTN_PX(32, 4);
+        else return -1;
+    }
+#undef VSK_ATTN_PX
+#undef VSK_ATTN_PE
     VSK_CHECK_LAUNCH();
     return 0;
 }

@@ -16,7 +16,7 @@ int vsk_qkv(const float *h, const float *Wqkv, const float *Wf, const float *bqk
 int vsk_attention(const float *q, const float *k, const float *v, const uint8_t *mask, float *out,
                   int B, int H, int T, int dh, float scale, hipStream_t st);
 int vsk_attention_packed(const float *q, const float *k, const float *v, float *out, int H, int Mtot, int dh,
-                         float scale, const int *cu, const int *work, int nwork, int nw, hipStream_t st);
+                         float scale, const int *cu, const int *work, int nwork, int nw, int prec, hipStream_t st);
 // prec 1: bf16 operands; 2: fp32 emulated with f16 hi+lo operand halves ("fp16x3")
 int vsk_attention_bf16(const float *q, const float *k, const float *v, const uint8_t *mask, float *out,
                        int B, int H, int T, int dh, float scale, int prec, hipStream_t st);

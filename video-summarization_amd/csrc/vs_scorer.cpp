@@ -238,6 +238,7 @@ struct PackedInfo {
     const int *cu;           // device [B+1] row offsets
     const int *work;         // device [nwork][2] (video, query tile)
     int nwork, nw;           // query tile = 32*nw rows
+    int prec;                // attention arithmetic: 0 exact fp32, 2 fp16x3
 };
 
 int forward_core(const vs_weights *w, const float *x, const uint8_t *key_pad_mask, int32_t B,
@@ -296,7 +297,7 @@ int forward_core(const vs_weights *w, const float *x, const uint8_t *key_pad_mas
             StageScope ps(VS_STAGE_ATTENTION, st);
             if (pk)
                 VS_LAUNCH(vsk_attention_packed(qkv, qkv + (size_t)M * d, qkv + 2 * (size_t)M * d, att, H, M, d / H, scale,
-                                               pk->cu, pk->work, pk->nwork, pk->nw, st));
+                                               pk->cu, pk->work, pk->nwork, pk->nw, pk->prec, st));
             else if (flags & (VS_FLAG_BF16_ATTENTION | VS_FLAG_F16X3_ATTENTION))
                 VS_LAUNCH(vsk_attention_bf16(qkv, qkv + (size_t)M * d, qkv + 2 * (size_t)M * d, key_pad_mask, att,
                                              B, H, T, d / H, scale, (flags & VS_FLAG_F16X3_ATTENTION) ? 2 : 1, st));
@@ -349,7 +350,7 @@ int vs_scorer_forward(const vs_weights *w, const float *x, const uint8_t *key_pa
 
 // ---- packed ragged batches ----
 static int packed_plan(const vs_weights *w, const int32_t *lengths, int32_t B, std::vector<int> &cu,
-                       std::vector<int> &work, int &nw) {
+                       std::vector<int> &work, int &nw, bool narrow_only = false) {
     if (!w || !lengths || B <= 0) return fail(VS_ERR_INVALID, "weights/lengths is NULL or B=%d", B);
     const vs_model_desc &D = w->desc;
     const int dh = D.d_model / D.num_heads;
@@ -366,7 +367,7 @@ static int packed_plan(const vs_weights *w, const int32_t *lengths, int32_t B, s
         r8 += (t + 255) / 256 * 256;
         r4 += (t + 127) / 128 * 128;
     }
-    nw = r8 * 100 <= r4 * 105 ? 8 : 4;            // 256-row query tiles unless the ragged tails waste too much
+    nw = (!narrow_only && r8 * 100 <= r4 * 105) ? 8 : 4;     // 256-row query tiles unless the ragged tails waste too much
     const int qb = 32 * nw;
     work.clear();
     for (int b = 0; b < B; ++b)
@@ -386,10 +387,14 @@ int vs_scorer_forward_packed(const vs_weights *w, const float *x, const int32_t 
                              int32_t B, uint32_t flags, float *scores, float *hidden, void *workspace,
                              size_t workspace_bytes, void *stream) {
     if (!lengths_dev) return fail(VS_ERR_INVALID, "lengths_dev is NULL");
-    if (flags & ~VS_FLAG_SIGMOID) return fail(VS_ERR_INVALID, "packed batches run the exact fp32 kernels only (flags=%u)", flags);
+    if (flags & (VS_FLAG_BF16_ATTENTION | VS_FLAG_BF16_LINEAR))
+        return fail(VS_ERR_INVALID, "packed batches run the exact fp32 or the fp16x3 kernels (flags=%u)", flags);
+    if (!w) return fail(VS_ERR_INVALID, "weights is NULL");
+    const int aprec = (flags & VS_FLAG_F16X3_ATTENTION) ? 2 : 0;
     std::vector<int> cu, work;
     int nw = 0;
-    if (int rc = packed_plan(w, lengths, B, cu, work, nw)) return rc;
+    // (the emulated attention has no 8-wave form for head dim 32)
+    if (int rc = packed_plan(w, lengths, B, cu, work, nw, aprec == 2 && w->desc.d_model / w->desc.num_heads == 32)) return rc;
     const size_t need = vs_scorer_workspace_bytes_packed(w, lengths, B);
     if (!workspace || workspace_bytes < need)
         return fail(VS_ERR_WORKSPACE, "workspace %zu bytes < %zu needed", workspace_bytes, need);
@@ -402,14 +407,14 @@ int vs_scorer_forward_packed(const vs_weights *w, const float *x, const int32_t 
     // the device builds its own copy of the plan from the device lengths (no host memory is read after return,
     // no synchronisation); the host copy above only sized the launch
     VS_LAUNCH(vsk_plan_packed(lengths_dev, B, 32 * nw, plan, plan + cu.size(), st));
-    PackedInfo pk{nullptr, plan, plan + cu.size(), (int)(work.size() / 2), nw};
+    PackedInfo pk{nullptr, plan, plan + cu.size(), (int)(work.size() / 2), nw, aprec};
     if (w->has_pe) {
         int tmax = 0;
         for (int b = 0; b < B; ++b) tmax = lengths[b] > tmax ? lengths[b] : tmax;
         VS_LAUNCH(vsk_gather_rows(w->p(w->pe), pk.cu, B, tmax, d, pe_rows, st));
         pk.pe_rows = pe_rows;
     }
-    return forward_core(w, x, nullptr, 1, M, flags, scores, hidden, workspace, 10 * md, stream, &pk);
+    return forward_core(w, x, nullptr, 1, M, flags & ~VS_FLAG_F16X3_ATTENTION, scores, hidden, workspace, 10 * md, stream, &pk);
 }
 
 int vs_profile_enable(int32_t on) {

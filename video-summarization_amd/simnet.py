@@ -317,14 +317,14 @@ class SimNet(nn.Module):
         """Scores a RAGGED batch without padding: x [sum(lengths), in_features] = the videos' frames concatenated.
         Returns (logits [Mtot, num_classes], hidden [Mtot, d_model]); video i = rows sum(lengths[:i]) ...  The reference
         pads with the 1000.0 sentinel and masks (dataset.py:157-161); here no padded row is computed, and each video's
-        result is bit-identical to scoring it alone.  Exact fp32 kernels (head dim 32 / 64)."""
+        result is bit-identical to scoring it alone.  Exact fp32 or fp16x3 kernels (not bf16), head dim 32 / 64."""
         if not x.is_cuda:
             raise RuntimeError("SimNet scoring runs on the MI355X HIP kernels only (no CPU path for the scorer)")
         if self.use_pos and max(int(t) for t in lengths) > self.pe_len:
             raise RuntimeError("T=%d exceeds the positional table (%d rows)" % (max(lengths), self.pe_len))
         packed = self._packed_weights(x.device)
         x32 = x if x.dtype == torch.float32 else x.float()
-        flags = _lib.VS_FLAG_SIGMOID if self.fused_sigmoid else 0
+        flags = (_lib.VS_FLAG_SIGMOID if self.fused_sigmoid else 0) | self._attention_flag()
         return score_frames_packed(x32, lengths, packed.handle, self.d_model, self.num_classes, flags, want_hidden)
 
     @torch.no_grad()
@@ -334,7 +334,8 @@ class SimNet(nn.Module):
             raise RuntimeError("score_packed() needs num_classes == 1")
         packed = self._packed_weights(x.device)
         x32 = x if x.dtype == torch.float32 else x.float()
-        s, _ = score_frames_packed(x32, lengths, packed.handle, self.d_model, 1, _lib.VS_FLAG_SIGMOID, False)
+        s, _ = score_frames_packed(x32, lengths, packed.handle, self.d_model, 1,
+                                   _lib.VS_FLAG_SIGMOID | self._attention_flag(), False)
         return s.squeeze(-1)
 
     def _attention_flag(self) -> int:
