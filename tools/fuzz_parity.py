@@ -65,6 +65,17 @@ def run(budget: float, seed: int, max_cases: int = 1 << 30, progress: bool = Fal
                         worst[mode] = max(worst[mode], err)
                         assert err < TOL[mode], "mode=%s pin=%s H=%d d=%d L=%d B=%d T=%d kind=%s err=%.3e" % (
                             mode, pin, H, d, L, B, T, kind, err)
+                        # right-padded batches: the PACKED form (frames concatenated, no padding, no mask) must give
+                        # the same bits on the valid frames
+                        if lengths is not None and mode != "bf16" and d // H in (32, 64):
+                            xp = torch.cat([x[b, :lengths[b]] for b in range(B)], dim=0).to(dev)
+                            lp, hp = m.forward_packed(xp, lengths)
+                            row = 0
+                            for b in range(B):
+                                t = lengths[b]
+                                assert torch.equal(lp[row:row + t], l[b, :t]) and torch.equal(hp[row:row + t], hdn[b, :t]), \
+                                    "packed != padded: mode=%s pin=%s H=%d d=%d L=%d B=%d T=%d video %d" % (mode, pin, H, d, L, B, T, b)
+                                row += t
             n += 1
             if progress and time.time() > t_print:       # a silent GPU job is taken for hung after a few minutes
                 print("  ... %d cases" % n, flush=True)
