@@ -898,6 +898,14 @@ def test_overlapped_host_streaming_matches_direct_scoring(vsa):
             want = m.score(x.to(_dev()), mask.to(_dev())).cpu()
             valid = ~mask
             assert torch.equal(o[valid], want[valid])
+        # packed batches through the same double-buffered stream
+        packed = []
+        for i in range(4):
+            lengths = [150 + 3 * i, 64, 201]
+            packed.append((torch.cat([synth.make_features(1, t, 70 + 10 * i + j, "pool5")[0] for j, t in enumerate(lengths)]), lengths))
+        outs = corpus.score_host_batches(lambda xx, ln: m.score_packed(xx, ln), packed, _dev())
+        for (xp, lengths), o in zip(packed, outs):
+            assert torch.equal(o, m.score_packed(xp.to(_dev()), lengths).cpu())
 
 
 def test_randomised_parity_slice(vsa):

@@ -129,7 +129,8 @@ def score_corpus(score_fn: ScoreFn, videos: Sequence[torch.Tensor], rank: int = 
 
 
 def score_host_batches(score_fn: ScoreFn, batches, device) -> List[torch.Tensor]:
-    """Scores a sequence of HOST batches (x [B,T,D] pinned or pageable, mask or None) with the host-to-device
+    """Scores a sequence of HOST batches - padded (x [B,T,D] pinned or pageable, mask or None) or packed
+    (x [sum T, D], list of lengths; `score_fn` is then `SimNet.score_packed`) - with the host-to-device
     copy of batch i+1 overlapped with the kernels of batch i: copies run on a side HIP stream into two device
     buffers that alternate, scores come back with an asynchronous D2H copy.  Returns the per-batch score tensors
     (host, valid after the final synchronize this function performs).  This is the PCIe-inclusive use of the
@@ -149,7 +150,8 @@ def score_host_batches(score_fn: ScoreFn, batches, device) -> List[torch.Tensor]
             if freed[slot] is not None:
                 copy.wait_event(freed[slot])              # do not overwrite a buffer the kernels still read
             dx = x.to(device, non_blocking=True)
-            dm = mask.to(device, non_blocking=True) if mask is not None else None
+            # (x [B,T,D], mask or None) for padded batches, or (x [sum T, D], lengths list) for packed ones
+            dm = mask.to(device, non_blocking=True) if isinstance(mask, torch.Tensor) else mask
             ev = torch.cuda.Event()
             ev.record(copy)
         staged[slot] = (dx, dm, ev)
@@ -162,7 +164,7 @@ def score_host_batches(score_fn: ScoreFn, batches, device) -> List[torch.Tensor]
         dx, dm, ev = staged[i & 1]
         compute.wait_event(ev)
         dx.record_stream(compute)
-        if dm is not None:
+        if isinstance(dm, torch.Tensor):
             dm.record_stream(compute)
         sc = score_fn(dx, dm)
         done = torch.cuda.Event()
