@@ -123,7 +123,7 @@ int vs_scorer_forward(const vs_weights *w, const float *x, const uint8_t *key_pa
  * Mtot = sum(lengths), scores [Mtot, num_classes], hidden [Mtot, d_model] or NULL.  No padding rows are computed and
  * no mask is needed; every video's scores are bit-identical to scoring it alone.  `lengths` is the HOST copy (it
  * sizes the launches), `lengths_dev` the same B values in device memory.  Head dim 32 / 64; flags:
- * VS_FLAG_SIGMOID, VS_FLAG_F16X3_LINEAR, VS_FLAG_F16X3_ATTENTION (exact fp32 or fp16x3 kernels; not bf16).  Like vs_scorer_forward it only enqueues work on `stream`. */
+ * VS_FLAG_SIGMOID and the precision flags of vs_scorer_forward.  Like vs_scorer_forward it only enqueues work on `stream`. */
 size_t vs_scorer_workspace_bytes_packed(const vs_weights *w, const int32_t *lengths, int32_t B);
 int vs_scorer_forward_packed(const vs_weights *w, const float *x, const int32_t *lengths,
                              const int32_t *lengths_dev, int32_t B, uint32_t flags,

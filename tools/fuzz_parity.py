@@ -67,13 +67,16 @@ def run(budget: float, seed: int, max_cases: int = 1 << 30, progress: bool = Fal
                             mode, pin, H, d, L, B, T, kind, err)
                         # right-padded batches: the PACKED form (frames concatenated, no padding, no mask) must give
                         # the same bits on the valid frames
-                        if lengths is not None and mode != "bf16" and d // H in (32, 64):
+                        if lengths is not None and d // H in (32, 64):
                             xp = torch.cat([x[b, :lengths[b]] for b in range(B)], dim=0).to(dev)
                             lp, hp = m.forward_packed(xp, lengths)
                             row = 0
                             for b in range(B):
                                 t = lengths[b]
-                                assert torch.equal(lp[row:row + t], l[b, :t]) and torch.equal(hp[row:row + t], hdn[b, :t]), \
+                                same = torch.equal(lp[row:row + t], l[b, :t]) and torch.equal(hp[row:row + t], hdn[b, :t])
+                                if mode == "bf16":       # bf16 Linears switch kernel family with the row count: tolerance
+                                    same = (lp[row:row + t] - l[b, :t]).abs().max().item() < TOL["bf16"]
+                                assert same, \
                                     "packed != padded: mode=%s pin=%s H=%d d=%d L=%d B=%d T=%d video %d" % (mode, pin, H, d, L, B, T, b)
                                 row += t
             n += 1

@@ -1112,12 +1112,17 @@ int vsk_attention_packed(const float *q, const float *k, const float *v, float *
     const int2 *wk = (const int2 *)work;
 #define VSK_ATTN_PX(DH_, NW_) \
     hipLaunchKernelGGL((attn_fwd_pipe<DH_, false, NW_, true>), grid, dim3(64 * NW_), 0, st, q, k, v, nullptr, out, H, 0, sl2, 0, cu, wk, Mtot)
-#define VSK_ATTN_PE(DH_, NW_) \
-    hipLaunchKernelGGL((attn_fwd_lp_pipe<DH_, NW_, 2, true>), grid, dim3(64 * NW_), 0, st, q, k, v, nullptr, out, H, 0, sl2, 0, cu, wk, Mtot)
+#define VSK_ATTN_PE(DH_, NW_, P_) \
+    hipLaunchKernelGGL((attn_fwd_lp_pipe<DH_, NW_, P_, true>), grid, dim3(64 * NW_), 0, st, q, k, v, nullptr, out, H, 0, sl2, 0, cu, wk, Mtot)
     if (prec == 2) {
-        if (dh == 64 && nw == 8) VSK_ATTN_PE(64, 8);
-        else if (dh == 64 && nw == 4) VSK_ATTN_PE(64, 4);
-        else if (dh == 32 && nw == 4) VSK_ATTN_PE(32, 4);
+        if (dh == 64 && nw == 8) VSK_ATTN_PE(64, 8, 2);
+        else if (dh == 64 && nw == 4) VSK_ATTN_PE(64, 4, 2);
+        else if (dh == 32 && nw == 4) VSK_ATTN_PE(32, 4, 2);
+        else return -1;
+    } else if (prec == 1) {
+        if (dh == 64 && nw == 8) VSK_ATTN_PE(64, 8, 1);
+        else if (dh == 64 && nw == 4) VSK_ATTN_PE(64, 4, 1);
+        else if (dh == 32 && nw == 4) VSK_ATTN_PE(32, 4, 1);
         else return -1;
     } else {
         if (dh == 64 && nw == 8) VSK_ATTN_PX(64, 8);

@@ -387,14 +387,14 @@ int vs_scorer_forward_packed(const vs_weights *w, const float *x, const int32_t 
                              int32_t B, uint32_t flags, float *scores, float *hidden, void *workspace,
                              size_t workspace_bytes, void *stream) {
     if (!lengths_dev) return fail(VS_ERR_INVALID, "lengths_dev is NULL");
-    if (flags & (VS_FLAG_BF16_ATTENTION | VS_FLAG_BF16_LINEAR))
-        return fail(VS_ERR_INVALID, "packed batches run the exact fp32 or the fp16x3 kernels (flags=%u)", flags);
     if (!w) return fail(VS_ERR_INVALID, "weights is NULL");
-    const int aprec = (flags & VS_FLAG_F16X3_ATTENTION) ? 2 : 0;
+    if ((flags & VS_FLAG_BF16_ATTENTION) && (flags & VS_FLAG_F16X3_ATTENTION))
+        return fail(VS_ERR_INVALID, "VS_FLAG_BF16_ATTENTION and VS_FLAG_F16X3_ATTENTION are exclusive");
+    const int aprec = (flags & VS_FLAG_F16X3_ATTENTION) ? 2 : (flags & VS_FLAG_BF16_ATTENTION) ? 1 : 0;
     std::vector<int> cu, work;
     int nw = 0;
-    // (the emulated attention has no 8-wave form for head dim 32)
-    if (int rc = packed_plan(w, lengths, B, cu, work, nw, aprec == 2 && w->desc.d_model / w->desc.num_heads == 32)) return rc;
+    // (the low-precision attention has no 8-wave form for head dim 32)
+    if (int rc = packed_plan(w, lengths, B, cu, work, nw, aprec != 0 && w->desc.d_model / w->desc.num_heads == 32)) return rc;
     const size_t need = vs_scorer_workspace_bytes_packed(w, lengths, B);
     if (!workspace || workspace_bytes < need)
         return fail(VS_ERR_WORKSPACE, "workspace %zu bytes < %zu needed", workspace_bytes, need);
@@ -414,7 +414,7 @@ int vs_scorer_forward_packed(const vs_weights *w, const float *x, const int32_t 
         VS_LAUNCH(vsk_gather_rows(w->p(w->pe), pk.cu, B, tmax, d, pe_rows, st));
         pk.pe_rows = pe_rows;
     }
-    return forward_core(w, x, nullptr, 1, M, flags & ~VS_FLAG_F16X3_ATTENTION, scores, hidden, workspace, 10 * md, stream, &pk);
+    return forward_core(w, x, nullptr, 1, M, flags & ~(VS_FLAG_F16X3_ATTENTION | VS_FLAG_BF16_ATTENTION), scores, hidden, workspace, 10 * md, stream, &pk);
 }
 
 int vs_profile_enable(int32_t on) {

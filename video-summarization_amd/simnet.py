@@ -317,7 +317,7 @@ class SimNet(nn.Module):
         """Scores a RAGGED batch without padding: x [sum(lengths), in_features] = the videos' frames concatenated.
         Returns (logits [Mtot, num_classes], hidden [Mtot, d_model]); video i = rows sum(lengths[:i]) ...  The reference
         pads with the 1000.0 sentinel and masks (dataset.py:157-161); here no padded row is computed, and each video's
-        result is bit-identical to scoring it alone.  Exact fp32 or fp16x3 kernels (not bf16), head dim 32 / 64."""
+        result is bit-identical to scoring it alone (fp32 and fp16x3 modes).  Head dim 32 / 64."""
         if not x.is_cuda:
             raise RuntimeError("SimNet scoring runs on the MI355X HIP kernels only (no CPU path for the scorer)")
         if self.use_pos and max(int(t) for t in lengths) > self.pe_len:
