@@ -138,3 +138,21 @@ def test_compute_dtype_switches_are_validated(vsa):
         wide.attention_dtype = "fp16x3"
     flags = vsa._lib
     assert flags.VS_FLAG_F16X3_LINEAR == 8 and flags.VS_FLAG_F16X3_ATTENTION == 16 and flags.VS_FLAG_BF16_LINEAR == 4
+
+
+def test_header_is_plain_c_and_the_c_client_compiles(vsa):
+    """include/vs_scorer.h + include/vs_eval.h compile as C99 (no C++, no torch types), and the plain-C client
+    (tests/cabi/score_demo.c, run on the GPU box by tests/test_cabi_c.py) type-checks against them."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    assert gcc
+    inc = os.path.join(ROOT, "include")
+    for hdr in ("vs_scorer.h", "vs_eval.h"):
+        r = subprocess.run([gcc, "-std=c99", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", os.path.join(inc, hdr)],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    r = subprocess.run([gcc, "-std=gnu99", "-fsyntax-only", "-I" + inc, "-I" + os.path.join(rocm, "include"),
+                        "-D__HIP_PLATFORM_AMD__", os.path.join(ROOT, "tests", "cabi", "score_demo.c")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
