@@ -59,17 +59,16 @@ class PretrainModel(nn.Module):
                 pen_met: str = "entropy"):
         # `visualize_attention` would make the reference unpack a 2-tuple into (out, attention) and crash a line
         # later (simnet_pretrain.py:75-78); no caller passes it, and it is ignored here.
-        scores, frame_features = self.encoder(x, mask, model_score=True)
-        frame_features = self.video_transform(frame_features)
-        repel_loss = self.repelling_loss(frame_features, mask)
-        if isinstance(mask, Tensor):
-            mask = mask.unsqueeze(2)
-            scores = scores.masked_fill(mask, float("-inf"))
-        mixture_scores = F.softmax(scores / self.sharpening_t, dim=1)
+        logits, hidden = self.encoder(x, mask, model_score=True)
+        feats = self.video_transform(hidden)                               # [B, T, 512]
+        repel = self.repelling_loss(feats, mask)
+        key_mask = mask.unsqueeze(2) if isinstance(mask, Tensor) else None
+        if key_mask is not None:
+            logits = logits.masked_fill(key_mask, float("-inf"))
+        weights = F.softmax(logits / self.sharpening_t, dim=1)             # mixture over the frames  [B, T, 1]
         if pen_met == "entropy":
-            center_loss = self.entropy(mixture_scores + 1e-9, mask)          # 1e-9: the reference's stabiliser
+            center = self.entropy(weights + 1e-9, key_mask)               # 1e-9: the reference's stabiliser
         else:
-            center_loss = torch.norm(mixture_scores, dim=1).mean()
-        video_representation_encoder = torch.matmul(mixture_scores.transpose(1, 2), frame_features)
-        loss = self.cross_entropy_loss(video_representation_encoder.squeeze(1), video_representation)
-        return loss, center_loss, repel_loss
+            center = torch.norm(weights, dim=1).mean()
+        pooled = torch.matmul(weights.transpose(1, 2), feats).squeeze(1)   # score-weighted video representation
+        return self.cross_entropy_loss(pooled, video_representation), center, repel
