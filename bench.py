@@ -1,31 +1,40 @@
 #!/usr/bin/env python3
 """Headline benchmark: frames/sec scored on synthetic [B, T=1024, D=1024] (BASELINE.json metric).
 
-    python bench.py --gpus 1 --steps 50 --warmup 10
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W
 
-One "step" = one scorer forward (reference ``SimNet.forward``, logits + hidden state) over one
-batch of B=64 videos x T=1024 frames x 1024-d features per GPU (BASELINE.json configs[2], model
-M-A = heads 4, d_model 256, layers 4 — run_finetune.sh:1), inputs already resident in HBM.  Videos
-are independent, so N GPUs score N disjoint batches (weak scaling) and RCCL only gathers the [B,T]
-score matrices (one async all_gather per step, overlapped with the next step's kernels).
+With N > 1 and no torchrun environment the script LAUNCHES ITS OWN RANKS: before anything touches the GPU it
+starts ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P
+bench.py ...`` as a child process, relays its output and exits with its code (a child, never an exec).  Started
+by torchrun itself (RANK / WORLD_SIZE set) it is one rank of that job.
+
+One "step" = one scorer forward (reference ``SimNet.forward``, logits + hidden state) over one batch of B=64
+videos x T=1024 frames x 1024-d features per GPU (BASELINE.json configs[2], model M-A = heads 4, d_model 256,
+layers 4 — run_finetune.sh:1), inputs already resident in HBM.  Videos are independent, so N GPUs score N disjoint
+batches (weak scaling) and RCCL only gathers the [B,T] score matrices (one async all_gather per step, overlapped
+with the next step's kernels).
 
 Prints ONE JSON line on rank 0 with the contract fields plus
-  roofline      the dominant kernel, from HIP events recorded around every launch of the timed region
-  cpu_baseline  the oracle (CPU restatement of the reference, "port") timed on this box's host cores
-  emulated_f32  the same K steps again with every product EMULATED on the f16 matrix pipe ("fp16x3": operands split
-                into f16 hi + lo halves, three products, fp32 accumulate; same 1e-4 parity in the tests) - reported
+  roofline      the dominant kernel: algorithmic FLOPs per launch / its mean launch duration, from HIP events the
+                library records around every launch in a SEPARATE profiled pass of the same K steps (the headline
+                `value` is timed with profiling off); `traffic` = HBM bytes per launch from the committed PMC passes
+                (profiles/r02_hbm_traffic.json, stamped with the kernel-source hash it was measured on; null when
+                the loaded sources differ)
+  cpu_baseline  the oracle (CPU restatement of the reference, "port") timed on this box's host cores:
+                B=8,T=1024 (throughput leg, = `value`'s unit) and B=1,T=320 x20 (SURVEY §8(d) latency leg)
+  latency       configs[1]: one T=320 video, GPU ms per forward (same model), beside the CPU's
+  emulated_f32  the same K steps again with every product EMULATED on the f16 matrix pipe ("fp16x3"): reported
                 beside `value`, never as `value`: the headline is the exact-fp32 MFMA path (--compute to change).
 """
 import argparse
+import hashlib
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -34,21 +43,37 @@ PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense fp32 matrix peak 
 PEAK_F16_MFMA_TFLOPS = 2500.0     # dense f16 / bf16 matrix peak; an fp16x3 product costs 3 f16 products
 # HBM bytes per launch per kernel come from separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; see
 # tools/collect_traffic.sh), committed under profiles/: counters cannot be read from inside the timed run.
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_v4_hbm_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
 STAGE_KERNEL = {"attention": "attn_fwd_pipe", "embed_pe": "gemm_nt_128<2", "qkv_proj": "gemm_nt_128<3",
                 "fc1_relu": "gemm_nt_128<1", "outproj_ln": "gemm_ln_rows", "fc2_ln_score": "gemm_ln_rows"}
 
 
+def kernel_source_hash():
+    """sha256 (16 hex) over the kernel sources the loaded library was built from: the stamp of the traffic file."""
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "video-summarization_amd", "csrc")
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".hip", ".h", ".cpp")):
+            h.update(name.encode())
+            h.update(open(os.path.join(csrc, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def measured_traffic(stage):
-    """HBM bytes per launch of the kernel behind `stage` from the committed PMC passes, or None."""
+    """(HBM bytes per launch of the kernel behind `stage`, provenance) from the committed PMC passes; bytes are
+    None when the file is missing or was measured on other kernel sources than the ones loaded now."""
     try:
         t = json.load(open(TRAFFIC_FILE))
     except (OSError, ValueError):
-        return None
+        return None, "no traffic file"
+    meta = t.get("_meta", {})
+    src = "%s @ csrc %s" % (os.path.relpath(TRAFFIC_FILE, ROOT), meta.get("csrc_sha256_16", "?"))
+    if meta.get("csrc_sha256_16") != kernel_source_hash():
+        return None, src + " (stale: loaded sources are %s)" % kernel_source_hash()
     for name, v in t.items():
         if name.startswith(STAGE_KERNEL.get(stage, "?")):
-            return int(v["hbm_bytes_per_launch"])
-    return None
+            return int(v["hbm_bytes_per_launch"]), src
+    return None, src
 
 
 def stage_flops(B, T, Din, d, H, L):
@@ -64,10 +89,47 @@ def stage_flops(B, T, Din, d, H, L):
     }
 
 
-def main():
+def free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a torchrun environment: start the N ranks as a CHILD job (nothing in this
+    process has touched the GPU yet; it only waits and passes the child's exit code on)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["VS_BENCH_SELF_LAUNCHED"] = "1"
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(rank, world):
+    """VS_BENCH_DRYRUN=1 (CPU test of the launch plumbing only, tests/test_bench_launch.py): every rank joins a gloo
+    group, the ranks all_gather their rank ids, rank 0 prints one JSON line.  No scorer, no GPU, no numbers."""
+    import torch
+    import torch.distributed as dist
+    ids = [rank]
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        got = torch.empty(world, dtype=torch.int64)
+        dist.all_gather_into_tensor(got, torch.tensor([rank], dtype=torch.int64))
+        ids = got.tolist()
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"dryrun": True, "n_gpus": world, "ranks": ids,
+                          "self_launched": os.environ.get("VS_BENCH_SELF_LAUNCHED") == "1"}), flush=True)
+    return None
+
+
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=64, help="videos per GPU per step")
     ap.add_argument("--frames", type=int, default=1024)
@@ -76,17 +138,24 @@ def main():
     ap.add_argument("--compute", default="fp32", choices=["fp32", "fp16x3", "bf16"],
                     help="matrix-product arithmetic of the timed path (default: exact fp32 MFMA)")
     ap.add_argument("--no-emulated", action="store_true", help="skip the secondary fp16x3 measurement")
+    ap.add_argument("--no-extras", action="store_true", help="skip the PCIe-inclusive and latency legs")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline sample length")
-    args = ap.parse_args()
+    return ap.parse_args()
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "RANK" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args.gpus))          # before any GPU call, before torch is even imported
+    import torch
 
     rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
-                     % (args.gpus, args.gpus))
         args.gpus = world
+    if os.environ.get("VS_BENCH_DRYRUN") == "1":
+        return dry_run(rank, world)
     assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU path for the scorer)"
     # VS_BENCH_REHEARSE=1: rehearsal of the N > 1 control flow on a ONE-GPU box (every rank on cuda:0, gloo instead
     # of RCCL, which refuses two ranks on one device).  Its numbers mean nothing; it only proves the path runs.
@@ -96,13 +165,18 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
+    backend = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearse:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
+            assert torch.cuda.device_count() >= world, "one GPU per rank: %d ranks, %d devices" % (world, torch.cuda.device_count())
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = dist.get_backend()
+        assert dist.get_world_size() == world and dist.get_rank() == rank
+        assert rehearse or backend == "nccl", "multi-GPU runs gather over RCCL (torch backend 'nccl'), got %r" % backend
 
     pkg = importlib.import_module("video-summarization_amd")
     lib = pkg._lib.load()
@@ -128,59 +202,70 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed(k):
+        fence()
+        t0 = time.perf_counter()
+        works = [step() for _ in range(k)]
+        for w in works:
+            if w is not None:
+                w.wait()
+        fence()
+        return time.perf_counter() - t0
+
     with torch.no_grad():
         for _ in range(args.warmup):
             w = step()
             if w is not None:
                 w.wait()
-        fence()
+        dt = timed(args.steps)                    # the headline: profiling OFF
+
+        # the same K steps again with the library's per-launch HIP events on (stage table / roofline only)
         lib.vs_profile_enable(1)
-        t0 = time.perf_counter()
-        works = [step() for _ in range(args.steps)]
-        for w in works:
-            if w is not None:
-                w.wait()
-        fence()
-        dt = time.perf_counter() - t0
+        timed(args.steps)
         stages = pkg._lib.profile_collect()
         lib.vs_profile_enable(0)
 
         # secondary: the same K steps with fp32 emulated on the f16 pipe (never `value`)
         emu = None
-        if args.compute == "fp32" and not args.no_emulated and d <= 256 and d // H in (32, 64):
+        if args.compute == "fp32" and not args.no_emulated and d // H in (32, 64, 128):
             exact_logits = model(x)[0].clone()
             model.set_compute_dtype("fp16x3")
             for _ in range(max(2, args.warmup // 2)):
                 w = step()
                 if w is not None:
                     w.wait()
-            fence()
-            t2 = time.perf_counter()
-            works = [step() for _ in range(args.steps)]
-            for w in works:
-                if w is not None:
-                    w.wait()
-            fence()
-            dt_emu = time.perf_counter() - t2
+            dt_emu = timed(args.steps)
             diff = (model(x)[0] - exact_logits).abs().max().item()
             model.set_compute_dtype("fp32")
             emu = (dt_emu, diff)
 
-        # PCIe-inclusive rates (never `value`): pinned host batches -> device -> forward.  Serial = copy then
-        # kernels on one stream; overlapped = corpus.score_host_batches (copy stream + compute stream).
-        fence()
-        t1 = time.perf_counter()
-        for _ in range(3):
-            model(x_host.to(dev, non_blocking=True))
-        torch.cuda.synchronize()
-        pcie_fps = 3 * B * T / (time.perf_counter() - t1)
-        corpus = importlib.import_module("video-summarization_amd.corpus")
-        nb = 8
-        host_batches = [(x_host, None)] * nb
-        corpus.score_host_batches(lambda xx, mm: model(xx)[0], host_batches[:2], dev)      # warm-up
-        t1 = time.perf_counter()
-        corpus.score_host_batches(lambda xx, mm: model(xx)[0], host_batches, dev)
-        pcie_overlap_fps = nb * B * T / (time.perf_counter() - t1)
+        pcie_fps = pcie_overlap_fps = lat_ms = None
+        if not args.no_extras:
+            # PCIe-inclusive rates (never `value`): pinned host batches -> device -> forward.  Serial = copy then
+            # kernels on one stream; overlapped = corpus.score_host_batches (copy stream + compute stream).
+            fence()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                model(x_host.to(dev, non_blocking=True))
+            torch.cuda.synchronize()
+            pcie_fps = 3 * B * T / (time.perf_counter() - t1)
+            corpus = importlib.import_module("video-summarization_amd.corpus")
+            nb = 8
+            host_batches = [(x_host, None)] * nb
+            corpus.score_host_batches(lambda xx, mm: model(xx)[0], host_batches[:2], dev)      # warm-up
+            t1 = time.perf_counter()
+            corpus.score_host_batches(lambda xx, mm: model(xx)[0], host_batches, dev)
+            pcie_overlap_fps = nb * B * T / (time.perf_counter() - t1)
+            # configs[1]: one T=320 video
+            x1 = x[:1, :320].contiguous()
+            for _ in range(10):
+                model(x1)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(200):
+                model(x1)
+            torch.cuda.synchronize()
+            lat_ms = (time.perf_counter() - t1) / 200 * 1e3
 
     if world > 1:
         t = torch.tensor([dt, emu[0] if emu else 0.0, emu[1] if emu else 0.0], dtype=torch.float64, device=dev)
@@ -194,9 +279,6 @@ def main():
     out = None
     if rank == 0:
         fl = stage_flops(B, T, Din, d, H, L)
-        if stages.get("fc1_relu", (0, 0))[1] == 0 and stages.get("fc2_ln_score", (0, 0))[1] > 0:
-            # d_model 256: fc1 + ReLU + fc2 + LayerNorm run as one fused kernel, recorded under the fc2 stage
-            fl["fc2_ln_score"] += fl["fc1_relu"]
         table = {}
         for name, (ms, n) in stages.items():
             if n:
@@ -210,23 +292,34 @@ def main():
         flops_per_frame = 2 * Din * d + L * (24 * d * d + 4 * T * d) + 2 * d
         # peak of the arithmetic the timed path used: fp32 MFMA, or f16 MFMA / 3 products (fp16x3), or bf16 MFMA
         peak = {"fp32": PEAK_F32_MFMA_TFLOPS, "fp16x3": PEAK_F16_MFMA_TFLOPS / 3, "bf16": PEAK_F16_MFMA_TFLOPS}[args.compute]
+        traffic, traffic_src = (None, "not the measured configuration")
+        if (B, T, args.model, args.compute) == (64, 1024, "A", "fp32"):
+            traffic, traffic_src = measured_traffic(dom)
         roofline = {"bound": "mfma", "kernel": dom, "achieved": table[dom]["tflops"], "peak": round(peak, 1),
                     "unit": "TFLOP/s", "frac": round(table[dom]["tflops"] / peak, 4),
-                    "traffic": measured_traffic(dom) if (B, T, args.model, args.compute) == (64, 1024, "A", "fp32") else None,
-                    "hbm_gbps": None,
+                    "traffic": traffic, "traffic_source": traffic_src, "hbm_gbps": None,
+                    "flop_per_launch": fl[dom],
                     "whole_forward": {"flop_per_frame": flops_per_frame,
                                       "achieved": round(value / world * flops_per_frame / 1e12, 2),
                                       "frac": round(value / world * flops_per_frame / 1e12 / peak, 4)},
                     "stages": table}
-        if roofline["traffic"]:
+        if traffic:
             # HBM GB/s of the dominant kernel: measured bytes per launch (PMC passes) / its live average duration
-            roofline["hbm_gbps"] = round(roofline["traffic"] / (table[dom]["avg_ms"] * 1e-3) / 1e9, 1)
+            roofline["hbm_gbps"] = round(traffic / (table[dom]["avg_ms"] * 1e-3) / 1e9, 1)
         cpu = None
+        latency = None
         if world == 1 and not args.no_cpu_baseline:
             from oracle.simnet_oracle import time_cpu_baseline      # the checker, timed as the CPU "port"
             fps, cores, sample = time_cpu_baseline(sd, H, 8, T, args.cpu_seconds)
+            fps1, cores1, sample1 = time_cpu_baseline(sd, H, 1, 320, 0.0, iters=20)
             cpu = {"value": round(fps, 1), "unit": "frames/s", "cores": cores, "kind": "port",
-                   "sample": "oracle/simnet_oracle.py (materialised [B,H,T,T] softmax, torch CPU fp32), " + sample}
+                   "sample": "oracle/simnet_oracle.py (materialised [B,H,T,T] softmax, torch CPU fp32), " + sample,
+                   "single_video": {"value": round(fps1, 1), "unit": "frames/s", "ms_per_video": round(320 / fps1 * 1e3, 3),
+                                    "cores": cores1, "sample": sample1}}
+        if lat_ms is not None:
+            latency = {"workload": "configs[1]: one video, T=320, D=1024, M-%s" % args.model, "gpu_ms": round(lat_ms, 4),
+                       "gpu_frames_per_s": round(320 / lat_ms * 1e3, 1),
+                       "cpu_ms": cpu["single_video"]["ms_per_video"] if cpu else None}
         out = {
             "metric": "frames/sec scored (whole node), synthetic [B,T=1024,D=1024]",
             "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
@@ -238,10 +331,12 @@ def main():
             "config": {"workload": "configs[2]: B=%d videos x T=%d frames x D=%d per GPU, scorer cfg M-%s "
                                    "(heads %d, d_model %d, layers %d), logits + hidden state" % (B, T, Din, args.model, H, d, L),
                        "global_batch": B * world, "frames_per_step": B * T * world,
-                       "parallelism": "videos sharded over %d GPU(s), RCCL all_gather of scores" % world},
-            "pcie_inclusive_value": round(pcie_fps * world, 1),
-            "pcie_inclusive_overlapped_value": round(pcie_overlap_fps * world, 1),
-            "roofline": roofline, "cpu_baseline": cpu,
+                       "parallelism": "videos sharded over %d GPU(s), %s all_gather of scores"
+                                      % (world, "RCCL" if backend == "nccl" else (backend or "no"))},
+            "collective_backend": backend,
+            "pcie_inclusive_value": round(pcie_fps * world, 1) if pcie_fps else None,
+            "pcie_inclusive_overlapped_value": round(pcie_overlap_fps * world, 1) if pcie_overlap_fps else None,
+            "roofline": roofline, "cpu_baseline": cpu, "latency": latency,
         }
         if emu:
             ev = frames / emu[0]

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define VS_ABI_VERSION 1
+#define VS_ABI_VERSION 2
 
 /* status codes */
 #define VS_OK 0
@@ -101,6 +101,11 @@ int vs_weights_pack(const vs_model_desc *desc, const vs_model_params *params,
                     void *stream, vs_weights **out);
 void vs_weights_free(vs_weights *w);
 
+/* Replaces: the parameter writes of an optimizer step / load_state_dict on an existing module (train.py:127,
+ * 42-43).  Re-copies every parameter into the handle's existing device storage (same desc, same device as
+ * vs_weights_pack; no allocation, no free) and rebuilds the kernel-layout copies, stream-ordered on `stream`. */
+int vs_weights_update(vs_weights *w, const vs_model_params *params, void *stream);
+
 /* Bytes of scratch vs_scorer_forward needs for a [B,T] batch (0 on invalid arguments). */
 size_t vs_scorer_workspace_bytes(const vs_weights *w, int32_t B, int32_t T);
 
@@ -144,6 +149,13 @@ int vs_scorer_forward_packed(const vs_weights *w, const float *x, const int32_t 
 int vs_profile_enable(int32_t on);
 int vs_profile_collect(double *ms_sum, int64_t *launches);
 const char *vs_stage_name(int32_t stage);
+
+/* A/B and test switches (DESIGN.md "Environment switches"; none selects a fallback).  Their defaults come from
+ * environment variables of the same name, read ONCE when the library is first used - no forward calls getenv.
+ * value < 0 restores the environment / built-in default.  Names: VS_SKINNY_ROWS, VS_LP_MIN_ROWS, VS_GEMM_NWM2,
+ * VS_GEMM_NJ2, VS_ATTN_NW4, VS_ATTN_LP_SIMPLE (+ VS_MLP_FUSION, VS_MLP_ABL, VS_ATTN_LEGACY, which only the
+ * diagnostic build of the library acts on).  Process-wide; not meant to be flipped while forwards are in flight. */
+int vs_set_option(const char *name, int32_t value);
 
 /* Per-kernel entry points (same stream/pointer conventions), exported so each HIP kernel can be
  * parity-tested against the oracle in isolation.  Not needed by a drop-in binding. */

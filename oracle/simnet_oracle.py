@@ -108,10 +108,11 @@ def _time_once(sd, num_heads, x, iters):
         return time.perf_counter() - t0
 
 
-def time_cpu_baseline(sd, num_heads: int, B: int, T: int, seconds: float = 12.0, seed: int = 1234):
+def time_cpu_baseline(sd, num_heads: int, B: int, T: int, seconds: float = 12.0, seed: int = 1234, iters: int = 0):
     """Times the restatement on host cores.  The thread count is chosen by a short sweep (the most
     favourable to the CPU wins) because a GPU box exposes far more logical CPUs than the share a
-    job may use.  Returns (frames_per_s, threads_used, sample_desc)."""
+    job may use.  ``iters`` > 0 fixes the iteration count (B=1,T=320 x20); otherwise it is
+    chosen to fill ``seconds``.  Returns (frames_per_s, threads_used, sample_desc)."""
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(B, T, sd["embedding_layer.feature_transform.weight"].shape[1], generator=g)
     cap = usable_cpus()
@@ -124,6 +125,6 @@ def time_cpu_baseline(sd, num_heads: int, B: int, T: int, seconds: float = 12.0,
         if t < best_t:
             best_n, best_t = n, t
     torch.set_num_threads(best_n)
-    iters = max(2, min(60, int(round(seconds / best_t))))
+    iters = iters if iters > 0 else max(2, min(60, int(round(seconds / best_t))))
     dt = _time_once(sd, num_heads, x, iters)
     return B * T * iters / dt, best_n, "B=%d,T=%d x%d iters, %d threads (best of %s)" % (B, T, iters, best_n, cands)

@@ -1,0 +1,44 @@
+"""bench.py's own rank launcher (`python bench.py --gpus N` without torchrun): CPU dry run of the launch plumbing
+(gloo, world size 2) and, on the GPU box, a two-rank rehearsal of the real control flow on one GPU."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, env_extra, timeout):
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True,
+                       timeout=timeout)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+def test_plain_python_invocation_starts_its_own_ranks():
+    """`python bench.py --gpus 2` (no torchrun env) must start 2 ranks itself and print ONE rank-0 line."""
+    out = _run(["--gpus", "2", "--steps", "1", "--warmup", "0"], {"VS_BENCH_DRYRUN": "1"}, 300)
+    assert out == {"dryrun": True, "n_gpus": 2, "ranks": [0, 1], "self_launched": True}
+
+
+def test_single_rank_does_not_relaunch():
+    out = _run(["--gpus", "1"], {"VS_BENCH_DRYRUN": "1"}, 120)
+    assert out["n_gpus"] == 1 and out["self_launched"] is False
+
+
+@pytest.mark.gpu
+def test_two_rank_rehearsal_through_the_self_launcher():
+    """The real N > 1 control flow (per-rank batches, async all_gather per step, max-over-ranks timing), two ranks on the
+    one GPU over gloo (VS_BENCH_REHEARSE=1: RCCL refuses two ranks on one device).  Numbers are meaningless here."""
+    out = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "2", "--frames", "256", "--no-cpu-baseline",
+                "--no-emulated", "--no-extras"], {"VS_BENCH_REHEARSE": "1"}, 600)
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 4 and out["value"] > 0
+    assert out["collective_backend"] == "gloo" and out["roofline"]["stages"]["attention"]["launches"] == 3 * 4

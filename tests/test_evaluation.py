@@ -103,3 +103,27 @@ def test_edge_cases(ev):
     assert abs(k - ok) < 1e-12 and abs(s - os_) < 1e-12
     with pytest.raises(ValueError):
         ev.evaluate_scores(np.zeros(5, np.float32), np.zeros((2, 6)))
+
+
+# ---- the NaN corner (tests/golden/make_golden_eval_nan.py: vectors from the imported reference) ----
+GN = np.load(os.path.join(GOLDEN, "eval_nan_golden.npz"))
+
+
+@pytest.mark.parametrize("j", range(8))
+def test_knapsack_nan_values_follow_python_max(ev, j):
+    """Python's max(a, b) keeps a unless b > a, so a NaN operand wins or loses by POSITION (knapsack_implementation.py:18)."""
+    wt, val, W, want = GN["k%d_wt" % j].tolist(), GN["k%d_val" % j].tolist(), int(GN["k%d_W" % j]), GN["k%d_sel" % j].tolist()
+    assert ev.knapSack(W, wt, val, len(wt)) == want
+    assert eval_oracle.knapsack(W, wt, val, len(wt)) == want
+
+
+@pytest.mark.parametrize("j", range(4))
+def test_shots_past_n_frames_have_nan_means_like_the_reference(ev, j):
+    """change_points past n_frames average an empty slice (generate_summary.py:42 -> NaN); selection stays bit-exact."""
+    import warnings
+    cps, scores, nf, picks = GN["v%d_cps" % j], GN["v%d_scores" % j], int(GN["v%d_nframes" % j]), GN["v%d_picks" % j]
+    got = ev.generate_summary([cps], [scores], [nf], [picks])[0]
+    assert np.array_equal(got, GN["v%d_summary" % j])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        assert np.array_equal(eval_oracle.generate_summary(cps, scores, nf, picks), GN["v%d_summary" % j])

@@ -32,16 +32,14 @@ def _model(vsa, c, sd):
     return m.to(_dev()).eval()
 
 
-@pytest.fixture(params=["auto", "tiled", "tiled+fused_mlp"])
-def kernel_path(request, monkeypatch):
-    """Small inputs take the skinny latency kernels by default; VS_SKINNY_ROWS=0 pins the LDS-tiled
-    throughput kernels, and VS_MLP_FUSION=1 additionally the opt-in fused MLP kernel, so every family is
-    held to the same vectors."""
+@pytest.fixture(params=["auto", "tiled"])
+def kernel_path(request, vsa):
+    """Small inputs take the skinny latency kernels by default; VS_SKINNY_ROWS=0 (vs_set_option) pins the
+    LDS-tiled throughput kernels, so both families are held to the same vectors."""
     if request.param != "auto":
-        monkeypatch.setenv("VS_SKINNY_ROWS", "0")
-    if request.param == "tiled+fused_mlp":
-        monkeypatch.setenv("VS_MLP_FUSION", "1")
-    return request.param
+        vsa._lib.set_option("VS_SKINNY_ROWS", 0)
+    yield request.param
+    vsa._lib.set_option("VS_SKINNY_ROWS", -1)
 
 
 @pytest.mark.parametrize("case", golden_cases(), ids=lambda c: c["name"])
@@ -263,13 +261,10 @@ def test_c_abi_rejects_bad_arguments(vsa):
 # full-size properties (BASELINE.json configs[2]: B=64, T=1024) that need no CPU oracle run
 # ---------------------------------------------------------------------------------------------
 
-@pytest.mark.parametrize("fused_mlp", [False, True])
-def test_full_size_batch_properties(vsa, fused_mlp, monkeypatch):
+def test_full_size_batch_properties(vsa):
     """At B=64,T=1024 (bench size): (i) videos are independent — scoring a slice of the batch gives
     bit-identical rows; (ii) a padded+masked copy of a short video scores its valid frames like the
     unpadded video within fp32 noise; (iii) outputs are finite."""
-    if fused_mlp:
-        monkeypatch.setenv("VS_MLP_FUSION", "1")     # the big batch then runs the fused kernel, the slices the skinny ones
     synth = vsa.synth
     sd = synth.make_state_dict(256, 4, 41)
     m = _model(vsa, dict(H=4, d=256, L=4), sd)
@@ -427,10 +422,12 @@ def test_val_step_end_to_end_matches_reference(vsa):
 
 
 @pytest.fixture
-def lp_linear_everywhere(monkeypatch):
+def lp_linear_everywhere(vsa):
     """The forward keeps the exact fp32 latency kernels for batches of up to 8192 frames whatever the precision
     flags say; VS_LP_MIN_ROWS=0 pins the low-precision Linear kernels so small test batches exercise them."""
-    monkeypatch.setenv("VS_LP_MIN_ROWS", "0")
+    vsa._lib.set_option("VS_LP_MIN_ROWS", 0)
+    yield
+    vsa._lib.set_option("VS_LP_MIN_ROWS", -1)
 
 
 # ---- opt-in bf16 attention (VS_FLAG_BF16_ATTENTION; BASELINE configs[4] names bf16) ----------------------
@@ -952,3 +949,37 @@ def test_packed_ragged_batch_is_bit_identical_to_scoring_each_video_alone(vsa, c
         m.forward_packed(x, lengths[:-1])                     # row count does not match
     with pytest.raises(RuntimeError):
         m.forward_packed(torch.cat([x, x[:1]]), lengths[:-1] + [2001])     # beyond the positional table
+
+
+@pytest.mark.parametrize("compute", ["fp32", "fp16x3", "bf16"])
+@pytest.mark.parametrize("cfg", [(8, 256, 1), (4, 128, 1), (4, 256, 1)])
+def test_packed_workspace_is_never_overrun(vsa, cfg, compute):
+    """vs_scorer_workspace_bytes_packed sizes the plan area for the 128-row tiling whatever tiling the flags of the
+    forward select (head dim 32 with a low-precision attention plans 128-row tiles where the size query used to assume
+    256): a guard region right behind a workspace of exactly `need` bytes must stay untouched."""
+    H, d, L = cfg
+    lib = vsa._lib.load()
+    m = vsa.SimNet(num_heads=H, d_model=d, num_layers=L, sparsity=0.0, dropout=0.3)
+    m.load_state_dict(vsa.synth.make_state_dict(d, L, 9), strict=True)
+    m = m.to(_dev()).eval().set_compute_dtype(compute)
+    lengths = [1024] * 16
+    M = sum(lengths)
+    x = torch.randn(M, 1024, device=_dev())
+    handle = m._packed_weights(x.device).handle
+    host = (C.c_int32 * len(lengths))(*lengths)
+    dev_len = torch.tensor(lengths, dtype=torch.int32, device=_dev())
+    need = lib.vs_scorer_workspace_bytes_packed(handle, host, len(lengths))
+    assert need > 0 and need % 256 == 0
+    guard = 1 << 16
+    buf = torch.full((need + guard,), 0xA5, dtype=torch.uint8, device=_dev())
+    scores = torch.empty(M, 1, device=_dev())
+    flags = m._attention_flag()
+    vsa._lib.check(lib.vs_scorer_forward_packed(handle, x.data_ptr(), host, dev_len.data_ptr(), len(lengths), flags,
+                                                scores.data_ptr(), None, buf.data_ptr(), need, _stream()))
+    torch.cuda.synchronize()
+    assert bool((buf[need:] == 0xA5).all()), "the forward wrote past its workspace"
+    assert torch.isfinite(scores).all()
+    # a workspace one byte short is refused
+    rc = lib.vs_scorer_forward_packed(handle, x.data_ptr(), host, dev_len.data_ptr(), len(lengths), flags,
+                                      scores.data_ptr(), None, buf.data_ptr(), need - 1, _stream())
+    assert rc == vsa._lib.VS_ERR_WORKSPACE

@@ -29,7 +29,7 @@ def run(budget: float, seed: int, max_cases: int = 1 << 30, progress: bool = Fal
     n = 0
     t_print = time.time() + 30
     worst = {k: 0.0 for k in TOL}
-    saved = {k: os.environ.get(k) for k in ("VS_SKINNY_ROWS", "VS_LP_MIN_ROWS")}
+    pins = ("VS_SKINNY_ROWS", "VS_LP_MIN_ROWS")      # library switches (vs_set_option; -1 = default)
     try:
         while time.time() < t_end and n < max_cases:
             H, d, L = ARCH[rng.integers(len(ARCH))]
@@ -53,11 +53,8 @@ def run(budget: float, seed: int, max_cases: int = 1 << 30, progress: bool = Fal
                 valid = torch.ones(B, T, dtype=torch.bool) if mask is None else ~mask
                 for mode in modes:
                     for pin in ("0", None):                      # tiled kernels pinned, then the default dispatch
-                        for k in saved:
-                            if pin is None:
-                                os.environ.pop(k, None)
-                            else:
-                                os.environ[k] = pin
+                        for k in pins:
+                            pkg._lib.set_option(k, -1 if pin is None else int(pin))
                         m.set_compute_dtype(mode)
                         l, hdn = m(x.to(dev), None if mask is None else mask.to(dev))
                         err = max((l.cpu() - rl).abs().squeeze(-1)[valid].max().item(),
@@ -84,11 +81,8 @@ def run(budget: float, seed: int, max_cases: int = 1 << 30, progress: bool = Fal
                 print("  ... %d cases" % n, flush=True)
                 t_print = time.time() + 30
     finally:
-        for k, v in saved.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+        for k in pins:
+            pkg._lib.set_option(k, -1)
     return n, worst
 
 

@@ -13,7 +13,7 @@ with torch.no_grad():
         x = torch.randn(B, 1024, 1024, device=dev)
         row = []
         for thr in (0, 4096, 8192, 16384, 32768):
-            os.environ["VS_SKINNY_ROWS"] = str(thr)
+            pkg._lib.set_option("VS_SKINNY_ROWS", thr)
             for _ in range(3): m(x)
             torch.cuda.synchronize(); t0 = time.perf_counter()
             for _ in range(20): m(x)

@@ -16,8 +16,9 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(ROOT, "include")
 LIB_PATH = os.path.join(HERE, "libvsscore.so")
+DIAG_LIB_PATH = os.path.join(HERE, "libvsscore_diag.so")
 SOURCES = ("vs_kernels.hip", "vs_attention.hip", "vs_scorer.cpp", "vs_eval.cpp")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 VS_OK, VS_ERR_INVALID, VS_ERR_WORKSPACE, VS_ERR_HIP = 0, 1, 2, 3
 VS_FLAG_SIGMOID = 1
@@ -27,7 +28,7 @@ VS_FLAG_F16X3_LINEAR = 8
 VS_FLAG_F16X3_ATTENTION = 16
 
 # every symbol include/vs_scorer.h declares
-EXPORTS = ("vs_abi_version", "vs_last_error", "vs_weights_pack", "vs_weights_free",
+EXPORTS = ("vs_abi_version", "vs_last_error", "vs_weights_pack", "vs_weights_free", "vs_weights_update", "vs_set_option",
            "vs_scorer_workspace_bytes", "vs_scorer_forward", "vs_scorer_workspace_bytes_packed",
            "vs_scorer_forward_packed", "vs_linear_f32", "vs_qkv_proj_f32",
            "vs_attention_f32", "vs_attention_bf16", "vs_attention_f16x3", "vs_linear_residual_layernorm_f32",
@@ -73,16 +74,24 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, diag: bool = False) -> str:
     """Cross-compiles the HIP sources for gfx950 into the in-tree ``libvsscore.so``
-    (works without a GPU).  Returns the library path."""
+    (works without a GPU).  Returns the library path.  ``diag=True`` builds ``libvsscore_diag.so`` instead: the same
+    sources with ``-DVS_WITH_DIAG`` (stamped GEMM instantiations, the fused-MLP negative result, the non-pipelined
+    attention) for ``tools/`` only - the product library does not carry them."""
+    if diag:
+        return _build(DIAG_LIB_PATH, ["-DVS_WITH_DIAG"], verbose)
     if not force and not needs_build():
         return LIB_PATH
+    return _build(LIB_PATH, [], verbose)
+
+
+def _build(out_path: str, extra, verbose: bool) -> str:
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-fno-slp-vectorize",
-             "-pthread", "-I" + INCLUDE, "-I" + CSRC]
+             "-pthread", "-I" + INCLUDE, "-I" + CSRC] + list(extra)
     # -fno-slp-vectorize: packed f32 VALU (v_pk_mul/add_f32) beside MFMAs costs more than the scalar
     # forms it replaces (MI355X_MICROARCH.md, cycle constants); keep elementwise epilogue/softmax ops scalar
-    tmp = LIB_PATH + ".tmp.%d" % os.getpid()
+    tmp = out_path + ".tmp.%d" % os.getpid()
     objs = [tmp + "." + os.path.splitext(src)[0] + ".o" for src in SOURCES]
 
     def compile_one(pair):
@@ -108,8 +117,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
         for o in objs:
             if os.path.exists(o):
                 os.remove(o)
-    os.replace(tmp, LIB_PATH)
-    return LIB_PATH
+    os.replace(tmp, out_path)
+    return out_path
 
 
 _lib = None
@@ -124,12 +133,14 @@ def load() -> C.CDLL:
     with _lock:
         if _lib is not None:
             return _lib
-        if not os.path.exists(LIB_PATH):
+        # VS_LIBRARY: tools/ point this at libvsscore_diag.so (build(diag=True)); never a fallback
+        path = os.environ.get("VS_LIBRARY") or LIB_PATH
+        if not os.path.exists(path):
             raise RuntimeError(
                 "libvsscore.so not found at %s — the HIP scorer library is not built. "
                 "Run `python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). "
-                "There is no PyTorch/CPU fallback for the scoring path." % LIB_PATH)
-        lib = C.CDLL(LIB_PATH)
+                "There is no PyTorch/CPU fallback for the scoring path." % path)
+        lib = C.CDLL(path)
         for name in EXPORTS + EVAL_EXPORTS:
             if not hasattr(lib, name):
                 raise RuntimeError("libvsscore.so lacks symbol %s (stale build?)" % name)
@@ -142,6 +153,10 @@ def load() -> C.CDLL:
                                         C.POINTER(C.c_void_p)]
         lib.vs_weights_free.restype = None
         lib.vs_weights_free.argtypes = [C.c_void_p]
+        lib.vs_weights_update.restype = C.c_int
+        lib.vs_weights_update.argtypes = [C.c_void_p, C.POINTER(ModelParams), C.c_void_p]
+        lib.vs_set_option.restype = C.c_int
+        lib.vs_set_option.argtypes = [C.c_char_p, C.c_int32]
         lib.vs_scorer_workspace_bytes.restype = C.c_size_t
         lib.vs_scorer_workspace_bytes.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
         lib.vs_scorer_forward.restype = C.c_int
@@ -192,6 +207,11 @@ def load() -> C.CDLL:
         lib.vs_stage_name.argtypes = [C.c_int32]
         _lib = lib
     return _lib
+
+
+def set_option(name: str, value: int) -> None:
+    """A/B / test switch of the library (include/vs_scorer.h: vs_set_option); value < 0 restores the default."""
+    check(load().vs_set_option(name.encode(), int(value)))
 
 
 def profile_collect():

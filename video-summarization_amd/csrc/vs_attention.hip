@@ -1071,16 +1071,19 @@ int vsk_attention(const float *q, const float *k, const float *v, const uint8_t 
     const float sl2 = scale * 1.4426950408889634f;
     const int BH = B * H;
     dim3 grid(8 * ((BH + 7) / 8) * ((T + 127) / 128));
-    static const bool legacy = getenv("VS_ATTN_LEGACY") != nullptr;      // A/B switch for tools/, not a fallback
+#ifdef VS_WITH_DIAG     // A/B switch for tools/ (diagnostic library only): the non-pipelined kernel at head dim 32 / 64
+    const bool legacy = vsk_options().attn_legacy != 0;
     if (dh == 32 && legacy)
         hipLaunchKernelGGL((attn_fwd<32, 2>), grid, dim3(256), 0, st, q, k, v, mask, out, H, T, sl2, BH);
     else if (dh == 64 && legacy)
         hipLaunchKernelGGL((attn_fwd<64, 2>), grid, dim3(256), 0, st, q, k, v, mask, out, H, T, sl2, BH);
-    else if (dh == 32 || dh == 64) {
+    else
+#endif
+    if (dh == 32 || dh == 64) {
         // 8-wave blocks (one per CU, 256 query rows) unless the ragged tail would waste more rows than
         // 4-wave blocks (two per CU, 128 query rows) do
         const int r8 = (T + 255) / 256 * 256, r4 = (T + 127) / 128 * 128;
-        const bool wide = !getenv("VS_ATTN_NW4") && r8 * 100 <= r4 * 105;
+        const bool wide = !vsk_options().attn_nw4 && r8 * 100 <= r4 * 105;
         const int nq = wide ? r8 / 256 : r4 / 128;
         dim3 g(8 * ((BH + 7) / 8) * nq), blk(wide ? 512 : 256);
 #define VSK_ATTN(DH_, MASK_, NW_) \
@@ -1143,9 +1146,9 @@ int vsk_attention_bf16(const float *q, const float *k, const float *v, const uin
     const int BH = B * H;
     // 8-wave blocks (256 query rows share one staged K/V tile) unless the ragged tail would waste too many rows
     const int r8 = (T + 255) / 256 * 256, r4 = (T + 127) / 128 * 128;
-    const bool wide = dh == 64 && !getenv("VS_ATTN_NW4") && r8 * 100 <= r4 * 105;
+    const bool wide = dh == 64 && !vsk_options().attn_nw4 && r8 * 100 <= r4 * 105;
     dim3 grid(8 * ((BH + 7) / 8) * (wide ? r8 / 256 : r4 / 128));
-    static const bool simple = getenv("VS_ATTN_LP_SIMPLE") != nullptr;      // A/B switch for tools/, not a fallback
+    const bool simple = vsk_options().attn_lp_simple != 0;      // A/B switch for tools/, not a fallback
 #define VSK_ATTN_LP(KERN_, P_)                                                                                           \
     if (dh == 64 && wide)                                                                                                \
         hipLaunchKernelGGL((KERN_<64, 8, P_>), grid, dim3(512), 0, st, q, k, v, mask, out, H, T, sl2, BH);               \

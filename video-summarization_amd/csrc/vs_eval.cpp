@@ -60,7 +60,8 @@ int upsample(const float *scores, int n_scores, const int32_t *positions, int n_
     return VS_OK;
 }
 
-void knapsack(int W, const int32_t *wt, const double *val, int n, std::vector<int32_t> &sel) {
+// returns false where the reference raises IndexError (NaN values can walk the capacity below -(W+1))
+bool knapsack(int W, const int32_t *wt, const double *val, int n, std::vector<int32_t> &sel) {
     // K[i][w] exactly as knapsack_implementation.py:11-21 (double == Python float)
     std::vector<double> K((size_t)(n + 1) * (W + 1), 0.0);
     for (int i = 1; i <= n; ++i) {
@@ -71,7 +72,7 @@ void knapsack(int W, const int32_t *wt, const double *val, int n, std::vector<in
         for (int w = 1; w <= W; ++w) {
             if (w_i <= w) {
                 const double take = v_i + prev[w - w_i];
-                cur[w] = take >= prev[w] ? take : prev[w];     // Python max(a, b): a unless b > a; NaN-free here
+                cur[w] = prev[w] > take ? prev[w] : take;      // Python max(a, b): a unless b > a - also when either is NaN (a shot past n_frames has a NaN mean)
             } else {
                 cur[w] = prev[w];
             }
@@ -80,12 +81,17 @@ void knapsack(int W, const int32_t *wt, const double *val, int n, std::vector<in
     sel.clear();
     int w = W;
     for (int i = n; i > 0; --i) {                               // :23-28
-        if (K[(size_t)i * (W + 1) + w] != K[(size_t)(i - 1) * (W + 1) + w]) {
+        // A NaN entry differs from everything, so the reference can "select" a shot that does not fit and carry a
+        // NEGATIVE capacity on; its K[i][w] then indexes from the end of the row (Python list semantics).
+        if (w < -(W + 1)) return false;
+        const int col = w < 0 ? w + W + 1 : w;
+        if (K[(size_t)i * (W + 1) + col] != K[(size_t)(i - 1) * (W + 1) + col]) {
             sel.push_back(i - 1);
             w -= wt[i - 1];
         }
     }
     std::reverse(sel.begin(), sel.end());
+    return true;
 }
 
 // scipy.stats.rankdata(-x) with method 'average', as doubles
@@ -197,7 +203,7 @@ int vs_eval_knapsack(int32_t W, const int32_t *wt, const double *val, int32_t n,
     if (!wt || !val || !selected || !n_selected || W < 0 || n < 0) return bad("knapsack: bad arguments");
     for (int i = 0; i < n; ++i) if (wt[i] < 0) return bad("knapsack: negative weight");
     std::vector<int32_t> sel;
-    knapsack(W, wt, val, n, sel);
+    if (!knapsack(W, wt, val, n, sel)) return bad("knapsack: capacity index out of range (IndexError in the reference)");
     std::copy(sel.begin(), sel.end(), selected);
     *n_selected = (int32_t)sel.size();
     return VS_OK;
@@ -224,7 +230,7 @@ int vs_eval_generate_summary(const float *scores, int32_t n_scores, const int32_
     }
     const int W = (int)((double)(last_end + 1) * 0.15);                       // :46
     std::vector<int32_t> sel;
-    knapsack(W, len.data(), imp.data(), n_shots, sel);
+    if (!knapsack(W, len.data(), imp.data(), n_shots, sel)) return bad("generate_summary: capacity index out of range (IndexError in the reference)");
     std::fill(summary, summary + summary_len, (int8_t)0);
     for (int s : sel) {
         const int a = std::max(0, change_points[2 * s]), b = std::min(summary_len - 1, change_points[2 * s + 1]);

@@ -33,6 +33,23 @@ int vsk_mlp_fused(const float *H1, const float *W1, const float *b1, const float
                   hipStream_t st);
 // packed ragged batches: row offsets cu[B+1] and the (video, query tile) work list from device lengths; gather of
 // the positional rows pe[t] of every frame into rows[Mtot, d]
-int vsk_plan_packed(const int *lengths_dev, int B, int qb, int *cu, int *work, hipStream_t st);
+int vsk_plan_packed(const int *lengths_dev, int B, int qb, int *cu, int *work, int work_cap, hipStream_t st);   // work_cap: (video, tile) pairs `work` can hold
 int vsk_gather_rows(const float *pe, const int *cu, int B, int tmax, int d, float *rows, hipStream_t st);
 int vsk_skinny_max_rows();      // rows up to which the skinny (latency) kernels are used
+
+// A/B and test switches (DESIGN.md "Environment switches").  Read from the environment ONCE, when the library is
+// first used; afterwards only vs_set_option() changes them, so no forward pays a getenv.
+struct VskOptions {
+    int skinny_rows;      // VS_SKINNY_ROWS   (default 16384)
+    int lp_min_rows;      // VS_LP_MIN_ROWS   (default 8192)
+    int gemm_nwm2;        // VS_GEMM_NWM2     128x128 four-wave GEMM blocks only
+    int gemm_nj2;         // VS_GEMM_NJ2      128-column GEMM tiles only
+    int attn_nw4;         // VS_ATTN_NW4      4-wave attention blocks only
+    int attn_lp_simple;   // VS_ATTN_LP_SIMPLE phase-aligned low-precision attention
+    int mlp_fusion;       // VS_MLP_FUSION    (diagnostic builds only)
+    int mlp_abl;          // VS_MLP_ABL       (diagnostic builds only)
+    int attn_legacy;      // VS_ATTN_LEGACY   (diagnostic builds only)
+};
+VskOptions &vsk_options();
+// per-device cache of the CU count (one process may drive several GPUs)
+int vsk_device_cus();

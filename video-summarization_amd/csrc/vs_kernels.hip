@@ -14,6 +14,8 @@
 // A lane fetches FOUR consecutive k of its row with one 16-byte LDS read (k = 8*g + 4*h + s,
 // s = 0..3) and feeds them to four MFMA steps; step s therefore contracts k in {8g+s, 8g+4+s}.
 // The k order inside a sum is irrelevant as long as A and B use the same one.
+#include <atomic>
+
 #include "vs_device.h"
 #include "vs_kernels.h"
 
@@ -824,6 +826,7 @@ __global__ __launch_bounds__(256, 2) void gemm_ln_rows(
     }
 }
 
+#ifdef VS_WITH_DIAG      // negative result kept for tools/ only: not in the product library
 // ------------------------------------------------------------------------------------------
 // Fused MLP block (d_model = 256, hidden = 1024):
 //     out = LN2( relu(h1 * W1^T + b1) * W2^T + b2 + h1 ) * gamma + beta      (+ score head)
@@ -1062,6 +1065,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_256(
         }
     }
 }
+#endif  // VS_WITH_DIAG
 
 // ------------------------------------------------------------------------------------------
 // Skinny-M kernels (latency path, M <= a few thousand rows: single videos, small batches).
@@ -1510,13 +1514,19 @@ __global__ __launch_bounds__(64 * NW) void skinny2_ln(
 
 // ---- packed ragged batches (vs_scorer_forward_packed) ----
 // one thread: B is a few hundred at most, and the launch is stream-ordered before its consumers
-__global__ void plan_packed(const int *__restrict__ lengths, int B, int qb, int *__restrict__ cu, int *__restrict__ work) {
+// work_cap: pairs `work` can hold; the host sized the launch from ITS copy of the lengths, so entries beyond the
+// capacity (device lengths that disagree with the host's) are dropped instead of written past the workspace
+__global__ void plan_packed(const int *__restrict__ lengths, int B, int qb, int *__restrict__ cu, int *__restrict__ work,
+                            int work_cap) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     int row = 0, n = 0;
     for (int b = 0; b < B; ++b) {
         cu[b] = row;
         const int t = lengths[b];
-        for (int q = 0; q < (t + qb - 1) / qb; ++q) { work[2 * n] = b; work[2 * n + 1] = q; ++n; }
+        for (int q = 0; q < (t + qb - 1) / qb; ++q) {
+            if (n < work_cap) { work[2 * n] = b; work[2 * n + 1] = q; }
+            ++n;
+        }
         row += t;
     }
     cu[B] = row;
@@ -1540,12 +1550,8 @@ __global__ __launch_bounds__(256) void gather_rows(const float *__restrict__ pe,
 
 // persistent grid: `per_cu` blocks per CU, a multiple of 8 so the XCD chunking is exact
 static int persistent_blocks(int ntiles, int per_cu = 2) {
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0; hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
-        cus = prop.multiProcessorCount;
-    }
+    const int cus = vsk_device_cus();
+    if (cus <= 0) return -1;
     int g = per_cu * cus;
     g -= g % 8;
     if (g < 8) g = 8;
@@ -1556,7 +1562,7 @@ static int persistent_blocks(int ntiles, int per_cu = 2) {
 // 256x128 tiles on 8-wave blocks when there is enough work to give every CU >= 2 such tiles and the
 // ragged M edge does not waste more than 128-row tiles would; else 128x128 tiles on 4-wave blocks
 static bool use_wide_tiles(int M, int N) {
-    if (getenv("VS_GEMM_NWM2")) return false;
+    if (vsk_options().gemm_nwm2) return false;
     const long r256 = (M + 255) / 256 * 256, r128 = (M + 127) / 128 * 128;
     const long tiles = (r256 / 256) * ((N + 127) / 128);
     return r256 * 100 <= r128 * 105 && tiles >= 512;
@@ -1564,8 +1570,8 @@ static bool use_wide_tiles(int M, int N) {
 
 // latency path: below this many rows the LDS-tiled kernels cannot fill the chip
 // measured hand-over (tools/sweep_skinny.py, T=1024, M-A): skinny wins through M = 16384, tiled from 32768
-int vsk_plan_packed(const int *lengths_dev, int B, int qb, int *cu, int *work, hipStream_t st) {
-    hipLaunchKernelGGL(plan_packed, dim3(1), dim3(64), 0, st, lengths_dev, B, qb, cu, work);
+int vsk_plan_packed(const int *lengths_dev, int B, int qb, int *cu, int *work, int work_cap, hipStream_t st) {
+    hipLaunchKernelGGL(plan_packed, dim3(1), dim3(64), 0, st, lengths_dev, B, qb, cu, work, work_cap);
     VSK_CHECK_LAUNCH();
     return 0;
 }
@@ -1576,26 +1582,34 @@ int vsk_gather_rows(const float *pe, const int *cu, int B, int tmax, int d, floa
     return 0;
 }
 
-int vsk_skinny_max_rows() {
-    const char *e = getenv("VS_SKINNY_ROWS");      // read per call so tests can pin either path
-    return e ? atoi(e) : 16384;
-}
+int vsk_skinny_max_rows() { return vsk_options().skinny_rows; }
 static int skinny_max_rows() { return vsk_skinny_max_rows(); }
 
 // dynamic LDS of the packed skinny kernels: 32 activation rows x (min(K,1024) + 4) floats (up to 128.5 KiB)
 static size_t skinny2_lds(int K) { return (size_t)32 * ((K < 1024 ? K : 1024) + 4) * sizeof(float); }
-template <class F>
-static int allow_big_lds(F *kernel) {
-    return (int)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 32 * 1028 * 4);
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute: set it once per (kernel, device).  `done` is
+// the call site's own per-device flag array (one per kernel instantiation).
+enum { VSK_MAX_DEVICES = 64 };
+static int allow_big_lds_on_device(const void *kernel, std::atomic<unsigned char> *done) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return (int)hipErrorInvalidDevice;
+    if (dev >= 0 && dev < VSK_MAX_DEVICES && done[dev].load(std::memory_order_acquire)) return 0;
+    const int rc = (int)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 32 * 1028 * 4);
+    if (rc == 0 && dev >= 0 && dev < VSK_MAX_DEVICES) done[dev].store(1, std::memory_order_release);
+    return rc;
 }
+#define VSK_ALLOW_BIG_LDS(kernel_)                                          \
+    ([]() -> int {                                                          \
+        static std::atomic<unsigned char> done_[VSK_MAX_DEVICES];           \
+        return allow_big_lds_on_device((const void *)(kernel_), done_);     \
+    }())
 
 template <int EPI>
 static int launch_gemm(const float *A, const float *W, const float *Wf, const float *bias, float *C, int M, int N, int K,
                        const float *pe, int T, int H, int dh, int bf16, hipStream_t st) {
     if (bf16 == 2 && Wf != nullptr && M <= skinny_max_rows() && N % 32 == 0 && K % 128 == 0) {
         // fp16x3 latency kernels (Wf is then the pack_fragments_f16x3 copy)
-        static const int attr_rc = allow_big_lds(skinny2_gemm<EPI, 2>);
-        if (attr_rc) return attr_rc;
+        if (const int attr_rc = VSK_ALLOW_BIG_LDS((skinny2_gemm<EPI, 2>))) return attr_rc;
         dim3 grid((M + 31) / 32, (N + 127) / 128);
         hipLaunchKernelGGL((skinny2_gemm<EPI, 2>), grid, dim3(256), skinny2_lds(K), st, A, Wf, bias, C, M, N, K, pe, T, H, dh);
         VSK_CHECK_LAUNCH();
@@ -1628,8 +1642,7 @@ static int launch_gemm(const float *A, const float *W, const float *Wf, const fl
         return 0;
     }
     if (Wf != nullptr && M <= skinny_max_rows() && N % 32 == 0 && K % 128 == 0) {
-        static const int attr_rc = allow_big_lds(skinny2_gemm<EPI, 0>);
-        if (attr_rc) return attr_rc;
+        if (const int attr_rc = VSK_ALLOW_BIG_LDS((skinny2_gemm<EPI, 0>))) return attr_rc;
         dim3 grid((M + 31) / 32, (N + 127) / 128);
         hipLaunchKernelGGL((skinny2_gemm<EPI, 0>), grid, dim3(256), skinny2_lds(K), st, A, Wf, bias, C, M, N, K, pe, T, H, dh);
         VSK_CHECK_LAUNCH();
@@ -1641,7 +1654,7 @@ static int launch_gemm(const float *A, const float *W, const float *Wf, const fl
         VSK_CHECK_LAUNCH();
         return 0;
     }
-    if (use_wide_tiles(M, N) && N % 256 == 0 && !getenv("VS_GEMM_NJ2")) {
+    if (use_wide_tiles(M, N) && N % 256 == 0 && !vsk_options().gemm_nj2) {
         const int blocks = persistent_blocks(((M + 255) / 256) * (N / 256), 1);
         if (blocks < 0) return (int)hipErrorInvalidDevice;
         hipLaunchKernelGGL((gemm_nt_128<EPI, 4, 0, 4, 0>), dim3(blocks), dim3(512), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr);
@@ -1665,6 +1678,7 @@ int vsk_linear(const float *A, const float *W, const float *Wf, const float *bia
     return launch_gemm<EPI_BIAS>(A, W, Wf, bias, C, M, N, K, nullptr, 1, 0, 0, bf16, st);
 }
 
+#ifdef VS_WITH_DIAG
 int vsk_mlp_fused(const float *H1, const float *W1, const float *b1, const float *W2, const float *b2,
                   const float *gamma, const float *beta, float *out, int M, int d,
                   const float *score_w, const float *score_b, int num_classes, int sigmoid, float *scores,
@@ -1673,14 +1687,14 @@ int vsk_mlp_fused(const float *H1, const float *W1, const float *b1, const float
     int blocks = persistent_blocks((M + 127) / 128, 1);
     if (blocks < 0) return (int)hipErrorInvalidDevice;
     if (blocks > (M + 127) / 128) blocks = (M + 127) / 128;
-    const char *ab = getenv("VS_MLP_ABL");
-    const int abl = ab ? atoi(ab) : 0;
+    const int abl = vsk_options().mlp_abl;
 #define VSK_MLP(A_) hipLaunchKernelGGL(mlp_fused_256<A_>, dim3(blocks), dim3(256), 0, st, H1, W1, b1, W2, b2, gamma, beta, out, M, score_w, score_b, num_classes, sigmoid, scores)
     if (abl == 1) VSK_MLP(1); else if (abl == 2) VSK_MLP(2); else if (abl == 3) VSK_MLP(3); else VSK_MLP(0);
 #undef VSK_MLP
     VSK_CHECK_LAUNCH();
     return 0;
 }
+#endif  // VS_WITH_DIAG
 
 int vsk_pack_fragments(const float *W, float *Wf, int N, int K, hipStream_t st) {
     if (N % 32 || K % 8) return -1;
@@ -1696,6 +1710,7 @@ int vsk_pack_fragments_f16x3(const float *W, float *Wh, int N, int K, hipStream_
     return 0;
 }
 
+#ifdef VS_WITH_DIAG
 // diagnostic: the fc1-shaped GEMM with per-wave stamps (VS_DIAG_MODE 1..3, VS_DIAG_NWM 2|4); `grid` <= 0
 // selects the product grid.  diag == nullptr runs the product kernel.
 int vsk_diag_gemm(const float *A, const float *W, const float *bias, float *C, int M, int N, int K,
@@ -1724,6 +1739,7 @@ int vsk_diag_gemm(const float *A, const float *W, const float *bias, float *C, i
     VSK_CHECK_LAUNCH();
     return 0;
 }
+#endif  // VS_WITH_DIAG
 
 int vsk_qkv(const float *h, const float *Wqkv, const float *Wf, const float *bqkv, float *qkv, int B, int T, int d,
             int H, int bf16, hipStream_t st) {
@@ -1738,8 +1754,7 @@ int vsk_linear_res_ln(const float *A, const float *W, const float *Wf, const flo
         const int blocks = (M + 31) / 32;       // fp16x3 latency kernel (Wf: pack_fragments_f16x3 copy)
 #define VSK_SLN3_CASE(NW_)                                                                                 \
     case NW_: {                                                                                            \
-        static const int attr_rc = allow_big_lds(skinny2_ln<NW_, 2>);                                      \
-        if (attr_rc) return attr_rc;                                                                       \
+        if (const int attr_rc = VSK_ALLOW_BIG_LDS((skinny2_ln<NW_, 2>))) return attr_rc;                   \
         hipLaunchKernelGGL((skinny2_ln<NW_, 2>), dim3(blocks), dim3(64 * NW_), skinny2_lds(K), st, A, Wf, bias, res, \
                            gamma, beta, out, M, K, score_w, score_b, num_classes, sigmoid, scores);        \
         break;                                                                                             \
@@ -1779,8 +1794,7 @@ int vsk_linear_res_ln(const float *A, const float *W, const float *Wf, const flo
         const int blocks = (M + 31) / 32;
 #define VSK_SLN2_CASE(NW_)                                                                                 \
     case NW_: {                                                                                            \
-        static const int attr_rc = allow_big_lds(skinny2_ln<NW_, 0>);                                      \
-        if (attr_rc) return attr_rc;                                                                       \
+        if (const int attr_rc = VSK_ALLOW_BIG_LDS((skinny2_ln<NW_, 0>))) return attr_rc;                   \
         hipLaunchKernelGGL((skinny2_ln<NW_, 0>), dim3(blocks), dim3(64 * NW_), skinny2_lds(K), st, A, Wf, bias, res, \
                            gamma, beta, out, M, K, score_w, score_b, num_classes, sigmoid, scores);        \
         break;                                                                                             \

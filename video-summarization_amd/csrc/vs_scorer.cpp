@@ -4,10 +4,12 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -51,17 +53,29 @@ namespace {
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // ---- optional per-stage HIP-event timing (bench.py's roofline leg) ----
+// Events come from a pool that vs_profile_collect refills, so a profiled forward creates none after the first.
 const char *const kStageNames[VS_NUM_STAGES] = {"embed_pe", "qkv_proj", "attention", "outproj_ln", "fc1_relu", "fc2_ln_score"};
 struct StageRec { int stage; hipEvent_t a, b; };
 std::mutex g_prof_mu;
-bool g_prof_on = false;
+std::atomic<bool> g_prof_on{false};
 std::vector<StageRec> g_prof;
+std::vector<hipEvent_t> g_event_pool;
+
+hipEvent_t take_event() {
+    {
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        if (!g_event_pool.empty()) { hipEvent_t e = g_event_pool.back(); g_event_pool.pop_back(); return e; }
+    }
+    hipEvent_t e = nullptr;
+    return hipEventCreate(&e) == hipSuccess ? e : nullptr;
+}
 
 struct StageScope {
     hipStream_t st; int stage; hipEvent_t a = nullptr, b = nullptr; bool on;
-    StageScope(int stage_, hipStream_t st_) : st(st_), stage(stage_), on(g_prof_on) {
+    StageScope(int stage_, hipStream_t st_) : st(st_), stage(stage_), on(g_prof_on.load(std::memory_order_relaxed)) {
         if (!on) return;
-        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { on = false; return; }
+        a = take_event(); b = take_event();
+        if (!a || !b) { on = false; return; }
         (void)hipEventRecord(a, st);
     }
     ~StageScope() {
@@ -97,10 +111,48 @@ int check_desc(const vs_model_desc *d) {
 
 }  // namespace
 
+// ---- A/B switches: environment read once, then only vs_set_option() ----
+namespace {
+struct OptionName { const char *name; int VskOptions::*field; int dflt; };
+const OptionName kOptions[] = {
+    {"VS_SKINNY_ROWS", &VskOptions::skinny_rows, 16384}, {"VS_LP_MIN_ROWS", &VskOptions::lp_min_rows, 8192},
+    {"VS_GEMM_NWM2", &VskOptions::gemm_nwm2, 0},         {"VS_GEMM_NJ2", &VskOptions::gemm_nj2, 0},
+    {"VS_ATTN_NW4", &VskOptions::attn_nw4, 0},           {"VS_ATTN_LP_SIMPLE", &VskOptions::attn_lp_simple, 0},
+    {"VS_MLP_FUSION", &VskOptions::mlp_fusion, 0},       {"VS_MLP_ABL", &VskOptions::mlp_abl, 0},
+    {"VS_ATTN_LEGACY", &VskOptions::attn_legacy, 0},
+};
+int option_from_env(const OptionName &o) {
+    const char *e = getenv(o.name);
+    if (!e) return o.dflt;
+    return *e ? atoi(e) : 1;      // "VAR=" (set but empty) counts as on, like the old `getenv != nullptr` switches
+}
+}  // namespace
+
+VskOptions &vsk_options() {
+    static VskOptions opts = [] {
+        VskOptions o{};
+        for (const auto &k : kOptions) o.*(k.field) = option_from_env(k);
+        return o;
+    }();
+    return opts;
+}
+
+int vsk_device_cus() {
+    static std::atomic<int> cus[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
+    if (dev >= 0 && dev < 64) { const int c = cus[dev].load(std::memory_order_relaxed); if (c > 0) return c; }
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return -1;
+    if (dev >= 0 && dev < 64) cus[dev].store(n, std::memory_order_relaxed);
+    return n;
+}
+
 struct vs_weights {
     vs_model_desc desc;
     float *blob = nullptr;        // one device allocation
     size_t blob_floats = 0;
+    int device = 0;               // the device the blob lives on
     size_t embed_w = 0, embed_b = 0, pe = 0, final_w = 0, final_b = 0, f_embed_w = 0, h_embed_w = 0;
     bool has_pe = false;
     std::vector<LayerOff> layers;
@@ -113,49 +165,15 @@ int vs_abi_version(void) { return VS_ABI_VERSION; }
 
 const char *vs_last_error(void) { return g_err.c_str(); }
 
-int vs_weights_pack(const vs_model_desc *desc, const vs_model_params *params, void *stream,
-                    vs_weights **out) {
-    if (int rc = check_desc(desc)) return rc;
-    if (!params || !out) return fail(VS_ERR_INVALID, "params/out is NULL");
+// copies the parameters into w->blob and rebuilds the fragment-major copies (all stream-ordered on `st`)
+static int fill_weights(vs_weights *w, const vs_model_params *params, hipStream_t st) {
+    const vs_model_desc *desc = &w->desc;
+    const size_t d = desc->d_model, din = desc->in_features, nc = desc->num_classes;
     if (!params->embed_w || !params->embed_b || !params->final_w || !params->final_b ||
         (desc->num_layers > 0 && !params->layers))
         return fail(VS_ERR_INVALID, "a required parameter pointer is NULL");
     if ((params->pos_embedding != nullptr) != (desc->max_len > 0))
         return fail(VS_ERR_INVALID, "pos_embedding / max_len mismatch");
-    hipStream_t st = (hipStream_t)stream;
-    const size_t d = desc->d_model, din = desc->in_features, nc = desc->num_classes;
-
-    vs_weights *w = new vs_weights();
-    w->desc = *desc;
-    size_t off = 0;
-    auto take = [&](size_t n) { size_t o = off; off += align_up(n, 64); return o; };   // 256-B aligned
-    w->embed_w = take(d * din);
-    w->embed_b = take(d);
-    w->has_pe = params->pos_embedding != nullptr;
-    if (w->has_pe) w->pe = take((size_t)desc->max_len * d);
-    w->layers.resize(desc->num_layers);
-    for (auto &L : w->layers) {
-        L.wqkv = take(3 * d * d); L.bqkv = take(3 * d);
-        L.wo = take(d * d);       L.bo = take(d);
-        L.ln1g = take(d);         L.ln1b = take(d);
-        L.w1 = take(4 * d * d);   L.b1 = take(4 * d);
-        L.w2 = take(4 * d * d);   L.b2 = take(d);
-        L.ln2g = take(d);         L.ln2b = take(d);
-    }
-    w->final_w = take(nc * d);
-    w->final_b = take(nc);
-    w->f_embed_w = take(d * din);
-    for (auto &L : w->layers) {
-        L.f_wqkv = take(3 * d * d); L.f_wo = take(d * d); L.f_w1 = take(4 * d * d); L.f_w2 = take(4 * d * d);
-    }
-    w->h_embed_w = take(d * din);
-    for (auto &L : w->layers) {
-        L.h_wqkv = take(3 * d * d); L.h_wo = take(d * d); L.h_w1 = take(4 * d * d); L.h_w2 = take(4 * d * d);
-    }
-    w->blob_floats = off;
-    hipError_t e = hipMalloc((void **)&w->blob, off * sizeof(float));
-    if (e != hipSuccess) { delete w; return fail(VS_ERR_HIP, "hipMalloc(%zu): %s", off * sizeof(float), hipGetErrorString(e)); }
-
     auto copy = [&](size_t dst, const float *src, size_t n) -> hipError_t {
         if (!src) return hipErrorInvalidValue;
         return hipMemcpyAsync(w->blob + dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, st);
@@ -186,12 +204,9 @@ int vs_weights_pack(const vs_model_desc *desc, const vs_model_params *params, vo
     }
     ok &= copy(w->final_w, params->final_w, nc * d) == hipSuccess;
     ok &= copy(w->final_b, params->final_b, nc) == hipSuccess;
-    if (!ok) {
-        (void)hipFree(w->blob);
-        delete w;
+    if (!ok)
         return fail(VS_ERR_HIP, "parameter copy failed (NULL pointer or hipMemcpyAsync error: %s)",
                     hipGetErrorString(hipGetLastError()));
-    }
     // fragment-major copies (stream-ordered after the copies above)
     bool pk = vsk_pack_fragments(w->blob + w->embed_w, w->blob + w->f_embed_w, (int)d, (int)din, st) == 0;
     for (const auto &L : w->layers) {
@@ -207,13 +222,62 @@ int vs_weights_pack(const vs_model_desc *desc, const vs_model_params *params, vo
         pk &= vsk_pack_fragments_f16x3(w->blob + L.w1, w->blob + L.h_w1, (int)(4 * d), (int)d, st) == 0;
         pk &= vsk_pack_fragments_f16x3(w->blob + L.w2, w->blob + L.h_w2, (int)d, (int)(4 * d), st) == 0;
     }
-    if (!pk) {
+    if (!pk) return fail(VS_ERR_HIP, "weight fragment packing failed: %s", hipGetErrorString(hipGetLastError()));
+    return VS_OK;
+}
+
+int vs_weights_pack(const vs_model_desc *desc, const vs_model_params *params, void *stream,
+                    vs_weights **out) {
+    if (int rc = check_desc(desc)) return rc;
+    if (!params || !out) return fail(VS_ERR_INVALID, "params/out is NULL");
+    const size_t d = desc->d_model, din = desc->in_features, nc = desc->num_classes;
+
+    vs_weights *w = new vs_weights();
+    w->desc = *desc;
+    size_t off = 0;
+    auto take = [&](size_t n) { size_t o = off; off += align_up(n, 64); return o; };   // 256-B aligned
+    w->embed_w = take(d * din);
+    w->embed_b = take(d);
+    w->has_pe = params->pos_embedding != nullptr;
+    if (w->has_pe) w->pe = take((size_t)desc->max_len * d);
+    w->layers.resize(desc->num_layers);
+    for (auto &L : w->layers) {
+        L.wqkv = take(3 * d * d); L.bqkv = take(3 * d);
+        L.wo = take(d * d);       L.bo = take(d);
+        L.ln1g = take(d);         L.ln1b = take(d);
+        L.w1 = take(4 * d * d);   L.b1 = take(4 * d);
+        L.w2 = take(4 * d * d);   L.b2 = take(d);
+        L.ln2g = take(d);         L.ln2b = take(d);
+    }
+    w->final_w = take(nc * d);
+    w->final_b = take(nc);
+    w->f_embed_w = take(d * din);
+    for (auto &L : w->layers) {
+        L.f_wqkv = take(3 * d * d); L.f_wo = take(d * d); L.f_w1 = take(4 * d * d); L.f_w2 = take(4 * d * d);
+    }
+    w->h_embed_w = take(d * din);
+    for (auto &L : w->layers) {
+        L.h_wqkv = take(3 * d * d); L.h_wo = take(d * d); L.h_w1 = take(4 * d * d); L.h_w2 = take(4 * d * d);
+    }
+    w->blob_floats = off;
+    if (hipGetDevice(&w->device) != hipSuccess) { delete w; return fail(VS_ERR_HIP, "hipGetDevice failed"); }
+    hipError_t e = hipMalloc((void **)&w->blob, off * sizeof(float));
+    if (e != hipSuccess) { delete w; return fail(VS_ERR_HIP, "hipMalloc(%zu): %s", off * sizeof(float), hipGetErrorString(e)); }
+    if (int rc = fill_weights(w, params, (hipStream_t)stream)) {
         (void)hipFree(w->blob);
         delete w;
-        return fail(VS_ERR_HIP, "weight fragment packing failed: %s", hipGetErrorString(hipGetLastError()));
+        return rc;
     }
     *out = w;
     return VS_OK;
+}
+
+int vs_weights_update(vs_weights *w, const vs_model_params *params, void *stream) {
+    if (!w || !params) return fail(VS_ERR_INVALID, "weights/params is NULL");
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev != w->device)
+        return fail(VS_ERR_INVALID, "vs_weights_update on device %d, handle was packed on device %d", dev, w->device);
+    return fill_weights(w, params, (hipStream_t)stream);
 }
 
 void vs_weights_free(vs_weights *w) {
@@ -274,8 +338,7 @@ int forward_core(const vs_weights *w, const float *x, const uint8_t *key_pad_mas
     // bf16 Linear kernels exist as LDS-tiled throughput kernels only: up to 8192 rows (measured crossover) the exact
     // fp32 latency kernels are faster and are used whatever that flag says.  fp16x3 has its own latency kernels
     // (same product order as its tiled kernels: a video's scores do not depend on the batch it is scored in).
-    const char *lpe = getenv("VS_LP_MIN_ROWS");          // tests / tools pin the bf16 tiled kernels with 0
-    const int lp_min_rows = lpe ? atoi(lpe) : 8192;
+    const int lp_min_rows = vsk_options().lp_min_rows;    // tests / tools pin the bf16 tiled kernels with 0
     const int lbf = (flags & VS_FLAG_F16X3_LINEAR) ? 2 : ((flags & VS_FLAG_BF16_LINEAR) && M > lp_min_rows) ? 1 : 0;
     // the bf16 Linear + LayerNorm kernels stop at d_model 256 (validated above); fp16x3 has a wide variant too
     const int lnbf = lbf;
@@ -311,12 +374,12 @@ int forward_core(const vs_weights *w, const float *x, const uint8_t *key_pad_mas
                                         nullptr, nullptr, 0, 0, nullptr, lnbf, st));
         }
         float *dst = (last && hidden) ? hidden : h0;
+#ifdef VS_WITH_DIAG     // diagnostic library only (tools/): the measured-slower fused MLP kernel
         // Opt-in alternative (VS_MLP_FUSION=1, d_model = 256): fc1 + ReLU + fc2 + residual + norm2 (+ score head)
         // as ONE kernel with the activations kept in registers (reported under the fc2 stage).  Bit-identical
         // to the two-kernel path but measured 6 % slower: its ~506 registers per lane allow one
         // wave per SIMD only, so nothing covers the weight loads' issue stalls.
-        const char *fz = getenv("VS_MLP_FUSION");
-        const bool fused = d == 256 && fz && atoi(fz) != 0 && M > vsk_skinny_max_rows() && !lbf;
+        const bool fused = d == 256 && vsk_options().mlp_fusion != 0 && M > vsk_skinny_max_rows() && !lbf;
         if (fused) {
             StageScope ps(VS_STAGE_FC2_LN, st);
             VS_LAUNCH(vsk_mlp_fused(h1, w->p(P.w1), w->p(P.b1), w->p(P.w2), w->p(P.b2), w->p(P.ln2g), w->p(P.ln2b), dst, M, d,
@@ -324,6 +387,7 @@ int forward_core(const vs_weights *w, const float *x, const uint8_t *key_pad_mas
                                     D.num_classes, sig, last ? scores : nullptr, st));
             continue;
         }
+#endif
         {
             StageScope ps(VS_STAGE_FC1, st);
             VS_LAUNCH(vsk_linear(h1, w->p(P.w1), w->p(lbf == 2 ? P.h_w1 : P.f_w1), w->p(P.b1), ffn, M, 4 * d, d, 1, nullptr, 1, lbf, st));
@@ -375,12 +439,21 @@ static int packed_plan(const vs_weights *w, const int32_t *lengths, int32_t B, s
     return VS_OK;
 }
 
+// (video, tile) pairs the plan area is sized for: ALWAYS the 128-row tiling, the longer of the two lists, so the
+// size does not depend on which tiling the forward picks for the flags it is given
+static size_t packed_plan_capacity(const int32_t *lengths, int32_t B) {
+    size_t n = 0;
+    for (int b = 0; b < B; ++b) n += (size_t)(lengths[b] + 127) / 128;
+    return n;
+}
+
 size_t vs_scorer_workspace_bytes_packed(const vs_weights *w, const int32_t *lengths, int32_t B) {
     std::vector<int> cu, work;
     int nw = 0;
     if (packed_plan(w, lengths, B, cu, work, nw) != VS_OK) return 0;
     const size_t md = align_up((size_t)cu[B] * w->desc.d_model * sizeof(float), 256);
-    return 11 * md + align_up((cu.size() + work.size()) * sizeof(int), 256);      // + gathered positional rows, plan
+    // + gathered positional rows, plan (row offsets + work list)
+    return 11 * md + align_up((cu.size() + 2 * packed_plan_capacity(lengths, B)) * sizeof(int), 256);
 }
 
 int vs_scorer_forward_packed(const vs_weights *w, const float *x, const int32_t *lengths, const int32_t *lengths_dev,
@@ -406,7 +479,9 @@ int vs_scorer_forward_packed(const vs_weights *w, const float *x, const int32_t 
     int *plan = (int *)((char *)workspace + 11 * md);
     // the device builds its own copy of the plan from the device lengths (no host memory is read after return,
     // no synchronisation); the host copy above only sized the launch
-    VS_LAUNCH(vsk_plan_packed(lengths_dev, B, 32 * nw, plan, plan + cu.size(), st));
+    const size_t cap = packed_plan_capacity(lengths, B);
+    if (work.size() / 2 > cap) return fail(VS_ERR_INVALID, "internal: packed plan %zu > capacity %zu", work.size() / 2, cap);
+    VS_LAUNCH(vsk_plan_packed(lengths_dev, B, 32 * nw, plan, plan + cu.size(), (int)cap, st));
     PackedInfo pk{nullptr, plan, plan + cu.size(), (int)(work.size() / 2), nw, aprec};
     if (w->has_pe) {
         int tmax = 0;
@@ -419,10 +494,24 @@ int vs_scorer_forward_packed(const vs_weights *w, const float *x, const int32_t 
 
 int vs_profile_enable(int32_t on) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    for (auto &r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    for (auto &r : g_prof) { g_event_pool.push_back(r.a); g_event_pool.push_back(r.b); }
     g_prof.clear();
-    g_prof_on = on != 0;
+    if (!on) {      // profiling off: give the events back to the runtime
+        for (hipEvent_t e : g_event_pool) (void)hipEventDestroy(e);
+        g_event_pool.clear();
+    }
+    g_prof_on.store(on != 0);
     return VS_OK;
+}
+
+int vs_set_option(const char *name, int32_t value) {
+    if (!name) return fail(VS_ERR_INVALID, "option name is NULL");
+    for (const auto &k : kOptions)
+        if (strcmp(k.name, name) == 0) {
+            vsk_options().*(k.field) = value < 0 ? option_from_env(k) : value;
+            return VS_OK;
+        }
+    return fail(VS_ERR_INVALID, "unknown option %s", name);
 }
 
 int vs_profile_collect(double *ms_sum, int64_t *launches) {
@@ -435,8 +524,8 @@ int vs_profile_collect(double *ms_sum, int64_t *launches) {
         VS_HIP(hipEventElapsedTime(&ms, r.a, r.b));
         ms_sum[r.stage] += ms;
         launches[r.stage] += 1;
-        (void)hipEventDestroy(r.a);
-        (void)hipEventDestroy(r.b);
+        g_event_pool.push_back(r.a);
+        g_event_pool.push_back(r.b);
     }
     g_prof.clear();
     return VS_OK;
@@ -446,6 +535,7 @@ const char *vs_stage_name(int32_t stage) {
     return (stage >= 0 && stage < VS_NUM_STAGES) ? kStageNames[stage] : "";
 }
 
+#ifdef VS_WITH_DIAG
 // Diagnostic entry (not part of include/vs_scorer.h): fc1-shaped GEMM with s_memtime phase stamps.
 // diag = [grid*4 waves][8] u64: issue, mfma, epilogue, stage, barrier, total cycles, k-tiles, t_begin.
 int vs_diag_gemm(const float *A, const float *W, const float *bias, float *C, int32_t M, int32_t N, int32_t K,
@@ -453,6 +543,7 @@ int vs_diag_gemm(const float *A, const float *W, const float *bias, float *C, in
     VS_LAUNCH(vsk_diag_gemm(A, W, bias, C, M, N, K, grid, diag, (hipStream_t)stream));
     return VS_OK;
 }
+#endif  // VS_WITH_DIAG
 
 static int linear_entry(const float *A, const float *W, const float *bias, float *C, int32_t M, int32_t N,
                         int32_t K, int32_t relu, const float *pe, int32_t T, int bf16, void *stream) {

@@ -173,6 +173,7 @@ class SimNet(nn.Module):
         self._linear_dtype = "fp32"       # "bf16": every Linear multiplies bf16-rounded operands (fp32 storage/accumulate)
         self._packed: Optional[_Packed] = None
         self._packed_key = None
+        self._packed_shape = None
 
     # ---- reference helper kept for API parity (simnet.py:47-56) ----
     def process_mask(self, mask: Tensor) -> Tensor:
@@ -206,6 +207,8 @@ class SimNet(nn.Module):
         key = (device,) + tuple((t.data_ptr(), t._version) for t in self._tensors())
         if self._packed is not None and key == self._packed_key:
             return self._packed
+        shape_key = (device, self.d_model, self.num_heads, self.num_layers, self.in_features,
+                     self.pe_len if self.use_pos else 0, self.num_classes)
         lib = _lib.load()
         ts = []
         for t in self._tensors():
@@ -225,12 +228,17 @@ class SimNet(nn.Module):
         P.final_w, P.final_b = next(it).data_ptr(), next(it).data_ptr()
         desc = _lib.ModelDesc(self.d_model, self.num_heads, self.num_layers, self.in_features,
                               self.pe_len if self.use_pos else 0, self.num_classes)
-        out = C.c_void_p()
         with torch.cuda.device(device):
             stream = torch.cuda.current_stream(device).cuda_stream
-            _lib.check(lib.vs_weights_pack(C.byref(desc), C.byref(P), stream, C.byref(out)))
+            if self._packed is not None and self._packed_shape == shape_key:
+                # parameters were written (optimizer step, load_state_dict): refill the existing device storage
+                _lib.check(lib.vs_weights_update(self._packed.handle, C.byref(P), stream))
+            else:
+                out = C.c_void_p()
+                _lib.check(lib.vs_weights_pack(C.byref(desc), C.byref(P), stream, C.byref(out)))
+                self._packed, self._packed_shape = _Packed(out.value, device), shape_key
         del ts      # stream-ordered: the async copies are already enqueued on the current stream
-        self._packed, self._packed_key = _Packed(out.value, device), key
+        self._packed_key = key
         return self._packed
 
     # ---- forward --------------------------------------------------------------------------
