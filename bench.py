@@ -48,14 +48,17 @@ STAGE_KERNEL = {"attention": "attn_fwd_pipe", "embed_pe": "gemm_nt_128<2", "qkv_
                 "fc1_relu": "gemm_nt_128<1", "outproj_ln": "gemm_ln_rows", "fc2_ln_score": "gemm_ln_rows"}
 
 
+FORWARD_SOURCES = ("vs_attention.hip", "vs_device.h", "vs_kernels.h", "vs_kernels.hip", "vs_scorer.cpp")
+
+
 def kernel_source_hash():
-    """sha256 (16 hex) over the kernel sources the loaded library was built from: the stamp of the traffic file."""
+    """sha256 (16 hex) over the sources of the scoring forward (the kernels the traffic file was measured on and
+    their launch code): the stamp of the traffic file."""
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, "video-summarization_amd", "csrc")
-    for name in sorted(os.listdir(csrc)):
-        if name.endswith((".hip", ".h", ".cpp")):
-            h.update(name.encode())
-            h.update(open(os.path.join(csrc, name), "rb").read())
+    for name in FORWARD_SOURCES:
+        h.update(name.encode())
+        h.update(open(os.path.join(csrc, name), "rb").read())
     return h.hexdigest()[:16]
 
 
