@@ -1,0 +1,107 @@
+/*
+ * vs_train.h — C ABI of the TRAINING path of libvsscore.so: SimNet.forward in train mode
+ * (dropout, activations kept) and its backward, as the reference's callers drive it:
+ *     pred, _ = model(feature, mask); loss = mse_with_mask_loss(pred, target, mask); loss.backward()
+ *                                                        reference src/train.py:111-131, src/pretrain.py:49-86
+ * The reference has no FFI; what a binding binds is torch.autograd's contract for this nn.Module: a forward that
+ * keeps what the backward needs, and a backward from (d_scores, d_hidden) to the gradients of every parameter
+ * (and of the input).  Same conventions as vs_scorer.h: device pointers, no allocation, work enqueued on the
+ * caller's stream, int status + vs_last_error().  All arithmetic is exact fp32 (v_mfma_f32_32x32x2_f32); every
+ * reduction runs in a fixed order, so a step is bitwise reproducible for a given dropout seed.
+ */
+#ifndef VS_TRAIN_H
+#define VS_TRAIN_H
+
+#include "vs_scorer.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* The dropout modules of the reference (all nn.Dropout, active in train mode only):
+ *   p_embed  PositionalEncoding.dropout, p = `sparsity`   simnet.py:224,237   (0 in train.py:33 / simnet_pretrain.py:30)
+ *   p        drop_rate of every EncoderBlock: attention weights simnet.py:159, dropout1 :107, mlp.dropout :181,
+ *            dropout2 :110
+ * The keep decisions are a counter-based hash of (seed, module, row, column) — see csrc/vs_train_device.h — so the
+ * backward rebuilds them from `seed` alone; pass the SAME struct to forward and backward.  torch's Philox stream is
+ * not reproduced (no re-implementation can): statistics and forward/backward consistency are what the tests pin. */
+typedef struct vs_dropout_cfg {
+    float p_embed;
+    float p;
+    uint64_t seed;
+} vs_dropout_cfg;
+
+/* Gradient destinations: the mirror of vs_layer_params / vs_model_params (nn.Linear layout [out, in]); every
+ * pointer is a device buffer of the parameter's shape that the backward OVERWRITES (it does not accumulate). */
+typedef struct vs_layer_grads {
+    float *wq, *bq, *wk, *bk, *wv, *bv;
+    float *wo, *bo;
+    float *ln1_g, *ln1_b;
+    float *w1, *b1, *w2, *b2;
+    float *ln2_g, *ln2_b;
+} vs_layer_grads;
+
+typedef struct vs_model_grads {
+    float *embed_w, *embed_b;
+    const vs_layer_grads *layers;               /* HOST array of num_layers entries */
+    float *final_w, *final_b;
+} vs_model_grads;
+
+/* Bytes of the activation record one forward leaves for its backward, and of the scratch either call needs. */
+size_t vs_train_saved_bytes(const vs_weights *w, int32_t B, int32_t T);
+size_t vs_train_workspace_bytes(const vs_weights *w, int32_t B, int32_t T);
+
+/* Replaces: SimNet.forward(x, mask) in TRAIN mode (simnet.py:32-45 with every nn.Dropout active).
+ *   x [B,T,in_features], key_pad_mask [B,T] bytes or NULL, scores [B,T,num_classes] raw logits,
+ *   hidden [B,T,d_model] or NULL, saved >= vs_train_saved_bytes, workspace >= vs_train_workspace_bytes (256-B aligned).
+ * `drop` may be NULL (no dropout: eval-mode values, but with the activation record kept). */
+int vs_train_forward(const vs_weights *w, const float *x, const uint8_t *key_pad_mask, int32_t B, int32_t T,
+                     const vs_dropout_cfg *drop, float *scores, float *hidden, void *saved, size_t saved_bytes,
+                     void *workspace, size_t workspace_bytes, void *stream);
+
+/* Replaces: autograd's backward through that forward (loss.backward(), train.py:126).
+ *   d_scores [B,T,num_classes] or NULL (zero), d_hidden [B,T,d_model] or NULL (zero): gradients of the two return
+ *   values of forward; `saved` as written by vs_train_forward for the same (w, x, mask, B, T, drop);
+ *   grads: every parameter's gradient (overwritten); dx [B,T,in_features] or NULL (input gradient not wanted).
+ * The handle must hold the parameter values the forward used (no vs_weights_update in between). */
+int vs_train_backward(vs_weights *w, const float *x, const uint8_t *key_pad_mask, int32_t B, int32_t T,
+                      const vs_dropout_cfg *drop, const float *d_scores, const float *d_hidden, const void *saved,
+                      size_t saved_bytes, const vs_model_grads *grads, float *dx, void *workspace,
+                      size_t workspace_bytes, void *stream);
+
+/* Replaces: utils.mse_with_mask_loss(output, targets, mask, reduction) (reference src/utils/utils.py:45-56, called
+ * at train.py:122): mean (reduction "avg") or sum over ALL n = B*T entries of ((output - target) * scale)^2 with
+ * scale = 0 on masked frames.  output/target [n] fp32, mask [n] bytes or NULL; scratch >= 256 floats; loss [1]. */
+int vs_mse_mask_loss_forward(const float *output, const float *target, const uint8_t *mask, int32_t n, int32_t mean,
+                             float *scratch, float *loss, void *stream);
+int vs_mse_mask_loss_backward(const float *output, const float *target, const uint8_t *mask, const float *d_loss,
+                              int32_t n, int32_t mean, float *d_output, void *stream);
+
+/* Per-kernel entry points for the parity tests (not needed by a binding). */
+
+/* softmax(q k^T * scale + keymask) with dropout p on the weights, times v; q,k,v head-major [B,H,T,dh]; out [B,T,H*dh];
+ * lse2 [B,H,T] = base-2 log-sum-exp of the scaled masked scores (what the backward re-normalises with). */
+int vs_train_attention_forward(const float *q, const float *k, const float *v, const uint8_t *key_pad_mask, float *out,
+                               float *lse2, int32_t B, int32_t H, int32_t T, int32_t dh, float scale, uint64_t seed,
+                               uint32_t site, float p, void *stream);
+/* d_out [B,T,H*dh] -> dqkv [B,T,3*H*dh] (columns dq | dk | dv, head h at h*dh); scratch >= B*H*T floats. */
+int vs_train_attention_backward(const float *q, const float *k, const float *v, const uint8_t *key_pad_mask,
+                                const float *out, const float *d_out, const float *lse2, float *dqkv, float *scratch,
+                                int32_t B, int32_t H, int32_t T, int32_t dh, float scale, uint64_t seed, uint32_t site,
+                                float p, void *stream);
+/* dW [N,K] = dY[M,N]^T X[M,K], db [N] = column sums of dY; scratch >= vs_train_wgrad_scratch_floats(M,N,K) floats. */
+size_t vs_train_wgrad_scratch_floats(int32_t M, int32_t N, int32_t K);
+int vs_train_wgrad(const float *dY, const float *X, int32_t M, int32_t N, int32_t K, float *dW, float *db,
+                   float *scratch, void *stream);
+/* keep masks (bytes, 1 = kept) exactly as the kernels draw them: attention weights [B,H,T,T]; elementwise [M,cols] */
+int vs_train_dropout_mask_attention(uint8_t *keep, int32_t B, int32_t H, int32_t T, uint64_t seed, uint32_t site,
+                                    float p, void *stream);
+int vs_train_dropout_mask_rows(uint8_t *keep, int32_t M, int32_t cols, uint64_t seed, uint32_t site, float p,
+                               void *stream);
+/* module numbers (`site`) of the dropouts: embedding = 0; layer l: 1 + 4*l + {0 attention, 1 dropout1, 2 mlp, 3 dropout2} */
+uint32_t vs_train_dropout_site(int32_t layer, int32_t which);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VS_TRAIN_H */

@@ -1,0 +1,346 @@
+"""GPU tests of the HIP TRAINING path (C ABI include/vs_train.h), through the C ABI.
+
+Checkers: (1) gradients produced by the IMPORTED reference in float64 (tests/golden/make_golden_train.py: reference
+SimNet in train mode with dropout 0 + reference utils.mse_with_mask_loss); (2) a float64 torch restatement with
+EXPLICIT dropout masks (tests/torch_ref.py) fed with the very masks the library draws, for everything dropout touches.
+
+Tolerances (fp32 arithmetic against a float64 truth): per tensor max|err| <= 1e-4 absolute AND <= 1e-3 of the tensor's
+largest entry (+1e-7 for gradients that are analytically zero, e.g. the key bias).  Observed: ~1e-6 relative."""
+import ctypes as C
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+import torch_ref
+
+pytestmark = pytest.mark.gpu
+ATOL, RTOL = 1e-4, 1e-3
+
+
+def _dev():
+    assert torch.cuda.is_available(), "these tests need a HIP device"
+    return torch.device("cuda:0")
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _close(got, want, what=""):
+    got, want = got.detach().double().cpu(), want.detach().double().cpu()
+    err = (got - want).abs().max().item()
+    scale = want.abs().max().item()
+    assert err <= ATOL and err <= RTOL * scale + 1e-7, "%s: max err %.3e (max |want| %.3e)" % (what, err, scale)
+    return err / (scale + 1e-30)
+
+
+def train_cases():
+    with open(os.path.join(GOLDEN, "train_index.json")) as f:
+        return json.load(f)["cases"]
+
+
+def _inputs(synth, c):
+    x = synth.make_features(c["B"], c["T"], c["xseed"], c["kind"], c.get("lengths"))
+    mask = None
+    if c.get("lengths") is not None:
+        mask = synth.padding_mask(x)
+    if c.get("randmask") is not None:
+        mask = synth.random_mask(c["B"], c["T"], c["randmask"])
+    rng = np.random.Generator(np.random.PCG64(c["tseed"]))
+    target = torch.from_numpy(rng.random(size=(c["B"], c["T"])).astype(np.float32))
+    R = torch.from_numpy(rng.standard_normal(size=(c["B"], c["T"], c["d"])).astype(np.float32))
+    return x, mask, target, R
+
+
+# ---------------------------------------------------------------------------------------------
+# whole model: gradients against the imported reference (float64)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", train_cases(), ids=lambda c: c["name"])
+def test_gradients_match_reference_golden(vsa, case):
+    c = case
+    z = np.load(os.path.join(GOLDEN, c["name"] + ".npz"))
+    sd = vsa.synth.make_state_dict(c["d"], c["L"], c["wseed"])
+    x, mask, target, R = _inputs(vsa.synth, c)
+    m = vsa.SimNet(num_heads=c["H"], d_model=c["d"], num_layers=c["L"], sparsity=0.0, dropout=0.0)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(_dev()).train()
+    xd = x.to(_dev()).requires_grad_(True)
+    md = None if mask is None else mask.to(_dev())
+    pred, hidden = m(xd, md)
+    assert pred.requires_grad and hidden.requires_grad
+    mk = md if md is not None else torch.zeros(x.shape[:2], dtype=torch.bool, device=_dev())
+    loss = vsa.mse_with_mask_loss(pred, target.to(_dev()), mk)                       # train.py:122
+    if c["hidden_w"]:
+        loss = loss + c["hidden_w"] * (hidden * R.to(_dev())).sum()
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(loss.item() - float(z["loss"])) <= 2e-6 * max(1.0, abs(float(z["loss"])))
+    valid = torch.ones(x.shape[:2], dtype=torch.bool) if mask is None else ~mask
+    assert (pred.detach().cpu() - torch.from_numpy(z["logits"]))[valid].abs().max().item() < 1e-4
+    grads = {"x": xd.grad}
+    grads.update({k: p.grad for k, p in m.named_parameters()})
+    keys = json.loads(str(z["keys"]))
+    assert sorted(keys) == sorted(grads.keys())
+    worst = 0.0
+    for k in keys:
+        g = grads[k]
+        assert g is not None and torch.isfinite(g).all(), k
+        g2 = g.reshape(-1, g.shape[-1]) if g.dim() > 1 else g.reshape(1, -1)
+        rows = torch.from_numpy(z["r:" + k])
+        want = torch.from_numpy(z["g:" + k])
+        tot, nrm, gmax, ref32 = z["s:" + k]
+        got = g2[rows.to(g2.device)].double().cpu()
+        err = (got - want.double()).abs().max().item()
+        assert err <= ATOL and err <= RTOL * gmax + 1e-7, "%s: err %.3e, max|g| %.3e (reference fp32 own err %.3e)" % (k, err, gmax, ref32)
+        # whole-tensor checks for the sampled ones: sum and L2 norm
+        assert abs(g.double().sum().item() - tot) <= 1e-4 * nrm + 1e-7, k
+        assert abs(g.double().norm().item() - nrm) <= 1e-4 * nrm + 1e-7, k
+        worst = max(worst, err / (gmax + 1e-12) if gmax > 1e-6 else 0.0)
+    print("%s: worst gradient error relative to the tensor's max: %.2e" % (c["name"], worst))
+
+
+def test_train_mode_without_dropout_equals_the_scoring_path(vsa):
+    """Dropout 0: the training forward and the scoring kernels compute the same function (different kernels)."""
+    sd = vsa.synth.make_state_dict(256, 2, 3)
+    m = vsa.SimNet(num_heads=4, d_model=256, num_layers=2, sparsity=0.0, dropout=0.0)
+    m.load_state_dict(sd)
+    m = m.to(_dev())
+    x = vsa.synth.make_features(2, 150, 4, "randn", [150, 99]).to(_dev())
+    mask = vsa.synth.padding_mask(x)
+    a, ha = m.train()(x, mask)
+    with torch.no_grad():
+        b, hb = m.eval()(x, mask)
+    valid = ~mask
+    assert a.requires_grad and not b.requires_grad
+    assert (a.detach() - b)[valid].abs().max().item() < 2e-5 and (ha.detach() - hb)[valid].abs().max().item() < 5e-5
+
+
+def test_training_has_no_cpu_fallback(vsa):
+    m = vsa.SimNet(num_heads=4, d_model=256, num_layers=1).train()
+    with pytest.raises(RuntimeError, match="HIP"):
+        m(torch.zeros(1, 8, 1024))
+
+
+# ---------------------------------------------------------------------------------------------
+# kernels in isolation
+# ---------------------------------------------------------------------------------------------
+def _qkv(B, H, T, dh, seed):
+    g = torch.Generator().manual_seed(seed)
+    return [torch.randn(B, H, T, dh, generator=g, dtype=torch.float64) for _ in range(3)]
+
+
+@pytest.mark.parametrize("B,H,T,dh,masked,p", [(2, 4, 320, 64, False, 0.0), (1, 2, 777, 64, False, 0.0), (2, 4, 200, 64, True, 0.0),
+                                                (2, 8, 65, 32, True, 0.0), (1, 4, 150, 128, True, 0.0), (1, 2, 33, 128, False, 0.0),
+                                                (2, 4, 130, 64, True, 0.3), (1, 8, 97, 32, False, 0.5), (1, 2, 260, 128, True, 0.2)])
+def test_attention_forward_and_backward_kernels(vsa, B, H, T, dh, masked, p):
+    """Forward (values + saved log-sum-exp) and backward (dq | dk | dv) against float64 torch autograd, with the
+    library's own dropout mask applied explicitly in the checker."""
+    lib = vsa._lib.load()
+    q, k, v = _qkv(B, H, T, dh, 100 + T)
+    q.requires_grad_(True), k.requires_grad_(True), v.requires_grad_(True)
+    mask = vsa.synth.random_mask(B, T, 5) if masked else None
+    scale = (H * dh) ** -0.5
+    seed, site = 0x1234567887654321, 7
+    keep = None
+    if p > 0:
+        kd = torch.empty(B, H, T, T, dtype=torch.uint8, device=_dev())
+        vsa._lib.check(lib.vs_train_dropout_mask_attention(kd.data_ptr(), B, H, T, seed, site, p, _stream()))
+        keep = kd.cpu()
+        rate = keep.double().mean().item()
+        assert abs(rate - (1 - p)) < 4 * math.sqrt(p * (1 - p) / keep.numel()) + 1e-3, rate
+    want, lse2 = torch_ref.attention_with_mask(q, k, v, mask, scale, keep, p)
+    dO = torch.randn(B, T, H * dh, generator=torch.Generator().manual_seed(9), dtype=torch.float64)
+    want.backward(dO)
+    qd, kd_, vd = (t.detach().float().to(_dev()).contiguous() for t in (q, k, v))
+    md = None if mask is None else mask.to(_dev()).view(torch.uint8)
+    out = torch.empty(B, T, H * dh, device=_dev())
+    lse = torch.empty(B, H, T, device=_dev())
+    vsa._lib.check(lib.vs_train_attention_forward(qd.data_ptr(), kd_.data_ptr(), vd.data_ptr(), None if md is None else md.data_ptr(),
+                                                  out.data_ptr(), lse.data_ptr(), B, H, T, dh, scale, seed, site, p, _stream()))
+    _close(out, want, "attention out")
+    assert (lse.cpu().double() - lse2.detach()).abs().max().item() < 1e-4
+    dqkv = torch.empty(B, T, 3 * H * dh, device=_dev())
+    scratch = torch.empty(B * H * T, device=_dev())
+    dOd = dO.float().to(_dev())
+    vsa._lib.check(lib.vs_train_attention_backward(qd.data_ptr(), kd_.data_ptr(), vd.data_ptr(), None if md is None else md.data_ptr(),
+                                                   out.data_ptr(), dOd.data_ptr(), lse.data_ptr(), dqkv.data_ptr(), scratch.data_ptr(),
+                                                   B, H, T, dh, scale, seed, site, p, _stream()))
+    torch.cuda.synchronize()
+    d = H * dh
+    tok = lambda g: g.permute(0, 2, 1, 3).reshape(B, T, d)       # noqa: E731  head-major grad -> token-major
+    _close(dqkv[:, :, :d], tok(q.grad), "dq")
+    _close(dqkv[:, :, d:2 * d], tok(k.grad), "dk")
+    _close(dqkv[:, :, 2 * d:], tok(v.grad), "dv")
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 256, 1024), (4096, 1024, 256), (77, 768, 256), (1000, 64, 192), (5000, 512, 2048),
+                                   (16, 256, 256), (1, 128, 64)])
+def test_wgrad_kernel(vsa, M, N, K):
+    lib = vsa._lib.load()
+    g = torch.Generator().manual_seed(M + N)
+    dY = torch.randn(M, N, generator=g, dtype=torch.float64)
+    X = torch.randn(M, K, generator=g, dtype=torch.float64)
+    dYd, Xd = dY.float().to(_dev()), X.float().to(_dev())
+    dW = torch.full((N, K), float("nan"), device=_dev())
+    db = torch.full((N,), float("nan"), device=_dev())
+    scratch = torch.empty(lib.vs_train_wgrad_scratch_floats(M, N, K), device=_dev())
+    for _ in range(2):       # twice: results must be bit-identical (fixed reduction order)
+        vsa._lib.check(lib.vs_train_wgrad(dYd.data_ptr(), Xd.data_ptr(), M, N, K, dW.data_ptr(), db.data_ptr(),
+                                          scratch.data_ptr(), _stream()))
+        torch.cuda.synchronize()
+        first = (dW.clone(), db.clone()) if _ == 0 else first
+    assert torch.equal(first[0], dW) and torch.equal(first[1], db)
+    _close(dW, dY.t() @ X, "dW")
+    _close(db, dY.sum(0), "db")
+
+
+def test_dropout_hash_statistics(vsa):
+    """Keep rate, independence across modules (sites) and seeds, and determinism of the counter hash."""
+    lib = vsa._lib.load()
+    M, cols, p = 512, 1024, 0.3
+
+    def draw(seed, site, pp=p):
+        k = torch.empty(M, cols, dtype=torch.uint8, device=_dev())
+        vsa._lib.check(lib.vs_train_dropout_mask_rows(k.data_ptr(), M, cols, seed, site, pp, _stream()))
+        return k.cpu().double()
+
+    a, a2, b, c = draw(11, 3), draw(11, 3), draw(11, 4), draw(12, 3)
+    assert torch.equal(a, a2)
+    n = a.numel()
+    sigma = math.sqrt(p * (1 - p) / n)
+    for k in (a, b, c):
+        assert abs(k.mean().item() - (1 - p)) < 5 * sigma
+    # rows, columns and the three draws are uncorrelated (|corr| ~ 1/sqrt(n))
+    for u, v in ((a, b), (a, c), (a[:, :-1], a[:, 1:]), (a[:-1], a[1:])):
+        cu, cv = u - u.mean(), v - v.mean()
+        corr = (cu * cv).mean().item() / (cu.std().item() * cv.std().item())
+        assert abs(corr) < 6 / math.sqrt(n), corr
+    assert abs(a.mean(0).std().item() - math.sqrt(p * (1 - p) / M)) < 0.2 * math.sqrt(p * (1 - p) / M)     # per-column rates spread as binomial
+    assert draw(5, 1, 0.0).min().item() == 1.0
+    assert abs(draw(5, 1, 0.9).mean().item() - 0.1) < 5 * math.sqrt(0.09 / n)
+
+
+# ---------------------------------------------------------------------------------------------
+# whole model WITH dropout: explicit-mask float64 model fed with the library's masks
+# ---------------------------------------------------------------------------------------------
+def _library_masks(vsa, B, T, d, H, L, seed, p, p_embed):
+    lib = vsa._lib.load()
+    M = B * T
+
+    def rows(site, cols, pp):
+        k = torch.empty(M, cols, dtype=torch.uint8, device=_dev())
+        vsa._lib.check(lib.vs_train_dropout_mask_rows(k.data_ptr(), M, cols, seed, site, pp, _stream()))
+        return k.cpu().view(B, T, cols)
+
+    masks = {}
+    if p_embed > 0:
+        masks["embed"] = rows(lib.vs_train_dropout_site(-1, 0), d, p_embed)
+    for l in range(L):
+        k = torch.empty(B, H, T, T, dtype=torch.uint8, device=_dev())
+        vsa._lib.check(lib.vs_train_dropout_mask_attention(k.data_ptr(), B, H, T, seed, lib.vs_train_dropout_site(l, 0), p, _stream()))
+        masks["attn%d" % l] = k.cpu()
+        masks["drop1_%d" % l] = rows(lib.vs_train_dropout_site(l, 1), d, p)
+        masks["mlp%d" % l] = rows(lib.vs_train_dropout_site(l, 2), 4 * d, p)
+        masks["drop2_%d" % l] = rows(lib.vs_train_dropout_site(l, 3), d, p)
+    return masks
+
+
+@pytest.mark.parametrize("H,d,L,B,T,p,p_embed,masked", [(4, 256, 2, 2, 90, 0.3, 0.0, True), (8, 256, 1, 1, 130, 0.2, 0.5, False),
+                                                        (4, 512, 1, 2, 70, 0.3, 0.0, True)])
+def test_training_step_with_dropout_matches_explicit_mask_model(vsa, H, d, L, B, T, p, p_embed, masked):
+    synth = vsa.synth
+    sd = synth.make_state_dict(d, L, 21)
+    m = vsa.SimNet(num_heads=H, d_model=d, num_layers=L, sparsity=p_embed, dropout=p)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(_dev()).train()
+    x = synth.make_features(B, T, 22, "randn", [T, T - 23][:B] if masked else None)
+    mask = synth.padding_mask(x) if masked else None
+    target = torch.rand(B, T, generator=torch.Generator().manual_seed(1))
+    torch.manual_seed(77)
+    seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())        # what _forward_train will draw
+    torch.manual_seed(77)
+    xd = x.to(_dev()).requires_grad_(True)
+    md = None if mask is None else mask.to(_dev())
+    pred, hidden = m(xd, md)
+    mk = md if md is not None else torch.zeros(B, T, dtype=torch.bool, device=_dev())
+    loss = vsa.mse_with_mask_loss(pred, target.to(_dev()), mk) + 1e-3 * hidden.sum()
+    loss.backward()
+    torch.cuda.synchronize()
+    # float64 model with the library's masks
+    masks = _library_masks(vsa, B, T, d, H, L, seed, p, p_embed)
+    params = {k: v.double().clone().requires_grad_(k != "embedding_layer.positional_encoding.pos_embedding") for k, v in sd.items()}
+    x64 = x.double().clone().requires_grad_(True)
+    rl, rh = torch_ref.forward_with_masks(params, x64, mask, H, p, p_embed, masks)
+    scale = torch.ones(B, T, dtype=torch.float64) if mask is None else (~mask).double()
+    rloss = (((rl.squeeze(2) - target.double()) * scale) ** 2).mean() + 1e-3 * rh.sum()
+    rloss.backward()
+    valid = torch.ones(B, T, dtype=torch.bool) if mask is None else ~mask
+    assert (pred.detach().cpu().double() - rl.detach())[valid].abs().max().item() < 1e-4
+    assert abs(loss.item() - rloss.item()) < 1e-5 * max(1.0, abs(rloss.item()))
+    _close(xd.grad, x64.grad, "dx")
+    for k, prm in m.named_parameters():
+        _close(prm.grad, params[k].grad, k)
+    # and dropout really happened: the same call in eval mode differs
+    with torch.no_grad():
+        e, _ = m.eval()(x.to(_dev()), md)
+    assert (e - pred.detach())[valid.to(_dev())].abs().max().item() > 1e-3
+
+
+def test_train_loop_like_the_reference(vsa):
+    """train.py:111-131 verbatim shape: autocast, GradScaler, Adam, masked MSE; the loss must fall, and two runs from
+    the same torch seed are bit-identical (dropout seeds come from torch's generator; every reduction is ordered)."""
+    synth = vsa.synth
+
+    def run():
+        torch.manual_seed(1234)                                                   # utils.set_seed
+        m = vsa.SimNet(num_heads=4, d_model=256, num_layers=2, sparsity=0.0, use_cls=False, dropout=0.3, num_classes=1,
+                       use_pos=True).to(_dev())
+        m.load_state_dict(synth.make_state_dict(256, 2, 3))
+        opt = torch.optim.Adam(m.parameters(), lr=1e-4, weight_decay=0.01)
+        scaler = torch.amp.GradScaler("cuda")
+        feature = synth.make_features(4, 120, 8, "pool5", [120, 100, 77, 51]).to(_dev())
+        target = torch.rand(4, 120, generator=torch.Generator().manual_seed(2)).to(_dev())
+        m.train()
+        losses = []
+        for _ in range(12):
+            mask = (feature[:, :, 0] == 1000)                                     # train.py:118
+            with torch.amp.autocast("cuda"):
+                pred, _h = m(feature, mask)
+                loss = vsa.mse_with_mask_loss(pred, target, mask)
+            opt.zero_grad()
+            scaler.scale(loss).backward()
+            scaler.step(opt)
+            scaler.update()
+            losses.append(loss.item())
+        return losses, [p.detach().clone() for p in m.parameters()]
+
+    l1, p1 = run()
+    l2, p2 = run()
+    assert all(math.isfinite(v) for v in l1) and min(l1[-3:]) < l1[0]
+    assert l1 == l2 and all(torch.equal(a, b) for a, b in zip(p1, p2))
+
+
+def test_mse_with_mask_loss_matches_reference_formula(vsa):
+    g = torch.Generator().manual_seed(4)
+    out = torch.randn(3, 50, 1, generator=g)
+    tgt = torch.rand(3, 50, generator=g)
+    mask = torch.zeros(3, 50, dtype=torch.bool)
+    mask[1, 30:] = True
+    mask[2, 10:] = True
+    for reduction in ("avg", "sum"):
+        o64 = out.double().clone().requires_grad_(True)
+        sc = torch.ones(3, 50, dtype=torch.float64)
+        sc[mask] = 0.0                                                             # utils.py:47-48
+        want = ((o64.squeeze(2) * sc - tgt.double() * sc) ** 2)
+        want = want.mean() if reduction == "avg" else want.sum()
+        want.backward()
+        od = out.to(_dev()).requires_grad_(True)
+        got = vsa.mse_with_mask_loss(od, tgt.to(_dev()), mask.to(_dev()), reduction)
+        (got * 3.0).backward()
+        assert abs(got.item() - want.item()) < 1e-6 * max(1.0, want.item())
+        assert (od.grad.cpu().double() - 3.0 * o64.grad).abs().max().item() < 1e-6

@@ -17,7 +17,8 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(ROOT, "include")
 LIB_PATH = os.path.join(HERE, "libvsscore.so")
 DIAG_LIB_PATH = os.path.join(HERE, "libvsscore_diag.so")
-SOURCES = ("vs_kernels.hip", "vs_attention.hip", "vs_scorer.cpp", "vs_eval.cpp")
+SOURCES = ("vs_kernels.hip", "vs_attention.hip", "vs_scorer.cpp", "vs_eval.cpp",
+           "vs_train_kernels.hip", "vs_train_attention.hip", "vs_train.cpp")
 ABI_VERSION = 2
 
 VS_OK, VS_ERR_INVALID, VS_ERR_WORKSPACE, VS_ERR_HIP = 0, 1, 2, 3
@@ -38,6 +39,11 @@ EXPORTS = ("vs_abi_version", "vs_last_error", "vs_weights_pack", "vs_weights_fre
 # include/vs_eval.h
 EVAL_EXPORTS = ("vs_eval_upsample", "vs_eval_knapsack", "vs_eval_generate_summary", "vs_eval_fscore",
                 "vs_eval_rank_correlation")
+# include/vs_train.h
+TRAIN_EXPORTS = ("vs_train_saved_bytes", "vs_train_workspace_bytes", "vs_train_forward", "vs_train_backward",
+                 "vs_mse_mask_loss_forward", "vs_mse_mask_loss_backward", "vs_train_attention_forward",
+                 "vs_train_attention_backward", "vs_train_wgrad_scratch_floats", "vs_train_wgrad",
+                 "vs_train_dropout_mask_attention", "vs_train_dropout_mask_rows", "vs_train_dropout_site")
 NUM_STAGES = 6
 
 
@@ -57,6 +63,14 @@ class LayerParams(C.Structure):
 class ModelParams(C.Structure):
     _fields_ = [("embed_w", C.c_void_p), ("embed_b", C.c_void_p), ("pos_embedding", C.c_void_p),
                 ("layers", C.POINTER(LayerParams)), ("final_w", C.c_void_p), ("final_b", C.c_void_p)]
+
+
+class DropoutCfg(C.Structure):
+    _fields_ = [("p_embed", C.c_float), ("p", C.c_float), ("seed", C.c_uint64)]
+
+
+LayerGrads = LayerParams        # same field names, destinations instead of sources
+ModelGrads = ModelParams
 
 
 def hipcc_path() -> str:
@@ -141,7 +155,7 @@ def load() -> C.CDLL:
                 "Run `python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). "
                 "There is no PyTorch/CPU fallback for the scoring path." % path)
         lib = C.CDLL(path)
-        for name in EXPORTS + EVAL_EXPORTS:
+        for name in EXPORTS + EVAL_EXPORTS + TRAIN_EXPORTS:
             if not hasattr(lib, name):
                 raise RuntimeError("libvsscore.so lacks symbol %s (stale build?)" % name)
         lib.vs_abi_version.restype = C.c_int
@@ -199,6 +213,43 @@ def load() -> C.CDLL:
                                        C.POINTER(C.c_double)]
         lib.vs_eval_rank_correlation.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_double),
                                                  C.POINTER(C.c_double)]
+        # include/vs_train.h
+        lib.vs_train_saved_bytes.restype = C.c_size_t
+        lib.vs_train_saved_bytes.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+        lib.vs_train_workspace_bytes.restype = C.c_size_t
+        lib.vs_train_workspace_bytes.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+        lib.vs_train_forward.restype = C.c_int
+        lib.vs_train_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(DropoutCfg),
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+        lib.vs_train_backward.restype = C.c_int
+        lib.vs_train_backward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(DropoutCfg),
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(ModelGrads), C.c_void_p,
+                                          C.c_void_p, C.c_size_t, C.c_void_p]
+        lib.vs_mse_mask_loss_forward.restype = C.c_int
+        lib.vs_mse_mask_loss_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
+                                                 C.c_void_p, C.c_void_p]
+        lib.vs_mse_mask_loss_backward.restype = C.c_int
+        lib.vs_mse_mask_loss_backward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                                  C.c_void_p, C.c_void_p]
+        lib.vs_train_attention_forward.restype = C.c_int
+        lib.vs_train_attention_forward.argtypes = ([C.c_void_p] * 6 + [C.c_int32] * 4 + [C.c_float, C.c_uint64, C.c_uint32,
+                                                                                       C.c_float, C.c_void_p])
+        lib.vs_train_attention_backward.restype = C.c_int
+        lib.vs_train_attention_backward.argtypes = ([C.c_void_p] * 9 + [C.c_int32] * 4 + [C.c_float, C.c_uint64, C.c_uint32,
+                                                                                        C.c_float, C.c_void_p])
+        lib.vs_train_wgrad_scratch_floats.restype = C.c_size_t
+        lib.vs_train_wgrad_scratch_floats.argtypes = [C.c_int32] * 3
+        lib.vs_train_wgrad.restype = C.c_int
+        lib.vs_train_wgrad.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p]
+        lib.vs_train_dropout_mask_attention.restype = C.c_int
+        lib.vs_train_dropout_mask_attention.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, C.c_uint32,
+                                                        C.c_float, C.c_void_p]
+        lib.vs_train_dropout_mask_rows.restype = C.c_int
+        lib.vs_train_dropout_mask_rows.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_uint64, C.c_uint32, C.c_float,
+                                                   C.c_void_p]
+        lib.vs_train_dropout_site.restype = C.c_uint32
+        lib.vs_train_dropout_site.argtypes = [C.c_int32, C.c_int32]
         lib.vs_profile_enable.restype = C.c_int
         lib.vs_profile_enable.argtypes = [C.c_int32]
         lib.vs_profile_collect.restype = C.c_int

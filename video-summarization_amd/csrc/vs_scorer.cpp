@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "vs_kernels.h"
+#include "vs_weights_impl.h"
 
 namespace {
 
@@ -86,12 +87,6 @@ struct StageScope {
     }
 };
 
-struct LayerOff {
-    size_t wqkv, bqkv, wo, bo, ln1g, ln1b, w1, b1, w2, b2, ln2g, ln2b;
-    size_t f_wqkv, f_wo, f_w1, f_w2;        // fragment-major copies for the latency kernels
-    size_t h_wqkv, h_wo, h_w1, h_w2;        // their fp16x3 counterparts (hi|lo f16 halves, same size)
-};
-
 int check_desc(const vs_model_desc *d) {
     if (!d) return fail(VS_ERR_INVALID, "desc is NULL");
     if (d->d_model <= 0 || d->d_model % 64 || d->d_model > 512)
@@ -147,17 +142,6 @@ int vsk_device_cus() {
     if (dev >= 0 && dev < 64) cus[dev].store(n, std::memory_order_relaxed);
     return n;
 }
-
-struct vs_weights {
-    vs_model_desc desc;
-    float *blob = nullptr;        // one device allocation
-    size_t blob_floats = 0;
-    int device = 0;               // the device the blob lives on
-    size_t embed_w = 0, embed_b = 0, pe = 0, final_w = 0, final_b = 0, f_embed_w = 0, h_embed_w = 0;
-    bool has_pe = false;
-    std::vector<LayerOff> layers;
-    const float *p(size_t off) const { return blob + off; }
-};
 
 extern "C" {
 
@@ -268,6 +252,7 @@ int vs_weights_pack(const vs_model_desc *desc, const vs_model_params *params, vo
         delete w;
         return rc;
     }
+    w->version = 1;
     *out = w;
     return VS_OK;
 }
@@ -277,12 +262,14 @@ int vs_weights_update(vs_weights *w, const vs_model_params *params, void *stream
     int dev = -1;
     if (hipGetDevice(&dev) != hipSuccess || dev != w->device)
         return fail(VS_ERR_INVALID, "vs_weights_update on device %d, handle was packed on device %d", dev, w->device);
+    ++w->version;        // the training side rebuilds its transposed copies on next use
     return fill_weights(w, params, (hipStream_t)stream);
 }
 
 void vs_weights_free(vs_weights *w) {
     if (!w) return;
     if (w->blob) (void)hipFree(w->blob);
+    if (w->tblob) (void)hipFree(w->tblob);
     delete w;
 }
 

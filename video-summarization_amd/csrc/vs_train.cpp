@@ -1,0 +1,361 @@
+// vs_train.cpp — the C ABI of include/vs_train.h: the train-mode forward of the scorer with its activation record,
+// and the backward pass.  Launch sequences only; the kernels are in vs_kernels.hip (NT GEMMs, reused for every
+// forward Linear and — against transposed weights — for every dgrad), vs_train_kernels.hip and
+// vs_train_attention.hip.
+#include "vs_train.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <mutex>
+
+#include "vs_train_device_sites.h"
+#include "vs_train_kernels.h"
+#include "vs_weights_impl.h"
+
+namespace {
+
+int failf(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    return vs_fail_msg(code, buf);
+}
+
+#define VST_LAUNCH(call)                                                                         \
+    do {                                                                                         \
+        int e_ = (call);                                                                         \
+        if (e_ > 0) return failf(VS_ERR_HIP, "%s: %s", #call, hipGetErrorString((hipError_t)e_)); \
+        if (e_ < 0) return failf(VS_ERR_INVALID, "%s: unsupported shape", #call);                \
+    } while (0)
+#define VST_HIP(call)                                                                            \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess) return failf(VS_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_));   \
+    } while (0)
+
+size_t align_floats(size_t n) { return (n + 63) / 64 * 64; }      // 256-byte granules
+
+// ---- activation record (floats) ----
+struct LayerSaved { size_t qkv, att, lse, z1, st1, y1, ffn, z2, st2, y2; };
+struct SavedLayout {
+    size_t h0 = 0, total = 0;
+    std::vector<LayerSaved> layers;
+};
+SavedLayout saved_layout(const vs_model_desc &D, int B, int T) {
+    SavedLayout S;
+    const size_t M = (size_t)B * T, d = D.d_model;
+    size_t off = 0;
+    auto take = [&](size_t n) { size_t o = off; off += align_floats(n); return o; };
+    S.h0 = take(M * d);
+    S.layers.resize(D.num_layers);
+    for (auto &L : S.layers) {
+        L.qkv = take(3 * M * d); L.att = take(M * d); L.lse = take((size_t)B * D.num_heads * T);
+        L.z1 = take(M * d); L.st1 = take(2 * M); L.y1 = take(M * d);
+        L.ffn = take(4 * M * d);
+        L.z2 = take(M * d); L.st2 = take(2 * M); L.y2 = take(M * d);
+    }
+    S.total = off;
+    return S;
+}
+
+// ---- scratch (floats): the forward uses `a` only ----
+struct WorkLayout { size_t a, g0, g1, dz, dbr, gf, dy1, datt, dqkv, delta, part, wg, total; };
+WorkLayout work_layout(const vs_model_desc &D, int B, int T) {
+    WorkLayout W{};
+    const size_t M = (size_t)B * T, d = D.d_model, din = D.in_features;
+    size_t off = 0;
+    auto take = [&](size_t n) { size_t o = off; off += align_floats(n); return o; };
+    W.a = take(M * d);
+    W.g0 = take(M * d); W.g1 = take(M * d);
+    W.dz = take(M * d); W.dbr = take(M * d);
+    W.gf = take(4 * M * d);
+    W.dy1 = take(M * d); W.datt = take(M * d);
+    W.dqkv = take(3 * M * d);
+    W.delta = take((size_t)B * D.num_heads * T);
+    const size_t nblk = (size_t)vst_ln_bwd_blocks((int)M);
+    W.part = take(nblk * (2 * d + 2));
+    size_t wg = 0;
+    const int Mi = (int)M, di = (int)d;
+    const size_t shapes[5][2] = {{d, 4 * d}, {4 * d, d}, {d, d}, {3 * d, d}, {d, din}};
+    for (auto &s : shapes) {
+        const size_t f = vst_wgrad_workspace_floats(Mi, (int)s[0], (int)s[1]);
+        wg = f > wg ? f : wg;
+    }
+    (void)di;
+    W.wg = take(wg);
+    W.total = off;
+    return W;
+}
+
+int check_common(const vs_weights *w, const float *x, int B, int T, const vs_dropout_cfg *drop) {
+    if (!w || !x) return failf(VS_ERR_INVALID, "weights/x is NULL");
+    if (B <= 0 || T <= 0) return failf(VS_ERR_INVALID, "B=%d T=%d", B, T);
+    if ((long long)B * T > (1ll << 28)) return failf(VS_ERR_INVALID, "B*T too large");
+    if (w->has_pe && T > w->desc.max_len)
+        return failf(VS_ERR_INVALID, "T=%d exceeds the positional table (max_len=%d)", T, w->desc.max_len);
+    if (drop && (drop->p < 0.f || drop->p >= 1.f || drop->p_embed < 0.f || drop->p_embed >= 1.f))
+        return failf(VS_ERR_INVALID, "dropout probabilities must be in [0, 1): p=%g p_embed=%g", drop->p, drop->p_embed);
+    if ((uintptr_t)x & 15) return failf(VS_ERR_INVALID, "x must be 16-byte aligned");
+    return VS_OK;
+}
+
+std::mutex g_tmu;
+
+// W^T copies for the dgrad GEMMs + a zero "bias"; rebuilt when the handle's parameters changed
+int ensure_transposed(vs_weights *w, hipStream_t st) {
+    std::lock_guard<std::mutex> lk(g_tmu);
+    const size_t d = w->desc.d_model, din = w->desc.in_features;
+    if (!w->tblob) {
+        size_t off = 0;
+        auto take = [&](size_t n) { size_t o = off; off += align_floats(n); return o; };
+        w->t_embed_w = take(d * din);
+        w->tlayers.resize(w->desc.num_layers);
+        for (auto &L : w->tlayers) { L.t_wqkv = take(3 * d * d); L.t_wo = take(d * d); L.t_w1 = take(4 * d * d); L.t_w2 = take(4 * d * d); }
+        const size_t nz = 4 * d > din ? 4 * d : din;
+        w->zeros = take(nz);
+        VST_HIP(hipMalloc((void **)&w->tblob, off * sizeof(float)));
+        VST_HIP(hipMemsetAsync(w->tblob + w->zeros, 0, nz * sizeof(float), st));
+        w->t_version = ~0ull;
+    }
+    if (w->t_version == w->version) return VS_OK;
+    VST_LAUNCH(vst_transpose(w->p(w->embed_w), w->tblob + w->t_embed_w, (int)d, (int)din, st));              // [d,din] -> [din,d]
+    for (int l = 0; l < w->desc.num_layers; ++l) {
+        const LayerOff &P = w->layers[l];
+        const LayerOffT &Q = w->tlayers[l];
+        VST_LAUNCH(vst_transpose(w->p(P.wqkv), w->tblob + Q.t_wqkv, (int)(3 * d), (int)d, st));               // [3d,d] -> [d,3d]
+        VST_LAUNCH(vst_transpose(w->p(P.wo), w->tblob + Q.t_wo, (int)d, (int)d, st));
+        VST_LAUNCH(vst_transpose(w->p(P.w1), w->tblob + Q.t_w1, (int)(4 * d), (int)d, st));                   // [4d,d] -> [d,4d]
+        VST_LAUNCH(vst_transpose(w->p(P.w2), w->tblob + Q.t_w2, (int)d, (int)(4 * d), st));                   // [d,4d] -> [4d,d]
+    }
+    w->t_version = w->version;
+    return VS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t vs_train_saved_bytes(const vs_weights *w, int32_t B, int32_t T) {
+    if (!w || B <= 0 || T <= 0) return 0;
+    return saved_layout(w->desc, B, T).total * sizeof(float);
+}
+
+size_t vs_train_workspace_bytes(const vs_weights *w, int32_t B, int32_t T) {
+    if (!w || B <= 0 || T <= 0) return 0;
+    return work_layout(w->desc, B, T).total * sizeof(float);
+}
+
+uint32_t vs_train_dropout_site(int32_t layer, int32_t which) { return layer < 0 ? VS_SITE_EMBED : VS_SITE_LAYER(layer, which); }
+
+int vs_train_forward(const vs_weights *w, const float *x, const uint8_t *key_pad_mask, int32_t B, int32_t T,
+                     const vs_dropout_cfg *drop, float *scores, float *hidden, void *saved, size_t saved_bytes,
+                     void *workspace, size_t workspace_bytes, void *stream) {
+    if (int rc = check_common(w, x, B, T, drop)) return rc;
+    if (!scores || !saved || !workspace) return failf(VS_ERR_INVALID, "scores/saved/workspace is NULL");
+    const vs_model_desc &D = w->desc;
+    const SavedLayout S = saved_layout(D, B, T);
+    const WorkLayout W = work_layout(D, B, T);
+    if (saved_bytes < S.total * sizeof(float))
+        return failf(VS_ERR_WORKSPACE, "saved %zu bytes < %zu needed", saved_bytes, S.total * sizeof(float));
+    if (workspace_bytes < W.total * sizeof(float))
+        return failf(VS_ERR_WORKSPACE, "workspace %zu bytes < %zu needed", workspace_bytes, W.total * sizeof(float));
+    if (((uintptr_t)saved & 255) || ((uintptr_t)workspace & 255) || (hidden && ((uintptr_t)hidden & 15)))
+        return failf(VS_ERR_INVALID, "saved/workspace must be 256-byte, hidden 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const int d = D.d_model, H = D.num_heads, L = D.num_layers, M = B * T;
+    const float p = drop ? drop->p : 0.f, p_embed = drop ? drop->p_embed : 0.f;
+    const unsigned long long seed = drop ? drop->seed : 0ull;
+    const float scale = 1.0f / sqrtf((float)d);              // simnet.py:126: d_model ** -0.5
+    float *sv = (float *)saved, *ws = (float *)workspace;
+    float *a = ws + W.a;
+
+    // Embedding + positional table + dropout(sparsity)   simnet.py:211, 237-238
+    float *h0 = sv + S.h0;
+    VST_LAUNCH(vsk_linear(x, w->p(w->embed_w), w->p(w->f_embed_w), w->p(w->embed_b), h0, M, d, D.in_features, 0,
+                          w->has_pe ? w->p(w->pe) : nullptr, T, 0, st));
+    if (p_embed > 0.f) VST_LAUNCH(vst_dropout_rows(h0, M, d, seed, VS_SITE_EMBED, p_embed, st));
+    const float *h_in = h0;
+    for (int l = 0; l < L; ++l) {
+        const LayerOff &P = w->layers[l];
+        const LayerSaved &A = S.layers[l];
+        const bool last = l == L - 1;
+        float *qkv = sv + A.qkv;
+        VST_LAUNCH(vsk_qkv(h_in, w->p(P.wqkv), w->p(P.f_wqkv), w->p(P.bqkv), qkv, B, T, d, H, 0, st));          // :148-153
+        VST_LAUNCH(vst_attention_fwd(qkv, qkv + (size_t)M * d, qkv + 2 * (size_t)M * d, key_pad_mask, sv + A.att,
+                                     sv + A.lse, B, H, T, d / H, scale, seed, VS_SITE_LAYER(l, VS_SITE_ATTN), p, st));   // :155-161
+        VST_LAUNCH(vsk_linear(sv + A.att, w->p(P.wo), w->p(P.f_wo), w->p(P.bo), a, M, d, d, 0, nullptr, 1, 0, st));       // :163
+        VST_LAUNCH(vst_rows_fwd(a, h_in, w->p(P.ln1g), w->p(P.ln1b), sv + A.z1, sv + A.y1, nullptr, sv + A.st1, M, d,
+                                seed, VS_SITE_LAYER(l, VS_SITE_DROP1), p, nullptr, nullptr, 0, nullptr, st));              // :107
+        VST_LAUNCH(vsk_linear(sv + A.y1, w->p(P.w1), w->p(P.f_w1), w->p(P.b1), sv + A.ffn, M, 4 * d, d, 1, nullptr, 1, 0, st));   // :181
+        if (p > 0.f) VST_LAUNCH(vst_dropout_rows(sv + A.ffn, M, 4 * d, seed, VS_SITE_LAYER(l, VS_SITE_MLP), p, st));
+        VST_LAUNCH(vsk_linear(sv + A.ffn, w->p(P.w2), w->p(P.f_w2), w->p(P.b2), a, M, d, 4 * d, 0, nullptr, 1, 0, st));   // :182
+        VST_LAUNCH(vst_rows_fwd(a, sv + A.y1, w->p(P.ln2g), w->p(P.ln2b), sv + A.z2, sv + A.y2, last ? hidden : nullptr,
+                                sv + A.st2, M, d, seed, VS_SITE_LAYER(l, VS_SITE_DROP2), p,
+                                last ? w->p(w->final_w) : nullptr, last ? w->p(w->final_b) : nullptr, D.num_classes,
+                                last ? scores : nullptr, st));                                                              // :110, :42
+        h_in = sv + A.y2;
+    }
+    return VS_OK;
+}
+
+int vs_train_backward(vs_weights *w, const float *x, const uint8_t *key_pad_mask, int32_t B, int32_t T,
+                      const vs_dropout_cfg *drop, const float *d_scores, const float *d_hidden, const void *saved,
+                      size_t saved_bytes, const vs_model_grads *grads, float *dx, void *workspace,
+                      size_t workspace_bytes, void *stream) {
+    if (int rc = check_common(w, x, B, T, drop)) return rc;
+    if (!saved || !workspace || !grads || !grads->layers || !grads->embed_w || !grads->embed_b || !grads->final_w ||
+        !grads->final_b)
+        return failf(VS_ERR_INVALID, "saved/workspace/grads is NULL");
+    const vs_model_desc &D = w->desc;
+    const SavedLayout S = saved_layout(D, B, T);
+    const WorkLayout W = work_layout(D, B, T);
+    if (saved_bytes < S.total * sizeof(float))
+        return failf(VS_ERR_WORKSPACE, "saved %zu bytes < %zu needed", saved_bytes, S.total * sizeof(float));
+    if (workspace_bytes < W.total * sizeof(float))
+        return failf(VS_ERR_WORKSPACE, "workspace %zu bytes < %zu needed", workspace_bytes, W.total * sizeof(float));
+    if (((uintptr_t)saved & 255) || ((uintptr_t)workspace & 255)) return failf(VS_ERR_INVALID, "saved/workspace must be 256-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    if (int rc = ensure_transposed(w, st)) return rc;
+    const int d = D.d_model, H = D.num_heads, L = D.num_layers, M = B * T, nc = D.num_classes;
+    const float p = drop ? drop->p : 0.f, p_embed = drop ? drop->p_embed : 0.f;
+    const unsigned long long seed = drop ? drop->seed : 0ull;
+    const float scale = 1.0f / sqrtf((float)d);
+    const float *sv = (const float *)saved;
+    float *ws = (float *)workspace;
+    float *g[2] = {ws + W.g0, ws + W.g1};
+    float *dz = ws + W.dz, *dbr = ws + W.dbr, *gf = ws + W.gf, *dy1 = ws + W.dy1, *datt = ws + W.datt;
+    float *dqkv = ws + W.dqkv, *delta = ws + W.delta, *part = ws + W.part, *wg = ws + W.wg;
+    const float *zeros = w->tp(w->zeros);
+    const int nblk = vst_ln_bwd_blocks(M);
+
+    // final_layer (simnet.py:42): d_W = d_scores^T hidden, d_b = column sums of d_scores
+    {
+        const float *y_last = sv + S.layers[L - 1].y2;
+        if (d_scores) {
+            for (int c = 0; c < nc; ++c) {
+                VST_LAUNCH(vst_weighted_colsum(d_scores + c, nc, y_last, part, M, d, st));
+                VST_LAUNCH(vst_reduce_rows(part, nblk, 1, d, grads->final_w + (size_t)c * d, nullptr, nullptr, 1, st));
+                VST_LAUNCH(vst_reduce_rows(part + (size_t)nblk * d, nblk, 1, 1, grads->final_b + c, nullptr, nullptr, 1, st));
+            }
+        } else {
+            VST_HIP(hipMemsetAsync(grads->final_w, 0, (size_t)nc * d * sizeof(float), st));
+            VST_HIP(hipMemsetAsync(grads->final_b, 0, (size_t)nc * sizeof(float), st));
+        }
+    }
+
+    int cur = 0;
+    for (int l = L - 1; l >= 0; --l) {
+        const LayerOff &P = w->layers[l];
+        const LayerOffT &Q = w->tlayers[l];
+        const LayerSaved &A = S.layers[l];
+        const vs_layer_grads &G = grads->layers[l];
+        const bool last = l == L - 1;
+        const float *h_in = l == 0 ? sv + S.h0 : sv + S.layers[l - 1].y2;
+        // norm2 (+ the score head's pull on the last layer); d(fc2 output) = dropout2 mask on dz2
+        VST_LAUNCH(vst_ln_bwd(last ? d_hidden : g[cur], last ? d_scores : nullptr, w->p(w->final_w), nc, sv + A.z2, sv + A.st2,
+                              w->p(P.ln2g), dz, p > 0.f ? dbr : nullptr, part, M, d, seed, VS_SITE_LAYER(l, VS_SITE_DROP2), p, st));
+        VST_LAUNCH(vst_reduce_rows(part, nblk, 2, d, G.ln2_g, G.ln2_b, nullptr, 1, st));
+        const float *dm = p > 0.f ? dbr : dz;
+        // mlp.fc2: weight/bias gradient, then the gradient of its input
+        VST_LAUNCH(vst_wgrad(dm, d, sv + A.ffn, 4 * d, M, d, 4 * d, G.w2, nullptr, nullptr, G.b2, nullptr, nullptr, d, wg, st));
+        VST_LAUNCH(vsk_linear(dm, w->tp(Q.t_w2), nullptr, zeros, gf, M, 4 * d, d, 0, nullptr, 1, 0, st));
+        // mlp.dropout + ReLU: the saved activation is > 0 exactly where both let the value through
+        VST_LAUNCH(vst_gate_bwd(gf, sv + A.ffn, (size_t)M * 4 * d, p > 0.f ? 1.0f / (1.0f - p) : 1.0f, st));
+        VST_LAUNCH(vst_wgrad(gf, 4 * d, sv + A.y1, d, M, 4 * d, d, G.w1, nullptr, nullptr, G.b1, nullptr, nullptr, 4 * d, wg, st));
+        // d y1 = dz2 (residual) + d(fc1 input): the residual rides in the GEMM epilogue
+        VST_LAUNCH(vsk_linear(gf, w->tp(Q.t_w1), nullptr, zeros, dy1, M, d, 4 * d, 0, dz, M, 0, st));
+        // norm1; d(feature_projection output) = dropout1 mask on dz1
+        VST_LAUNCH(vst_ln_bwd(dy1, nullptr, nullptr, 0, sv + A.z1, sv + A.st1, w->p(P.ln1g), dz, p > 0.f ? dbr : nullptr, part,
+                              M, d, seed, VS_SITE_LAYER(l, VS_SITE_DROP1), p, st));
+        VST_LAUNCH(vst_reduce_rows(part, nblk, 2, d, G.ln1_g, G.ln1_b, nullptr, 1, st));
+        const float *da = p > 0.f ? dbr : dz;
+        VST_LAUNCH(vst_wgrad(da, d, sv + A.att, d, M, d, d, G.wo, nullptr, nullptr, G.bo, nullptr, nullptr, d, wg, st));
+        VST_LAUNCH(vsk_linear(da, w->tp(Q.t_wo), nullptr, zeros, datt, M, d, d, 0, nullptr, 1, 0, st));
+        // attention
+        const float *qkv = sv + A.qkv;
+        VST_LAUNCH(vst_head_rowdot(datt, sv + A.att, delta, M, T, H, d / H, st));
+        VST_LAUNCH(vst_attention_bwd(qkv, qkv + (size_t)M * d, qkv + 2 * (size_t)M * d, key_pad_mask, datt, sv + A.lse, delta,
+                                     dqkv, B, H, T, d / H, scale, seed, VS_SITE_LAYER(l, VS_SITE_ATTN), p, st));
+        // q / k / v projections: one [3d, d] weight gradient dealt to the three parameters
+        VST_LAUNCH(vst_wgrad(dqkv, 3 * d, h_in, d, M, 3 * d, d, G.wq, G.wk, G.wv, G.bq, G.bk, G.bv, d, wg, st));
+        // gradient of the layer input = dz1 (residual) + dqkv Wqkv
+        VST_LAUNCH(vsk_linear(dqkv, w->tp(Q.t_wqkv), nullptr, zeros, g[cur ^ 1], M, d, 3 * d, 0, dz, M, 0, st));
+        cur ^= 1;
+    }
+    // Embedding (simnet.py:211, 237-238): dropout(sparsity) mask, then the Linear
+    float *gh0 = g[cur];
+    if (p_embed > 0.f) VST_LAUNCH(vst_dropout_rows(gh0, M, d, seed, VS_SITE_EMBED, p_embed, st));
+    VST_LAUNCH(vst_wgrad(gh0, d, x, D.in_features, M, d, D.in_features, grads->embed_w, nullptr, nullptr, grads->embed_b,
+                         nullptr, nullptr, d, wg, st));
+    if (dx) VST_LAUNCH(vsk_linear(gh0, w->tp(w->t_embed_w), nullptr, zeros, dx, M, D.in_features, d, 0, nullptr, 1, 0, st));
+    return VS_OK;
+}
+
+int vs_mse_mask_loss_forward(const float *output, const float *target, const uint8_t *mask, int32_t n, int32_t mean,
+                             float *scratch, float *loss, void *stream) {
+    if (!output || !target || !scratch || !loss || n <= 0) return failf(VS_ERR_INVALID, "mse_mask_loss: bad arguments");
+    VST_LAUNCH(vst_mse_mask_fwd(output, target, mask, n, mean, scratch, loss, (hipStream_t)stream));
+    return VS_OK;
+}
+
+int vs_mse_mask_loss_backward(const float *output, const float *target, const uint8_t *mask, const float *d_loss,
+                              int32_t n, int32_t mean, float *d_output, void *stream) {
+    if (!output || !target || !d_loss || !d_output || n <= 0) return failf(VS_ERR_INVALID, "mse_mask_loss: bad arguments");
+    VST_LAUNCH(vst_mse_mask_bwd(output, target, mask, d_loss, n, mean, d_output, (hipStream_t)stream));
+    return VS_OK;
+}
+
+int vs_train_attention_forward(const float *q, const float *k, const float *v, const uint8_t *key_pad_mask, float *out,
+                               float *lse2, int32_t B, int32_t H, int32_t T, int32_t dh, float scale, uint64_t seed,
+                               uint32_t site, float p, void *stream) {
+    if (!q || !k || !v || !out || !lse2) return failf(VS_ERR_INVALID, "NULL pointer");
+    if (B <= 0 || H <= 0 || T <= 0) return failf(VS_ERR_INVALID, "B=%d H=%d T=%d", B, H, T);
+    VST_LAUNCH(vst_attention_fwd(q, k, v, key_pad_mask, out, lse2, B, H, T, dh, scale, seed, site, p, (hipStream_t)stream));
+    return VS_OK;
+}
+
+int vs_train_attention_backward(const float *q, const float *k, const float *v, const uint8_t *key_pad_mask,
+                                const float *out, const float *d_out, const float *lse2, float *dqkv, float *scratch,
+                                int32_t B, int32_t H, int32_t T, int32_t dh, float scale, uint64_t seed, uint32_t site,
+                                float p, void *stream) {
+    if (!q || !k || !v || !out || !d_out || !lse2 || !dqkv || !scratch) return failf(VS_ERR_INVALID, "NULL pointer");
+    if (B <= 0 || H <= 0 || T <= 0) return failf(VS_ERR_INVALID, "B=%d H=%d T=%d", B, H, T);
+    hipStream_t st = (hipStream_t)stream;
+    VST_LAUNCH(vst_head_rowdot(d_out, out, scratch, B * T, T, H, dh, st));
+    VST_LAUNCH(vst_attention_bwd(q, k, v, key_pad_mask, d_out, lse2, scratch, dqkv, B, H, T, dh, scale, seed, site, p, st));
+    return VS_OK;
+}
+
+size_t vs_train_wgrad_scratch_floats(int32_t M, int32_t N, int32_t K) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    return vst_wgrad_workspace_floats(M, N, K);
+}
+
+int vs_train_wgrad(const float *dY, const float *X, int32_t M, int32_t N, int32_t K, float *dW, float *db,
+                   float *scratch, void *stream) {
+    if (!dY || !X || !dW || !scratch) return failf(VS_ERR_INVALID, "NULL pointer");
+    if (M <= 0 || N <= 0 || K <= 0 || N % 4 || K % 4) return failf(VS_ERR_INVALID, "M=%d N=%d K=%d unsupported (N, K multiples of 4)", M, N, K);
+    VST_LAUNCH(vst_wgrad(dY, N, X, K, M, N, K, dW, nullptr, nullptr, db, nullptr, nullptr, N, scratch, (hipStream_t)stream));
+    return VS_OK;
+}
+
+int vs_train_dropout_mask_attention(uint8_t *keep, int32_t B, int32_t H, int32_t T, uint64_t seed, uint32_t site,
+                                    float p, void *stream) {
+    if (!keep || B <= 0 || H <= 0 || T <= 0) return failf(VS_ERR_INVALID, "bad arguments");
+    VST_LAUNCH(vst_attention_dropout_mask(keep, B, H, T, seed, site, p, (hipStream_t)stream));
+    return VS_OK;
+}
+
+int vs_train_dropout_mask_rows(uint8_t *keep, int32_t M, int32_t cols, uint64_t seed, uint32_t site, float p,
+                               void *stream) {
+    if (!keep || M <= 0 || cols <= 0) return failf(VS_ERR_INVALID, "bad arguments");
+    VST_LAUNCH(vst_rows_dropout_mask(keep, M, cols, seed, site, p, (hipStream_t)stream));
+    return VS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,56 @@
+// Internal C++ launcher interface between the training C ABI (vs_train.cpp) and its kernels
+// (vs_train_kernels.hip, vs_train_attention.hip).  Same conventions as vs_kernels.h: every launcher enqueues on
+// `st`, never synchronises, and returns 0, a hipError_t (> 0) or -1 (unsupported shape).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "vs_kernels.h"
+
+// z = dropout_{p,site}(a) + res; y = LayerNorm(z) * gamma + beta (y_copy: optional second copy); stats[row] = (mean, rstd);
+// optional score head scores[row, c] = y . score_w[c] + score_b[c]
+int vst_rows_fwd(const float *a, const float *res, const float *gamma, const float *beta, float *z, float *y,
+                 float *y_copy, float *stats, int M, int d, unsigned long long seed, unsigned site, float p,
+                 const float *score_w, const float *score_b, int num_classes, float *scores, hipStream_t st);
+// LayerNorm backward; part = [vst_ln_bwd_blocks(M)][2][d] partial (d_gamma, d_beta); dbranch (optional) = forward
+// dropout mask applied to dz; dy may be NULL (zero) and dsc/score_w add the score head's contribution
+int vst_ln_bwd_blocks(int M);
+int vst_ln_bwd(const float *dy, const float *dsc, const float *score_w, int num_classes, const float *z,
+               const float *stats, const float *gamma, float *dz, float *dbranch, float *part, int M, int d,
+               unsigned long long seed, unsigned site, float p, hipStream_t st);
+int vst_dropout_rows(float *x, int M, int cols, unsigned long long seed, unsigned site, float p, hipStream_t st);
+int vst_gate_bwd(float *g, const float *act, size_t n, float scale, hipStream_t st);
+int vst_head_rowdot(const float *dO, const float *O, float *delta, int M, int T, int H, int dh, hipStream_t st);
+// part = [nblk = vst_ln_bwd_blocks(M)][d] partial sums of w[row*ws] * Y[row,:], then [nblk] partial sums of w[row*ws]
+int vst_weighted_colsum(const float *w, int ws, const float *Y, float *part, int M, int d, hipStream_t st);
+// dW[N,K] = dY[M,N]^T X[M,K] (+ db = column sums of dY when db0 != NULL); rows of the result are dealt to up to three
+// destination tensors of rows_per_dest rows; work >= vst_wgrad_workspace_floats(M, N, K) floats
+int vst_wgrad_splits(int M, int N, int K);
+size_t vst_wgrad_workspace_floats(int M, int N, int K);
+int vst_wgrad(const float *dY, int ldy, const float *X, int ldx, int M, int N, int K, float *dW0, float *dW1, float *dW2,
+              float *db0, float *db1, float *db2, int rows_per_dest, float *work, hipStream_t st);
+int vst_reduce_rows(const float *part, int S, int rows, int cols, float *d0, float *d1, float *d2, int rows_per_dest,
+                    hipStream_t st);
+int vst_transpose(const float *in, float *out, int rows, int cols, hipStream_t st);
+int vst_mse_mask_blocks(int n);
+int vst_mse_mask_fwd(const float *out, const float *tgt, const unsigned char *mask, int n, int mean, float *part,
+                     float *loss, hipStream_t st);
+int vst_mse_mask_bwd(const float *out, const float *tgt, const unsigned char *mask, const float *gout, int n, int mean,
+                     float *dout, hipStream_t st);
+
+// ---- attention (vs_train_attention.hip); q, k, v head-major [B,H,T,dh]; out / dO token-major [B*T, H*dh] ----
+// forward with dropout on the attention weights; lse2[b,h,t] = log2 sum_j exp(s_ij) (base-2 log-sum-exp of the
+// scaled, masked scores) is saved for the backward
+int vst_attention_fwd(const float *q, const float *k, const float *v, const uint8_t *mask, float *out, float *lse2,
+                      int B, int H, int T, int dh, float scale, unsigned long long seed, unsigned site, float p,
+                      hipStream_t st);
+// dqkv token-major [B*T, 3*H*dh] (columns: dq | dk | dv, head h at h*dh); delta from vst_head_rowdot
+int vst_attention_bwd(const float *q, const float *k, const float *v, const uint8_t *mask, const float *dO,
+                      const float *lse2, const float *delta, float *dqkv, int B, int H, int T, int dh, float scale,
+                      unsigned long long seed, unsigned site, float p, hipStream_t st);
+// test hook: keep[b,h,i,j] (bytes) of the attention-weight dropout, exactly as the two kernels above draw it
+int vst_attention_dropout_mask(uint8_t *keep, int B, int H, int T, unsigned long long seed, unsigned site, float p,
+                               hipStream_t st);
+// test hook: keep[row, col] (bytes) of the elementwise dropouts
+int vst_rows_dropout_mask(uint8_t *keep, int M, int cols, unsigned long long seed, unsigned site, float p, hipStream_t st);

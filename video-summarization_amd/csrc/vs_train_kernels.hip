@@ -1,0 +1,598 @@
+// vs_train_kernels.hip — gfx950 kernels of the TRAINING path: everything of
+// SimNet.forward in train mode and its backward that is not a plain NT GEMM (those reuse gemm_nt_128 of
+// vs_kernels.hip: a dgrad is an NT GEMM against the transposed weight) and not attention (vs_train_attention.hip).
+//
+//   train_rows_fwd     z = dropout(a) + residual;  y = LayerNorm(z);  saves z and (mean, rstd); optional score head
+//                      (reference simnet.py:107,110: norm(dropout(x1) + x); :42 final_layer)
+//   ln_bwd_rows        LayerNorm backward per row + per-block partial d_gamma / d_beta; on the last layer the
+//                      incoming gradient is d_hidden + d_scores * final_layer.weight
+//   dropout_rows       elementwise dropout in place (PositionalEncoding.dropout simnet.py:237, MLP.dropout :181)
+//   gate_bwd           ReLU + dropout backward: g = ffn > 0 ? g / (1 - p) : 0
+//   head_rowdot        delta[b,h,t] = sum_c dO[t, h*dh + c] * O[t, h*dh + c]   (flash-attention backward)
+//   weighted_colsum    partial sums of w[row] * Y[row, :] (final_layer weight / bias gradients)
+//   wgrad_tn           dW[n,k] = sum_m dY[m,n] * X[m,k] on the fp32 matrix pipe, split over m, + column sums of dY
+//   reduce_partials    deterministic sum of the per-split partials into the parameter-gradient tensors
+//   transpose2d        W^T for the dgrad GEMMs
+//   mse_mask_*         utils.mse_with_mask_loss forward / backward (reference utils.py:45-56)
+//
+// All reductions run in a fixed order: the training step is bitwise reproducible for a given seed.
+#include "vs_train_device.h"
+#include "vs_train_kernels.h"
+
+namespace {
+
+constexpr float LN_EPS = 1e-5f;      // nn.LayerNorm default (simnet.py:99-100)
+
+// ------------------------------------------------------------------------------------------
+// Row kernels: one wave per row, lane l owns columns 4l .. 4l+3 (+256 per extra vector, d <= 512)
+// ------------------------------------------------------------------------------------------
+template <int NV>
+__global__ __launch_bounds__(256) void train_rows_fwd(
+    const float *__restrict__ a, const float *__restrict__ res, const float *__restrict__ gamma,
+    const float *__restrict__ beta, float *__restrict__ z, float *__restrict__ y, float *__restrict__ y_copy,
+    float *__restrict__ stats, int M, int d, unsigned long long seed, unsigned site, float p,
+    const float *__restrict__ score_w, const float *__restrict__ score_b, int num_classes,
+    float *__restrict__ scores) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const DropSite ds = drop_site(seed, site, p);
+    for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+        f32x4 v[NV];
+        float s = 0.f;
+        const unsigned rk = drop_rowkey(ds, (unsigned)row);
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int c = 4 * lane + 256 * u;
+            v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (c < d) {
+                f32x4 av = *(const f32x4 *)(a + (size_t)row * d + c);
+                if (p > 0.f) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) av[e] = drop_keep(ds, rk, (unsigned)(c + e)) ? av[e] * ds.scale : 0.f;
+                }
+                const f32x4 rv = *(const f32x4 *)(res + (size_t)row * d + c);
+                v[u] = av + rv;
+                *(f32x4 *)(z + (size_t)row * d + c) = v[u];
+                s += v[u][0] + v[u][1] + v[u][2] + v[u][3];
+            }
+        }
+        const float mean = wave_sum(s) / (float)d;
+        float s2 = 0.f;
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int c = 4 * lane + 256 * u;
+            if (c < d) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float t = v[u][e] - mean; s2 += t * t; }
+            }
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(s2) / (float)d + LN_EPS);
+        if (lane == 0) { stats[2 * (size_t)row] = mean; stats[2 * (size_t)row + 1] = rstd; }
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int c = 4 * lane + 256 * u;
+            if (c < d) {
+                const f32x4 g = *(const f32x4 *)(gamma + c), b = *(const f32x4 *)(beta + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[u][e] = (v[u][e] - mean) * rstd * g[e] + b[e];
+                *(f32x4 *)(y + (size_t)row * d + c) = v[u];
+                if (y_copy) *(f32x4 *)(y_copy + (size_t)row * d + c) = v[u];
+            }
+        }
+        if (score_w != nullptr) {
+            for (int cls = 0; cls < num_classes; ++cls) {
+                float dot = 0.f;
+#pragma unroll
+                for (int u = 0; u < NV; ++u) {
+                    const int c = 4 * lane + 256 * u;
+                    if (c < d) {
+                        const f32x4 w = *(const f32x4 *)(score_w + (size_t)cls * d + c);
+                        dot += v[u][0] * w[0] + v[u][1] * w[1] + v[u][2] * w[2] + v[u][3] * w[3];
+                    }
+                }
+                dot = wave_sum(dot);
+                if (lane == 0) scores[(size_t)row * num_classes + cls] = dot + score_b[cls];
+            }
+        }
+    }
+}
+
+// LayerNorm backward.  dy_row = dy[row] (or 0) + sum_cls dsc[row, cls] * score_w[cls]   (the latter on the last layer only)
+//   xh = (z - mean) * rstd;  g = dy * gamma;  dz = rstd * (g - mean(g) - xh * mean(g * xh))
+//   dbranch (optional) = dropout mask of the forward applied to dz (the gradient of the Linear that fed this norm)
+//   part[blockIdx][0][:] += dy * xh (d_gamma),  part[blockIdx][1][:] += dy (d_beta)
+template <int NV>
+__global__ __launch_bounds__(256) void ln_bwd_rows(
+    const float *__restrict__ dy, const float *__restrict__ dsc, const float *__restrict__ score_w, int num_classes,
+    const float *__restrict__ z, const float *__restrict__ stats, const float *__restrict__ gamma,
+    float *__restrict__ dz, float *__restrict__ dbranch, float *__restrict__ part, int M, int d,
+    unsigned long long seed, unsigned site, float p) {
+    __shared__ float red[4][2][512];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const DropSite ds = drop_site(seed, site, p);
+    f32x4 ag[NV], ab[NV], gm[NV];
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+        ag[u] = f32x4{0.f, 0.f, 0.f, 0.f}; ab[u] = ag[u]; gm[u] = ag[u];
+        const int c = 4 * lane + 256 * u;
+        if (c < d) gm[u] = *(const f32x4 *)(gamma + c);
+    }
+    for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+        const float mean = stats[2 * (size_t)row], rstd = stats[2 * (size_t)row + 1];
+        f32x4 g[NV], xh[NV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int c = 4 * lane + 256 * u;
+            g[u] = f32x4{0.f, 0.f, 0.f, 0.f}; xh[u] = g[u];
+            if (c < d) {
+                f32x4 dv = dy ? *(const f32x4 *)(dy + (size_t)row * d + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+                if (dsc != nullptr) {
+                    for (int cls = 0; cls < num_classes; ++cls) {
+                        const float w = dsc[(size_t)row * num_classes + cls];
+                        const f32x4 sw = *(const f32x4 *)(score_w + (size_t)cls * d + c);
+                        dv += sw * w;
+                    }
+                }
+                const f32x4 zv = *(const f32x4 *)(z + (size_t)row * d + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    xh[u][e] = (zv[e] - mean) * rstd;
+                    g[u][e] = dv[e] * gm[u][e];
+                    s1 += g[u][e];
+                    s2 += g[u][e] * xh[u][e];
+                    ag[u][e] += dv[e] * xh[u][e];
+                    ab[u][e] += dv[e];
+                }
+            }
+        }
+        const float m1 = wave_sum(s1) / (float)d, m2 = wave_sum(s2) / (float)d;
+        const unsigned rk = drop_rowkey(ds, (unsigned)row);
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int c = 4 * lane + 256 * u;
+            if (c < d) {
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = rstd * (g[u][e] - m1 - xh[u][e] * m2);
+                *(f32x4 *)(dz + (size_t)row * d + c) = o;
+                if (dbranch != nullptr) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = drop_keep(ds, rk, (unsigned)(c + e)) ? o[e] * ds.scale : 0.f;
+                    *(f32x4 *)(dbranch + (size_t)row * d + c) = o;
+                }
+            }
+        }
+    }
+    // block partial of d_gamma / d_beta: waves summed in wave order
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+        const int c = 4 * lane + 256 * u;
+        if (c < d) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { red[wave][0][c + e] = ag[u][e]; red[wave][1][c + e] = ab[u][e]; }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * d; i += 256) {
+        const int which = i / d, c = i - which * d;
+        part[((size_t)blockIdx.x * 2 + which) * d + c] =
+            ((red[0][which][c] + red[1][which][c]) + red[2][which][c]) + red[3][which][c];
+    }
+}
+
+// x[row, c] = keep(row, c) ? x * scale : 0   (in place; cols = row length)
+__global__ __launch_bounds__(256) void dropout_rows(float *__restrict__ x, int M, int cols, unsigned long long seed,
+                                                    unsigned site, float p) {
+    const DropSite ds = drop_site(seed, site, p);
+    const int c4n = cols / 4;
+    const size_t total = (size_t)M * c4n;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const unsigned row = (unsigned)(i / c4n), c = (unsigned)(i % c4n) * 4;
+        const unsigned rk = drop_rowkey(ds, row);
+        f32x4 v = *(f32x4 *)(x + i * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = drop_keep(ds, rk, c + e) ? v[e] * ds.scale : 0.f;
+        *(f32x4 *)(x + i * 4) = v;
+    }
+}
+
+// g = act > 0 ? g * scale : 0   (act = dropout(relu(fc1)) as saved by the forward: > 0 <=> relu passed AND kept)
+__global__ __launch_bounds__(256) void gate_bwd(float *__restrict__ g, const float *__restrict__ act, size_t n4, float scale) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        f32x4 v = *(f32x4 *)(g + i * 4);
+        const f32x4 a = *(const f32x4 *)(act + i * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = a[e] > 0.f ? v[e] * scale : 0.f;
+        *(f32x4 *)(g + i * 4) = v;
+    }
+}
+
+// delta[(b*H + h)*T + t] = sum_c dO[m, h*dh + c] * O[m, h*dh + c],  m = b*T + t
+template <int NV>
+__global__ __launch_bounds__(256) void head_rowdot(const float *__restrict__ dO, const float *__restrict__ O,
+                                                   float *__restrict__ delta, int M, int T, int H, int dh) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, d = H * dh, gl = dh / 4;   // gl lanes per head
+    for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+        const int b = row / T, t = row - b * T;
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int c = 4 * lane + 256 * u;
+            float s = 0.f;
+            if (c < d) {
+                const f32x4 x = *(const f32x4 *)(dO + (size_t)row * d + c), o = *(const f32x4 *)(O + (size_t)row * d + c);
+                s = x[0] * o[0] + x[1] * o[1] + x[2] * o[2] + x[3] * o[3];
+            }
+            for (int off = 1; off < gl; off <<= 1) s += __shfl_xor(s, off);
+            if (c < d && (lane % gl) == 0) delta[((size_t)b * H + c / dh) * T + t] = s;
+        }
+    }
+}
+
+// part[blockIdx][0:d] = sum_rows w[row*ws] * Y[row, :];  part[gridDim.x * d + blockIdx] = sum_rows w[row*ws]
+template <int NV>
+__global__ __launch_bounds__(256) void weighted_colsum(const float *__restrict__ w, int ws, const float *__restrict__ Y,
+                                                       float *__restrict__ part, int M, int d) {
+    __shared__ float red[4][516];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    f32x4 acc[NV];
+    float sw = 0.f;
+#pragma unroll
+    for (int u = 0; u < NV; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+        const float wv = w[(size_t)row * ws];
+        sw += wv;
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int c = 4 * lane + 256 * u;
+            if (c < d) acc[u] += *(const f32x4 *)(Y + (size_t)row * d + c) * wv;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+        const int c = 4 * lane + 256 * u;
+        if (c < d) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) red[wave][c + e] = acc[u][e];
+        }
+    }
+    if (lane == 0) red[wave][d] = sw;
+    __syncthreads();
+    for (int i = threadIdx.x; i <= d; i += 256) {
+        const float tot = ((red[0][i] + red[1][i]) + red[2][i]) + red[3][i];
+        if (i < d) part[(size_t)blockIdx.x * d + i] = tot;
+        else part[(size_t)gridDim.x * d + blockIdx.x] = tot;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Weight gradient:  dW[n, k] = sum_m dY[m, n] * X[m, k]   ("TN": both operands are contracted over their ROW index)
+//   This orientation is the natural one for v_mfma_f32_32x32x2_f32: the A operand wants A[i][kk] with i on the lane,
+//   and consecutive lanes read consecutive n of one dY row - straight, conflict-free LDS rows, no transposition.
+//   Block = 4 waves (2 x 2), tile 128 (n) x 128 (k); a wave owns 64 x 64 as 2 x 2 MFMA tiles with the INTERLEAVED
+//   column map  n = n0 + 64*wn + 2*i + ib  (i = MFMA row, ib = which of the two tiles): one ds_read_b64 at
+//   [m][.. + 2r] then feeds both tiles, and the output store is a float2 per lane (256 contiguous bytes per row).
+//   The contraction runs over the frames m, which is the LONG dimension (65 536 at the bench size) while the output is
+//   at most 1024 x 1024: the grid is (tiles, splits) and every split writes its own partial; reduce_partials sums
+//   them in split order (deterministic; no atomics).  Blocks with tile_k == 0 also produce the column sums of dY
+//   (the bias gradient) from the values they stage anyway.
+//   16 rows per stage, double-buffered LDS, next stage's global loads in flight under the current stage's 32 MFMAs.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void wgrad_tn(const float *__restrict__ dY, int ldy, const float *__restrict__ X, int ldx,
+                                                float *__restrict__ partW, float *__restrict__ partB, int M, int N, int K,
+                                                int rows_per_split) {
+    constexpr int BR = 16, LDP = 128 + 8;
+    __shared__ __attribute__((aligned(16))) float Ys[2][BR][LDP];
+    __shared__ __attribute__((aligned(16))) float Xs[2][BR][LDP];
+    const int tiles_k = (K + 127) / 128;
+    const int tile_n = blockIdx.x / tiles_k, tile_k = blockIdx.x - tile_n * tiles_k;
+    const int n0 = tile_n * 128, k0 = tile_k * 128;
+    const int split = blockIdx.y;
+    const int m_begin = split * rows_per_split, m_end = min(M, m_begin + rows_per_split);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int wn = wave >> 1, wk = wave & 1;
+    const int srow = tid >> 5, sc4 = (tid & 31) * 4;
+    const bool n_ok = n0 + sc4 < N, k_ok = k0 + sc4 < K;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) acc[i][j][t] = 0.f;
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+    f32x4 py[2], px[2];
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    auto gload = [&](int m0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = m0 + srow + 8 * i;
+            py[i] = (m < m_end && n_ok) ? *(const f32x4 *)(dY + (size_t)m * ldy + n0 + sc4) : zero4;
+            px[i] = (m < m_end && k_ok) ? *(const f32x4 *)(X + (size_t)m * ldx + k0 + sc4) : zero4;
+        }
+    };
+    auto stage = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            *(f32x4 *)&Ys[buf][srow + 8 * i][sc4] = py[i];
+            *(f32x4 *)&Xs[buf][srow + 8 * i][sc4] = px[i];
+            bsum += py[i];
+        }
+    };
+    if (m_begin < m_end) {
+        gload(m_begin);
+        stage(0);
+        __syncthreads();
+        int buf = 0;
+        for (int m0 = m_begin; m0 < m_end; m0 += BR) {
+            const bool more = m0 + BR < m_end;
+            if (more) gload(m0 + BR);
+#pragma unroll
+            for (int s = 0; s < BR / 2; ++s) {
+                const f32x2 a2 = *(const f32x2 *)&Ys[buf][2 * s + h][64 * wn + 2 * r];
+                const f32x2 b2 = *(const f32x2 *)&Xs[buf][2 * s + h][64 * wk + 2 * r];
+                acc[0][0] = MFMA32(a2[0], b2[0], acc[0][0]);
+                acc[0][1] = MFMA32(a2[0], b2[1], acc[0][1]);
+                acc[1][0] = MFMA32(a2[1], b2[0], acc[1][0]);
+                acc[1][1] = MFMA32(a2[1], b2[1], acc[1][1]);
+            }
+            if (more) stage(buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
+        }
+    }
+    // partial tile: n = n0 + 64*wn + 2*acc_row(t,h) + ib,  k = k0 + 64*wk + 2*r + {0,1}
+    float *pw = partW + (size_t)split * N * K;
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int n = n0 + 64 * wn + 2 * acc_row(t, h) + ib, k = k0 + 64 * wk + 2 * r;
+            if (n < N && k < K) *(f32x2 *)(pw + (size_t)n * K + k) = f32x2{acc[ib][0][t], acc[ib][1][t]};
+        }
+    if (partB != nullptr && tile_k == 0) {
+        // column sums of the staged dY values: 8 row groups (srow) per column quad, summed in srow order
+        __syncthreads();
+        float(*red)[LDP] = Ys[0];
+        *(f32x4 *)&red[srow][sc4] = bsum;
+        __syncthreads();
+        if (tid < 128 && n0 + tid < N) {
+            float s = 0.f;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) s += red[g][tid];
+            partB[(size_t)split * N + n0 + tid] = s;
+        }
+    }
+}
+
+// out[row, c] = sum_s part[s][row][c]  (s ascending), rows dealt to up to three destination tensors of
+// rows_per_dest rows each (q / k / v weight gradients come out of ONE [3d, d] product).  cols % VEC == 0.
+template <int VEC>
+__global__ __launch_bounds__(256) void reduce_partials(const float *__restrict__ part, int S, int rows, int cols,
+                                                       float *d0, float *d1, float *d2, int rows_per_dest) {
+    typedef float vec_t __attribute__((ext_vector_type(VEC)));
+    const size_t per = (size_t)rows * cols, nvec = per / VEC;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
+        const size_t e = i * VEC;
+        float acc[VEC];
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) acc[q] = 0.f;
+        for (int s = 0; s < S; ++s) {
+            if constexpr (VEC == 1) {
+                acc[0] += part[(size_t)s * per + e];
+            } else {
+                const vec_t v = *(const vec_t *)(part + (size_t)s * per + e);
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) acc[q] += v[q];
+            }
+        }
+        const int row = (int)(e / cols), c = (int)(e - (size_t)row * cols);
+        const int which = row / rows_per_dest;
+        float *dst = (which == 0 ? d0 : which == 1 ? d1 : d2) + (size_t)(row - which * rows_per_dest) * cols + c;
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) dst[q] = acc[q];
+    }
+}
+
+// out[c, r] = in[r, c]   (32 x 32 tiles through LDS; grid (cols/32, rows/32), block 256)
+__global__ __launch_bounds__(256) void transpose2d(const float *__restrict__ in, float *__restrict__ out, int rows, int cols) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int rr = r0 + ty + 8 * i, cc = c0 + tx;
+        if (rr < rows && cc < cols) tile[ty + 8 * i][tx] = in[(size_t)rr * cols + cc];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int cc = c0 + ty + 8 * i, rr = r0 + tx;
+        if (rr < rows && cc < cols) out[(size_t)cc * rows + rr] = tile[tx][ty + 8 * i];
+    }
+}
+
+// ---- utils.mse_with_mask_loss (reference utils.py:45-56): mean (or sum) over ALL B*T entries of
+//      ((output - target) * scale)^2, scale = 0 on masked frames ----
+__global__ __launch_bounds__(256) void mse_mask_partial(const float *__restrict__ out, const float *__restrict__ tgt,
+                                                        const unsigned char *__restrict__ mask, int n, float *__restrict__ part) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const float sc = (mask && mask[i]) ? 0.f : 1.f;
+        const float dlt = out[i] * sc - tgt[i] * sc;
+        s += dlt * dlt;
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+}
+__global__ void mse_mask_final(const float *__restrict__ part, int nblk, float inv_n, float *__restrict__ loss) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        float s = 0.f;
+        for (int i = 0; i < nblk; ++i) s += part[i];
+        loss[0] = s * inv_n;
+    }
+}
+// d_out = gout * 2 * scale * (out*scale - tgt*scale) * inv_n
+__global__ __launch_bounds__(256) void mse_mask_bwd(const float *__restrict__ out, const float *__restrict__ tgt,
+                                                    const unsigned char *__restrict__ mask, const float *__restrict__ gout,
+                                                    int n, float inv_n, float *__restrict__ dout) {
+    const float g = gout[0] * 2.0f * inv_n;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const float sc = (mask && mask[i]) ? 0.f : 1.f;
+        dout[i] = g * sc * (out[i] * sc - tgt[i] * sc);
+    }
+}
+
+int row_grid(int M) { const int b = (M + 3) / 4; return b < 1024 ? (b < 1 ? 1 : b) : 1024; }
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------
+int vst_rows_fwd(const float *a, const float *res, const float *gamma, const float *beta, float *z, float *y,
+                 float *y_copy, float *stats, int M, int d, unsigned long long seed, unsigned site, float p,
+                 const float *score_w, const float *score_b, int num_classes, float *scores, hipStream_t st) {
+    if (d % 4 || d > 512) return -1;
+    const dim3 grid((M + 3) / 4 < 4096 ? (M + 3) / 4 : 4096);
+    if (d <= 256)
+        hipLaunchKernelGGL(train_rows_fwd<1>, grid, dim3(256), 0, st, a, res, gamma, beta, z, y, y_copy, stats, M, d, seed,
+                           site, p, score_w, score_b, num_classes, scores);
+    else
+        hipLaunchKernelGGL(train_rows_fwd<2>, grid, dim3(256), 0, st, a, res, gamma, beta, z, y, y_copy, stats, M, d, seed,
+                           site, p, score_w, score_b, num_classes, scores);
+    VSK_CHECK_LAUNCH();
+    return 0;
+}
+
+int vst_ln_bwd_blocks(int M) { return row_grid(M); }
+
+int vst_ln_bwd(const float *dy, const float *dsc, const float *score_w, int num_classes, const float *z,
+               const float *stats, const float *gamma, float *dz, float *dbranch, float *part, int M, int d,
+               unsigned long long seed, unsigned site, float p, hipStream_t st) {
+    if (d % 4 || d > 512) return -1;
+    const dim3 grid(row_grid(M));
+    if (d <= 256)
+        hipLaunchKernelGGL(ln_bwd_rows<1>, grid, dim3(256), 0, st, dy, dsc, score_w, num_classes, z, stats, gamma, dz,
+                           dbranch, part, M, d, seed, site, p);
+    else
+        hipLaunchKernelGGL(ln_bwd_rows<2>, grid, dim3(256), 0, st, dy, dsc, score_w, num_classes, z, stats, gamma, dz,
+                           dbranch, part, M, d, seed, site, p);
+    VSK_CHECK_LAUNCH();
+    return 0;
+}
+
+int vst_dropout_rows(float *x, int M, int cols, unsigned long long seed, unsigned site, float p, hipStream_t st) {
+    if (cols % 4) return -1;
+    const size_t total = (size_t)M * (cols / 4);
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(dropout_rows, dim3(blocks < 1 ? 1 : blocks), dim3(256), 0, st, x, M, cols, seed, site, p);
+    VSK_CHECK_LAUNCH();
+    return 0;
+}
+
+int vst_gate_bwd(float *g, const float *act, size_t n, float scale, hipStream_t st) {
+    if (n % 4) return -1;
+    const size_t n4 = n / 4;
+    const int blocks = (int)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192);
+    hipLaunchKernelGGL(gate_bwd, dim3(blocks < 1 ? 1 : blocks), dim3(256), 0, st, g, act, n4, scale);
+    VSK_CHECK_LAUNCH();
+    return 0;
+}
+
+int vst_head_rowdot(const float *dO, const float *O, float *delta, int M, int T, int H, int dh, hipStream_t st) {
+    const int d = H * dh;
+    if (d > 512 || (dh != 32 && dh != 64 && dh != 128)) return -1;
+    const dim3 grid((M + 3) / 4 < 4096 ? (M + 3) / 4 : 4096);
+    if (d <= 256) hipLaunchKernelGGL(head_rowdot<1>, grid, dim3(256), 0, st, dO, O, delta, M, T, H, dh);
+    else hipLaunchKernelGGL(head_rowdot<2>, grid, dim3(256), 0, st, dO, O, delta, M, T, H, dh);
+    VSK_CHECK_LAUNCH();
+    return 0;
+}
+
+int vst_weighted_colsum(const float *w, int ws, const float *Y, float *part, int M, int d, hipStream_t st) {
+    if (d % 4 || d > 512) return -1;
+    const dim3 grid(row_grid(M));
+    if (d <= 256) hipLaunchKernelGGL(weighted_colsum<1>, grid, dim3(256), 0, st, w, ws, Y, part, M, d);
+    else hipLaunchKernelGGL(weighted_colsum<2>, grid, dim3(256), 0, st, w, ws, Y, part, M, d);
+    VSK_CHECK_LAUNCH();
+    return 0;
+}
+
+// splits for the wgrad of an [N, K] weight over M rows: enough blocks for ~2 per CU, at least 64 rows per split
+int vst_wgrad_splits(int M, int N, int K) {
+    const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
+    int cus = vsk_device_cus();
+    if (cus <= 0) cus = 256;
+    int S = (2 * cus + tiles - 1) / tiles;
+    const int maxS = (M + 63) / 64;
+    if (S > maxS) S = maxS;
+    return S < 1 ? 1 : S;
+}
+
+size_t vst_wgrad_workspace_floats(int M, int N, int K) {
+    const size_t S = (size_t)vst_wgrad_splits(M, N, K);
+    return S * ((size_t)N * K + N);
+}
+
+int vst_wgrad(const float *dY, int ldy, const float *X, int ldx, int M, int N, int K, float *dW0, float *dW1, float *dW2,
+              float *db0, float *db1, float *db2, int rows_per_dest, float *work, hipStream_t st) {
+    if (N % 4 || K % 4 || ldy % 4 || ldx % 4) return -1;
+    const int S = vst_wgrad_splits(M, N, K);
+    int rps = (M + S - 1) / S;
+    rps = (rps + 15) / 16 * 16;
+    float *partW = work, *partB = work + (size_t)S * N * K;
+    const dim3 grid(((N + 127) / 128) * ((K + 127) / 128), S);
+    hipLaunchKernelGGL(wgrad_tn, grid, dim3(256), 0, st, dY, ldy, X, ldx, partW, db0 ? partB : nullptr, M, N, K, rps);
+    VSK_CHECK_LAUNCH();
+    {
+        const size_t nvec = (size_t)N * K / 4;
+        const int blocks = (int)((nvec + 255) / 256 < 4096 ? (nvec + 255) / 256 : 4096);
+        hipLaunchKernelGGL(reduce_partials<4>, dim3(blocks), dim3(256), 0, st, partW, S, N, K, dW0, dW1, dW2, rows_per_dest);
+        VSK_CHECK_LAUNCH();
+    }
+    if (db0) {
+        hipLaunchKernelGGL(reduce_partials<1>, dim3((N + 255) / 256), dim3(256), 0, st, partB, S, N, 1, db0, db1, db2, rows_per_dest);
+        VSK_CHECK_LAUNCH();
+    }
+    return 0;
+}
+
+// sums `S` partial rows of `cols` floats into up to 3 destinations (LayerNorm gamma / beta, final_layer gradients)
+int vst_reduce_rows(const float *part, int S, int rows, int cols, float *d0, float *d1, float *d2, int rows_per_dest,
+                    hipStream_t st) {
+    const size_t n = (size_t)rows * cols;
+    hipLaunchKernelGGL(reduce_partials<1>, dim3((int)((n + 255) / 256)), dim3(256), 0, st, part, S, rows, cols, d0, d1, d2,
+                       rows_per_dest);
+    VSK_CHECK_LAUNCH();
+    return 0;
+}
+
+int vst_transpose(const float *in, float *out, int rows, int cols, hipStream_t st) {
+    hipLaunchKernelGGL(transpose2d, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0, st, in, out, rows, cols);
+    VSK_CHECK_LAUNCH();
+    return 0;
+}
+
+int vst_mse_mask_blocks(int n) { const int b = (n + 255) / 256; return b < 256 ? (b < 1 ? 1 : b) : 256; }
+
+int vst_mse_mask_fwd(const float *out, const float *tgt, const unsigned char *mask, int n, int mean, float *part,
+                     float *loss, hipStream_t st) {
+    const int blocks = vst_mse_mask_blocks(n);
+    hipLaunchKernelGGL(mse_mask_partial, dim3(blocks), dim3(256), 0, st, out, tgt, mask, n, part);
+    VSK_CHECK_LAUNCH();
+    hipLaunchKernelGGL(mse_mask_final, dim3(1), dim3(64), 0, st, part, blocks, mean ? 1.0f / (float)n : 1.0f, loss);
+    VSK_CHECK_LAUNCH();
+    return 0;
+}
+
+int vst_mse_mask_bwd(const float *out, const float *tgt, const unsigned char *mask, const float *gout, int n, int mean,
+                     float *dout, hipStream_t st) {
+    hipLaunchKernelGGL(mse_mask_bwd, dim3(vst_mse_mask_blocks(n)), dim3(256), 0, st, out, tgt, mask, gout, n,
+                       mean ? 1.0f / (float)n : 1.0f, dout);
+    VSK_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,39 @@
+// vs_weights_impl.h — the packed-parameter handle behind `vs_weights` (include/vs_scorer.h), shared by the scoring
+// C ABI (vs_scorer.cpp) and the training C ABI (vs_train.cpp).  Internal: not part of the public headers.
+#pragma once
+#include <stddef.h>
+
+#include <vector>
+
+#include "vs_scorer.h"
+
+struct LayerOff {
+    size_t wqkv, bqkv, wo, bo, ln1g, ln1b, w1, b1, w2, b2, ln2g, ln2b;
+    size_t f_wqkv, f_wo, f_w1, f_w2;        // fragment-major copies for the latency kernels
+    size_t h_wqkv, h_wo, h_w1, h_w2;        // their fp16x3 counterparts (hi|lo f16 halves, same size)
+};
+
+// transposed weights for the dgrad GEMMs of the training backward (dX = dY W is an NT GEMM against W^T); built
+// lazily by the first vs_train_backward after each pack / update, never for a scoring-only user
+struct LayerOffT { size_t t_wqkv, t_wo, t_w1, t_w2; };
+
+struct vs_weights {
+    vs_model_desc desc;
+    float *blob = nullptr;        // one device allocation
+    size_t blob_floats = 0;
+    int device = 0;               // the device the blob lives on
+    size_t embed_w = 0, embed_b = 0, pe = 0, final_w = 0, final_b = 0, f_embed_w = 0, h_embed_w = 0;
+    bool has_pe = false;
+    std::vector<LayerOff> layers;
+    const float *p(size_t off) const { return blob + off; }
+
+    // ---- training side ----
+    unsigned long long version = 0;       // bumped by every pack / update
+    float *tblob = nullptr;               // second device allocation: transposed weights + a zero vector
+    unsigned long long t_version = ~0ull; // version the transposes were built from
+    size_t t_embed_w = 0, zeros = 0;
+    std::vector<LayerOffT> tlayers;
+    const float *tp(size_t off) const { return tblob + off; }
+};
+
+int vs_fail_msg(int code, const char *msg);     // vs_scorer.cpp: sets the thread-local error text

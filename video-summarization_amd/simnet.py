@@ -6,19 +6,18 @@ Same constructor, ``forward`` signature/return tuple and ``state_dict`` key set 
 and reference checkpoints load ``strict=True``.
 
 Scoring (eval / no-grad) runs entirely in the hand-written gfx950 kernels of ``libvsscore.so``
-through the custom op ``vs_amd::score_frames`` — there is NO PyTorch or CPU fallback for it: a
-missing library or a non-HIP tensor raises.  Calls that need autograd (``train.py:121``,
-``pretrain.py:61``: train mode, dropout, backward) take ``_forward_autograd``, a composed-torch
-path on the same device; a HIP backward is a later row of SURVEY.md §8(f).
+through the custom op ``vs_amd::score_frames``; calls that need autograd (``train.py:121``,
+``pretrain.py:61``: train mode, dropout, backward) run ``_TrainForward``, a ``torch.autograd.Function``
+over the training C ABI (``include/vs_train.h``): HIP forward that keeps its activations, HIP backward
+(flash-attention backward, dgrad / wgrad GEMMs, LayerNorm / ReLU / dropout backward).  There is NO PyTorch
+or CPU fallback for either: a missing library or a non-HIP tensor raises.
 """
 from __future__ import annotations
 
 import ctypes as C
-import math
 from typing import Optional, Tuple
 
 import torch
-import torch.nn.functional as F
 from torch import Tensor, nn
 
 from . import _lib
@@ -105,6 +104,78 @@ def score_frames_packed(x: Tensor, lengths, handle: int, d_model: int, num_class
                                                 scores.data_ptr(), hidden.data_ptr() if want_hidden else None,
                                                 ws.data_ptr(), ws.numel(), stream))
     return scores, hidden
+
+
+# --------------------------------------------------------------------------------------------
+# training path: torch.autograd.Function over include/vs_train.h
+# --------------------------------------------------------------------------------------------
+
+
+class _TrainForward(torch.autograd.Function):
+    """``SimNet.forward`` under autograd (reference train.py:121 / pretrain.py:61): forward and backward are the HIP
+    kernels behind ``vs_train_forward`` / ``vs_train_backward``.  The parameters are passed as inputs so autograd
+    routes their gradients; the activation record is one uint8 tensor saved for the backward."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)     # train.py:120 calls under amp.autocast()
+    def forward(ctx, module, x, mask, p, p_embed, seed, *params):
+        lib = _lib.load()
+        B, T, _ = x.shape
+        x = x.contiguous()
+        m = None
+        if mask is not None:
+            m = mask.contiguous()
+            m = m.view(torch.uint8) if m.dtype == torch.bool else m.to(torch.uint8)
+        packed = module._packed_weights(x.device)
+        scores = torch.empty((B, T, module.num_classes), dtype=torch.float32, device=x.device)
+        hidden = torch.empty((B, T, module.d_model), dtype=torch.float32, device=x.device)
+        cfg = _lib.DropoutCfg(float(p_embed), float(p), int(seed))
+        with torch.cuda.device(x.device):
+            saved = torch.empty((lib.vs_train_saved_bytes(packed.handle, B, T),), dtype=torch.uint8, device=x.device)
+            ws = torch.empty((lib.vs_train_workspace_bytes(packed.handle, B, T),), dtype=torch.uint8, device=x.device)
+            stream = torch.cuda.current_stream(x.device).cuda_stream
+            _lib.check(lib.vs_train_forward(packed.handle, x.data_ptr(), _ptr(m), B, T, C.byref(cfg), scores.data_ptr(),
+                                            hidden.data_ptr(), saved.data_ptr(), saved.numel(), ws.data_ptr(), ws.numel(),
+                                            stream))
+        ctx.save_for_backward(x, m, saved)
+        ctx.module, ctx.cfg, ctx.packed, ctx.packed_key = module, (float(p_embed), float(p), int(seed)), packed, module._packed_key
+        ctx.set_materialize_grads(False)
+        return scores, hidden
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, d_scores, d_hidden):
+        lib = _lib.load()
+        x, m, saved = ctx.saved_tensors
+        module, packed = ctx.module, ctx.packed
+        if module._packed_key != ctx.packed_key or module._packed is not packed:
+            raise RuntimeError("SimNet parameters were modified between forward and backward")
+        B, T, _ = x.shape
+        params = [t for t in module._tensors() if isinstance(t, nn.Parameter)]
+        grads = [torch.empty_like(t, dtype=torch.float32, memory_format=torch.contiguous_format) for t in params]
+        it = iter(grads)
+        G = _lib.ModelGrads()
+        G.embed_w, G.embed_b = next(it).data_ptr(), next(it).data_ptr()
+        G.pos_embedding = None
+        layers = (_lib.LayerGrads * max(module.num_layers, 1))()
+        for l in range(module.num_layers):
+            for name in ("wq", "bq", "wk", "bk", "wv", "bv", "wo", "bo", "ln1_g", "ln1_b",
+                         "w1", "b1", "w2", "b2", "ln2_g", "ln2_b"):
+                setattr(layers[l], name, next(it).data_ptr())
+        G.layers = layers
+        G.final_w, G.final_b = next(it).data_ptr(), next(it).data_ptr()
+        dx = torch.empty_like(x) if ctx.needs_input_grad[1] else None
+        ds = None if d_scores is None else d_scores.contiguous().float()
+        dh = None if d_hidden is None else d_hidden.contiguous().float()
+        cfg = _lib.DropoutCfg(*ctx.cfg)
+        with torch.cuda.device(x.device):
+            ws = torch.empty((lib.vs_train_workspace_bytes(packed.handle, B, T),), dtype=torch.uint8, device=x.device)
+            stream = torch.cuda.current_stream(x.device).cuda_stream
+            _lib.check(lib.vs_train_backward(packed.handle, x.data_ptr(), _ptr(m), B, T, C.byref(cfg), _ptr(ds), _ptr(dh),
+                                             saved.data_ptr(), saved.numel(), C.byref(G), _ptr(dx), ws.data_ptr(),
+                                             ws.numel(), stream))
+        out = [g if t.requires_grad else None for g, t in zip(grads, params)]
+        return (None, dx, None, None, None, None, *out)
 
 
 # --------------------------------------------------------------------------------------------
@@ -247,6 +318,16 @@ class SimNet(nn.Module):
             return False
         return self.training or x.requires_grad or any(p.requires_grad for p in self.parameters())
 
+    def _forward_train(self, x: Tensor, mask: Optional[Tensor]):
+        """forward under autograd: dropout (train mode only, like nn.Dropout) with a fresh seed drawn from torch's
+        default CPU generator (so ``set_seed`` / ``torch.manual_seed``, reference utils.py:9-12, reproduces a run)."""
+        p = self.drop_rate if self.training else 0.0
+        p_embed = self.sparsity if (self.training and self.use_pos) else 0.0
+        seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item()) if (p > 0.0 or p_embed > 0.0) else 0
+        params = [t for t in self._tensors() if isinstance(t, nn.Parameter)]
+        x32 = x if x.dtype == torch.float32 else x.float()
+        return _TrainForward.apply(self, x32, mask, p, p_embed, seed, *params)
+
     def forward(self, x: Tensor, mask=None, vis_attention=None, model_score: bool = False):
         """Same contract as reference ``SimNet.forward`` (simnet.py:32-45): returns
         ``(final_out [B,T,num_classes] raw logits, hidden [B,T,d])``; a non-Tensor ``mask`` is ignored
@@ -257,11 +338,11 @@ class SimNet(nn.Module):
         mask = mask if isinstance(mask, Tensor) else None
         if self.use_pos and x.size(1) > self.pe_len:
             raise RuntimeError("T=%d exceeds the positional table (%d rows)" % (x.size(1), self.pe_len))
-        if self._needs_autograd(x):
-            return self._forward_autograd(x, mask)
         if not x.is_cuda:
-            raise RuntimeError("SimNet scoring runs on the MI355X HIP kernels only: move the module and its "
+            raise RuntimeError("SimNet runs on the MI355X HIP kernels only: move the module and its "
                                "input to a HIP device (there is no CPU path for the scorer)")
+        if self._needs_autograd(x):
+            return self._forward_train(x, mask)
         flags = (_lib.VS_FLAG_SIGMOID if self.fused_sigmoid else 0) | self._attention_flag()
         x32 = x if x.dtype == torch.float32 else x.float()
         packed = self._packed_weights(x.device)
@@ -351,23 +432,3 @@ class SimNet(nn.Module):
                 | (_lib.VS_FLAG_F16X3_ATTENTION if self._attention_dtype == "fp16x3" else 0)
                 | (_lib.VS_FLAG_BF16_LINEAR if self._linear_dtype == "bf16" else 0)
                 | (_lib.VS_FLAG_F16X3_LINEAR if self._linear_dtype == "fp16x3" else 0))
-
-    # ---- autograd-capable path for train.py / pretrain.py (dropout, backward, autocast) -----
-    def _forward_autograd(self, x: Tensor, mask: Optional[Tensor]):
-        B, T, _ = x.shape
-        H, d = self.num_heads, self.d_model
-        p_drop = self.drop_rate if self.training else 0.0
-        emb = self.embedding_layer
-        h = emb.feature_transform(x)
-        if self.use_pos:
-            h = F.dropout(h + emb.positional_encoding.pos_embedding[:, :T], self.sparsity, self.training)
-        keep = None if mask is None else ~mask.view(B, 1, 1, T)      # True = attend
-        for blk in self.encoder.module_list:
-            q, k, v = (lin(h).view(B, T, H, d // H).transpose(1, 2) for lin in (blk.sa.q, blk.sa.k, blk.sa.v))
-            a = F.scaled_dot_product_attention(q, k, v, attn_mask=keep, dropout_p=p_drop,
-                                               scale=1.0 / math.sqrt(d))          # scale = d_model^-0.5 (Q1)
-            a = blk.sa.feature_projection(a.transpose(1, 2).reshape(B, T, d))
-            h = blk.norm1(F.dropout(a, p_drop, self.training) + h)
-            f = blk.mlp.fc2(F.dropout(F.relu(blk.mlp.fc1(h)), p_drop, self.training))
-            h = blk.norm2(F.dropout(f, p_drop, self.training) + h)
-        return self.final_layer(h), h
