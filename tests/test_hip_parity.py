@@ -25,6 +25,21 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+_F64 = {}
+
+
+def _fp64_goldens():
+    if not _F64:
+        import json
+        import os
+        import numpy as np
+        from conftest import GOLDEN
+        _F64["npz"] = np.load(os.path.join(GOLDEN, "forward_fp64.npz"))
+        with open(os.path.join(GOLDEN, "forward_fp64.json")) as f:
+            _F64["meta"] = json.load(f)
+    return _F64
+
+
 def _model(vsa, c, sd):
     m = vsa.SimNet(num_heads=c["H"], d_model=c["d"], num_layers=c["L"], sparsity=0.0, dropout=0.3,
                    num_classes=c.get("num_classes", 1), use_pos=c.get("use_pos", True))
@@ -59,6 +74,16 @@ def test_forward_matches_reference_golden(vsa, case, kernel_path):
     dh = (hidden.cpu()[:, g["rows"]] - g["hidden"])[valid[:, g["rows"]]].abs().max().item()
     assert dl < TOL and dh < TOL, (dl, dh)
     assert torch.equal(logits, logits2) and torch.equal(hidden, inter)
+    # float64 truth (tests/golden/make_golden_fp64.py: the reference run in double): the HIP path's distance to it,
+    # beside the distance of the reference's own fp32 run (the primary golden above) to it
+    f64 = _fp64_goldens()
+    l64, h64 = torch.from_numpy(f64["npz"][case["name"] + ":logits"]), torch.from_numpy(f64["npz"][case["name"] + ":hidden"])
+    dl64 = (logits.cpu().double() - l64)[valid].abs().max().item()
+    dh64 = (hidden.cpu()[:, g["rows"]].double() - h64)[valid[:, g["rows"]]].abs().max().item()
+    ref = f64["meta"]["cases"][case["name"]]
+    print("%s [%s]: HIP vs fp64 logits %.2e hidden %.2e | reference fp32 vs fp64 logits %.2e hidden %.2e | HIP vs fp32 golden %.2e %.2e"
+          % (case["name"], kernel_path, dl64, dh64, ref["ref32_vs_ref64_logits"], ref["ref32_vs_ref64_hidden"], dl, dh))
+    assert dl64 < TOL and dh64 < TOL, (dl64, dh64)
 
 
 def test_padded_query_rows_match_oracle_too(vsa):

@@ -31,11 +31,11 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-def _close(got, want, what=""):
+def _close(got, want, what="", atol=ATOL, rtol=RTOL):
     got, want = got.detach().double().cpu(), want.detach().double().cpu()
     err = (got - want).abs().max().item()
     scale = want.abs().max().item()
-    assert err <= ATOL and err <= RTOL * scale + 1e-7, "%s: max err %.3e (max |want| %.3e)" % (what, err, scale)
+    assert (atol is None or err <= atol) and err <= rtol * scale + 1e-7, "%s: max err %.3e (max |want| %.3e)" % (what, err, scale)
     return err / (scale + 1e-30)
 
 
@@ -98,7 +98,7 @@ def test_gradients_match_reference_golden(vsa, case):
         err = (got - want.double()).abs().max().item()
         assert err <= ATOL and err <= RTOL * gmax + 1e-7, "%s: err %.3e, max|g| %.3e (reference fp32 own err %.3e)" % (k, err, gmax, ref32)
         # whole-tensor checks for the sampled ones: sum and L2 norm
-        assert abs(g.double().sum().item() - tot) <= 1e-4 * nrm + 1e-7, k
+        assert abs(g.double().sum().item() - tot) <= 1e-3 * max(abs(tot), nrm) + 1e-7, k     # coherent over a row: looser
         assert abs(g.double().norm().item() - nrm) <= 1e-4 * nrm + 1e-7, k
         worst = max(worst, err / (gmax + 1e-12) if gmax > 1e-6 else 0.0)
     print("%s: worst gradient error relative to the tensor's max: %.2e" % (c["name"], worst))
@@ -195,8 +195,9 @@ def test_wgrad_kernel(vsa, M, N, K):
         torch.cuda.synchronize()
         first = (dW.clone(), db.clone()) if _ == 0 else first
     assert torch.equal(first[0], dW) and torch.equal(first[1], db)
-    _close(dW, dY.t() @ X, "dW")
-    _close(db, dY.sum(0), "db")
+    # unnormalised N(0,1) operands: entries grow like sqrt(M), so the bound is relative (fp32: ~1e-6 observed)
+    _close(dW, dY.t() @ X, "dW", atol=None, rtol=2e-5)
+    _close(db, dY.sum(0), "db", atol=None, rtol=2e-5)
 
 
 def test_dropout_hash_statistics(vsa):

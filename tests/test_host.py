@@ -79,6 +79,18 @@ def test_training_has_no_cpu_fallback_either(vsa):
         m(torch.zeros(1, 8, 1024), torch.zeros(1, 8, dtype=torch.bool))
 
 
+def test_default_positional_buffer_is_the_torch_formula_and_seeded_weights_use_the_stable_one(vsa):
+    """The module's default buffer is the reference's own torch fp32 op sequence (bit-equal on one machine, asserted
+    against the reference in tests/golden/make_golden.py); seeded test weights carry the machine-independent
+    evaluation (synth.positional_table(stable=True)), within 1.3e-4 of it."""
+    m = vsa.SimNet(num_heads=4, d_model=256, num_layers=1)
+    buf = m.state_dict()["embedding_layer.positional_encoding.pos_embedding"]
+    assert torch.equal(buf, vsa.synth.positional_table(256, 2000))
+    st = vsa.synth.make_state_dict(256, 1, 1)["embedding_layer.positional_encoding.pos_embedding"]
+    assert torch.equal(st, vsa.synth.positional_table(256, 2000, stable=True))
+    assert (st - buf).abs().max().item() < 1.3e-4
+
+
 def test_positional_table_formula(vsa):
     pe = vsa.synth.positional_table(256, 2000)
     assert pe.shape == (1, 2000, 256) and pe[0, 0, 0] == 0 and pe[0, 0, 1] == 1

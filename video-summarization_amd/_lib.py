@@ -69,8 +69,12 @@ class DropoutCfg(C.Structure):
     _fields_ = [("p_embed", C.c_float), ("p", C.c_float), ("seed", C.c_uint64)]
 
 
-LayerGrads = LayerParams        # same field names, destinations instead of sources
-ModelGrads = ModelParams
+LayerGrads = LayerParams        # vs_layer_grads: same field names, destinations instead of sources
+
+
+class ModelGrads(C.Structure):  # vs_model_grads (no positional table: it is a buffer, not a parameter)
+    _fields_ = [("embed_w", C.c_void_p), ("embed_b", C.c_void_p), ("layers", C.POINTER(LayerParams)),
+                ("final_w", C.c_void_p), ("final_b", C.c_void_p)]
 
 
 def hipcc_path() -> str:

@@ -156,7 +156,6 @@ class _TrainForward(torch.autograd.Function):
         it = iter(grads)
         G = _lib.ModelGrads()
         G.embed_w, G.embed_b = next(it).data_ptr(), next(it).data_ptr()
-        G.pos_embedding = None
         layers = (_lib.LayerGrads * max(module.num_layers, 1))()
         for l in range(module.num_layers):
             for name in ("wq", "bq", "wk", "bk", "wv", "bv", "wo", "bo", "ln1_g", "ln1_b",

@@ -23,10 +23,28 @@ PE_MAX_LEN = 2000       # reference simnet.py:188 (Embedding default; SimNet.max
 PAD_VALUE = 1000.0      # reference data/dataset.py:159-160
 
 
-def positional_table(d_model: int, max_len: int = PE_MAX_LEN) -> torch.Tensor:
-    """Sinusoidal table [1, max_len, d_model], fp32, bit-equal to the reference buffer
-    (``simnet.py:226-232``): pe[p,2i]=sin(p*w_i), pe[p,2i+1]=cos(p*w_i),
-    w_i = exp(-2i*ln(10000)/d) evaluated in fp32 exactly as torch does there."""
+def positional_table(d_model: int, max_len: int = PE_MAX_LEN, stable: bool = False) -> torch.Tensor:
+    """Sinusoidal table [1, max_len, d_model], fp32: pe[p,2i]=sin(p*w_i), pe[p,2i+1]=cos(p*w_i),
+    w_i = exp(-2i*ln(10000)/d)  (reference ``simnet.py:226-232``).
+
+    ``stable=False`` (the module's default buffer): the reference's own torch fp32 op sequence, so on one machine
+    the buffer is bit-equal to the reference's.  That sequence is NOT reproducible across machines: torch's
+    vectorised fp32 ``exp`` differs in the last bit between CPUs (3 of the 128 w_i at d = 256 differ from the
+    correctly rounded value in the build container), and one ulp of w_i (6e-8) times p = 2000 is a phase shift of
+    1.2e-4 - the table, hence every score, then moves by up to ~1e-4 between the machine that made a golden vector
+    and the machine that checks it.  Real deployments are not affected (the table is a ``state_dict`` buffer and
+    travels with the checkpoint), but seeded test weights are, so ``make_state_dict`` uses
+    ``stable=True``: every fp32 operation of the same formula evaluated in float64 and rounded once (correctly
+    rounded exp / sin / cos of the same fp32 arguments) - identical on every IEEE machine, and within 1.3e-4 of the
+    reference's buffer on any of them."""
+    if stable:
+        t = (-torch.arange(0, d_model, 2) * math.log(10000) / d_model).numpy()          # exact fp32 ops (mul, div)
+        w = torch.from_numpy(np.exp(t.astype(np.float64)).astype(np.float32))
+        arg = (torch.arange(0, max_len).reshape(max_len, 1) * w).numpy().astype(np.float64)   # fp32 product, then widened
+        pe = torch.zeros((max_len, d_model))
+        pe[:, 0::2] = torch.from_numpy(np.sin(arg).astype(np.float32))
+        pe[:, 1::2] = torch.from_numpy(np.cos(arg).astype(np.float32))
+        return pe.unsqueeze(0)
     w = torch.exp(-torch.arange(0, d_model, 2) * math.log(10000) / d_model)
     pos = torch.arange(0, max_len).reshape(max_len, 1)
     pe = torch.zeros((max_len, d_model))
@@ -75,7 +93,7 @@ def make_state_dict(d_model: int, num_layers: int, seed: int, num_classes: int =
     for key, shape, kind in state_dict_keys(d_model, num_layers, num_classes, use_pos,
                                             in_features, max_len):
         if kind == "pe":
-            sd[key] = positional_table(d_model, max_len)
+            sd[key] = positional_table(d_model, max_len, stable=True)     # machine-independent (see positional_table)
             continue
         if kind == "w":
             bound = 1.0 / math.sqrt(shape[-1])
