@@ -77,6 +77,31 @@ int vs_mse_mask_loss_forward(const float *output, const float *target, const uin
 int vs_mse_mask_loss_backward(const float *output, const float *target, const uint8_t *mask, const float *d_loss,
                               int32_t n, int32_t mean, float *d_output, void *stream);
 
+/* Replaces: PretrainModel.forward below its encoder call (reference src/model/simnet_pretrain.py:79-98 with
+ * repelling_loss :49-71, entropy :43-47, cross_entropy_loss :35-41): video_transform Linear on the scorer's hidden
+ * state, the repelling loss, the masked score-softmax pooling with its centering penalty and the soft cross-entropy
+ * against the video representation - forward and backward.
+ *   hidden [B,T,d] and logits [B,T]: the two outputs of the scorer; key_pad_mask [B,T] bytes or NULL;
+ *   vid [B,F] the target video representation; vt_w [F,d], vt_b [F]: video_transform (F = 512 in the reference);
+ *   temp = sharpening_t (:29);  entropy_penalty != 0: pen_met == "entropy" (:88), else the norm penalty (:92).
+ *   feats [B,T,F] (out: video_transform(hidden), kept for the backward), head_state >= vs_pretrain_head_state_bytes
+ *   (out: per-video statistics, kept for the backward), losses [3] = (distillation, centering, repelling) batch means.
+ * The repelling loss is evaluated as (||sum_t x^_t||^2 - sum_t ||x^_t||^2) / T^2 - the mean of the reference's
+ * [T,T] cosine matrix without its diagonal, never materialised. */
+size_t vs_pretrain_head_state_bytes(int32_t B, int32_t T, int32_t F);
+size_t vs_pretrain_head_workspace_bytes(int32_t B, int32_t T, int32_t d, int32_t F);
+int vs_pretrain_head_forward(const float *hidden, const float *logits, const uint8_t *key_pad_mask, const float *vid,
+                             const float *vt_w, const float *vt_b, int32_t B, int32_t T, int32_t d, int32_t F,
+                             float temp, int32_t entropy_penalty, float *feats, void *head_state, float *losses,
+                             void *stream);
+/* d_losses [3]: gradients of the three returned losses.  Outputs (all overwritten): d_hidden [B,T,d], d_logits [B,T],
+ * d_vt_w [F,d], d_vt_b [F].  workspace >= vs_pretrain_head_workspace_bytes, 256-byte aligned. */
+int vs_pretrain_head_backward(const float *hidden, const float *logits, const uint8_t *key_pad_mask, const float *vid,
+                              const float *vt_w, const float *feats, void *head_state, const float *d_losses,
+                              int32_t B, int32_t T, int32_t d, int32_t F, float temp, int32_t entropy_penalty,
+                              float *d_hidden, float *d_logits, float *d_vt_w, float *d_vt_b, void *workspace,
+                              size_t workspace_bytes, void *stream);
+
 /* Per-kernel entry points for the parity tests (not needed by a binding). */
 
 /* softmax(q k^T * scale + keymask) with dropout p on the weights, times v; q,k,v head-major [B,H,T,dh]; out [B,T,H*dh];

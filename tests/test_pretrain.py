@@ -59,3 +59,62 @@ def test_repelling_loss_equals_the_materialised_form(vsa):
     assert abs(m.repelling_loss(x, None).item() -
                (torch.matmul(x / (x.norm(dim=2, keepdim=True) + 1e-9), (x / (x.norm(dim=2, keepdim=True) + 1e-9)).transpose(1, 2))
                 * (torch.eye(50) == 0).float()).mean(dim=1).mean().item()) < 1e-6
+
+
+def _head_reference(hidden, logits, vid, mask, W, b, temp, pen):
+    """The reference's formulas (simnet_pretrain.py:35-98) restated op for op in float64 torch, [T,T] matrix included."""
+    import torch.nn.functional as F
+    feats = F.linear(hidden, W, b)
+    x = feats * (mask == False).unsqueeze(2) if mask is not None else feats      # noqa: E712
+    x = x / (x.norm(dim=2, keepdim=True) + 1e-9)
+    T = x.shape[1]
+    sim = torch.matmul(x, x.transpose(1, 2)) * (torch.eye(T, dtype=x.dtype) == 0).to(x.dtype).unsqueeze(0)
+    repel = sim.mean(dim=1).mean()
+    sc = logits
+    if mask is not None:
+        sc = sc.masked_fill(mask.unsqueeze(2), float("-inf"))
+    mix = F.softmax(sc / temp, dim=1)
+    if pen == "entropy":
+        e = (mix + 1e-9) * torch.log(mix + 1e-9)
+        if mask is not None:
+            e = e.masked_fill(mask.unsqueeze(2), 0.)
+        center = e.mean(dim=1).mean()
+    else:
+        center = torch.norm(mix, dim=1).mean()
+    pooled = torch.matmul(mix.transpose(1, 2), feats).squeeze(1)
+    loss = (-F.softmax(vid, dim=1) * torch.log(F.softmax(pooled, dim=1))).mean()
+    return loss, center, repel
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,T,d,pen,masked", [(3, 150, 256, "entropy", True), (2, 64, 128, "norm", True), (1, 333, 512, "entropy", False),
+                                              (4, 65, 256, "norm", False)])
+def test_pretrain_head_kernels_match_float64_formulas(vsa, B, T, d, pen, masked):
+    """_PretrainHead (video_transform + repel + pooling + penalties + soft CE, forward and backward kernels) against
+    the reference's formulas in float64, for a weighted sum of the three losses (pretrain.py:62)."""
+    from importlib import import_module
+    head = import_module("video-summarization_amd.pretrain")._PretrainHead
+    g = torch.Generator().manual_seed(B * T + d)
+    hidden = torch.randn(B, T, d, generator=g, dtype=torch.float64)
+    logits = torch.randn(B, T, 1, generator=g, dtype=torch.float64)
+    vid = torch.randn(B, 512, generator=g, dtype=torch.float64)
+    W = torch.randn(512, d, generator=g, dtype=torch.float64) / d ** 0.5
+    bias = 0.1 * torch.randn(512, generator=g, dtype=torch.float64)
+    mask = None
+    if masked:
+        mask = torch.zeros(B, T, dtype=torch.bool)
+        for i in range(B):
+            mask[i, T - 7 * i - 3:] = True
+    leaves = [t.clone().requires_grad_(True) for t in (hidden, logits, W, bias)]
+    want = _head_reference(leaves[0], leaves[1], vid, mask, leaves[2], leaves[3], 0.4, pen)
+    (want[0] + 0.5 * want[1] + 1.0 * want[2]).backward()
+    dl = [t.detach().float().to(DEV).requires_grad_(True) for t in (hidden, logits, W, bias)]
+    got = head.apply(dl[0], dl[1], vid.float().to(DEV), None if mask is None else mask.to(DEV), dl[2], dl[3], 0.4, pen == "entropy")
+    (got[0] + 0.5 * got[1] + 1.0 * got[2]).backward()
+    torch.cuda.synchronize()
+    for i, name in enumerate(("distillation", "centering", "repelling")):
+        assert abs(got[i].item() - want[i].item()) < 2e-6 * max(1.0, abs(want[i].item())), (name, got[i].item(), want[i].item())
+    for a, r, name in zip(dl, leaves, ("d_hidden", "d_logits", "d_weight", "d_bias")):
+        err = (a.grad.double().cpu() - r.grad).abs().max().item()
+        scale = r.grad.abs().max().item()
+        assert err <= 2e-5 * scale + 1e-9, "%s: err %.3e, max %.3e" % (name, err, scale)

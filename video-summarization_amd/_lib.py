@@ -18,7 +18,7 @@ INCLUDE = os.path.join(ROOT, "include")
 LIB_PATH = os.path.join(HERE, "libvsscore.so")
 DIAG_LIB_PATH = os.path.join(HERE, "libvsscore_diag.so")
 SOURCES = ("vs_kernels.hip", "vs_attention.hip", "vs_scorer.cpp", "vs_eval.cpp",
-           "vs_train_kernels.hip", "vs_train_attention.hip", "vs_train.cpp")
+           "vs_train_kernels.hip", "vs_train_attention.hip", "vs_pretrain_kernels.hip", "vs_train.cpp")
 ABI_VERSION = 2
 
 VS_OK, VS_ERR_INVALID, VS_ERR_WORKSPACE, VS_ERR_HIP = 0, 1, 2, 3
@@ -43,7 +43,9 @@ EVAL_EXPORTS = ("vs_eval_upsample", "vs_eval_knapsack", "vs_eval_generate_summar
 TRAIN_EXPORTS = ("vs_train_saved_bytes", "vs_train_workspace_bytes", "vs_train_forward", "vs_train_backward",
                  "vs_mse_mask_loss_forward", "vs_mse_mask_loss_backward", "vs_train_attention_forward",
                  "vs_train_attention_backward", "vs_train_wgrad_scratch_floats", "vs_train_wgrad",
-                 "vs_train_dropout_mask_attention", "vs_train_dropout_mask_rows", "vs_train_dropout_site")
+                 "vs_train_dropout_mask_attention", "vs_train_dropout_mask_rows", "vs_train_dropout_site",
+                 "vs_pretrain_head_state_bytes", "vs_pretrain_head_workspace_bytes", "vs_pretrain_head_forward",
+                 "vs_pretrain_head_backward")
 NUM_STAGES = 6
 
 
@@ -252,6 +254,16 @@ def load() -> C.CDLL:
         lib.vs_train_dropout_mask_rows.restype = C.c_int
         lib.vs_train_dropout_mask_rows.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_uint64, C.c_uint32, C.c_float,
                                                    C.c_void_p]
+        lib.vs_pretrain_head_state_bytes.restype = C.c_size_t
+        lib.vs_pretrain_head_state_bytes.argtypes = [C.c_int32] * 3
+        lib.vs_pretrain_head_workspace_bytes.restype = C.c_size_t
+        lib.vs_pretrain_head_workspace_bytes.argtypes = [C.c_int32] * 4
+        lib.vs_pretrain_head_forward.restype = C.c_int
+        lib.vs_pretrain_head_forward.argtypes = ([C.c_void_p] * 6 + [C.c_int32] * 4 + [C.c_float, C.c_int32]
+                                                 + [C.c_void_p] * 4)
+        lib.vs_pretrain_head_backward.restype = C.c_int
+        lib.vs_pretrain_head_backward.argtypes = ([C.c_void_p] * 8 + [C.c_int32] * 4 + [C.c_float, C.c_int32]
+                                                  + [C.c_void_p] * 5 + [C.c_size_t, C.c_void_p])
         lib.vs_train_dropout_site.restype = C.c_uint32
         lib.vs_train_dropout_site.argtypes = [C.c_int32, C.c_int32]
         lib.vs_profile_enable.restype = C.c_int

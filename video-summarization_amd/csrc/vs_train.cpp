@@ -310,6 +310,73 @@ int vs_mse_mask_loss_backward(const float *output, const float *target, const ui
     return VS_OK;
 }
 
+size_t vs_pretrain_head_state_bytes(int32_t B, int32_t T, int32_t F) {
+    if (B <= 0 || T <= 0 || F <= 0) return 0;
+    return align_floats(vsp_head_scratch_floats(B, T, F)) * sizeof(float);
+}
+
+namespace {
+struct HeadWork { size_t dfeats, wt, zeros, wg, total; };
+HeadWork head_work(int B, int T, int d, int F) {
+    HeadWork W{};
+    const size_t M = (size_t)B * T;
+    size_t off = 0;
+    auto take = [&](size_t n) { size_t o = off; off += align_floats(n); return o; };
+    W.dfeats = take(M * F);
+    W.wt = take((size_t)d * F);
+    W.zeros = take((size_t)(d > F ? d : F));
+    W.wg = take(vst_wgrad_workspace_floats((int)M, F, d));
+    W.total = off;
+    return W;
+}
+}  // namespace
+
+size_t vs_pretrain_head_workspace_bytes(int32_t B, int32_t T, int32_t d, int32_t F) {
+    if (B <= 0 || T <= 0 || d <= 0 || F <= 0) return 0;
+    return head_work(B, T, d, F).total * sizeof(float);
+}
+
+int vs_pretrain_head_forward(const float *hidden, const float *logits, const uint8_t *key_pad_mask, const float *vid,
+                             const float *vt_w, const float *vt_b, int32_t B, int32_t T, int32_t d, int32_t F,
+                             float temp, int32_t entropy_penalty, float *feats, void *head_state, float *losses,
+                             void *stream) {
+    if (!hidden || !logits || !vid || !vt_w || !vt_b || !feats || !head_state || !losses)
+        return failf(VS_ERR_INVALID, "pretrain head: NULL pointer");
+    if (B <= 0 || T <= 0 || d <= 0 || d % 32 || (F != 256 && F != 512 && F != 768 && F != 1024) || !(temp > 0.f))
+        return failf(VS_ERR_INVALID, "pretrain head: B=%d T=%d d=%d F=%d temp=%g unsupported (d %% 32 == 0, F in {256,512,768,1024})", B, T, d, F, temp);
+    hipStream_t st = (hipStream_t)stream;
+    VST_LAUNCH(vsk_linear(hidden, vt_w, nullptr, vt_b, feats, B * T, F, d, 0, nullptr, 1, 0, st));           // :79
+    VST_LAUNCH(vsp_head_forward(feats, logits, key_pad_mask, vid, B, T, F, 1.0f / temp, entropy_penalty,
+                                (float *)head_state, losses, st));
+    return VS_OK;
+}
+
+int vs_pretrain_head_backward(const float *hidden, const float *logits, const uint8_t *key_pad_mask, const float *vid,
+                              const float *vt_w, const float *feats, void *head_state, const float *d_losses,
+                              int32_t B, int32_t T, int32_t d, int32_t F, float temp, int32_t entropy_penalty,
+                              float *d_hidden, float *d_logits, float *d_vt_w, float *d_vt_b, void *workspace,
+                              size_t workspace_bytes, void *stream) {
+    if (!hidden || !logits || !vid || !vt_w || !feats || !head_state || !d_losses || !d_hidden || !d_logits || !d_vt_w ||
+        !d_vt_b || !workspace)
+        return failf(VS_ERR_INVALID, "pretrain head: NULL pointer");
+    if (B <= 0 || T <= 0 || d <= 0 || d % 32 || (F != 256 && F != 512 && F != 768 && F != 1024) || !(temp > 0.f))
+        return failf(VS_ERR_INVALID, "pretrain head: B=%d T=%d d=%d F=%d temp=%g unsupported", B, T, d, F, temp);
+    const HeadWork W = head_work(B, T, d, F);
+    if (workspace_bytes < W.total * sizeof(float) || ((uintptr_t)workspace & 255))
+        return failf(VS_ERR_WORKSPACE, "pretrain head: workspace %zu bytes < %zu needed (256-byte aligned)", workspace_bytes, W.total * sizeof(float));
+    hipStream_t st = (hipStream_t)stream;
+    float *ws = (float *)workspace;
+    const int M = B * T;
+    VST_LAUNCH(vsp_head_backward(feats, logits, key_pad_mask, vid, B, T, F, 1.0f / temp, entropy_penalty,
+                                 (const float *)head_state, d_losses, ws + W.dfeats, d_logits, st));
+    // video_transform: weight / bias gradient, then the gradient of the hidden state (NT GEMM against W^T)
+    VST_LAUNCH(vst_wgrad(ws + W.dfeats, F, hidden, d, M, F, d, d_vt_w, nullptr, nullptr, d_vt_b, nullptr, nullptr, F, ws + W.wg, st));
+    VST_LAUNCH(vst_transpose(vt_w, ws + W.wt, F, d, st));                                     // [F,d] -> [d,F]
+    VST_HIP(hipMemsetAsync(ws + W.zeros, 0, (size_t)(d > F ? d : F) * sizeof(float), st));
+    VST_LAUNCH(vsk_linear(ws + W.dfeats, ws + W.wt, nullptr, ws + W.zeros, d_hidden, M, d, F, 0, nullptr, 1, 0, st));
+    return VS_OK;
+}
+
 int vs_train_attention_forward(const float *q, const float *k, const float *v, const uint8_t *key_pad_mask, float *out,
                                float *lse2, int32_t B, int32_t H, int32_t T, int32_t dh, float scale, uint64_t seed,
                                uint32_t site, float p, void *stream) {

@@ -54,3 +54,13 @@ int vst_attention_dropout_mask(uint8_t *keep, int B, int H, int T, unsigned long
                                hipStream_t st);
 // test hook: keep[row, col] (bytes) of the elementwise dropouts
 int vst_rows_dropout_mask(uint8_t *keep, int M, int cols, unsigned long long seed, unsigned site, float p, hipStream_t st);
+
+// ---- PretrainModel head (vs_pretrain_kernels.hip; reference simnet_pretrain.py:49-69, 80-98) ----
+// feats [B,T,F] (video_transform output), scores [B,T] (the scorer's logits), mask [B,T] bytes or NULL, vid [B,F].
+// stats (device, floats): per video [B][VSP_STATS] (see vs_pretrain_kernels.hip) + pooled / sumx vectors; part: scratch.
+size_t vsp_head_scratch_floats(int B, int T, int F);
+int vsp_head_forward(const float *feats, const float *scores, const uint8_t *mask, const float *vid, int B, int T, int F,
+                     float inv_temp, int entropy_penalty, float *scratch, float *losses /*[3]*/, hipStream_t st);
+int vsp_head_backward(const float *feats, const float *scores, const uint8_t *mask, const float *vid, int B, int T, int F,
+                      float inv_temp, int entropy_penalty, const float *scratch, const float *g_losses /*[3]*/,
+                      float *d_feats, float *d_scores, hipStream_t st);

@@ -365,32 +365,64 @@ __global__ __launch_bounds__(256) void wgrad_tn(const float *__restrict__ dY, in
     }
 }
 
-// out[row, c] = sum_s part[s][row][c]  (s ascending), rows dealt to up to three destination tensors of
-// rows_per_dest rows each (q / k / v weight gradients come out of ONE [3d, d] product).  cols % VEC == 0.
+// out[row, c] = sum_s part[s][row][c], rows dealt to up to three destination tensors of rows_per_dest rows each
+// (q / k / v weight gradients come out of ONE [3d, d] product).  Fixed summation order (bitwise reproducible):
+// thread group g of 16 sums s = g, g + 16, ... in ascending order (4 independent loads in flight), then the 16 group
+// sums are added in group order.  Block = 16 groups x 16 vectors of VEC floats; cols % VEC == 0.
 template <int VEC>
 __global__ __launch_bounds__(256) void reduce_partials(const float *__restrict__ part, int S, int rows, int cols,
                                                        float *d0, float *d1, float *d2, int rows_per_dest) {
     typedef float vec_t __attribute__((ext_vector_type(VEC)));
+    __shared__ float red[16][16 * VEC];
     const size_t per = (size_t)rows * cols, nvec = per / VEC;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
-        const size_t e = i * VEC;
-        float acc[VEC];
+    const int g = threadIdx.x >> 4, v = threadIdx.x & 15;
+    const size_t i = (size_t)blockIdx.x * 16 + v;
+    float acc[VEC];
 #pragma unroll
-        for (int q = 0; q < VEC; ++q) acc[q] = 0.f;
-        for (int s = 0; s < S; ++s) {
-            if constexpr (VEC == 1) {
-                acc[0] += part[(size_t)s * per + e];
-            } else {
-                const vec_t v = *(const vec_t *)(part + (size_t)s * per + e);
+    for (int q = 0; q < VEC; ++q) acc[q] = 0.f;
+    if (i < nvec) {
+        const float *p0 = part + i * VEC;
+        int s = g;
+        for (; s + 48 < S; s += 64) {
+            float t[4][VEC];
 #pragma unroll
-                for (int q = 0; q < VEC; ++q) acc[q] += v[q];
+            for (int u = 0; u < 4; ++u) {
+                if constexpr (VEC == 1) t[u][0] = p0[(size_t)(s + 16 * u) * per];
+                else {
+                    const vec_t w = *(const vec_t *)(p0 + (size_t)(s + 16 * u) * per);
+#pragma unroll
+                    for (int q = 0; q < VEC; ++q) t[u][q] = w[q];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) acc[q] += t[u][q];
+        }
+        for (; s < S; s += 16) {
+            if constexpr (VEC == 1) acc[0] += p0[(size_t)s * per];
+            else {
+                const vec_t w = *(const vec_t *)(p0 + (size_t)s * per);
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) acc[q] += w[q];
             }
         }
+    }
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) red[g][v * VEC + q] = acc[q];
+    __syncthreads();
+    if (g == 0 && i < nvec) {
+        const size_t e = i * VEC;
         const int row = (int)(e / cols), c = (int)(e - (size_t)row * cols);
         const int which = row / rows_per_dest;
         float *dst = (which == 0 ? d0 : which == 1 ? d1 : d2) + (size_t)(row - which * rows_per_dest) * cols + c;
 #pragma unroll
-        for (int q = 0; q < VEC; ++q) dst[q] = acc[q];
+        for (int q = 0; q < VEC; ++q) {
+            float tot = red[0][v * VEC + q];
+#pragma unroll
+            for (int gg = 1; gg < 16; ++gg) tot += red[gg][v * VEC + q];
+            dst[q] = tot;
+        }
     }
 }
 
@@ -446,7 +478,7 @@ __global__ __launch_bounds__(256) void mse_mask_bwd(const float *__restrict__ ou
     }
 }
 
-int row_grid(int M) { const int b = (M + 3) / 4; return b < 1024 ? (b < 1 ? 1 : b) : 1024; }
+int row_grid(int M) { const int b = (M + 3) / 4; return b < 512 ? (b < 1 ? 1 : b) : 512; }      // blocks of the partial-sum row kernels
 
 }  // namespace
 
@@ -550,12 +582,11 @@ int vst_wgrad(const float *dY, int ldy, const float *X, int ldx, int M, int N, i
     VSK_CHECK_LAUNCH();
     {
         const size_t nvec = (size_t)N * K / 4;
-        const int blocks = (int)((nvec + 255) / 256 < 4096 ? (nvec + 255) / 256 : 4096);
-        hipLaunchKernelGGL(reduce_partials<4>, dim3(blocks), dim3(256), 0, st, partW, S, N, K, dW0, dW1, dW2, rows_per_dest);
+        hipLaunchKernelGGL(reduce_partials<4>, dim3((unsigned)((nvec + 15) / 16)), dim3(256), 0, st, partW, S, N, K, dW0, dW1, dW2, rows_per_dest);
         VSK_CHECK_LAUNCH();
     }
     if (db0) {
-        hipLaunchKernelGGL(reduce_partials<1>, dim3((N + 255) / 256), dim3(256), 0, st, partB, S, N, 1, db0, db1, db2, rows_per_dest);
+        hipLaunchKernelGGL(reduce_partials<1>, dim3((N + 15) / 16), dim3(256), 0, st, partB, S, N, 1, db0, db1, db2, rows_per_dest);
         VSK_CHECK_LAUNCH();
     }
     return 0;
@@ -565,7 +596,7 @@ int vst_wgrad(const float *dY, int ldy, const float *X, int ldx, int M, int N, i
 int vst_reduce_rows(const float *part, int S, int rows, int cols, float *d0, float *d1, float *d2, int rows_per_dest,
                     hipStream_t st) {
     const size_t n = (size_t)rows * cols;
-    hipLaunchKernelGGL(reduce_partials<1>, dim3((int)((n + 255) / 256)), dim3(256), 0, st, part, S, rows, cols, d0, d1, d2,
+    hipLaunchKernelGGL(reduce_partials<1>, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, st, part, S, rows, cols, d0, d1, d2,
                        rows_per_dest);
     VSK_CHECK_LAUNCH();
     return 0;

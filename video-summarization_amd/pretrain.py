@@ -3,24 +3,84 @@ the scorer's hidden output in ``pretrain.py``: same co
 (``encoder.*`` = SimNet, ``video_transform.{weight,bias}``), same ``forward`` signature and return triple
 ``(distillation loss, centering loss, repelling loss)``.
 
-It is a TRAINING loss head: every call site runs it under autograd (pretrain.py:61-66), so it is composed from
-torch ops on the module's device (like ``SimNet._forward_autograd``) rather than hand-written kernels - with one
-algorithmic change.  The reference materialises the [B,T,T] cosine-similarity tensor to average its off-diagonal
+``forward`` runs on the HIP kernels end to end: the encoder is the HIP training path (``simnet._TrainForward``) and
+everything below it - ``video_transform``, the repelling loss, the masked score-softmax pooling, the centering penalty
+and the soft cross-entropy, forward and backward - is ``_PretrainHead``, a ``torch.autograd.Function`` over
+``vs_pretrain_head_forward / _backward`` (``include/vs_train.h``, kernels ``csrc/vs_pretrain_kernels.hip``).  There is
+no PyTorch fallback: CPU tensors raise.
+
+One algorithmic change.  The reference materialises the [B,T,T] cosine-similarity tensor to average its off-diagonal
 (simnet_pretrain.py:56-69); the same number is
 
     sum_{i != j} x^_i . x^_j = || sum_i x^_i ||^2 - sum_i || x^_i ||^2        (x^ = masked, normalised rows)
 
 which costs O(T d) instead of O(T^2 d) time and memory (T = 2000, d = 512: 16 MB of [T,T] per video avoided in
-the forward and again in the backward), and differs from the reference only by fp32 rounding.
+the forward and again in the backward), and differs from the reference only by fp32 rounding.  The methods
+``cross_entropy_loss`` / ``entropy`` / ``repelling_loss`` are kept with the reference's signatures for callers that use
+them on their own tensors; ``forward`` does not go through them.
 """
 from __future__ import annotations
+
+import ctypes as C
 
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 from torch import Tensor
 
+from . import _lib
 from .simnet import SimNet
+
+
+class _PretrainHead(torch.autograd.Function):
+    """(hidden [B,T,d], logits [B,T,1], vid [B,F], mask, video_transform.weight, .bias) -> losses [3]."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)        # pretrain.py:59 calls under autocast
+    def forward(ctx, hidden, logits, vid, mask, weight, bias, temp, entropy):
+        lib = _lib.load()
+        B, T, d = hidden.shape
+        Fo = weight.shape[0]
+        hidden, logits, vid = hidden.contiguous(), logits.contiguous(), vid.contiguous()
+        w, bvec = weight.detach().contiguous(), bias.detach().contiguous()
+        m = None
+        if mask is not None:
+            m = mask.contiguous()
+            m = m.view(torch.uint8) if m.dtype == torch.bool else m.to(torch.uint8)
+        dev = hidden.device
+        feats = torch.empty((B, T, Fo), dtype=torch.float32, device=dev)
+        losses = torch.empty((3,), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            state = torch.empty((lib.vs_pretrain_head_state_bytes(B, T, Fo),), dtype=torch.uint8, device=dev)
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            _lib.check(lib.vs_pretrain_head_forward(hidden.data_ptr(), logits.data_ptr(), None if m is None else m.data_ptr(),
+                                                    vid.data_ptr(), w.data_ptr(), bvec.data_ptr(), B, T, d, Fo, float(temp),
+                                                    int(entropy), feats.data_ptr(), state.data_ptr(), losses.data_ptr(), stream))
+        ctx.save_for_backward(hidden, logits, vid, m, w, feats, state)
+        ctx.cfg = (float(temp), int(entropy), logits.shape)
+        return losses
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, d_losses):
+        lib = _lib.load()
+        hidden, logits, vid, m, w, feats, state = ctx.saved_tensors
+        temp, entropy, lshape = ctx.cfg
+        B, T, d = hidden.shape
+        Fo = w.shape[0]
+        dev = hidden.device
+        g = d_losses.contiguous().float()
+        d_hidden, d_logits = torch.empty_like(hidden), torch.empty((B, T), dtype=torch.float32, device=dev)
+        d_w, d_b = torch.empty_like(w), torch.empty((Fo,), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            ws = torch.empty((lib.vs_pretrain_head_workspace_bytes(B, T, d, Fo),), dtype=torch.uint8, device=dev)
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            _lib.check(lib.vs_pretrain_head_backward(hidden.data_ptr(), logits.data_ptr(), None if m is None else m.data_ptr(),
+                                                     vid.data_ptr(), w.data_ptr(), feats.data_ptr(), state.data_ptr(),
+                                                     g.data_ptr(), B, T, d, Fo, temp, entropy, d_hidden.data_ptr(),
+                                                     d_logits.data_ptr(), d_w.data_ptr(), d_b.data_ptr(), ws.data_ptr(),
+                                                     ws.numel(), stream))
+        return d_hidden, d_logits.view(lshape), None, None, d_w, d_b, None, None
 
 
 class PretrainModel(nn.Module):
@@ -59,16 +119,12 @@ class PretrainModel(nn.Module):
                 pen_met: str = "entropy"):
         # `visualize_attention` would make the reference unpack a 2-tuple into (out, attention) and crash a line
         # later (simnet_pretrain.py:75-78); no caller passes it, and it is ignored here.
-        logits, hidden = self.encoder(x, mask, model_score=True)
-        feats = self.video_transform(hidden)                               # [B, T, 512]
-        repel = self.repelling_loss(feats, mask)
-        key_mask = mask.unsqueeze(2) if isinstance(mask, Tensor) else None
-        if key_mask is not None:
-            logits = logits.masked_fill(key_mask, float("-inf"))
-        weights = F.softmax(logits / self.sharpening_t, dim=1)             # mixture over the frames  [B, T, 1]
-        if pen_met == "entropy":
-            center = self.entropy(weights + 1e-9, key_mask)               # 1e-9: the reference's stabiliser
-        else:
-            center = torch.norm(weights, dim=1).mean()
-        pooled = torch.matmul(weights.transpose(1, 2), feats).squeeze(1)   # score-weighted video representation
-        return self.cross_entropy_loss(pooled, video_representation), center, repel
+        logits, hidden = self.encoder(x, mask, model_score=True)                                      # :77
+        if not hidden.is_cuda:
+            raise RuntimeError("PretrainModel runs on the MI355X HIP kernels only (HIP tensors)")
+        if logits.size(2) != 1:
+            raise RuntimeError("PretrainModel needs num_classes == 1 (one score per frame)")
+        losses = _PretrainHead.apply(hidden, logits, video_representation.to(hidden.device), mask if isinstance(mask, Tensor) else None,
+                                     self.video_transform.weight, self.video_transform.bias, self.sharpening_t,
+                                     pen_met == "entropy")
+        return losses[0], losses[1], losses[2]
