@@ -1,0 +1,168 @@
+"""Input pipeline, file half (video-summarization_amd/data.py; reference src/data/dataset.py:64-168, path.py).
+CPU: the dataset surface against containers written in the reference's `video_N/field` layout (npz, and an h5py
+stand-in exposing the same keys), collate functions, the packed ragged feeder.  GPU: files -> pinned ring -> packed
+scoring -> keyshot evaluation against the reference-generated val_step golden."""
+import importlib
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+
+
+@pytest.fixture(scope="module")
+def data(vsa):
+    return importlib.import_module("video-summarization_amd.data")
+
+
+def _video(rng, T, n_frames=None):
+    n_frames = n_frames or 15 * T
+    return dict(features=rng.random((T, 1024)).astype(np.float64),          # stored as float64: the loader casts (:96)
+                gtscore=rng.random(T), user_summary=(rng.random((3, n_frames)) < 0.2).astype(np.float32),
+                user_scores=rng.integers(1, 6, (3, n_frames)).astype(np.float32),
+                change_points=np.array([[0, n_frames // 2 - 1], [n_frames // 2, n_frames - 1]]),
+                n_frames=np.array(n_frames), picks=np.arange(0, n_frames, 15))
+
+
+@pytest.fixture()
+def root(tmp_path, data):
+    rng = np.random.Generator(np.random.PCG64(1))
+    tv = {"video_%d" % i: _video(rng, T) for i, T in enumerate([60, 51, 50, 30, 120, 77], 1)}
+    sm = {"video_%d" % i: _video(rng, T) for i, T in enumerate([90, 40, 66], 1)}
+    data.write_npz_container(str(tmp_path / data.PATH["tvsum"][:-3]), tv)
+    data.write_npz_container(str(tmp_path / data.PATH["summe"][:-3]), sm)
+    return str(tmp_path), tv, sm
+
+
+def test_val_split_reads_the_split_keys_with_user_summaries(data, root):
+    path, tv, _ = root
+    keys = ["../datasets/eccv16_dataset_tvsum_google_pool5.h5/video_5", "../datasets/x.h5/video_2"]     # splits_dsnet/*.yaml form
+    ds = data.TSDataset(path, "tvsum", "tvsum+summe", keys, split="val")
+    assert len(ds) == 2 and [u.name for u in ds.user_summaries] == ["video_5", "video_2"]
+    f, t, u = ds[0]
+    assert f.dtype == torch.float32 and f.shape == (120, 1024) and t.shape == (120,)
+    assert np.array_equal(f.numpy(), tv["video_5"]["features"].astype(np.float32))
+    assert np.array_equal(u.change_points, tv["video_5"]["change_points"]) and int(u.n_frames) == 1800
+    assert np.array_equal(u.picks, np.arange(0, 1800, 15)) and u.user_summary.shape == (3, 1800)
+    x, y, user = data.collate_fn_test([ds[1]])                                  # dataset.py:164-168
+    assert x.shape == (1, 51, 1024) and y.shape == (1, 51) and user.name == "video_2"
+    assert len(data.TSDataset(path, "tvsum", "tvsum", None, split="val")) == 6      # no key: the whole experiment dataset
+
+
+def test_train_split_filters_short_videos_and_restricts_only_the_experiment_dataset(data, root):
+    path, tv, sm = root
+    keys = ["a/video_1", "a/video_3", "a/video_4", "a/video_6"]
+    ds = data.TSDataset(path, "tvsum", "tvsum+summe", keys, split="train")
+    # tvsum: of the 4 keyed videos only those with > 50 frames (60, 77); summe: all with > 50 frames (90, 66)
+    assert [d.shape[0] for d in ds.data] == [60, 77, 90, 66]
+    f, t = ds[0]
+    assert f.shape == (60, 1024) and t.shape == (60,)
+    x, y = data.collate_fn_train([ds[0], ds[2], ds[1]])                          # dataset.py:157-161
+    assert x.shape == (3, 90, 1024) and y.shape == (3, 90)
+    mask = x[:, :, 0] == 1000                                                    # train.py:118
+    assert mask.sum(1).tolist() == [30, 0, 13] and bool((x[0, 60:] == 1000).all()) and bool((y[0, 60:] == 1000).all())
+
+
+def test_h5_branch_through_a_stand_in_module(data, root, monkeypatch, tmp_path):
+    """With an `h5py` importable and a .h5 file present the HDF5 opener is used: a stand-in module whose File exposes
+    the same keys()/[key][field][...] protocol over the npz twin proves the branch without the real library."""
+    path, tv, _ = root
+    h5 = os.path.join(path, data.PATH["tvsum"])
+    open(h5, "wb").write(b"\x89HDF\r\n\x1a\n")
+    calls = []
+
+    class File(data.NpzContainer):
+        def __init__(self, p, mode):
+            calls.append((p, mode))
+            super().__init__(p[:-3] + ".npz")
+
+    monkeypatch.setitem(sys.modules, "h5py", types.SimpleNamespace(File=File))
+    ds = data.TSDataset(path, "tvsum", "tvsum", None, split="val")
+    assert calls == [(h5, "r")] and len(ds) == 6
+
+
+def test_missing_h5py_and_missing_files_fail_loudly(data, tmp_path, monkeypatch):
+    monkeypatch.setitem(sys.modules, "h5py", None)                                # import h5py -> ImportError
+    p = tmp_path / data.PATH["ovp"]
+    p.write_bytes(b"\x89HDF")
+    with pytest.raises(ImportError, match="h5_to_npz"):
+        data.open_container(str(p))
+    with pytest.raises(FileNotFoundError):
+        data.open_container(str(tmp_path / "nothing.h5"))
+
+
+def test_pretrain_dataset_and_collate(data, tmp_path):
+    (tmp_path / "frames").mkdir()
+    (tmp_path / "video").mkdir()
+    rng = np.random.Generator(np.random.PCG64(2))
+    for name, T in (("a", 12), ("b", 30)):
+        np.save(tmp_path / "frames" / (name + ".npy"), rng.random((T, 1024)).astype(np.float32))
+        np.save(tmp_path / "video" / (name + ".npy"), rng.random(512).astype(np.float32))
+    ds = data.PreTrainDataset(str(tmp_path))
+    assert len(ds) == 2
+    x, v = data.collate_fn_pretrain([ds[0], ds[1]])                               # dataset.py:139-143
+    assert x.shape == (2, 30, 1024) and v.shape == (2, 512) and sorted((x[:, :, 0] == 1000).sum(1).tolist()) == [0, 18]
+
+
+def test_ragged_feeder_packs_every_video_once_in_bucketed_batches(data):
+    rng = np.random.Generator(np.random.PCG64(3))
+    lengths = [320, 51, 640, 77, 200, 333, 64, 1000, 90, 129]
+    videos = [rng.random((t, 32)).astype(np.float32) for t in lengths]
+    feeder = data.RaggedFeeder(videos, max_frames=1500, slots=2)
+    seen = []
+    for slot, x, lens, idx in feeder:
+        assert x.shape == (sum(lens), 32) and lens == [lengths[i] for i in idx]
+        assert max(lens) * len(lens) <= 1500 or len(lens) == 1                   # corpus.bucket_batches' padded-frame budget
+        row = 0
+        for i, t in zip(idx, lens):
+            assert np.array_equal(x[row:row + t].numpy(), videos[i])
+            row += t
+        seen += idx
+        feeder.done(slot, None)
+    assert sorted(seen) == list(range(len(videos)))
+
+
+def test_feeder_errors_reach_the_consumer(data):
+    class Bad:
+        shape = (10, 32)
+
+        def __array__(self, *a, **k):
+            raise ValueError("corrupt member")
+    feeder = data.RaggedFeeder([np.zeros((10, 32), np.float32), Bad()], max_frames=100)
+    with pytest.raises(ValueError, match="corrupt"):
+        for slot, *_ in feeder:
+            feeder.done(slot, None)
+
+
+@pytest.mark.gpu
+def test_val_step_from_files_matches_the_reference_golden(vsa, data, tmp_path):
+    """The reference's val_step on split-0-shaped records (tests/golden/make_golden_valstep.py: reference model +
+    reference evaluation) — here from a dataset FILE through the pinned ring and packed scoring."""
+    sys.path.insert(0, GOLDEN)
+    mk = importlib.import_module("make_golden_valstep")
+    g = np.load(os.path.join(GOLDEN, "valstep_golden.npz"))
+    recs = mk.make_records()
+    videos = {}
+    for feats, target, u in recs:
+        videos[u.name] = dict(features=feats.numpy(), gtscore=target.numpy(), user_summary=u.user_summary, user_scores=u.user_scores,
+                              change_points=u.change_points, n_frames=np.array(u.n_frames), picks=u.picks)
+    data.write_npz_container(str(tmp_path / data.PATH["tvsum"][:-3]), videos)
+    keys = ["../datasets/eccv16_dataset_tvsum_google_pool5.h5/" + n for n in mk.NAMES]
+    ds = data.TSDataset(str(tmp_path), "tvsum", "tvsum", keys, split="val")
+    dev = torch.device("cuda:0")
+    m = vsa.SimNet(num_heads=4, d_model=256, num_layers=4, sparsity=0.0, dropout=0.3)
+    m.load_state_dict(vsa.synth.make_state_dict(256, 4, mk.WSEED), strict=True)
+    m = m.to(dev).eval()
+    loss, f, k, s = data.val_step_from_dataset(m, ds, dev, max_frames=1024)       # several batches: exercises the ring
+    assert abs(loss - float(g["loss"])) < 1e-6
+    assert abs(f - g["metrics"][0]) < 1e-6 and abs(k - g["metrics"][1]) < 1e-6 and abs(s - g["metrics"][2]) < 1e-6
+    scores = data.score_dataset(m, ds.data, dev, max_frames=1024)
+    with torch.no_grad():
+        for i, (feats, _t, u) in enumerate(recs):
+            alone = m.score(feats[None].to(dev))[0].cpu()
+            assert torch.equal(scores[i], alone)                                   # packed + streamed == alone, bit for bit
+            assert (scores[i].numpy() - g["scores_" + u.name]).max() < 1e-4

@@ -1,0 +1,113 @@
+"""GPU tests at the FULL sizes of BASELINE.json's configs (the goldens cover them at reduced sizes):
+configs[3] — the 75-video TVSum+SumMe-shaped corpus, packed and padded, sharded 8 ways; configs[4] — B=8, T=8192,
+D=2048 (all three compute modes) through size-independent properties; and the host-side suites (keyshot evaluation)
+run once more on the GPU box, where the round-end driver only collects `-m gpu` tests."""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+from oracle.simnet_oracle import oracle_forward
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _dev():
+    assert torch.cuda.is_available(), "these tests need a HIP device"
+    return torch.device("cuda:0")
+
+
+def _corpus_lengths():
+    """SURVEY §8(d) cfg 4: 50 videos T~U[150,650] (TVSum) + 25 videos T~U[100,650] (SumMe), seeded."""
+    rng = np.random.Generator(np.random.PCG64(75))
+    return [int(t) for t in rng.integers(150, 651, 50)] + [int(t) for t in rng.integers(100, 651, 25)]
+
+
+def test_config3_full_corpus_packed_padded_and_sharded(vsa):
+    corpus = importlib.import_module("video-summarization_amd.corpus")
+    lengths = _corpus_lengths()
+    assert len(lengths) == 75
+    rng = np.random.Generator(np.random.PCG64(76))
+    videos = [torch.from_numpy((np.abs(rng.standard_normal((t, 1024))) * 0.5).astype(np.float32)) for t in lengths]
+    sd = vsa.synth.make_state_dict(256, 4, 11)
+    m = vsa.SimNet(num_heads=4, d_model=256, num_layers=4, sparsity=0.0, dropout=0.3)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(_dev()).eval()
+    padded = corpus.score_corpus(lambda x, mk: m.score(x, mk), videos, device=_dev(), max_frames=16384)
+    packed = corpus.score_corpus(lambda x, mk: m.score(x, mk), videos, device=_dev(), max_frames=16384,
+                                 packed_fn=lambda x, lens: m.score_packed(x, lens))
+    assert sorted(padded) == sorted(packed) == list(range(75))
+    for i in range(75):
+        assert padded[i].shape == (lengths[i],) and torch.isfinite(padded[i]).all()
+        assert torch.equal(padded[i], packed[i]), i                  # a video's scores do not depend on how it is batched
+    # the 8-way shard plan of configs[3]: disjoint, complete, and every rank's shard scored on its own gives the same bits
+    shards = corpus.plan_shards(lengths, 8)
+    assert sorted(i for s in shards for i in s) == list(range(75))
+    cost = [sum(corpus.video_cost(lengths[i]) for i in s) for s in shards]
+    assert max(cost) / (sum(cost) / 8) < 1.08                        # balanced to a few percent
+    for r in (0, 3, 7):
+        idx = shards[r]
+        part = corpus.score_corpus(lambda x, mk: m.score(x, mk), [videos[i] for i in idx], device=_dev(), max_frames=16384,
+                                   packed_fn=lambda x, lens: m.score_packed(x, lens))
+        for j, i in enumerate(idx):
+            assert torch.equal(part[j], packed[i])
+    # the oracle on a sample (shortest, median, longest)
+    order = sorted(range(75), key=lambda i: lengths[i])
+    for i in (order[0], order[37], order[-1]):
+        rl, _ = oracle_forward(sd, videos[i][None], None, 4)
+        assert (packed[i] - torch.sigmoid(rl[0, :, 0])).abs().max().item() < TOL
+
+
+@pytest.mark.parametrize("compute", ["fp32", "fp16x3", "bf16"])
+def test_config4_full_size_properties(vsa, compute):
+    """B=8, T=8192, D=2048 (CLIP-ViT-shaped features; outside the reference's envelope, so the module is
+    re-parameterised: in_features=2048, an 8192-row positional table).  No CPU oracle finishes at this size; the
+    properties: finite; a video scored alone equals its row of the batch (bit for bit in fp32 / fp16x3); a padded
+    copy of a shorter video scores its valid frames like the unpadded video; the low-precision modes stay within their
+    stated distance of the exact path (bf16 2e-2 on logits, fp16x3 1e-4)."""
+    B, T, D = 8, 8192, 2048
+    sd = vsa.synth.make_state_dict(256, 4, 5, in_features=D, max_len=T)
+    m = vsa.SimNet(num_heads=4, d_model=256, num_layers=4, sparsity=0.0, dropout=0.3, in_features=D, pe_len=T)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(_dev()).eval()
+    g = torch.Generator(device="cpu").manual_seed(8192)
+    x = torch.randn(B, T, D, generator=g).to(_dev())
+    with torch.no_grad():
+        exact, _ = m(x)
+        m.set_compute_dtype(compute)
+        full, hid = m(x)
+        assert torch.isfinite(full).all() and torch.isfinite(hid).all()
+        alone, _ = m(x[3:4].contiguous())
+        if compute == "bf16":
+            assert (alone - full[3:4]).abs().max().item() < 2e-2       # bf16 Linears change kernel family with the row count
+        else:
+            assert torch.equal(alone, full[3:4])
+        short = x[:1, :5000].contiguous()
+        padded = torch.full((1, T, D), 1000.0, device=_dev())
+        padded[:, :5000] = short
+        a, _ = m(padded, padded[:, :, 0] == 1000.0)
+        b, _ = m(short)
+        assert (a[:, :5000] - b).abs().max().item() < (2e-2 if compute == "bf16" else 5e-5)
+        dist = (full - exact).abs().max().item()
+        assert dist < {"fp32": 1e-12, "fp16x3": 1e-4, "bf16": 2e-2}[compute], dist
+
+
+def test_host_side_suites_on_the_gpu_box(vsa):
+    """tests/test_evaluation.py is CPU-marked (host C++ through the C ABI); run its cases here once more so the
+    `-m gpu` collection of the round-end driver exercises vs_eval.cpp on the GPU box's CPU too."""
+    te = importlib.import_module("test_evaluation")
+    ev = importlib.import_module("video-summarization_amd.evaluation")
+    te.test_knapsack_reference_known_answer(ev)
+    for j in range(6):
+        te.test_knapsack_matches_reference(ev, j)
+    te.test_float32_shot_means_follow_numpy_pairwise_order(ev)
+    for i in range(5):
+        te.test_per_video_pipeline_matches_reference(ev, i)
+    te.test_eval_metrics_drop_in(ev)
+    te.test_edge_cases(ev)
+    for j in range(8):
+        te.test_knapsack_nan_values_follow_python_max(ev, j)
+    for j in range(4):
+        te.test_shots_past_n_frames_have_nan_means_like_the_reference(ev, j)
