@@ -24,6 +24,10 @@ int vsk_linear_res_ln(const float *A, const float *W, const float *Wf, const flo
                       const float *gamma, const float *beta, float *out, int M, int N, int K,
                       const float *score_w, const float *score_b, int num_classes, int sigmoid,
                       float *scores, int bf16, hipStream_t st);
+// out = LayerNorm(a + res) * gamma + beta (+ score head): the row pass behind a plain GEMM for d_model > 256
+int vsk_rows_res_ln(const float *a, const float *res, const float *gamma, const float *beta, float *out, int M, int d,
+                    const float *score_w, const float *score_b, int num_classes, int sigmoid, float *scores,
+                    hipStream_t st);
 int vsk_diag_gemm(const float *A, const float *W, const float *bias, float *C, int M, int N, int K,
                   int grid, unsigned long long *diag, hipStream_t st);
 // fc1 + ReLU + fc2 + residual + LayerNorm (+ score head) in one kernel; d_model == 256 only (-1 otherwise)

@@ -1512,6 +1512,76 @@ __global__ __launch_bounds__(64 * NW) void skinny2_ln(
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// out = LayerNorm(a + residual) * gamma + beta (+ score head, + sigmoid), one wave per row  (d_model > 256).
+// For wide models the fused projection + LayerNorm kernel (gemm_res_ln: 4 waves share 64 rows, statistics through
+// LDS) runs at 0.58-0.67 of the matrix peak while the plain persistent GEMM reaches 0.88 on the same product
+// (M-B, d 512: fc2 1.31 ms fused vs 1.00 ms + this 0.09 ms pass).  So d_model > 256 takes the plain GEMM (bias in
+// its accumulator init) and this HBM-bound row pass: two-pass variance, lane-local float4s, wave shuffles only.
+// Per-row arithmetic does not depend on M: a video's scores stay bit-identical whatever batch it is scored in.
+// ------------------------------------------------------------------------------------------
+template <int NV>
+__global__ __launch_bounds__(256) void rows_res_ln(const float *__restrict__ a, const float *__restrict__ res,
+                                                   const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                   float *__restrict__ out, int M, int d,
+                                                   const float *__restrict__ score_w, const float *__restrict__ score_b,
+                                                   int num_classes, int sigmoid, float *__restrict__ scores) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    auto wsum = [](float v) __attribute__((always_inline)) { v += __shfl_xor(v, 32); return half_sum(v); };
+    for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+        f32x4 v[NV];
+        float s = 0.f;
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int c = 4 * lane + 256 * u;
+            v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (c < d) {
+                v[u] = *(const f32x4 *)(a + (size_t)row * d + c) + *(const f32x4 *)(res + (size_t)row * d + c);
+                s += v[u][0] + v[u][1] + v[u][2] + v[u][3];
+            }
+        }
+        const float mean = wsum(s) / (float)d;
+        float s2 = 0.f;
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            if (4 * lane + 256 * u < d) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float t = v[u][e] - mean; s2 += t * t; }
+            }
+        }
+        const float rstd = 1.0f / sqrtf(wsum(s2) / (float)d + 1e-5f);
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int c = 4 * lane + 256 * u;
+            if (c < d) {
+                const f32x4 g = *(const f32x4 *)(gamma + c), b = *(const f32x4 *)(beta + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[u][e] = (v[u][e] - mean) * rstd * g[e] + b[e];
+                *(f32x4 *)(out + (size_t)row * d + c) = v[u];
+            }
+        }
+        if (score_w != nullptr) {
+            for (int cls = 0; cls < num_classes; ++cls) {
+                float dot = 0.f;
+#pragma unroll
+                for (int u = 0; u < NV; ++u) {
+                    const int c = 4 * lane + 256 * u;
+                    if (c < d) {
+                        const f32x4 w = *(const f32x4 *)(score_w + (size_t)cls * d + c);
+                        dot += v[u][0] * w[0] + v[u][1] * w[1] + v[u][2] * w[2] + v[u][3] * w[3];
+                    }
+                }
+                dot = wsum(dot);
+                if (lane == 0) {
+                    float sc = dot + score_b[cls];
+                    if (sigmoid) sc = 1.0f / (1.0f + expf(-sc));
+                    scores[(size_t)row * num_classes + cls] = sc;
+                }
+            }
+        }
+    }
+}
+
 // ---- packed ragged batches (vs_scorer_forward_packed) ----
 // one thread: B is a few hundred at most, and the launch is stream-ordered before its consumers
 // work_cap: pairs `work` can hold; the host sized the launch from ITS copy of the lengths, so entries beyond the
@@ -1578,6 +1648,22 @@ int vsk_plan_packed(const int *lengths_dev, int B, int qb, int *cu, int *work, i
 
 int vsk_gather_rows(const float *pe, const int *cu, int B, int tmax, int d, float *rows, hipStream_t st) {
     hipLaunchKernelGGL(gather_rows, dim3((tmax + 63) / 64, B), dim3(256), 0, st, pe, cu, d, rows);
+    VSK_CHECK_LAUNCH();
+    return 0;
+}
+
+int vsk_rows_res_ln(const float *a, const float *res, const float *gamma, const float *beta, float *out, int M, int d,
+                    const float *score_w, const float *score_b, int num_classes, int sigmoid, float *scores,
+                    hipStream_t st) {
+    if (d % 4 || d > 512) return -1;
+    const int rows4 = (M + 3) / 4;
+    const dim3 grid(rows4 < 8192 ? (rows4 < 1 ? 1 : rows4) : 8192);
+    if (d <= 256)
+        hipLaunchKernelGGL(rows_res_ln<1>, grid, dim3(256), 0, st, a, res, gamma, beta, out, M, d, score_w, score_b,
+                           num_classes, sigmoid, scores);
+    else
+        hipLaunchKernelGGL(rows_res_ln<2>, grid, dim3(256), 0, st, a, res, gamma, beta, out, M, d, score_w, score_b,
+                           num_classes, sigmoid, scores);
     VSK_CHECK_LAUNCH();
     return 0;
 }

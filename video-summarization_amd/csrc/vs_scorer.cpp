@@ -355,8 +355,15 @@ int forward_core(const vs_weights *w, const float *x, const uint8_t *key_pad_mas
                 VS_LAUNCH(vsk_attention(qkv, qkv + (size_t)M * d, qkv + 2 * (size_t)M * d, key_pad_mask, att, B, H,
                                         T, d / H, scale, st));
         }
+        // d_model > 256: plain GEMM + the row LayerNorm pass (faster than the fused wide kernel at every M; the
+        // GEMM's output goes to a region of the workspace that is free at that point: q after the attention, att after fc1)
+        const bool split_ln = d > 256 && lnbf != 1;
         {
             StageScope ps(VS_STAGE_OUTPROJ_LN, st);
+            if (split_ln) {
+                VS_LAUNCH(vsk_linear(att, w->p(P.wo), w->p(lnbf == 2 ? P.h_wo : P.f_wo), w->p(P.bo), qkv, M, d, d, 0, nullptr, 1, lnbf, st));
+                VS_LAUNCH(vsk_rows_res_ln(qkv, h0, w->p(P.ln1g), w->p(P.ln1b), h1, M, d, nullptr, nullptr, 0, 0, nullptr, st));
+            } else
             VS_LAUNCH(vsk_linear_res_ln(att, w->p(P.wo), w->p(lnbf == 2 ? P.h_wo : P.f_wo), w->p(P.bo), h0, w->p(P.ln1g), w->p(P.ln1b), h1, M, d, d,
                                         nullptr, nullptr, 0, 0, nullptr, lnbf, st));
         }
@@ -379,7 +386,12 @@ int forward_core(const vs_weights *w, const float *x, const uint8_t *key_pad_mas
             StageScope ps(VS_STAGE_FC1, st);
             VS_LAUNCH(vsk_linear(h1, w->p(P.w1), w->p(lbf == 2 ? P.h_w1 : P.f_w1), w->p(P.b1), ffn, M, 4 * d, d, 1, nullptr, 1, lbf, st));
         }
-        {
+        if (split_ln) {
+            StageScope ps(VS_STAGE_FC2_LN, st);
+            VS_LAUNCH(vsk_linear(ffn, w->p(P.w2), w->p(lnbf == 2 ? P.h_w2 : P.f_w2), w->p(P.b2), att, M, d, 4 * d, 0, nullptr, 1, lnbf, st));
+            VS_LAUNCH(vsk_rows_res_ln(att, h1, w->p(P.ln2g), w->p(P.ln2b), dst, M, d, last ? w->p(w->final_w) : nullptr,
+                                      last ? w->p(w->final_b) : nullptr, D.num_classes, sig, last ? scores : nullptr, st));
+        } else {
             StageScope ps(VS_STAGE_FC2_LN, st);
             VS_LAUNCH(vsk_linear_res_ln(ffn, w->p(P.w2), w->p(lnbf == 2 ? P.h_w2 : P.f_w2), w->p(P.b2), h1, w->p(P.ln2g), w->p(P.ln2b), dst, M, d,
                                         4 * d, last ? w->p(w->final_w) : nullptr,
