@@ -16,7 +16,7 @@
 // The k order inside a sum is irrelevant as long as A and B use the same one.
 #include <atomic>
 
-#include "vs_device.h"
+#include "vs_train_device.h"     // dropout hash (vs_device.h comes with it)
 #include "vs_kernels.h"
 
 namespace {
@@ -34,7 +34,16 @@ namespace {
 //   Blocks that share an XCD (blockIdx % 8) own one contiguous chunk of the tile list, so the
 //   N-tiles of one A row-panel are consumed through one L2.
 // ------------------------------------------------------------------------------------------
-enum { EPI_BIAS = 0, EPI_RELU = 1, EPI_PE = 2, EPI_QKV = 3 };
+enum { EPI_BIAS = 0, EPI_RELU = 1, EPI_PE = 2, EPI_QKV = 3,
+       // training path only (vs_train.cpp):
+       EPI_GATE = 4,          // C = gate > 0 ? C * scale : 0, gate = `pe` [M,N]: ReLU + dropout backward riding in the dgrad GEMM
+       EPI_RELU_DROP = 5 };   // C = dropout(relu(C)): mlp.dropout riding in the fc1 GEMM (reference simnet.py:181)
+struct EpiArgs {              // extra epilogue operands of EPI_GATE / EPI_RELU_DROP (zero for every other epilogue)
+    unsigned long long seed;
+    unsigned site;
+    float p;
+    float scale;
+};
 
 // Diagnostic stamps (cdna guide §7 "In-kernel stamps"): compiled only into the DIAG instantiation,
 // which is reachable only through vs_diag_gemm(); no product launch executes a stamp.
@@ -61,7 +70,7 @@ template <int EPI, int NWM = 2, int DIAG = 0, int NJ = 2, int PREC = 0>     // D
 __global__ __launch_bounds__(128 * NWM, 2) void gemm_nt_128(
     const float *__restrict__ A, const float *__restrict__ W, const float *__restrict__ bias,
     float *__restrict__ C, int M, int N, int K, const float *__restrict__ pe, int T, int H, int dh,
-    unsigned long long *__restrict__ diag = nullptr) {
+    unsigned long long *__restrict__ diag = nullptr, EpiArgs ea = EpiArgs{0ull, 0u, 0.f, 0.f}) {
     constexpr int BM = 64 * NWM, BN = 64 * NJ, BK = 32, LD = BK + 4;
     constexpr int NT = 128 * NWM;                       // threads
     constexpr int LA = BM * 8 / NT, LW = BN * 8 / NT;   // float4 of A / of W per thread per k-tile (4, 4 | 4, 2)
@@ -333,7 +342,7 @@ __global__ __launch_bounds__(128 * NWM, 2) void gemm_nt_128(
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         v[e] = acc[i][jj][4 * q + e];
-                        if (EPI == EPI_RELU) v[e] = relu1(v[e]);
+                        if (EPI == EPI_RELU || EPI == EPI_RELU_DROP) v[e] = relu1(v[e]);
                     }
                     *(f32x4 *)&tp[r * LD + 8 * q + 4 * h] = v;
                 }
@@ -353,6 +362,17 @@ __global__ __launch_bounds__(128 * NWM, 2) void gemm_nt_128(
                             const f32x4 pv = *(const f32x4 *)(pe + (size_t)tt * N + c32 + tc4);
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] += pv[e];
+                        }
+                        if (EPI == EPI_GATE) {
+                            const f32x4 gv = *(const f32x4 *)(pe + (size_t)row * N + c32 + tc4);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = gv[e] > 0.f ? v[e] * ea.scale : 0.f;
+                        }
+                        if (EPI == EPI_RELU_DROP) {
+                            const DropSite dsite = drop_site(ea.seed, ea.site, ea.p);
+                            const unsigned rk = drop_rowkey(dsite, (unsigned)row);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = drop_keep(dsite, rk, (unsigned)(c32 + tc4 + e)) ? v[e] * dsite.scale : 0.f;
                         }
                         if (EPI == EPI_QKV)
                             *(f32x4 *)(C + (size_t)which * M * (H * dh) + (((size_t)bb * H + head) * T + tt) * dh + e0 + tc4) = v;
@@ -1118,7 +1138,7 @@ __device__ __forceinline__ void skinny_mainloop(f32x16 &acc, const float *__rest
 template <int EPI>
 __global__ __launch_bounds__(256) void skinny_gemm(
     const float *__restrict__ A, const float *__restrict__ W, const float *__restrict__ bias,
-    float *__restrict__ C, int M, int N, int K, const float *__restrict__ pe, int T, int H, int dh) {
+    float *__restrict__ C, int M, int N, int K, const float *__restrict__ pe, int T, int H, int dh, EpiArgs ea) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
     const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 128 + 32 * wave;
     if (n0 >= N) return;
@@ -1139,7 +1159,7 @@ __global__ __launch_bounds__(256) void skinny_gemm(
         f32x4 v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = acc[4 * q + e];
-        if (EPI == EPI_RELU) {
+        if (EPI == EPI_RELU || EPI == EPI_RELU_DROP) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = relu1(v[e]);
         }
@@ -1147,6 +1167,17 @@ __global__ __launch_bounds__(256) void skinny_gemm(
             const f32x4 pv = *(const f32x4 *)(pe + (size_t)tt * N + n0 + co);
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] += pv[e];
+        }
+        if (EPI == EPI_GATE) {
+            const f32x4 gv = *(const f32x4 *)(pe + (size_t)row * N + n0 + co);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = gv[e] > 0.f ? v[e] * ea.scale : 0.f;
+        }
+        if (EPI == EPI_RELU_DROP) {
+            const DropSite dsite = drop_site(ea.seed, ea.site, ea.p);
+            const unsigned rk = drop_rowkey(dsite, (unsigned)row);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = drop_keep(dsite, rk, (unsigned)(n0 + co + e)) ? v[e] * dsite.scale : 0.f;
         }
         if (EPI == EPI_QKV)
             *(f32x4 *)(C + (size_t)which * M * (H * dh) + (((size_t)bb * H + head) * T + tt) * dh + e0 + co) = v;
@@ -1374,7 +1405,7 @@ __device__ __forceinline__ void skinny3_stage(unsigned char *As, const float *__
 template <int EPI, int PREC = 0>       // PREC 2: Wf is the pack_fragments_f16x3 copy
 __global__ __launch_bounds__(256) void skinny2_gemm(
     const float *__restrict__ A, const float *__restrict__ Wf, const float *__restrict__ bias,
-    float *__restrict__ C, int M, int N, int K, const float *__restrict__ pe, int T, int H, int dh) {
+    float *__restrict__ C, int M, int N, int K, const float *__restrict__ pe, int T, int H, int dh, EpiArgs ea) {
     extern __shared__ __attribute__((aligned(16))) float As[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
     const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 128 + 32 * wave;
@@ -1409,7 +1440,7 @@ __global__ __launch_bounds__(256) void skinny2_gemm(
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = acc[4 * q + e];
         if constexpr (PREC == 2) v *= 1.0f / F16X3_WS;
-        if (EPI == EPI_RELU) {
+        if (EPI == EPI_RELU || EPI == EPI_RELU_DROP) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = relu1(v[e]);
         }
@@ -1417,6 +1448,17 @@ __global__ __launch_bounds__(256) void skinny2_gemm(
             const f32x4 pv = *(const f32x4 *)(pe + (size_t)tt * N + n0 + co);
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] += pv[e];
+        }
+        if (EPI == EPI_GATE) {
+            const f32x4 gv = *(const f32x4 *)(pe + (size_t)row * N + n0 + co);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = gv[e] > 0.f ? v[e] * ea.scale : 0.f;
+        }
+        if (EPI == EPI_RELU_DROP) {
+            const DropSite dsite = drop_site(ea.seed, ea.site, ea.p);
+            const unsigned rk = drop_rowkey(dsite, (unsigned)row);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = drop_keep(dsite, rk, (unsigned)(n0 + co + e)) ? v[e] * dsite.scale : 0.f;
         }
         if (EPI == EPI_QKV)
             *(f32x4 *)(C + (size_t)which * M * (H * dh) + (((size_t)bb * H + head) * T + tt) * dh + e0 + co) = v;
@@ -1692,12 +1734,13 @@ static int allow_big_lds_on_device(const void *kernel, std::atomic<unsigned char
 
 template <int EPI>
 static int launch_gemm(const float *A, const float *W, const float *Wf, const float *bias, float *C, int M, int N, int K,
-                       const float *pe, int T, int H, int dh, int bf16, hipStream_t st) {
+                       const float *pe, int T, int H, int dh, int bf16, hipStream_t st,
+                       EpiArgs ea = EpiArgs{0ull, 0u, 0.f, 0.f}) {
     if (bf16 == 2 && Wf != nullptr && M <= skinny_max_rows() && N % 32 == 0 && K % 128 == 0) {
         // fp16x3 latency kernels (Wf is then the pack_fragments_f16x3 copy)
         if (const int attr_rc = VSK_ALLOW_BIG_LDS((skinny2_gemm<EPI, 2>))) return attr_rc;
         dim3 grid((M + 31) / 32, (N + 127) / 128);
-        hipLaunchKernelGGL((skinny2_gemm<EPI, 2>), grid, dim3(256), skinny2_lds(K), st, A, Wf, bias, C, M, N, K, pe, T, H, dh);
+        hipLaunchKernelGGL((skinny2_gemm<EPI, 2>), grid, dim3(256), skinny2_lds(K), st, A, Wf, bias, C, M, N, K, pe, T, H, dh, ea);
         VSK_CHECK_LAUNCH();
         return 0;
     }
@@ -1705,11 +1748,11 @@ static int launch_gemm(const float *A, const float *W, const float *Wf, const fl
         if (N % 256 == 0 && M > 128) {
             const int blocks = persistent_blocks(((M + 255) / 256) * (N / 256), 1);
             if (blocks < 0) return (int)hipErrorInvalidDevice;
-            hipLaunchKernelGGL((gemm_nt_128<EPI, 4, 0, 4, 2>), dim3(blocks), dim3(512), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr);
+            hipLaunchKernelGGL((gemm_nt_128<EPI, 4, 0, 4, 2>), dim3(blocks), dim3(512), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr, ea);
         } else {
             const int blocks = persistent_blocks(((M + 127) / 128) * ((N + 127) / 128), 2);
             if (blocks < 0) return (int)hipErrorInvalidDevice;
-            hipLaunchKernelGGL((gemm_nt_128<EPI, 2, 0, 2, 2>), dim3(blocks), dim3(256), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr);
+            hipLaunchKernelGGL((gemm_nt_128<EPI, 2, 0, 2, 2>), dim3(blocks), dim3(256), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr, ea);
         }
         VSK_CHECK_LAUNCH();
         return 0;
@@ -1718,11 +1761,11 @@ static int launch_gemm(const float *A, const float *W, const float *Wf, const fl
         if (N % 256 == 0 && M > 128) {
             const int blocks = persistent_blocks(((M + 255) / 256) * (N / 256), 1);
             if (blocks < 0) return (int)hipErrorInvalidDevice;
-            hipLaunchKernelGGL((gemm_nt_128<EPI, 4, 0, 4, 1>), dim3(blocks), dim3(512), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr);
+            hipLaunchKernelGGL((gemm_nt_128<EPI, 4, 0, 4, 1>), dim3(blocks), dim3(512), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr, ea);
         } else {
             const int blocks = persistent_blocks(((M + 127) / 128) * ((N + 127) / 128), 2);
             if (blocks < 0) return (int)hipErrorInvalidDevice;
-            hipLaunchKernelGGL((gemm_nt_128<EPI, 2, 0, 2, 1>), dim3(blocks), dim3(256), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr);
+            hipLaunchKernelGGL((gemm_nt_128<EPI, 2, 0, 2, 1>), dim3(blocks), dim3(256), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr, ea);
         }
         VSK_CHECK_LAUNCH();
         return 0;
@@ -1730,28 +1773,28 @@ static int launch_gemm(const float *A, const float *W, const float *Wf, const fl
     if (Wf != nullptr && M <= skinny_max_rows() && N % 32 == 0 && K % 128 == 0) {
         if (const int attr_rc = VSK_ALLOW_BIG_LDS((skinny2_gemm<EPI, 0>))) return attr_rc;
         dim3 grid((M + 31) / 32, (N + 127) / 128);
-        hipLaunchKernelGGL((skinny2_gemm<EPI, 0>), grid, dim3(256), skinny2_lds(K), st, A, Wf, bias, C, M, N, K, pe, T, H, dh);
+        hipLaunchKernelGGL((skinny2_gemm<EPI, 0>), grid, dim3(256), skinny2_lds(K), st, A, Wf, bias, C, M, N, K, pe, T, H, dh, ea);
         VSK_CHECK_LAUNCH();
         return 0;
     }
     if (M <= skinny_max_rows() && N % 32 == 0 && K % 128 == 0) {
         dim3 grid((M + 31) / 32, (N + 127) / 128);
-        hipLaunchKernelGGL((skinny_gemm<EPI>), grid, dim3(256), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh);
+        hipLaunchKernelGGL((skinny_gemm<EPI>), grid, dim3(256), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, ea);
         VSK_CHECK_LAUNCH();
         return 0;
     }
     if (use_wide_tiles(M, N) && N % 256 == 0 && !vsk_options().gemm_nj2) {
         const int blocks = persistent_blocks(((M + 255) / 256) * (N / 256), 1);
         if (blocks < 0) return (int)hipErrorInvalidDevice;
-        hipLaunchKernelGGL((gemm_nt_128<EPI, 4, 0, 4, 0>), dim3(blocks), dim3(512), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr);
+        hipLaunchKernelGGL((gemm_nt_128<EPI, 4, 0, 4, 0>), dim3(blocks), dim3(512), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr, ea);
     } else if (use_wide_tiles(M, N)) {
         const int blocks = persistent_blocks(((M + 255) / 256) * ((N + 127) / 128), 1);
         if (blocks < 0) return (int)hipErrorInvalidDevice;
-        hipLaunchKernelGGL((gemm_nt_128<EPI, 4, 0, 2, 0>), dim3(blocks), dim3(512), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr);
+        hipLaunchKernelGGL((gemm_nt_128<EPI, 4, 0, 2, 0>), dim3(blocks), dim3(512), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr, ea);
     } else {
         const int blocks = persistent_blocks(((M + 127) / 128) * ((N + 127) / 128), 2);
         if (blocks < 0) return (int)hipErrorInvalidDevice;
-        hipLaunchKernelGGL((gemm_nt_128<EPI, 2, 0, 2, 0>), dim3(blocks), dim3(256), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr);
+        hipLaunchKernelGGL((gemm_nt_128<EPI, 2, 0, 2, 0>), dim3(blocks), dim3(256), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr, ea);
     }
     VSK_CHECK_LAUNCH();
     return 0;
@@ -1762,6 +1805,19 @@ int vsk_linear(const float *A, const float *W, const float *Wf, const float *bia
     if (pe != nullptr) return launch_gemm<EPI_PE>(A, W, Wf, bias, C, M, N, K, pe, T, 0, 0, bf16, st);
     if (relu) return launch_gemm<EPI_RELU>(A, W, Wf, bias, C, M, N, K, nullptr, 1, 0, 0, bf16, st);
     return launch_gemm<EPI_BIAS>(A, W, Wf, bias, C, M, N, K, nullptr, 1, 0, 0, bf16, st);
+}
+
+// training path: C = (gate > 0 ? (A W^T + bias) * scale : 0), gate [M,N] - the ReLU / mlp.dropout backward in the
+// epilogue of the fc2 dgrad GEMM (exact fp32 kernels only)
+int vsk_linear_gate(const float *A, const float *W, const float *bias, const float *gate, float scale, float *C, int M,
+                    int N, int K, hipStream_t st) {
+    return launch_gemm<EPI_GATE>(A, W, nullptr, bias, C, M, N, K, gate, 1, 0, 0, 0, st, EpiArgs{0ull, 0u, 0.f, scale});
+}
+
+// training path: C = dropout_{seed,site,p}(relu(A W^T + bias)) - mlp.fc1 + ReLU + mlp.dropout in one GEMM
+int vsk_linear_relu_dropout(const float *A, const float *W, const float *Wf, const float *bias, float *C, int M, int N,
+                            int K, unsigned long long seed, unsigned site, float p, hipStream_t st) {
+    return launch_gemm<EPI_RELU_DROP>(A, W, Wf, bias, C, M, N, K, nullptr, 1, 0, 0, 0, st, EpiArgs{seed, site, p, 0.f});
 }
 
 #ifdef VS_WITH_DIAG

@@ -191,8 +191,11 @@ int vs_train_forward(const vs_weights *w, const float *x, const uint8_t *key_pad
         VST_LAUNCH(vsk_linear(sv + A.att, w->p(P.wo), w->p(P.f_wo), w->p(P.bo), a, M, d, d, 0, nullptr, 1, 0, st));       // :163
         VST_LAUNCH(vst_rows_fwd(a, h_in, w->p(P.ln1g), w->p(P.ln1b), sv + A.z1, sv + A.y1, nullptr, sv + A.st1, M, d,
                                 seed, VS_SITE_LAYER(l, VS_SITE_DROP1), p, nullptr, nullptr, 0, nullptr, st));              // :107
-        VST_LAUNCH(vsk_linear(sv + A.y1, w->p(P.w1), w->p(P.f_w1), w->p(P.b1), sv + A.ffn, M, 4 * d, d, 1, nullptr, 1, 0, st));   // :181
-        if (p > 0.f) VST_LAUNCH(vst_dropout_rows(sv + A.ffn, M, 4 * d, seed, VS_SITE_LAYER(l, VS_SITE_MLP), p, st));
+        if (p > 0.f)        // fc1 + ReLU + mlp.dropout in one GEMM epilogue (:181)
+            VST_LAUNCH(vsk_linear_relu_dropout(sv + A.y1, w->p(P.w1), w->p(P.f_w1), w->p(P.b1), sv + A.ffn, M, 4 * d, d, seed,
+                                               VS_SITE_LAYER(l, VS_SITE_MLP), p, st));
+        else
+            VST_LAUNCH(vsk_linear(sv + A.y1, w->p(P.w1), w->p(P.f_w1), w->p(P.b1), sv + A.ffn, M, 4 * d, d, 1, nullptr, 1, 0, st));
         VST_LAUNCH(vsk_linear(sv + A.ffn, w->p(P.w2), w->p(P.f_w2), w->p(P.b2), a, M, d, 4 * d, 0, nullptr, 1, 0, st));   // :182
         VST_LAUNCH(vst_rows_fwd(a, sv + A.y1, w->p(P.ln2g), w->p(P.ln2b), sv + A.z2, sv + A.y2, last ? hidden : nullptr,
                                 sv + A.st2, M, d, seed, VS_SITE_LAYER(l, VS_SITE_DROP2), p,
@@ -263,9 +266,9 @@ int vs_train_backward(vs_weights *w, const float *x, const uint8_t *key_pad_mask
         const float *dm = p > 0.f ? dbr : dz;
         // mlp.fc2: weight/bias gradient, then the gradient of its input
         VST_LAUNCH(vst_wgrad(dm, d, sv + A.ffn, 4 * d, M, d, 4 * d, G.w2, nullptr, nullptr, G.b2, nullptr, nullptr, d, wg, st));
-        VST_LAUNCH(vsk_linear(dm, w->tp(Q.t_w2), nullptr, zeros, gf, M, 4 * d, d, 0, nullptr, 1, 0, st));
-        // mlp.dropout + ReLU: the saved activation is > 0 exactly where both let the value through
-        VST_LAUNCH(vst_gate_bwd(gf, sv + A.ffn, (size_t)M * 4 * d, p > 0.f ? 1.0f / (1.0f - p) : 1.0f, st));
+        // ... through mlp.dropout + ReLU in the GEMM's epilogue: the saved activation is > 0 exactly where both let
+        // the value through
+        VST_LAUNCH(vsk_linear_gate(dm, w->tp(Q.t_w2), zeros, sv + A.ffn, p > 0.f ? 1.0f / (1.0f - p) : 1.0f, gf, M, 4 * d, d, st));
         VST_LAUNCH(vst_wgrad(gf, 4 * d, sv + A.y1, d, M, 4 * d, d, G.w1, nullptr, nullptr, G.b1, nullptr, nullptr, 4 * d, wg, st));
         // d y1 = dz2 (residual) + d(fc1 input): the residual rides in the GEMM epilogue
         VST_LAUNCH(vsk_linear(gf, w->tp(Q.t_w1), nullptr, zeros, dy1, M, d, 4 * d, 0, dz, M, 0, st));
