@@ -123,6 +123,12 @@ int vs_train_dropout_mask_attention(uint8_t *keep, int32_t B, int32_t H, int32_t
                                     float p, void *stream);
 int vs_train_dropout_mask_rows(uint8_t *keep, int32_t M, int32_t cols, uint64_t seed, uint32_t site, float p,
                                void *stream);
+/* Test hook: where a field of layer `layer` lives in the activation record of vs_train_forward (byte offset and
+ * float count).  field 0: the MLP activation dropout(relu(fc1)) [B*T, 4*d_model] - its sign pattern is the ReLU /
+ * dropout gate the backward applies, which a float64 checker must share (a ReLU input within fp32 rounding of zero
+ * may switch the other way in float64); 1: attention output [B*T, d]; 2: y1 [B*T, d]; 3: y2 [B*T, d]. */
+int vs_train_saved_field(const vs_weights *w, int32_t B, int32_t T, int32_t layer, int32_t field, size_t *offset_bytes,
+                         size_t *count);
 /* module numbers (`site`) of the dropouts: embedding = 0; layer l: 1 + 4*l + {0 attention, 1 dropout1, 2 mlp, 3 dropout2} */
 uint32_t vs_train_dropout_site(int32_t layer, int32_t which);
 

@@ -229,6 +229,21 @@ def test_dropout_hash_statistics(vsa):
 # ---------------------------------------------------------------------------------------------
 # whole model WITH dropout: explicit-mask float64 model fed with the library's masks
 # ---------------------------------------------------------------------------------------------
+def _hip_gates(vsa, module, out_tensor, B, T, d, L):
+    """The ReLU-and-dropout gate the HIP backward applies, per layer: sign pattern of the MLP activation in the
+    activation record the forward left for its backward (vs_train_saved_field)."""
+    lib = vsa._lib.load()
+    saved = out_tensor.grad_fn.saved_tensors[2]
+    handle = module._packed.handle
+    gates = {}
+    for l in range(L):
+        off, cnt = C.c_size_t(), C.c_size_t()
+        vsa._lib.check(lib.vs_train_saved_field(handle, B, T, l, 0, C.byref(off), C.byref(cnt)))
+        act = saved[off.value: off.value + 4 * cnt.value].view(torch.float32).view(B, T, 4 * d)
+        gates["gate%d" % l] = (act > 0).cpu()
+    return gates
+
+
 def _library_masks(vsa, B, T, d, H, L, seed, p, p_embed):
     lib = vsa._lib.load()
     M = B * T
@@ -276,7 +291,10 @@ def test_training_step_with_dropout_matches_explicit_mask_model(vsa, H, d, L, B,
     masks = _library_masks(vsa, B, T, d, H, L, seed, p, p_embed)
     params = {k: v.double().clone().requires_grad_(k != "embedding_layer.positional_encoding.pos_embedding") for k, v in sd.items()}
     x64 = x.double().clone().requires_grad_(True)
-    rl, rh = torch_ref.forward_with_masks(params, x64, mask, H, p, p_embed, masks)
+    # the checker shares the implementation's ReLU-and-dropout gate (a ReLU input within fp32 rounding of zero may fall
+    # on the other side in float64; the gate pattern is read from the forward's activation record)
+    gates = _hip_gates(vsa, m, pred, B, T, d, L)
+    rl, rh = torch_ref.forward_with_masks(params, x64, mask, H, p, p_embed, masks, None, gates)
     scale = torch.ones(B, T, dtype=torch.float64) if mask is None else (~mask).double()
     rloss = (((rl.squeeze(2) - target.double()) * scale) ** 2).mean() + 1e-3 * rh.sum()
     rloss.backward()

@@ -15,10 +15,15 @@ def _drop(t, keep, p):
     return t * keep.to(t.dtype) / (1.0 - p)
 
 
-def forward_with_masks(params, x, mask, num_heads, p=0.0, p_embed=0.0, masks=None):
+def forward_with_masks(params, x, mask, num_heads, p=0.0, p_embed=0.0, masks=None, stats=None, gates=None):
     """params: dict name -> tensor (reference state_dict names, any float dtype, may require grad).
     masks: dict with 'embed' [B,T,d] and per layer l 'attn%d' [B,H,T,T], 'drop1_%d' [B,T,d], 'mlp%d' [B,T,4d],
-    'drop2_%d' [B,T,d] (bool/uint8, 1 = kept).  Returns (logits [B,T,nc], hidden [B,T,d])."""
+    'drop2_%d' [B,T,d] (bool/uint8, 1 = kept).  Returns (logits [B,T,nc], hidden [B,T,d]).
+    stats (optional dict): receives 'min_abs_fc1' = the smallest |fc1 pre-activation| of the run - a ReLU whose input
+    is within fp32 rounding of zero may legitimately switch the other way in an fp32 implementation.
+    gates (optional dict 'gate%d' -> bool [B,T,4d]): the implementation's own ReLU-and-dropout gate of layer l (the sign
+    pattern of its saved MLP activation); when given it replaces relu + mlp dropout, so checker and implementation
+    differentiate the SAME piecewise-linear function even where a ReLU input is within rounding of zero."""
     masks = masks or {}
     B, T, _ = x.shape
     d = params["embedding_layer.feature_transform.weight"].shape[0]
@@ -44,7 +49,13 @@ def forward_with_masks(params, x, mask, num_heads, p=0.0, p_embed=0.0, masks=Non
         o = torch.matmul(w, v).permute(0, 2, 1, 3).contiguous().view(B, T, d)
         o = lin(o, "sa.feature_projection")
         h = F.layer_norm(_drop(o, masks.get("drop1_%d" % l), p) + h, (d,), params[pre + "norm1.weight"], params[pre + "norm1.bias"], 1e-5)
-        f = _drop(F.relu(lin(h, "mlp.fc1")), masks.get("mlp%d" % l), p)
+        pre_act = lin(h, "mlp.fc1")
+        if stats is not None:
+            stats["min_abs_fc1"] = min(stats.get("min_abs_fc1", float("inf")), pre_act.detach().abs().min().item())
+        if gates is not None:
+            f = pre_act * gates["gate%d" % l].to(pre_act.dtype) / (1.0 - p)
+        else:
+            f = _drop(F.relu(pre_act), masks.get("mlp%d" % l), p)
         f = lin(f, "mlp.fc2")
         h = F.layer_norm(_drop(f, masks.get("drop2_%d" % l), p) + h, (d,), params[pre + "norm2.weight"], params[pre + "norm2.bias"], 1e-5)
     return F.linear(h, params["final_layer.weight"], params["final_layer.bias"]), h

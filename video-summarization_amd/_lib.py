@@ -43,7 +43,7 @@ EVAL_EXPORTS = ("vs_eval_upsample", "vs_eval_knapsack", "vs_eval_generate_summar
 TRAIN_EXPORTS = ("vs_train_saved_bytes", "vs_train_workspace_bytes", "vs_train_forward", "vs_train_backward",
                  "vs_mse_mask_loss_forward", "vs_mse_mask_loss_backward", "vs_train_attention_forward",
                  "vs_train_attention_backward", "vs_train_wgrad_scratch_floats", "vs_train_wgrad",
-                 "vs_train_dropout_mask_attention", "vs_train_dropout_mask_rows", "vs_train_dropout_site",
+                 "vs_train_dropout_mask_attention", "vs_train_dropout_mask_rows", "vs_train_dropout_site", "vs_train_saved_field",
                  "vs_pretrain_head_state_bytes", "vs_pretrain_head_workspace_bytes", "vs_pretrain_head_forward",
                  "vs_pretrain_head_backward")
 NUM_STAGES = 6
@@ -264,6 +264,9 @@ def load() -> C.CDLL:
         lib.vs_pretrain_head_backward.restype = C.c_int
         lib.vs_pretrain_head_backward.argtypes = ([C.c_void_p] * 8 + [C.c_int32] * 4 + [C.c_float, C.c_int32]
                                                   + [C.c_void_p] * 5 + [C.c_size_t, C.c_void_p])
+        lib.vs_train_saved_field.restype = C.c_int
+        lib.vs_train_saved_field.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_size_t),
+                                             C.POINTER(C.c_size_t)]
         lib.vs_train_dropout_site.restype = C.c_uint32
         lib.vs_train_dropout_site.argtypes = [C.c_int32, C.c_int32]
         lib.vs_profile_enable.restype = C.c_int

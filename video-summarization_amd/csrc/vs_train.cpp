@@ -150,6 +150,23 @@ size_t vs_train_workspace_bytes(const vs_weights *w, int32_t B, int32_t T) {
     return work_layout(w->desc, B, T).total * sizeof(float);
 }
 
+int vs_train_saved_field(const vs_weights *w, int32_t B, int32_t T, int32_t layer, int32_t field, size_t *offset_bytes,
+                         size_t *count) {
+    if (!w || !offset_bytes || !count || B <= 0 || T <= 0 || layer < 0 || layer >= w->desc.num_layers)
+        return failf(VS_ERR_INVALID, "saved_field: bad arguments");
+    const SavedLayout S = saved_layout(w->desc, B, T);
+    const LayerSaved &A = S.layers[layer];
+    const size_t Md = (size_t)B * T * w->desc.d_model;
+    switch (field) {
+        case 0: *offset_bytes = A.ffn * sizeof(float); *count = 4 * Md; break;
+        case 1: *offset_bytes = A.att * sizeof(float); *count = Md; break;
+        case 2: *offset_bytes = A.y1 * sizeof(float); *count = Md; break;
+        case 3: *offset_bytes = A.y2 * sizeof(float); *count = Md; break;
+        default: return failf(VS_ERR_INVALID, "saved_field: unknown field %d", field);
+    }
+    return VS_OK;
+}
+
 uint32_t vs_train_dropout_site(int32_t layer, int32_t which) { return layer < 0 ? VS_SITE_EMBED : VS_SITE_LAYER(layer, which); }
 
 int vs_train_forward(const vs_weights *w, const float *x, const uint8_t *key_pad_mask, int32_t B, int32_t T,
