@@ -285,15 +285,15 @@ def test_training_step_with_dropout_matches_explicit_mask_model(vsa, H, d, L, B,
     pred, hidden = m(xd, md)
     mk = md if md is not None else torch.zeros(B, T, dtype=torch.bool, device=_dev())
     loss = vsa.mse_with_mask_loss(pred, target.to(_dev()), mk) + 1e-3 * hidden.sum()
+    # the checker shares the implementation's ReLU-and-dropout gate (a ReLU input within fp32 rounding of zero may fall
+    # on the other side in float64): read it from the forward's activation record BEFORE backward frees it
+    gates = _hip_gates(vsa, m, pred, B, T, d, L)
     loss.backward()
     torch.cuda.synchronize()
     # float64 model with the library's masks
     masks = _library_masks(vsa, B, T, d, H, L, seed, p, p_embed)
     params = {k: v.double().clone().requires_grad_(k != "embedding_layer.positional_encoding.pos_embedding") for k, v in sd.items()}
     x64 = x.double().clone().requires_grad_(True)
-    # the checker shares the implementation's ReLU-and-dropout gate (a ReLU input within fp32 rounding of zero may fall
-    # on the other side in float64; the gate pattern is read from the forward's activation record)
-    gates = _hip_gates(vsa, m, pred, B, T, d, L)
     rl, rh = torch_ref.forward_with_masks(params, x64, mask, H, p, p_embed, masks, None, gates)
     scale = torch.ones(B, T, dtype=torch.float64) if mask is None else (~mask).double()
     rloss = (((rl.squeeze(2) - target.double()) * scale) ** 2).mean() + 1e-3 * rh.sum()

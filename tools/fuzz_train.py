@@ -63,12 +63,12 @@ def run(budget, seed, progress=True):
         pred, hidden = m(xd, md)
         mk = md if md is not None else torch.zeros(B, T, dtype=torch.bool, device=dev)
         loss = pkg.mse_with_mask_loss(pred, target.to(dev), mk) + hidden_w * (hidden * R.to(dev)).sum()
+        gates = tht._hip_gates(pkg, m, pred, B, T, d, L)      # before backward frees the activation record
         loss.backward()
         masks = tht._library_masks(pkg, B, T, d, H, L, seed64, p, p_embed) if (p > 0 or p_embed > 0) else None
         params = {k: v.double().clone().requires_grad_("pos_embedding" not in k) for k, v in sd.items()}
         x64 = x.double().clone().requires_grad_(True)
         stats = {}
-        gates = tht._hip_gates(pkg, m, pred, B, T, d, L)
         rl, rh = torch_ref.forward_with_masks(params, x64, mask, H, p, p_embed, masks, stats, gates)
         risky = False
         rtol = RTOL
