@@ -5,7 +5,7 @@ SimNet in train mode with dropout 0 + reference utils.mse_with_mask_loss); (2) a
 EXPLICIT dropout masks (tests/torch_ref.py) fed with the very masks the library draws, for everything dropout touches.
 
 Tolerances (fp32 arithmetic against a float64 truth): per tensor max|err| <= 1e-4 absolute AND <= 1e-3 of the tensor's
-largest entry (+1e-7 for gradients that are analytically zero, e.g. the key bias).  Observed: ~1e-6 relative."""
+largest entry (+1e-6 for gradients that are analytically zero, e.g. the key bias: a sum that cancels).  Observed: ~1e-6 relative."""
 import ctypes as C
 import json
 import math
@@ -35,7 +35,7 @@ def _close(got, want, what="", atol=ATOL, rtol=RTOL):
     got, want = got.detach().double().cpu(), want.detach().double().cpu()
     err = (got - want).abs().max().item()
     scale = want.abs().max().item()
-    assert (atol is None or err <= atol) and err <= rtol * scale + 1e-7, "%s: max err %.3e (max |want| %.3e)" % (what, err, scale)
+    assert (atol is None or err <= atol) and err <= rtol * scale + 1e-6, "%s: max err %.3e (max |want| %.3e)" % (what, err, scale)
     return err / (scale + 1e-30)
 
 
@@ -96,7 +96,7 @@ def test_gradients_match_reference_golden(vsa, case):
         tot, nrm, gmax, ref32 = z["s:" + k]
         got = g2[rows.to(g2.device)].double().cpu()
         err = (got - want.double()).abs().max().item()
-        assert err <= ATOL and err <= RTOL * gmax + 1e-7, "%s: err %.3e, max|g| %.3e (reference fp32 own err %.3e)" % (k, err, gmax, ref32)
+        assert err <= ATOL and err <= RTOL * gmax + 1e-6, "%s: err %.3e, max|g| %.3e (reference fp32 own err %.3e)" % (k, err, gmax, ref32)
         # whole-tensor checks for the sampled ones: sum and L2 norm
         assert abs(g.double().sum().item() - tot) <= 1e-3 * max(abs(tot), nrm) + 1e-7, k     # coherent over a row: looser
         assert abs(g.double().norm().item() - nrm) <= 1e-4 * nrm + 1e-7, k
