@@ -58,7 +58,6 @@ struct VskOptions {
     int mlp_fusion;       // VS_MLP_FUSION    (diagnostic builds only)
     int mlp_abl;          // VS_MLP_ABL       (diagnostic builds only)
     int attn_legacy;      // VS_ATTN_LEGACY   (diagnostic builds only)
-    int ln_stagger_pct;   // VS_LN_STAGGER_PCT  start offset of the second block of each CU in gemm_ln_rows, % of one block's MFMA time
 };
 VskOptions &vsk_options();
 // per-device cache of the CU count (one process may drive several GPUs)

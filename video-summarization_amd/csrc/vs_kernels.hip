@@ -597,20 +597,9 @@ __global__ __launch_bounds__(256, 2) void gemm_ln_rows(
     const float *__restrict__ res, const float *__restrict__ gamma, const float *__restrict__ beta,
     float *__restrict__ out, int M, int K,
     const float *__restrict__ score_w, const float *__restrict__ score_b, int num_classes,
-    int sigmoid, float *__restrict__ scores, int stagger_ticks = 0) {
+    int sigmoid, float *__restrict__ scores) {
     constexpr int BM = 128, N = 32 * NT, BK = 16, LD = BK + 4;
     constexpr int WL = (N * BK / 4 + 255) / 256;       // float4 of W per thread per k-tile (N=256: 4)
-    // De-phasing (speed only).  At the bench size the grid is 2 blocks per CU with ONE tile each: every block of the
-    // chip reads its 128 KB of residual / first operands at the same moment and writes its 128 KB of output at the
-    // same moment - two chip-wide HBM bursts (64 MB each) during which no MFMA issues, ~35 % of the kernel at K = 256.
-    // The second half of the grid (the blocks that share a CU with a block of the first half: workgroups are dealt
-    // round-robin, so b and b + gridDim/2 co-reside) starts `stagger_ticks` (100 MHz realtime clock) later: each
-    // half's bursts then run under the other half's MFMAs.  Placement is not guaranteed by HIP - a different
-    // placement only makes the delay useless, never wrong.
-    if (stagger_ticks > 0 && blockIdx.x >= (gridDim.x >> 1)) {
-        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-        while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)stagger_ticks) __builtin_amdgcn_s_sleep(16);
-    }
     __shared__ __attribute__((aligned(16))) float smem[2 * (BM + N) * LD + 4 * N];
     float *gam_s = smem + 2 * (BM + N) * LD, *bet_s = gam_s + N, *sw_s = bet_s + N, *bias_s = sw_s + N;
 
@@ -1979,15 +1968,10 @@ int vsk_linear_res_ln(const float *A, const float *W, const float *Wf, const flo
         int blocks = persistent_blocks((M + 127) / 128);
         if (blocks < 0) return (int)hipErrorInvalidDevice;
         if (blocks > (M + 127) / 128) blocks = (M + 127) / 128;
-        // de-phase the two blocks of a CU when the grid is exactly two blocks per CU (see the kernel); the delay is a
-        // fraction of one block's MFMA time: K/16 k-tiles x 8*NT MFMAs x 64 cycles, two blocks sharing the pipe
-        int stagger = 0;
-        if (blocks == 2 * vsk_device_cus() && vsk_options().ln_stagger_pct > 0)
-            stagger = (int)((double)(K / 16) * (8.0 * (N / 32)) * 64.0 / 2.4e9 * 1e8 * vsk_options().ln_stagger_pct / 100.0);
 #define VSK_LNR_CASE(NT_)                                                                             \
     case NT_:                                                                                         \
         hipLaunchKernelGGL((gemm_ln_rows<NT_, 0>), dim3(blocks), dim3(256), 0, st, A, W, bias, res, gamma, \
-                           beta, out, M, K, score_w, score_b, num_classes, sigmoid, scores, stagger); \
+                           beta, out, M, K, score_w, score_b, num_classes, sigmoid, scores);          \
         break;
         switch (N / 32) {
             VSK_LNR_CASE(2) VSK_LNR_CASE(4) VSK_LNR_CASE(6) VSK_LNR_CASE(8)

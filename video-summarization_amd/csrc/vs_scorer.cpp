@@ -114,7 +114,7 @@ const OptionName kOptions[] = {
     {"VS_GEMM_NWM2", &VskOptions::gemm_nwm2, 0},         {"VS_GEMM_NJ2", &VskOptions::gemm_nj2, 0},
     {"VS_ATTN_NW4", &VskOptions::attn_nw4, 0},           {"VS_ATTN_LP_SIMPLE", &VskOptions::attn_lp_simple, 0},
     {"VS_MLP_FUSION", &VskOptions::mlp_fusion, 0},       {"VS_MLP_ABL", &VskOptions::mlp_abl, 0},
-    {"VS_ATTN_LEGACY", &VskOptions::attn_legacy, 0},     {"VS_LN_STAGGER_PCT", &VskOptions::ln_stagger_pct, 0},
+    {"VS_ATTN_LEGACY", &VskOptions::attn_legacy, 0},
 };
 int option_from_env(const OptionName &o) {
     const char *e = getenv(o.name);
