@@ -1,13 +1,22 @@
+# Round checkpoint on the GPU box: the whole -m gpu suite, smoke(), the headline bench, the HBM-traffic PMC passes, the
+# rocprofv3 kernel-trace of the same bench command, PMC summaries, M-B and training profiles.  Outputs: gpurun_out/rNN/
 set -e
+TAG=${1:-r02b}
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r02a
-python -m pytest tests -x -q -m gpu > gpurun_out/r02a/gputest.log 2>&1 || { tail -40 gpurun_out/r02a/gputest.log; exit 1; }
-tail -3 gpurun_out/r02a/gputest.log
-python bench.py > gpurun_out/r02a/bench.json 2> gpurun_out/r02a/bench.err
-cat gpurun_out/r02a/bench.json
-bash tools/collect_traffic.sh > gpurun_out/r02a/traffic.log 2>&1
-cp gpurun_out/traffic.json gpurun_out/r02a/traffic.json
-cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/r02a/prof -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras > $GRAFT_REPO_ROOT/gpurun_out/r02a/prof_bench.json 2>$GRAFT_REPO_ROOT/gpurun_out/r02a/prof.err
-cd $GRAFT_REPO_ROOT && bash tools/pmc_summary.sh > gpurun_out/r02a/pmc_summary.txt 2>&1
+mkdir -p gpurun_out/$TAG
+python -m pytest tests -x -q -m gpu > gpurun_out/$TAG/gputest.log 2>&1 || { tail -40 gpurun_out/$TAG/gputest.log; exit 1; }
+tail -3 gpurun_out/$TAG/gputest.log
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+python bench.py > gpurun_out/$TAG/bench.json 2> gpurun_out/$TAG/bench.err
+cat gpurun_out/$TAG/bench.json
+bash tools/collect_traffic.sh > gpurun_out/$TAG/traffic.log 2>&1
+cp gpurun_out/traffic.json gpurun_out/$TAG/traffic.json
+( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/$TAG/prof -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras > $GRAFT_REPO_ROOT/gpurun_out/$TAG/prof_bench.json 2>$GRAFT_REPO_ROOT/gpurun_out/$TAG/prof.err )
+( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/$TAG/prof_mb -- python3 $GRAFT_REPO_ROOT/bench.py --model B --steps 20 --warmup 5 --no-cpu-baseline --no-extras > $GRAFT_REPO_ROOT/gpurun_out/$TAG/prof_bench_mb.json 2>$GRAFT_REPO_ROOT/gpurun_out/$TAG/prof_mb.err )
+( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/$TAG/prof_train -- python3 $GRAFT_REPO_ROOT/tools/bench_train.py --shapes 64x1024 --iters 5 > /dev/null 2>&1 )
+python tools/bench_train.py --torch > gpurun_out/$TAG/bench_train.txt 2>&1
+python tools/bench_train.py --model B --shapes 4x320,64x1024 >> gpurun_out/$TAG/bench_train.txt 2>&1
+bash tools/pmc_cmd.sh gpurun_out/$TAG/pmc_summary.txt bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-extras > /dev/null 2>&1
+bash tools/pmc_cmd.sh gpurun_out/$TAG/pmc_summary_mb.txt bench.py --model B --steps 6 --warmup 2 --no-cpu-baseline --no-extras --no-emulated > /dev/null 2>&1
+python tools/bench_configs.py > gpurun_out/$TAG/bench_configs.txt 2>&1
 echo done
