@@ -148,10 +148,9 @@ __global__ __launch_bounds__(256) void attn_fwd_train(
         l_run = l_run * alpha + ls;
         m_run = m_new;
         if (DROP) {
-            const unsigned cb = rkq + (unsigned)(32 * kt + 4 * h) * DROP_COL_STRIDE;       // key 32 kt + acc_row(e, h)
 #pragma unroll
             for (int e = 0; e < 16; ++e)
-                s[e] = drop_keep_at(ds, cb + (unsigned)((e & 3) + 8 * (e >> 2)) * DROP_COL_STRIDE) ? s[e] * ds.scale : 0.f;
+                s[e] = drop_keep(ds, rkq, (unsigned)(32 * kt + acc_row(e, h))) ? s[e] * ds.scale : 0.f;
         }
 #pragma unroll
         for (int cb = 0; cb < DH / 32; ++cb)
@@ -239,12 +238,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq(
 #pragma unroll
             for (int e = 0; e < 4; ++e) dp = MFMA32(vf[e], dof[g][e], dp);
         }
-        const unsigned cb = rkq + (unsigned)(32 * kt + 4 * h) * DROP_COL_STRIDE;           // key 32 kt + acc_row(e, h)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const float pe = __builtin_amdgcn_exp2f(s[e] - lq);
             float g = dp[e];
-            if (DROP) g = drop_keep_at(ds, cb + (unsigned)((e & 3) + 8 * (e >> 2)) * DROP_COL_STRIDE) ? g * ds.scale : 0.f;
+            if (DROP) g = drop_keep(ds, rkq, (unsigned)(32 * kt + acc_row(e, h))) ? g * ds.scale : 0.f;
             s[e] = pe * (g - dq_delta);
         }
 #pragma unroll
@@ -299,7 +297,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv(
         vf[g] = *(const f32x4 *)(vb + (size_t)kc * DH + 8 * g + 4 * h);
     }
     const float kbias = (ki >= T || (mask != nullptr && mask[(size_t)b * T + kc])) ? NEG_INF : 0.f;
-    const unsigned colmix = (unsigned)ki * DROP_COL_STRIDE;
     f32x16 dk[DH / 32], dv[DH / 32];
 #pragma unroll
     for (int cb = 0; cb < DH / 32; ++cb) { dk[cb] = zero16(); dv[cb] = zero16(); }
@@ -352,7 +349,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv(
                 const float pe = __builtin_amdgcn_exp2f(s[i] + kbias);
                 float g = dp[i], pk = pe;
                 if (DROP) {
-                    const bool keep = drop_keep_at(ds, rk4[e] + colmix);
+                    const bool keep = drop_keep(ds, rk4[e], (unsigned)ki);
                     g = keep ? g * ds.scale : 0.f;
                     pk = keep ? pe * ds.scale : 0.f;
                 }
