@@ -169,8 +169,12 @@ def main():
     dev = torch.device("cuda", local)
     dist = None
     backend = None
-    if world > 1:
+    # VS_BENCH_FORCE_DIST=1: join a process group even with one rank, so that a ONE-GPU box runs the real RCCL
+    # all_gather of the N-GPU path (tests/test_bench_launch.py); the numbers are those of N = 1.
+    force_dist = os.environ.get("VS_BENCH_FORCE_DIST") == "1"
+    if world > 1 or force_dist:
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearse:
             dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -192,16 +196,16 @@ def main():
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)       # disjoint videos per rank
     x_host = torch.randn(B, T, Din, generator=g).pin_memory()
     x = x_host.to(dev)
-    gathered = torch.empty((world * B, T), dtype=torch.float32, device=dev) if world > 1 else None   # rank-major rows
+    gathered = torch.empty((world * B, T), dtype=torch.float32, device=dev) if dist is not None else None   # rank-major rows
 
     def step():
         logits, _hidden = model(x)
-        if world > 1:
+        if dist is not None:
             return dist.all_gather_into_tensor(gathered, logits.view(B, T), async_op=True)
         return None
 
     def fence():
-        if world > 1:
+        if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -270,7 +274,7 @@ def main():
             torch.cuda.synchronize()
             lat_ms = (time.perf_counter() - t1) / 200 * 1e3
 
-    if world > 1:
+    if dist is not None:
         t = torch.tensor([dt, emu[0] if emu else 0.0, emu[1] if emu else 0.0], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t[0].item()
@@ -350,7 +354,7 @@ def main():
                 "speedup_vs_value": round(ev / value, 3), "max_abs_logit_diff_vs_exact": emu[1],
                 "f32_equivalent_tflops": round(ev / world * flops_per_frame / 1e12, 2)}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     return out

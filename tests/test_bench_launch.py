@@ -42,3 +42,13 @@ def test_two_rank_rehearsal_through_the_self_launcher():
                 "--no-emulated", "--no-extras"], {"VS_BENCH_REHEARSE": "1"}, 600)
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 4 and out["value"] > 0
     assert out["collective_backend"] == "gloo" and out["roofline"]["stages"]["attention"]["launches"] == 3 * 4
+
+
+@pytest.mark.gpu
+def test_bench_runs_its_rccl_gather_on_one_gpu():
+    """VS_BENCH_FORCE_DIST=1: one rank, backend 'nccl' - every step's async all_gather_into_tensor of the [B,T] scores
+    and the barriers of the timed region run over RCCL itself (the transport the 8-GPU run uses)."""
+    out = _run(["--gpus", "1", "--steps", "5", "--warmup", "2", "--batch", "4", "--frames", "256", "--no-cpu-baseline",
+                "--no-emulated", "--no-extras"], {"VS_BENCH_FORCE_DIST": "1"}, 600)
+    assert out["n_gpus"] == 1 and out["collective_backend"] == "nccl" and out["value"] > 0
+    assert "RCCL all_gather" in out["config"]["parallelism"]

@@ -71,3 +71,42 @@ def test_two_ranks_with_hip_kernels_equal_one_rank_bit_for_bit(vsa, compute):
         for i in range(len(vids)):
             assert torch.equal(torch.tensor(res[i]), single[i]), (rank, i)
             assert torch.equal(single[i], padded[i]), i          # packed and padded batches: the same bits
+
+
+def _rccl_worker(port, q):
+    """One rank, backend 'nccl' (= RCCL on ROCm): the device-tensor branch of the gather (send / recv buffers on the
+    GPU, all_gather_into_tensor on the device) and of the metric all_reduce, which the gloo runs cannot reach."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    vsa = importlib.import_module("video-summarization_amd")
+    corpus = importlib.import_module("video-summarization_amd.corpus")
+    m = _model(vsa, dev)
+    vids = _corpus(9, 5)
+    with torch.no_grad():
+        plain = corpus.score_corpus(lambda x, mk: m.score(x, mk), vids, device=dev, max_frames=4096)
+        gathered = corpus.score_corpus(lambda x, mk: m.score(x, mk), vids, rank=0, world=1, device=dev, max_frames=4096,
+                                       force_collective=True)
+        t = torch.tensor([1.0, 2.0, 3.0, 4.0], dtype=torch.float64, device=dev)
+        dist.all_reduce(t)
+    ok = dist.get_backend() == "nccl" and all(torch.equal(plain[i], gathered[i]) for i in range(len(vids))) and t.tolist() == [1.0, 2.0, 3.0, 4.0]
+    q.put(bool(ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rccl_backend_branch_with_one_rank(vsa):
+    """RCCL itself on the one GPU there is: a one-rank 'nccl' group runs the score gather and the metric all_reduce with
+    DEVICE tensors (the N-GPU code path of bench.py / score_corpus / val_step_batched, minus the second rank)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(port, q))
+    p.start()
+    assert q.get(timeout=300) is True
+    p.join(timeout=120)
+    assert p.exitcode == 0

@@ -78,11 +78,12 @@ PackedScoreFn = Callable[[torch.Tensor, List[int]], torch.Tensor]           # (x
 
 def score_corpus(score_fn: ScoreFn, videos: Sequence[torch.Tensor], rank: int = 0, world: int = 1,
                  group=None, device=None, max_frames: int = 65536,
-                 packed_fn: Optional[PackedScoreFn] = None) -> Dict[int, torch.Tensor]:
+                 packed_fn: Optional[PackedScoreFn] = None, force_collective: bool = False) -> Dict[int, torch.Tensor]:
     """Scores every video once across `world` ranks and returns {video index: scores [T_i]} on EVERY
     rank (CPU tensors).  `score_fn` is `SimNet.score` on a GPU box.  With world == 1 no
-    `torch.distributed` call is made.  With `packed_fn` (`SimNet.score_packed`) the batches are PACKED - the videos'
-    frames concatenated, no sentinel padding, no mask - instead of padded; the scores are the same bits."""
+    `torch.distributed` call is made (unless `force_collective`: the gather then runs over a one-rank group - how the
+    RCCL branch is exercised on a one-GPU box).  With `packed_fn` (`SimNet.score_packed`) the batches are PACKED - the
+    videos' frames concatenated, no sentinel padding, no mask - instead of padded; the scores are the same bits."""
     lengths = [int(v.shape[0]) for v in videos]
     mine = plan_shards(lengths, world)[rank]
     local: Dict[int, torch.Tensor] = {}
@@ -103,7 +104,7 @@ def score_corpus(score_fn: ScoreFn, videos: Sequence[torch.Tensor], rank: int = 
                 row += lengths[i]
             else:
                 local[i] = sh[b, : lengths[i]].clone()
-    if world == 1:
+    if world == 1 and not force_collective:
         return local
     import torch.distributed as dist
     # one padded all_gather: [n_max, 1 + t_max] rows = (video id, scores...), -1 id = empty slot
