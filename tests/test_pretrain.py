@@ -118,3 +118,40 @@ def test_pretrain_head_kernels_match_float64_formulas(vsa, B, T, d, pen, masked)
         err = (a.grad.double().cpu() - r.grad).abs().max().item()
         scale = r.grad.abs().max().item()
         assert err <= 2e-5 * scale + 1e-9, "%s: err %.3e, max %.3e" % (name, err, scale)
+
+
+@pytest.mark.gpu
+def test_pretrain_loop_like_the_reference(vsa):
+    """pretrain.py:49-86 in shape: autocast, the three losses combined (main + 0.5 center + repel), GradScaler, Adam on
+    the ENCODER's parameters only (:40), sentinel-padded batches with the caller-side mask (:57).  The loss must fall
+    and two runs from one torch seed must be bit-identical (HIP encoder with dropout + HIP head, ordered reductions)."""
+    synth = vsa.synth
+
+    def run():
+        torch.manual_seed(4321)
+        m = vsa.PretrainModel(num_heads=4, feature_dim=256, num_layers=2, sparsity=0.5, dropout=0.2, num_classes=1,
+                              use_pos=True).to(DEV)
+        m.encoder.load_state_dict(synth.make_state_dict(256, 2, 3))
+        opt = torch.optim.Adam(m.encoder.parameters(), lr=1e-4, weight_decay=5e-4)
+        scaler = torch.amp.GradScaler("cuda")
+        features = synth.make_features(4, 90, 8, "pool5", [90, 71, 60, 33]).to(DEV)
+        vid_rep = torch.randn(4, 512, generator=torch.Generator().manual_seed(2)).to(DEV)
+        m.train()
+        losses = []
+        for _ in range(10):
+            mask = (features[:, :, 0] == 1000)                                   # pretrain.py:57
+            with torch.amp.autocast("cuda"):
+                main_loss, center_loss, repel_loss = m(features, vid_rep, mask)
+                loss = main_loss + center_loss * 0.5 + 1. * repel_loss           # pretrain.py:62
+            opt.zero_grad()
+            scaler.scale(loss).backward()
+            scaler.step(opt)
+            scaler.update()
+            losses.append(loss.item())
+        assert m.video_transform.weight.grad is not None                        # the head's own Linear gets gradients too
+        return losses, [p.detach().clone() for p in m.parameters()]
+
+    l1, p1 = run()
+    l2, p2 = run()
+    assert all(np.isfinite(l1)) and min(l1[-3:]) < l1[0]
+    assert l1 == l2 and all(torch.equal(a, b) for a, b in zip(p1, p2))
