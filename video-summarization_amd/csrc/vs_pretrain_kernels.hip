@@ -130,7 +130,8 @@ __global__ __launch_bounds__(256) void head_final(const float *__restrict__ scor
         float acc = 0.f;
         for (int c = 0; c < L.nc; ++c) acc += part[(size_t)c * (2 * F + 4) + i];
         vec[i / F][i % F] = acc;
-        (i < F ? scratch + L.pooled + (size_t)b * F : scratch + L.sumx + (size_t)b * F - F)[i] = acc;
+        if (i < F) scratch[L.pooled + (size_t)b * F + i] = acc;
+        else scratch[L.sumx + (size_t)b * F + (i - F)] = acc;
     }
     for (int i = tid; i < F; i += 256) vec[2][i] = vid[(size_t)b * F + i];
     __syncthreads();

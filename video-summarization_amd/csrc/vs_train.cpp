@@ -79,14 +79,12 @@ WorkLayout work_layout(const vs_model_desc &D, int B, int T) {
     W.delta = take((size_t)B * D.num_heads * T);
     const size_t nblk = (size_t)vst_ln_bwd_blocks((int)M);
     W.part = take(nblk * (2 * d + 2));
-    size_t wg = 0;
-    const int Mi = (int)M, di = (int)d;
+    size_t wg = 0;                      // the largest split-partial area of the five weight shapes [N, K]
     const size_t shapes[5][2] = {{d, 4 * d}, {4 * d, d}, {d, d}, {3 * d, d}, {d, din}};
     for (auto &s : shapes) {
-        const size_t f = vst_wgrad_workspace_floats(Mi, (int)s[0], (int)s[1]);
+        const size_t f = vst_wgrad_workspace_floats((int)M, (int)s[0], (int)s[1]);
         wg = f > wg ? f : wg;
     }
-    (void)di;
     W.wg = take(wg);
     W.total = off;
     return W;
@@ -101,6 +99,9 @@ int check_common(const vs_weights *w, const float *x, int B, int T, const vs_dro
     if (drop && (drop->p < 0.f || drop->p >= 1.f || drop->p_embed < 0.f || drop->p_embed >= 1.f))
         return failf(VS_ERR_INVALID, "dropout probabilities must be in [0, 1): p=%g p_embed=%g", drop->p, drop->p_embed);
     if ((uintptr_t)x & 15) return failf(VS_ERR_INVALID, "x must be 16-byte aligned");
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev != w->device)
+        return failf(VS_ERR_INVALID, "called on device %d, the weights handle lives on device %d", dev, w->device);
     return VS_OK;
 }
 
