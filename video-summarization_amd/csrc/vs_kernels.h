@@ -9,8 +9,8 @@
 int vsk_linear(const float *A, const float *W, const float *Wf, const float *bias, float *C, int M, int N, int K,
                int relu, const float *pe, int T, int bf16, hipStream_t st);
 // training-path epilogues on the same GEMM kernels (exact fp32): ReLU/dropout gate of a dgrad; fc1 + ReLU + dropout
-int vsk_linear_gate(const float *A, const float *W, const float *bias, const float *gate, float scale, float *C, int M,
-                    int N, int K, hipStream_t st);
+int vsk_linear_gate(const float *A, const float *W, const float *Wf, const float *bias, const float *gate, float scale,
+                    float *C, int M, int N, int K, hipStream_t st);
 int vsk_linear_relu_dropout(const float *A, const float *W, const float *Wf, const float *bias, float *C, int M, int N,
                             int K, unsigned long long seed, unsigned site, float p, hipStream_t st);
 int vsk_pack_fragments(const float *W, float *Wf, int N, int K, hipStream_t st);

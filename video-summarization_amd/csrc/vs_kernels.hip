@@ -1809,9 +1809,9 @@ int vsk_linear(const float *A, const float *W, const float *Wf, const float *bia
 
 // training path: C = (gate > 0 ? (A W^T + bias) * scale : 0), gate [M,N] - the ReLU / mlp.dropout backward in the
 // epilogue of the fc2 dgrad GEMM (exact fp32 kernels only)
-int vsk_linear_gate(const float *A, const float *W, const float *bias, const float *gate, float scale, float *C, int M,
-                    int N, int K, hipStream_t st) {
-    return launch_gemm<EPI_GATE>(A, W, nullptr, bias, C, M, N, K, gate, 1, 0, 0, 0, st, EpiArgs{0ull, 0u, 0.f, scale});
+int vsk_linear_gate(const float *A, const float *W, const float *Wf, const float *bias, const float *gate, float scale,
+                    float *C, int M, int N, int K, hipStream_t st) {
+    return launch_gemm<EPI_GATE>(A, W, Wf, bias, C, M, N, K, gate, 1, 0, 0, 0, st, EpiArgs{0ull, 0u, 0.f, scale});
 }
 
 // training path: C = dropout_{seed,site,p}(relu(A W^T + bias)) - mlp.fc1 + ReLU + mlp.dropout in one GEMM

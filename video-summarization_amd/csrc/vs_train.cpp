@@ -115,8 +115,12 @@ int ensure_transposed(vs_weights *w, hipStream_t st) {
         size_t off = 0;
         auto take = [&](size_t n) { size_t o = off; off += align_floats(n); return o; };
         w->t_embed_w = take(d * din);
+        w->tf_embed_w = take(d * din);
         w->tlayers.resize(w->desc.num_layers);
-        for (auto &L : w->tlayers) { L.t_wqkv = take(3 * d * d); L.t_wo = take(d * d); L.t_w1 = take(4 * d * d); L.t_w2 = take(4 * d * d); }
+        for (auto &L : w->tlayers) {
+            L.t_wqkv = take(3 * d * d); L.t_wo = take(d * d); L.t_w1 = take(4 * d * d); L.t_w2 = take(4 * d * d);
+            L.tf_wqkv = take(3 * d * d); L.tf_wo = take(d * d); L.tf_w1 = take(4 * d * d); L.tf_w2 = take(4 * d * d);
+        }
         const size_t nz = 4 * d > din ? 4 * d : din;
         w->zeros = take(nz);
         VST_HIP(hipMalloc((void **)&w->tblob, off * sizeof(float)));
@@ -124,14 +128,19 @@ int ensure_transposed(vs_weights *w, hipStream_t st) {
         w->t_version = ~0ull;
     }
     if (w->t_version == w->version) return VS_OK;
-    VST_LAUNCH(vst_transpose(w->p(w->embed_w), w->tblob + w->t_embed_w, (int)d, (int)din, st));              // [d,din] -> [din,d]
+    // W [N,K] -> W^T [K,N] row-major, and its fragment-major copy for the latency kernels (as vs_weights_pack does for W)
+    auto both = [&](const float *W, size_t t_off, size_t tf_off, int N, int K) -> int {
+        if (int rc = vst_transpose(W, w->tblob + t_off, N, K, st)) return rc;
+        return vsk_pack_fragments(w->tblob + t_off, w->tblob + tf_off, K, N, st);
+    };
+    VST_LAUNCH(both(w->p(w->embed_w), w->t_embed_w, w->tf_embed_w, (int)d, (int)din));                       // [d,din] -> [din,d]
     for (int l = 0; l < w->desc.num_layers; ++l) {
         const LayerOff &P = w->layers[l];
         const LayerOffT &Q = w->tlayers[l];
-        VST_LAUNCH(vst_transpose(w->p(P.wqkv), w->tblob + Q.t_wqkv, (int)(3 * d), (int)d, st));               // [3d,d] -> [d,3d]
-        VST_LAUNCH(vst_transpose(w->p(P.wo), w->tblob + Q.t_wo, (int)d, (int)d, st));
-        VST_LAUNCH(vst_transpose(w->p(P.w1), w->tblob + Q.t_w1, (int)(4 * d), (int)d, st));                   // [4d,d] -> [d,4d]
-        VST_LAUNCH(vst_transpose(w->p(P.w2), w->tblob + Q.t_w2, (int)d, (int)(4 * d), st));                   // [d,4d] -> [4d,d]
+        VST_LAUNCH(both(w->p(P.wqkv), Q.t_wqkv, Q.tf_wqkv, (int)(3 * d), (int)d));                           // [3d,d] -> [d,3d]
+        VST_LAUNCH(both(w->p(P.wo), Q.t_wo, Q.tf_wo, (int)d, (int)d));
+        VST_LAUNCH(both(w->p(P.w1), Q.t_w1, Q.tf_w1, (int)(4 * d), (int)d));                                 // [4d,d] -> [d,4d]
+        VST_LAUNCH(both(w->p(P.w2), Q.t_w2, Q.tf_w2, (int)d, (int)(4 * d)));                                 // [d,4d] -> [4d,d]
     }
     w->t_version = w->version;
     return VS_OK;
@@ -286,17 +295,17 @@ int vs_train_backward(vs_weights *w, const float *x, const uint8_t *key_pad_mask
         VST_LAUNCH(vst_wgrad(dm, d, sv + A.ffn, 4 * d, M, d, 4 * d, G.w2, nullptr, nullptr, G.b2, nullptr, nullptr, d, wg, st));
         // ... through mlp.dropout + ReLU in the GEMM's epilogue: the saved activation is > 0 exactly where both let
         // the value through
-        VST_LAUNCH(vsk_linear_gate(dm, w->tp(Q.t_w2), zeros, sv + A.ffn, p > 0.f ? 1.0f / (1.0f - p) : 1.0f, gf, M, 4 * d, d, st));
+        VST_LAUNCH(vsk_linear_gate(dm, w->tp(Q.t_w2), w->tp(Q.tf_w2), zeros, sv + A.ffn, p > 0.f ? 1.0f / (1.0f - p) : 1.0f, gf, M, 4 * d, d, st));
         VST_LAUNCH(vst_wgrad(gf, 4 * d, sv + A.y1, d, M, 4 * d, d, G.w1, nullptr, nullptr, G.b1, nullptr, nullptr, 4 * d, wg, st));
         // d y1 = dz2 (residual) + d(fc1 input): the residual rides in the GEMM epilogue
-        VST_LAUNCH(vsk_linear(gf, w->tp(Q.t_w1), nullptr, zeros, dy1, M, d, 4 * d, 0, dz, M, 0, st));
+        VST_LAUNCH(vsk_linear(gf, w->tp(Q.t_w1), w->tp(Q.tf_w1), zeros, dy1, M, d, 4 * d, 0, dz, M, 0, st));
         // norm1; d(feature_projection output) = dropout1 mask on dz1
         VST_LAUNCH(vst_ln_bwd(dy1, nullptr, nullptr, 0, sv + A.z1, sv + A.st1, w->p(P.ln1g), dz, p > 0.f ? dbr : nullptr, part,
                               M, d, seed, VS_SITE_LAYER(l, VS_SITE_DROP1), p, st));
         VST_LAUNCH(vst_reduce_rows(part, nblk, 2, d, G.ln1_g, G.ln1_b, nullptr, 1, st));
         const float *da = p > 0.f ? dbr : dz;
         VST_LAUNCH(vst_wgrad(da, d, sv + A.att, d, M, d, d, G.wo, nullptr, nullptr, G.bo, nullptr, nullptr, d, wg, st));
-        VST_LAUNCH(vsk_linear(da, w->tp(Q.t_wo), nullptr, zeros, datt, M, d, d, 0, nullptr, 1, 0, st));
+        VST_LAUNCH(vsk_linear(da, w->tp(Q.t_wo), w->tp(Q.tf_wo), zeros, datt, M, d, d, 0, nullptr, 1, 0, st));
         // attention
         const float *qkv = sv + A.qkv;
         VST_LAUNCH(vst_head_rowdot(datt, sv + A.att, delta, M, T, H, d / H, st));
@@ -305,7 +314,7 @@ int vs_train_backward(vs_weights *w, const float *x, const uint8_t *key_pad_mask
         // q / k / v projections: one [3d, d] weight gradient dealt to the three parameters
         VST_LAUNCH(vst_wgrad(dqkv, 3 * d, h_in, d, M, 3 * d, d, G.wq, G.wk, G.wv, G.bq, G.bk, G.bv, d, wg, st));
         // gradient of the layer input = dz1 (residual) + dqkv Wqkv
-        VST_LAUNCH(vsk_linear(dqkv, w->tp(Q.t_wqkv), nullptr, zeros, g[cur ^ 1], M, d, 3 * d, 0, dz, M, 0, st));
+        VST_LAUNCH(vsk_linear(dqkv, w->tp(Q.t_wqkv), w->tp(Q.tf_wqkv), zeros, g[cur ^ 1], M, d, 3 * d, 0, dz, M, 0, st));
         cur ^= 1;
     }
     // Embedding (simnet.py:211, 237-238): dropout(sparsity) mask, then the Linear
@@ -313,7 +322,7 @@ int vs_train_backward(vs_weights *w, const float *x, const uint8_t *key_pad_mask
     if (p_embed > 0.f) VST_LAUNCH(vst_dropout_rows(gh0, M, d, seed, VS_SITE_EMBED, p_embed, st));
     VST_LAUNCH(vst_wgrad(gh0, d, x, D.in_features, M, d, D.in_features, grads->embed_w, nullptr, nullptr, grads->embed_b,
                          nullptr, nullptr, d, wg, st));
-    if (dx) VST_LAUNCH(vsk_linear(gh0, w->tp(w->t_embed_w), nullptr, zeros, dx, M, D.in_features, d, 0, nullptr, 1, 0, st));
+    if (dx) VST_LAUNCH(vsk_linear(gh0, w->tp(w->t_embed_w), w->tp(w->tf_embed_w), zeros, dx, M, D.in_features, d, 0, nullptr, 1, 0, st));
     return VS_OK;
 }
 

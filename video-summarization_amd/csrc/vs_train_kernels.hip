@@ -426,6 +426,49 @@ __global__ __launch_bounds__(256) void reduce_partials(const float *__restrict__
     }
 }
 
+// One launch for a wgrad's two reductions: blocks [0, nb_w) sum the weight partials (float4), the rest the bias
+// partials (scalars) - at small batch the reductions are launch-latency bound (5 us each, 17 pairs per step).
+__global__ __launch_bounds__(256) void reduce_wgrad(const float *__restrict__ partW, const float *__restrict__ partB, int S,
+                                                    int N, int K, float *w0, float *w1, float *w2, float *b0, float *b1,
+                                                    float *b2, int rows_per_dest, int nb_w) {
+    __shared__ float red[16][64];
+    const int g = threadIdx.x >> 4, v = threadIdx.x & 15;
+    const bool is_w = (int)blockIdx.x < nb_w;
+    const int VEC = is_w ? 4 : 1;
+    const size_t per = is_w ? (size_t)N * K : (size_t)N, nvec = per / VEC;
+    const size_t i = (size_t)(is_w ? blockIdx.x : blockIdx.x - nb_w) * 16 + v;
+    const float *part = is_w ? partW : partB;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (i < nvec) {
+        for (int s = g; s < S; s += 16) {
+            if (is_w) {
+                const f32x4 w = *(const f32x4 *)(part + (size_t)s * per + i * 4);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] += w[q];
+            } else {
+                acc[0] += part[(size_t)s * per + i];
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) red[g][v * 4 + q] = acc[q];
+    __syncthreads();
+    if (g == 0 && i < nvec) {
+        const int cols = is_w ? K : 1;
+        const size_t e = i * VEC;
+        const int row = (int)(e / cols), c = (int)(e - (size_t)row * cols);
+        const int which = row / rows_per_dest;
+        float *d0 = is_w ? w0 : b0, *d1 = is_w ? w1 : b1, *d2 = is_w ? w2 : b2;
+        float *dst = (which == 0 ? d0 : which == 1 ? d1 : d2) + (size_t)(row - which * rows_per_dest) * cols + c;
+        for (int q = 0; q < VEC; ++q) {
+            float tot = red[0][v * 4 + q];
+#pragma unroll
+            for (int gg = 1; gg < 16; ++gg) tot += red[gg][v * 4 + q];
+            dst[q] = tot;
+        }
+    }
+}
+
 // out[c, r] = in[r, c]   (32 x 32 tiles through LDS; grid (cols/32, rows/32), block 256)
 __global__ __launch_bounds__(256) void transpose2d(const float *__restrict__ in, float *__restrict__ out, int rows, int cols) {
     __shared__ float tile[32][33];
@@ -582,11 +625,9 @@ int vst_wgrad(const float *dY, int ldy, const float *X, int ldx, int M, int N, i
     VSK_CHECK_LAUNCH();
     {
         const size_t nvec = (size_t)N * K / 4;
-        hipLaunchKernelGGL(reduce_partials<4>, dim3((unsigned)((nvec + 15) / 16)), dim3(256), 0, st, partW, S, N, K, dW0, dW1, dW2, rows_per_dest);
-        VSK_CHECK_LAUNCH();
-    }
-    if (db0) {
-        hipLaunchKernelGGL(reduce_partials<1>, dim3((N + 15) / 16), dim3(256), 0, st, partB, S, N, 1, db0, db1, db2, rows_per_dest);
+        const int nb_w = (int)((nvec + 15) / 16), nb_b = db0 ? (N + 15) / 16 : 0;
+        hipLaunchKernelGGL(reduce_wgrad, dim3(nb_w + nb_b), dim3(256), 0, st, partW, partB, S, N, K, dW0, dW1, dW2, db0, db1,
+                           db2, rows_per_dest, nb_w);
         VSK_CHECK_LAUNCH();
     }
     return 0;

@@ -15,7 +15,10 @@ struct LayerOff {
 
 // transposed weights for the dgrad GEMMs of the training backward (dX = dY W is an NT GEMM against W^T); built
 // lazily by the first vs_train_backward after each pack / update, never for a scoring-only user
-struct LayerOffT { size_t t_wqkv, t_wo, t_w1, t_w2; };
+struct LayerOffT {
+    size_t t_wqkv, t_wo, t_w1, t_w2;          // W^T, row-major
+    size_t tf_wqkv, tf_wo, tf_w1, tf_w2;      // the same in fragment-major order (latency kernels at small batch)
+};
 
 struct vs_weights {
     vs_model_desc desc;
@@ -31,7 +34,7 @@ struct vs_weights {
     unsigned long long version = 0;       // bumped by every pack / update
     float *tblob = nullptr;               // second device allocation: transposed weights + a zero vector
     unsigned long long t_version = ~0ull; // version the transposes were built from
-    size_t t_embed_w = 0, zeros = 0;
+    size_t t_embed_w = 0, tf_embed_w = 0, zeros = 0;
     std::vector<LayerOffT> tlayers;
     const float *tp(size_t off) const { return tblob + off; }
 };
