@@ -111,3 +111,37 @@ def test_host_side_suites_on_the_gpu_box(vsa):
         te.test_knapsack_nan_values_follow_python_max(ev, j)
     for j in range(4):
         te.test_shots_past_n_frames_have_nan_means_like_the_reference(ev, j)
+
+
+def test_three_times_the_bench_batch_scoring_and_training(vsa):
+    """B=192, T=1024 (3x the bench batch: 196 608 frames, 0.8 GB of features, ~10 GB of training activations): index
+    arithmetic beyond 2^31 bytes in every kernel family.  Scoring: finite, and rows 100..103 equal the same videos
+    scored alone (bit for bit).  Training (dropout 0.3): finite loss and gradients, and the gradient of a batch made
+    of ONE video repeated is, for every parameter, 192x the single-video gradient only in expectation - so instead the
+    check is bitwise reproducibility of the whole step at this size."""
+    B, T = 192, 1024
+    sd = vsa.synth.make_state_dict(256, 4, 7)
+    m = vsa.SimNet(num_heads=4, d_model=256, num_layers=4, sparsity=0.0, dropout=0.3)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(_dev())
+    g = torch.Generator(device="cpu").manual_seed(192)
+    x = torch.randn(B, T, 1024, generator=g).to(_dev())
+    with torch.no_grad():
+        full, hid = m.eval()(x)
+        part, _ = m(x[100:104].contiguous())
+    assert torch.isfinite(full).all() and torch.isfinite(hid).all() and torch.equal(full[100:104], part)
+    target = torch.rand(B, T, generator=g).to(_dev())
+    mask = torch.zeros(B, T, dtype=torch.bool, device=_dev())
+    mask[5, 900:] = True
+    m.train()
+    grads = []
+    for _ in range(2):
+        torch.manual_seed(99)
+        m.zero_grad(set_to_none=True)
+        pred, _ = m(x, mask)
+        loss = vsa.mse_with_mask_loss(pred, target, mask)
+        loss.backward()
+        assert torch.isfinite(loss)
+        grads.append([p.grad.clone() for p in m.parameters()])
+    for a, b in zip(*grads):
+        assert torch.isfinite(a).all() and torch.equal(a, b)
