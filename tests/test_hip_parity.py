@@ -931,12 +931,12 @@ def test_overlapped_host_streaming_matches_direct_scoring(vsa):
 
 
 def test_randomised_parity_slice(vsa):
-    """A fixed-seed slice of tools/fuzz_parity.py (random architecture, batch, lengths, mask kind; every compute
+    """A fixed-seed slice of tests/fuzz_parity.py (random architecture, batch, lengths, mask kind; every compute
     mode; tiled and default dispatch) against the oracle.  The full soak (thousands of cases) is run by hand."""
     import importlib.util
     import os as _os
     spec = importlib.util.spec_from_file_location(
-        "fuzz_parity", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "tools", "fuzz_parity.py"))
+        "fuzz_parity", _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "fuzz_parity.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     n, worst = mod.run(budget=60.0, seed=7, max_cases=40)
