@@ -43,14 +43,20 @@ def oracle_forward(sd: Dict[str, torch.Tensor], x: torch.Tensor,
     d = sd["embedding_layer.feature_transform.weight"].shape[0]
     H = num_heads
     dh = d // H
-    # Embedding.forward simnet.py:208-217 (use_cls=False)
+    # Embedding.forward simnet.py:208-217
     h = _linear(x, sd, "embedding_layer.feature_transform")                      # :211
     pe_key = "embedding_layer.positional_encoding.pos_embedding"
     if pe_key in sd:
         h = h + sd[pe_key][:, :T]                                                # :237-238 (dropout: eval identity)
+    use_cls = "embedding_layer.cls_token" in sd
+    if use_cls:                                                                  # :214-216: token prepended after the PE
+        h = torch.cat([sd["embedding_layer.cls_token"].expand(B, 1, d), h], dim=1)
+        T = T + 1
     # SimNet.process_mask simnet.py:47-56
     kmask = None
     if isinstance(mask, torch.Tensor):
+        if use_cls:                                                              # :48-51 (the token is never padding)
+            mask = torch.cat([torch.zeros((B, 1), dtype=mask.dtype), mask], dim=1)
         kmask = mask.view(B, 1, 1, T).expand(B, H, T, T)
     scale = d ** -0.5                                                            # :126  (d_model, NOT head_dim)
     L = 0

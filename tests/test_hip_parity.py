@@ -1008,3 +1008,36 @@ def test_packed_workspace_is_never_overrun(vsa, cfg, compute):
     rc = lib.vs_scorer_forward_packed(handle, x.data_ptr(), host, dev_len.data_ptr(), len(lengths), flags,
                                       scores.data_ptr(), None, buf.data_ptr(), need - 1, _stream())
     assert rc == vsa._lib.VS_ERR_WORKSPACE
+
+
+def test_class_token_model_matches_reference_golden_and_oracle(vsa):
+    """use_cls=True (reference simnet.py:47-51, 205-206, 214-216; no reference caller enables it): T + 1 output rows.
+    Mask-free calls against vectors from the imported reference; masked calls against the oracle (the reference's
+    own mask branch needs a CUDA device, simnet.py:49, so it cannot produce vectors in the build container)."""
+    import json
+    import os
+    import numpy as np
+    from conftest import GOLDEN
+    z = np.load(os.path.join(GOLDEN, "cls_golden.npz"))
+    for c in json.loads(str(z["cases"])):
+        sd = vsa.synth.make_state_dict(c["d"], c["L"], c["wseed"], use_cls=True)
+        m = vsa.SimNet(num_heads=c["H"], d_model=c["d"], num_layers=c["L"], sparsity=0.0, use_cls=True, dropout=0.3)
+        m.load_state_dict(sd, strict=True)
+        m = m.to(_dev()).eval()
+        x = vsa.synth.make_features(c["B"], c["T"], c["xseed"], "randn")
+        with torch.no_grad():
+            logits, hidden = m(x.to(_dev()))
+            assert logits.shape == (c["B"], c["T"] + 1, 1) and hidden.shape == (c["B"], c["T"] + 1, c["d"])
+            assert (logits.cpu() - torch.from_numpy(z[c["name"] + ":logits"])).abs().max().item() < TOL
+            assert (hidden.cpu() - torch.from_numpy(z[c["name"] + ":hidden"])).abs().max().item() < TOL
+            # with a key mask (the class token itself is never masked)
+            mask = vsa.synth.random_mask(c["B"], c["T"], 3)
+            lm, hm = m(x.to(_dev()), mask.to(_dev()))
+            rl, rh = oracle_forward(sd, x, mask, c["H"])
+            assert (lm.cpu() - rl).abs().max().item() < TOL and (hm.cpu() - rh).abs().max().item() < TOL
+            s = m.score(x.to(_dev()), mask.to(_dev()))
+            assert s.shape == (c["B"], c["T"] + 1) and (s.cpu() - torch.sigmoid(rl.squeeze(-1))).abs().max().item() < TOL
+        with pytest.raises(NotImplementedError):
+            m.train()(x.to(_dev()))                          # training with a class token is not offered
+        with pytest.raises(NotImplementedError):
+            m.score_packed(x[0].to(_dev()), [c["T"]])

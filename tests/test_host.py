@@ -57,8 +57,9 @@ def test_state_dict_key_set_matches_reference_layout(vsa):
 def test_ctor_defaults_and_attributes(vsa):
     m = vsa.SimNet()
     assert (m.num_heads, m.d_model, m.num_layers, m.num_classes, m.in_features, m.max_len) == (8, 512, 4, 1, 1024, 2500)
-    with pytest.raises(NotImplementedError):
-        vsa.SimNet(use_cls=True)
+    cls = vsa.SimNet(num_heads=4, d_model=256, num_layers=1, use_cls=True)      # simnet.py:205-206: token first in the state_dict
+    assert list(cls.state_dict())[0] == "embedding_layer.cls_token" and cls.state_dict()["embedding_layer.cls_token"].shape == (1, 1, 256)
+    assert cls.process_mask(torch.zeros(2, 7, dtype=torch.bool)).shape == (2, 4, 8, 8)       # simnet.py:48-51
     with pytest.raises(AssertionError):
         vsa.SimNet(num_heads=3, d_model=256)
     mask = torch.zeros(2, 7, dtype=torch.bool)

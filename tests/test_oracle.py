@@ -40,3 +40,19 @@ def test_padded_valid_frames_equal_unpadded(vsa):
         lp, _ = oracle_forward(sd, x, synth.padding_mask(x), 4)
         lu, _ = oracle_forward(sd, x[:, :61], None, 4)
     assert (lp[:, :61] - lu).abs().max().item() < 1e-5
+
+
+def test_oracle_class_token_branch_matches_reference_golden(vsa):
+    """use_cls=True (simnet.py:205-206, 214-216): vectors from the imported reference (tests/golden/make_golden_cls.py)."""
+    import json
+    import os
+    import numpy as np
+    from conftest import GOLDEN
+    z = np.load(os.path.join(GOLDEN, "cls_golden.npz"))
+    for c in json.loads(str(z["cases"])):
+        sd = vsa.synth.make_state_dict(c["d"], c["L"], c["wseed"], use_cls=True)
+        x = vsa.synth.make_features(c["B"], c["T"], c["xseed"], "randn")
+        logits, hidden = oracle_forward(sd, x, None, c["H"])
+        assert logits.shape == (c["B"], c["T"] + 1, 1)
+        assert (logits - torch.from_numpy(z[c["name"] + ":logits"])).abs().max().item() < 2e-5
+        assert (hidden - torch.from_numpy(z[c["name"] + ":hidden"])).abs().max().item() < 2e-5

@@ -216,10 +216,6 @@ class SimNet(nn.Module):
         (rows of the positional table, simnet.py:188: 2000) — BASELINE configs[4] (T=8192, 2048-d CLIP
         features) needs both; the oracle for it is the re-parameterised restatement."""
         super().__init__()
-        if use_cls:
-            # no reference caller enables it (train.py:33, simnet_pretrain.py:30) and the reference's own
-            # branch hard-codes device "cuda" (simnet.py:49); out of scope — see DESIGN.md
-            raise NotImplementedError("use_cls=True is not supported by the MI355X scorer")
         if d_model % num_heads:
             raise AssertionError("d_model must be divisible by num_heads")      # simnet.py:123
         self.num_heads, self.d_model, self.num_layers = num_heads, d_model, num_layers
@@ -232,6 +228,10 @@ class SimNet(nn.Module):
         if use_pos:
             emb["positional_encoding"] = _SinusoidTable(d_model, pe_len)        # simnet.py:188 (2000, not max_len)
         self.embedding_layer = _Bag(**emb)
+        if use_cls:
+            # simnet.py:205-206: a learnable token prepended AFTER the positional encoding (:214-216); a direct
+            # parameter of the embedding module, so it comes first in the state_dict like the reference's
+            self.embedding_layer.cls_token = nn.Parameter(torch.zeros((1, 1, d_model)))
         self.encoder = _Bag(module_list=nn.ModuleList(_encoder_block(d_model) for _ in range(num_layers)),
                             module_score=nn.ModuleList())                        # stays empty: SURVEY Q2
         self.final_layer = nn.Linear(d_model, num_classes)
@@ -247,6 +247,8 @@ class SimNet(nn.Module):
 
     # ---- reference helper kept for API parity (simnet.py:47-56) ----
     def process_mask(self, mask: Tensor) -> Tensor:
+        if self.use_cls:                                     # simnet.py:48-51: the class token is never padding
+            mask = torch.cat([torch.zeros((mask.size(0), 1), dtype=mask.dtype, device=mask.device), mask], dim=1)
         B, N = mask.size()
         return mask.view(B, 1, 1, N).expand(B, self.num_heads, N, N)
 
@@ -340,6 +342,8 @@ class SimNet(nn.Module):
         if not x.is_cuda:
             raise RuntimeError("SimNet runs on the MI355X HIP kernels only: move the module and its "
                                "input to a HIP device (there is no CPU path for the scorer)")
+        if self.use_cls:
+            return self._forward_cls(x, mask)
         if self._needs_autograd(x):
             return self._forward_train(x, mask)
         flags = (_lib.VS_FLAG_SIGMOID if self.fused_sigmoid else 0) | self._attention_flag()
@@ -349,12 +353,81 @@ class SimNet(nn.Module):
                                                        self.num_classes, flags, True)
         return scores, hidden
 
+    def _forward_cls(self, x: Tensor, mask: Optional[Tensor]):
+        """``use_cls=True`` (simnet.py:47-51, 205-206, 214-216; no reference caller enables it): a learnable class token
+        is prepended after the embedding, so the encoder sees T + 1 positions and both outputs have T + 1 rows.  Scoring
+        only (no-grad): the embedding runs through ``vs_linear_f32`` and the encoder blocks through the per-kernel C
+        entry points (``vs_qkv_proj_f32``, ``vs_attention_f32``, ``vs_linear_residual_layernorm_f32``) - the same HIP
+        kernels as the packed-weight path, driven layer by layer, because the token has to enter between them."""
+        if self._needs_autograd(x):
+            raise NotImplementedError("use_cls=True is supported for scoring (torch.no_grad / eval with frozen "
+                                      "parameters) only; no reference caller trains with a class token")
+        lib = _lib.load()
+        B, T, _ = x.shape
+        d, H, dev = self.d_model, self.num_heads, x.device
+        T1, M1 = T + 1, B * (T + 1)
+        emb = self.embedding_layer
+
+        def f32(t):
+            return t.detach().to(torch.float32).contiguous()
+
+        with torch.cuda.device(dev):
+            st = torch.cuda.current_stream(dev).cuda_stream
+            xe = f32(x).view(B * T, self.in_features)
+            e = torch.empty((B * T, d), dtype=torch.float32, device=dev)
+            w, b = f32(emb.feature_transform.weight), f32(emb.feature_transform.bias)
+            pe = f32(emb.positional_encoding.pos_embedding)[0, :T] if self.use_pos else None
+            _lib.check(lib.vs_linear_f32(xe.data_ptr(), w.data_ptr(), b.data_ptr(), e.data_ptr(), B * T, d, self.in_features,
+                                         0, _ptr(pe), T if self.use_pos else 0, st))
+            h = torch.cat([f32(emb.cls_token).expand(B, 1, d), e.view(B, T, d)], dim=1).contiguous()      # :214-216
+            m = None
+            if mask is not None:
+                mk = mask.view(torch.uint8) if mask.dtype == torch.bool else mask.to(torch.uint8)
+                m = torch.cat([torch.zeros((B, 1), dtype=torch.uint8, device=dev), mk], dim=1).contiguous()
+            scores = torch.empty((B, T1, self.num_classes), dtype=torch.float32, device=dev)
+            qkv = torch.empty((3, B, H, T1, d // H), dtype=torch.float32, device=dev)
+            att, h1, ffn = (torch.empty((M1, n), dtype=torch.float32, device=dev) for n in (d, d, 4 * d))
+            L = self.num_layers
+            for l, blk in enumerate(self.encoder.module_list):
+                wqkv = torch.cat([f32(blk.sa.q.weight), f32(blk.sa.k.weight), f32(blk.sa.v.weight)], dim=0)
+                bqkv = torch.cat([f32(blk.sa.q.bias), f32(blk.sa.k.bias), f32(blk.sa.v.bias)], dim=0)
+                _lib.check(lib.vs_qkv_proj_f32(h.data_ptr(), wqkv.data_ptr(), bqkv.data_ptr(), qkv.data_ptr(), B, T1, d, H, st))
+                _lib.check(lib.vs_attention_f32(qkv[0].data_ptr(), qkv[1].data_ptr(), qkv[2].data_ptr(), _ptr(m), att.data_ptr(),
+                                                B, H, T1, d // H, float(d) ** -0.5, st))
+                wo, bo = f32(blk.sa.feature_projection.weight), f32(blk.sa.feature_projection.bias)
+                g1, b1 = f32(blk.norm1.weight), f32(blk.norm1.bias)
+                _lib.check(lib.vs_linear_residual_layernorm_f32(att.data_ptr(), wo.data_ptr(), bo.data_ptr(), h.data_ptr(),
+                                                                g1.data_ptr(), b1.data_ptr(), h1.data_ptr(), M1, d, d,
+                                                                None, None, 0, 0, None, st))
+                w1, bb1 = f32(blk.mlp.fc1.weight), f32(blk.mlp.fc1.bias)
+                _lib.check(lib.vs_linear_f32(h1.data_ptr(), w1.data_ptr(), bb1.data_ptr(), ffn.data_ptr(), M1, 4 * d, d, 1,
+                                             None, 0, st))
+                w2, bb2 = f32(blk.mlp.fc2.weight), f32(blk.mlp.fc2.bias)
+                g2, b2 = f32(blk.norm2.weight), f32(blk.norm2.bias)
+                last = l == L - 1
+                fw, fb = f32(self.final_layer.weight), f32(self.final_layer.bias)
+                out = torch.empty((B, T1, d), dtype=torch.float32, device=dev)
+                _lib.check(lib.vs_linear_residual_layernorm_f32(ffn.data_ptr(), w2.data_ptr(), bb2.data_ptr(), h1.data_ptr(),
+                                                                g2.data_ptr(), b2.data_ptr(), out.data_ptr(), M1, d, 4 * d,
+                                                                fw.data_ptr() if last else None, fb.data_ptr() if last else None,
+                                                                self.num_classes, 1 if self.fused_sigmoid else 0,
+                                                                scores.data_ptr() if last else None, st))
+                h = out
+        return scores, h
+
     @torch.no_grad()
     def score(self, x: Tensor, mask: Optional[Tensor] = None) -> Tensor:
         """Sigmoid importance scores [B,T] in one launch sequence: the ``val_step`` head
         (train.py:143-144) with the sigmoid fused and the hidden-state store skipped."""
         if self.num_classes != 1:
             raise RuntimeError("score() needs num_classes == 1")
+        if self.use_cls:                                    # T + 1 scores (class token first), sigmoid fused as well
+            prev, self.fused_sigmoid = self.fused_sigmoid, True
+            try:
+                s, _ = self._forward_cls(x, mask if isinstance(mask, Tensor) else None)
+            finally:
+                self.fused_sigmoid = prev
+            return s.squeeze(-1)
         x32 = x if x.dtype == torch.float32 else x.float()
         packed = self._packed_weights(x.device)
         scores, _ = torch.ops.vs_amd.score_frames(x32, mask, packed.handle, self.d_model, 1,
@@ -408,6 +481,8 @@ class SimNet(nn.Module):
         result is bit-identical to scoring it alone (fp32 and fp16x3 modes).  Head dim 32 / 64."""
         if not x.is_cuda:
             raise RuntimeError("SimNet scoring runs on the MI355X HIP kernels only (no CPU path for the scorer)")
+        if self.use_cls:
+            raise NotImplementedError("packed batches are not available with use_cls=True")
         if self.use_pos and max(int(t) for t in lengths) > self.pe_len:
             raise RuntimeError("T=%d exceeds the positional table (%d rows)" % (max(lengths), self.pe_len))
         packed = self._packed_weights(x.device)
@@ -420,6 +495,8 @@ class SimNet(nn.Module):
         """Sigmoid importance scores [Mtot] of a packed ragged batch (see forward_packed)."""
         if self.num_classes != 1:
             raise RuntimeError("score_packed() needs num_classes == 1")
+        if self.use_cls:
+            raise NotImplementedError("packed batches are not available with use_cls=True")
         packed = self._packed_weights(x.device)
         x32 = x if x.dtype == torch.float32 else x.float()
         s, _ = score_frames_packed(x32, lengths, packed.handle, self.d_model, 1,

@@ -55,11 +55,12 @@ def positional_table(d_model: int, max_len: int = PE_MAX_LEN, stable: bool = Fal
 
 def state_dict_keys(d_model: int, num_layers: int, num_classes: int = 1,
                     use_pos: bool = True, in_features: int = IN_FEATURES,
-                    max_len: int = PE_MAX_LEN):
+                    max_len: int = PE_MAX_LEN, use_cls: bool = False):
     """(key, shape, kind) in the reference's registration order."""
     d = d_model
-    out = [("embedding_layer.feature_transform.weight", (d, in_features), "w"),
-           ("embedding_layer.feature_transform.bias", (d,), "b:%d" % in_features)]
+    out = [("embedding_layer.cls_token", (1, 1, d), "beta")] if use_cls else []      # simnet.py:205-206: first in the state_dict
+    out += [("embedding_layer.feature_transform.weight", (d, in_features), "w"),
+            ("embedding_layer.feature_transform.bias", (d,), "b:%d" % in_features)]
     if use_pos:
         out.append(("embedding_layer.positional_encoding.pos_embedding", (1, max_len, d), "pe"))
     for l in range(num_layers):
@@ -84,14 +85,20 @@ def state_dict_keys(d_model: int, num_layers: int, num_classes: int = 1,
 
 def make_state_dict(d_model: int, num_layers: int, seed: int, num_classes: int = 1,
                     use_pos: bool = True, in_features: int = IN_FEATURES,
-                    max_len: int = PE_MAX_LEN, trained_like: bool = True) -> Dict[str, torch.Tensor]:
+                    max_len: int = PE_MAX_LEN, trained_like: bool = True, use_cls: bool = False) -> Dict[str, torch.Tensor]:
     """Seeded weights with nn.Linear's default distribution U(-1/sqrt(fan_in), 1/sqrt(fan_in))
     for weights and biases.  ``trained_like`` perturbs the LayerNorm affine away from (1, 0)
     so the fused LN epilogues are really exercised."""
     rng = np.random.Generator(np.random.PCG64(seed))
     sd: Dict[str, torch.Tensor] = {}
+    cls_token = None
+    if use_cls:      # drawn from its own stream so that every other tensor equals the use_cls=False dict of the same seed
+        cls_token = torch.from_numpy(np.random.Generator(np.random.PCG64(seed + 7919)).standard_normal((1, 1, d_model)).astype(np.float32))
     for key, shape, kind in state_dict_keys(d_model, num_layers, num_classes, use_pos,
-                                            in_features, max_len):
+                                            in_features, max_len, use_cls):
+        if key == "embedding_layer.cls_token":
+            sd[key] = cls_token
+            continue
         if kind == "pe":
             sd[key] = positional_table(d_model, max_len, stable=True)     # machine-independent (see positional_table)
             continue
