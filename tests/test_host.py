@@ -26,6 +26,12 @@ def test_library_builds_and_exports_every_declared_symbol(vsa):
     assert declared == set(vsa._lib.EVAL_EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
+    hdr = open(os.path.join(ROOT, "include", "vs_train.h")).read()          # the training C ABI
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(vs_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(vsa._lib.TRAIN_EXPORTS), declared ^ set(vsa._lib.TRAIN_EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
 
 
 def test_c_abi_argument_checks_need_no_gpu(vsa):
@@ -137,11 +143,14 @@ def test_header_is_plain_c_and_the_c_client_compiles(vsa):
     gcc = shutil.which("gcc")
     assert gcc
     inc = os.path.join(ROOT, "include")
-    for hdr in ("vs_scorer.h", "vs_eval.h"):
+    for hdr in ("vs_scorer.h", "vs_eval.h", "vs_train.h"):
         r = subprocess.run([gcc, "-std=c99", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", os.path.join(inc, hdr)],
                            capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
     rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
     r = subprocess.run([gcc, "-std=gnu99", "-fsyntax-only", "-I" + inc, "-I" + os.path.join(rocm, "include"),
                         "-D__HIP_PLATFORM_AMD__", os.path.join(ROOT, "tests", "cabi", "score_demo.c")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([gcc, "-std=gnu99", "-fsyntax-only", "-I" + inc, "-I" + os.path.join(rocm, "include"),
+                        "-D__HIP_PLATFORM_AMD__", os.path.join(ROOT, "tests", "cabi", "train_demo.c")], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
