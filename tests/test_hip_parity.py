@@ -766,8 +766,6 @@ def test_linear_residual_layernorm_f16x3_kernel(vsa, M, N, K, nc, sig):
 @pytest.mark.parametrize("case", golden_cases(), ids=lambda c: c["name"])
 def test_f16x3_linear_mode_matches_reference_golden(vsa, lp_linear_everywhere, case):
     """linear_dtype='fp16x3' against the reference-generated goldens, at the fp32 path's own 1e-4 bar."""
-    if case["d"] > 256:
-        pytest.skip("f16x3 Linear kernels: d_model <= 256")
     g = load_golden(case["name"])
     sd, x, mask = build_case(vsa.synth, case)
     m = _model(vsa, case, sd)
