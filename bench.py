@@ -48,7 +48,7 @@ STAGE_KERNEL = {"attention": "attn_fwd_pipe", "embed_pe": "gemm_nt_128<2", "qkv_
                 "fc1_relu": "gemm_nt_128<1", "outproj_ln": "gemm_ln_rows", "fc2_ln_score": "gemm_ln_rows"}
 
 
-FORWARD_SOURCES = ("vs_attention.hip", "vs_device.h", "vs_kernels.h", "vs_kernels.hip", "vs_scorer.cpp")
+FORWARD_SOURCES = ("vs_attention.hip", "vs_device.h", "vs_kernels.h", "vs_kernels.hip", "vs_mlp_fused.hip", "vs_scorer.cpp")
 
 
 def kernel_source_hash():

@@ -153,7 +153,7 @@ const char *vs_stage_name(int32_t stage);
 /* A/B and test switches (DESIGN.md "Environment switches"; none selects a fallback).  Their defaults come from
  * environment variables of the same name, read ONCE when the library is first used - no forward calls getenv.
  * value < 0 restores the environment / built-in default.  Names: VS_SKINNY_ROWS, VS_LP_MIN_ROWS, VS_GEMM_NWM2,
- * VS_GEMM_NJ2, VS_ATTN_NW4, VS_ATTN_LP_SIMPLE (+ VS_MLP_FUSION, VS_MLP_ABL, VS_ATTN_LEGACY, which only the
+ * VS_GEMM_NJ2, VS_ATTN_NW4, VS_ATTN_LP_SIMPLE, VS_LP_STORE32, VS_LP_MLP_UNFUSED (+ VS_MLP_FUSION, VS_MLP_ABL, VS_ATTN_LEGACY, which only the
  * diagnostic build of the library acts on).  Process-wide; not meant to be flipped while forwards are in flight. */
 int vs_set_option(const char *name, int32_t value);
 
@@ -218,6 +218,13 @@ int vs_linear_residual_layernorm_f16x3(const float *A, const float *W, const flo
                                        float *out, int32_t M, int32_t N, int32_t K,
                                        const float *score_w, const float *score_b, int32_t num_classes,
                                        int32_t sigmoid, float *scores, void *stream);
+
+/* The whole MLP block of encoder layer `layer` of a packed model as ONE kernel on the bf16 matrix pipe (the form the
+ * bf16 mode runs at d_model == 256; EncoderBlock / MLP, simnet.py:109-110, 180-183):
+ *   out = LayerNorm(relu(h W1^T + b1) W2^T + b2 + h) * gamma2 + beta2,   h, out [M, d_model]
+ * with_head != 0 also writes scores[M, num_classes] = out . final_w^T + final_b (through sigmoid if `sigmoid`). */
+int vs_mlp_block_bf16(const vs_weights *w, int32_t layer, const float *h, float *out, int32_t M,
+                      int32_t with_head, int32_t sigmoid, float *scores, void *stream);
 
 #ifdef __cplusplus
 }

@@ -707,6 +707,128 @@ def test_bf16_compute_long_video(vsa, lp_linear_everywhere):
     assert err < BF16_FULL_LOGIT_TOL
 
 
+@pytest.mark.parametrize("cfg", ["M-A", "M-B8", "M-A-short"])
+def test_bf16_storage_is_bit_identical_to_fp32_storage(vsa, lp_linear_everywhere, cfg):
+    """In the bf16 mode q*scale, k, v, the attention output and the MLP hidden tensor are written to HBM as bf16 by
+    their producers (every consumer rounds them to bf16 on entry anyway).  VS_LP_STORE32=1 keeps them fp32: the two
+    must agree BIT FOR BIT - padded batch, masked batch, packed ragged batch, 4- and 8-wave attention blocks, head dim
+    64 and 32, the score head and the hidden state."""
+    synth = vsa.synth
+    d, H, L = (256, 8, 3) if cfg == "M-B8" else (256, 4, 2)
+    sd = synth.make_state_dict(d, L, 171, trained_like=True)
+    lengths = [130, 77, 64, 1] if cfg == "M-A-short" else [512, 333, 256, 31]
+    x = synth.make_features(4, max(lengths), 172, "pool5", lengths=lengths)
+    mask = synth.padding_mask(x)
+    m = vsa.SimNet(num_heads=H, d_model=d, num_layers=L, sparsity=0.0, dropout=0.3)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(_dev()).eval().set_compute_dtype("bf16")
+    dx, dm = x.to(_dev()), mask.to(_dev())
+    packed = torch.cat([x[i, :t] for i, t in enumerate(lengths)]).to(_dev())
+    lens = torch.tensor(lengths, dtype=torch.int32)
+
+    def run():
+        with torch.no_grad():
+            a = m(dx, dm)
+            b = m(dx[:1].contiguous())
+            c = m.score_packed(packed, lens)
+        return [t.clone() for t in (*a, *b, c)]
+
+    try:
+        vsa._lib.set_option("VS_LP_MLP_UNFUSED", 1)      # (the fused MLP kernel has its own test below)
+        vsa._lib.set_option("VS_LP_STORE32", 1)
+        ref = run()
+        vsa._lib.set_option("VS_LP_STORE32", -1)
+        got = run()
+    finally:
+        vsa._lib.set_option("VS_LP_STORE32", -1)
+        vsa._lib.set_option("VS_LP_MLP_UNFUSED", -1)
+    for g, r in zip(got, ref):
+        assert torch.isfinite(g).all() and torch.equal(g, r)
+
+
+def _bf16_round(t):
+    return t.to(torch.bfloat16).double()
+
+
+@pytest.mark.parametrize("M,nc,sig", [(256, 0, 0), (1000, 1, 1), (257, 3, 0), (31, 1, 0), (4096, 1, 0), (70000, 1, 0)])
+def test_mlp_block_bf16_kernel(vsa, M, nc, sig):
+    """vs_mlp_block_bf16 (fc1 + ReLU + fc2 + residual + LayerNorm + score head as one kernel, bf16 matrix pipe) against
+    a float64 evaluation that shares its rounding points: h, W1, W2 and relu(fc1) rounded to bf16, everything else
+    exact.  The kernel accumulates in fp32, so a hidden activation within fp32 rounding of a bf16 tie can round the
+    other way (one bf16 ulp of one of 1024 terms): bar 2e-3 on the LayerNorm output (measured: ~1e-5 typical)."""
+    lib = vsa._lib.load()
+    sd = vsa.synth.make_state_dict(256, 2, 300 + M, trained_like=True, num_classes=max(nc, 1))
+    m = vsa.SimNet(num_heads=4, d_model=256, num_layers=2, sparsity=0.0, dropout=0.3, num_classes=max(nc, 1))
+    m.load_state_dict(sd, strict=True)
+    m = m.to(_dev()).eval()
+    packed = m._packed_weights(_dev())
+    g = torch.Generator().manual_seed(M)
+    h = torch.randn(M, 256, generator=g)
+    pre = "encoder.module_list.1."
+    W1, b1 = sd[pre + "mlp.fc1.weight"], sd[pre + "mlp.fc1.bias"].double()
+    W2, b2 = sd[pre + "mlp.fc2.weight"], sd[pre + "mlp.fc2.bias"].double()
+    act = _bf16_round(F.relu(_bf16_round(h) @ _bf16_round(W1).T + b1).float())
+    y = act @ _bf16_round(W2).T + b2 + h.double()
+    ref = F.layer_norm(y, (256,), sd[pre + "norm2.weight"].double(), sd[pre + "norm2.bias"].double(), 1e-5)
+    sc = ref @ sd["final_layer.weight"].double().T + sd["final_layer.bias"].double()
+    if sig:
+        sc = torch.sigmoid(sc)
+    dh = h.to(_dev())
+    out = torch.full((M, 256), float("nan"), device=_dev())
+    scores = torch.full((M, max(nc, 1)), float("nan"), device=_dev())
+    vsa._lib.check(lib.vs_mlp_block_bf16(packed.handle, 1, dh.data_ptr(), out.data_ptr(), M, 1 if nc else 0, sig,
+                                         scores.data_ptr(), _stream()))
+    torch.cuda.synchronize()
+    err = (out.cpu().double() - ref).abs()
+    print("mlp_block_bf16 M=%d: max err %.2e, median %.2e" % (M, err.max().item(), err.median().item()))
+    assert err.max().item() < 2e-3 and err.median().item() < 1e-5
+    if nc:
+        assert (scores.cpu().double() - sc).abs().max().item() < 2e-3
+
+
+@pytest.mark.parametrize("cfg", ["M-A", "M-A-ragged"])
+def test_bf16_fused_mlp_matches_the_two_kernel_path(vsa, lp_linear_everywhere, cfg):
+    """bf16 mode, d_model 256: fc1 + ReLU + fc2 + residual + LayerNorm (+ score head) run as ONE kernel whose hidden
+    activations stay in registers (vs_mlp_fused.hip).  Same rounding points as the two-kernel path (VS_LP_MLP_UNFUSED=1);
+    only the order of the 16 products inside an MFMA step differs, so the two agree to fp32 rounding amplified by an
+    occasional 1-ulp flip of a bf16-rounded activation - and every later layer re-rounds its inputs to bf16, so a 1e-5
+    difference after layer 1 flips some 2^-9-relative roundings in layer 2.  Bar 1e-2 on logits and hidden state
+    (measured 1e-3 / 3e-3 over three layers; a wrong index map would show as O(1)); the kernel's own arithmetic is
+    pinned at 2e-3 with shared rounding points by test_mlp_block_bf16_kernel."""
+    synth = vsa.synth
+    sd = synth.make_state_dict(256, 3, 271, trained_like=True)
+    lengths = [700, 333, 256, 31] if cfg == "M-A" else [257, 1, 100, 513, 7]
+    x = synth.make_features(len(lengths), max(lengths), 272, "pool5", lengths=lengths)
+    mask = synth.padding_mask(x)
+    m = vsa.SimNet(num_heads=4, d_model=256, num_layers=3, sparsity=0.0, dropout=0.3)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(_dev()).eval().set_compute_dtype("bf16")
+    dx, dm = x.to(_dev()), mask.to(_dev())
+
+    def run():
+        with torch.no_grad():
+            a = m(dx, dm)
+            b = m.score(dx, dm)
+        return [t.clone() for t in (*a, b)]
+
+    try:
+        vsa._lib.set_option("VS_LP_MLP_UNFUSED", 1)
+        ref = run()
+        vsa._lib.set_option("VS_LP_MLP_UNFUSED", -1)
+        got = run()
+    finally:
+        vsa._lib.set_option("VS_LP_MLP_UNFUSED", -1)
+    valid = ~dm
+    for g, r in zip(got, ref):
+        assert torch.isfinite(g).all()
+        gv, rv = (g[valid], r[valid]) if g.dim() >= 2 and g.shape[:2] == valid.shape else (g, r)
+        err = (gv - rv).abs().max().item()
+        print("fused vs two-kernel MLP (%s): %.3e" % (cfg, err))
+        assert err < 1e-2
+    rl, rh = oracle_forward(sd, x, mask, 4)
+    assert (got[0].cpu() - rl).abs().squeeze(-1)[~mask].max().item() < BF16_FULL_LOGIT_TOL
+
+
 # ---- opt-in fp32 emulation on the f16 matrix pipe (VS_FLAG_F16X3_LINEAR, "fp16x3") ------------------------
 # Operands are split into two f16 halves (22 bits) and three products are accumulated in fp32, so the checker is
 # the plain fp64 product of the UNROUNDED operands, and the bar is the fp32 path's own 1e-4 (per-kernel 5e-5).

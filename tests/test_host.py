@@ -154,3 +154,34 @@ def test_header_is_plain_c_and_the_c_client_compiles(vsa):
     r = subprocess.run([gcc, "-std=gnu99", "-fsyntax-only", "-I" + inc, "-I" + os.path.join(rocm, "include"),
                         "-D__HIP_PLATFORM_AMD__", os.path.join(ROOT, "tests", "cabi", "train_demo.c")], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_fused_mlp_chunk_loop_has_only_its_counted_dma_on_the_vector_memory_counter(vsa, tmp_path):
+    """The fused bf16 MLP kernel keeps one chunk of weights in flight across its per-chunk barrier with a COUNTED
+    `s_waitcnt vmcnt(5)`: that count is only right if the 5 LDS-DMA copies are the loop's only vector-memory
+    instructions.  A register spill reloaded inside the loop (scratch_load) or a hoisted global load would silently
+    let the barrier pass before the weights have landed - so the ISA of the loop is checked at build time."""
+    import subprocess
+    csrc = os.path.join(ROOT, "video-summarization_amd", "csrc")
+    asm = str(tmp_path / "mlp.s")
+    r = subprocess.run([vsa._lib.hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + csrc,
+                        "-I" + os.path.join(ROOT, "include"), "-S", "--cuda-device-only",
+                        os.path.join(csrc, "vs_mlp_fused.hip"), "-o", asm], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    text = open(asm).read()
+    start = text.index("mlp_fused_bf16ILi0E")
+    body = text[text.index("mlp_fused_bf16ILi0E", start + 1):]
+    body = body[:body.index(".Lfunc_end")]
+    # basic blocks; the chunk loop is the one with the 32 MFMAs
+    blocks = re.split(r"\n\.LBB\d+_\d+:", body)
+    loops = [b for b in blocks if len(re.findall(r"\bv_mfma_f32_32x32x16_bf16\b", b)) == 32]
+    assert len(loops) == 1, [len(re.findall(r"v_mfma", b)) for b in blocks]
+    loop = loops[0]
+    loop = loop[:loop.index("s_cbranch")]           # up to the back edge; what follows is the epilogue's fall-through
+    assert len(re.findall(r"\bv_mfma_f32_32x32x16_bf16\b", loop)) == 32
+    assert len(re.findall(r"\bglobal_load_lds_dwordx4\b", loop)) == 5
+    vm = re.findall(r"\b(scratch_\w+|buffer_\w+|flat_\w+|global_(?!load_lds_dwordx4)\w+)\b", loop)
+    assert vm == [], vm
+    waits = re.findall(r"s_waitcnt[^\n]*vmcnt\((\d+)\)", loop)
+    assert waits == ["5"], waits
+    assert len(re.findall(r"\bs_barrier\b", loop)) == 1

@@ -17,7 +17,7 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(ROOT, "include")
 LIB_PATH = os.path.join(HERE, "libvsscore.so")
 DIAG_LIB_PATH = os.path.join(HERE, "libvsscore_diag.so")
-SOURCES = ("vs_kernels.hip", "vs_attention.hip", "vs_scorer.cpp", "vs_eval.cpp",
+SOURCES = ("vs_kernels.hip", "vs_attention.hip", "vs_mlp_fused.hip", "vs_scorer.cpp", "vs_eval.cpp",
            "vs_train_kernels.hip", "vs_train_attention.hip", "vs_pretrain_kernels.hip", "vs_train.cpp")
 ABI_VERSION = 2
 
@@ -34,7 +34,7 @@ EXPORTS = ("vs_abi_version", "vs_last_error", "vs_weights_pack", "vs_weights_fre
            "vs_scorer_forward_packed", "vs_linear_f32", "vs_qkv_proj_f32",
            "vs_attention_f32", "vs_attention_bf16", "vs_attention_f16x3", "vs_linear_residual_layernorm_f32",
            "vs_linear_bf16", "vs_linear_residual_layernorm_bf16", "vs_linear_f16x3",
-           "vs_linear_residual_layernorm_f16x3",
+           "vs_linear_residual_layernorm_f16x3", "vs_mlp_block_bf16",
            "vs_profile_enable", "vs_profile_collect", "vs_stage_name")
 # include/vs_eval.h
 EVAL_EXPORTS = ("vs_eval_upsample", "vs_eval_knapsack", "vs_eval_generate_summary", "vs_eval_fscore",
@@ -209,6 +209,9 @@ def load() -> C.CDLL:
         lib.vs_linear_f16x3.argtypes = lib.vs_linear_f32.argtypes
         lib.vs_linear_residual_layernorm_f16x3.restype = C.c_int
         lib.vs_linear_residual_layernorm_f16x3.argtypes = lib.vs_linear_residual_layernorm_f32.argtypes
+        lib.vs_mlp_block_bf16.restype = C.c_int
+        lib.vs_mlp_block_bf16.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                          C.c_void_p, C.c_void_p]
         for name in EVAL_EXPORTS:
             getattr(lib, name).restype = C.c_int
         lib.vs_eval_upsample.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]

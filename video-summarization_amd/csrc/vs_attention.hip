@@ -445,7 +445,9 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_lp(
 // buffer loads of K(t+3) / V(t+2) between them.  One barrier per tile; K and V double-buffered in LDS, the
 // key-mask bias triple-buffered (it is read two iterations after it is written).
 // ------------------------------------------------------------------------------------------
-template <int DH, int NW, int PREC, bool VARLEN = false>       // VARLEN: packed ragged batches, see attn_fwd_pipe
+// IO16 (PREC 1 only): q (already multiplied by scale * log2 e), k, v arrive as bf16 and the output is written as bf16
+// (the QKV epilogue / the out-projection do the rounding this kernel / that kernel would do anyway: same bits)
+template <int DH, int NW, int PREC, bool VARLEN = false, bool IO16 = false>       // VARLEN: packed ragged batches, see attn_fwd_pipe
 __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_lp_pipe(
     const float *__restrict__ Q, const float *__restrict__ Kg, const float *__restrict__ Vg,
     const uint8_t *__restrict__ mask, float *__restrict__ out, int H, int T, float scale_log2e, int BH,
@@ -457,6 +459,8 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_lp_pipe(
     static_assert(KPT == 2 || KPT == 4, "staging packs 2 or 4 keys per V^T store");
     constexpr float THR = 8.0f;
     typedef unsigned short h16;
+    static_assert(!IO16 || PREC == 1, "bf16 storage belongs to the bf16 mode");
+    constexpr int ES = IO16 ? 2 : 4;                  // bytes per stored q/k/v element
     __shared__ __attribute__((aligned(16))) h16 Kb[2][NP][KT * LDK];
     __shared__ __attribute__((aligned(16))) h16 Vt[2][NP][DH * LDV];
     __shared__ __attribute__((aligned(16))) float mb[3][KT];
@@ -502,6 +506,11 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_lp_pipe(
     {
         int qr = q0 + r; qr = qr < T ? qr : T - 1;
         const float *qp = Q + base + (size_t)qr * DH + 8 * h;
+        if constexpr (IO16) {
+            const h16 *qp16 = (const h16 *)Q + base + (size_t)qr * DH + 8 * h;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) qreg[s][0] = *(const u32x4 *)(qp16 + 16 * s);
+        } else
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             const f32x4 v0 = *(const f32x4 *)(qp + 16 * s), v1 = *(const f32x4 *)(qp + 16 * s + 4);
@@ -527,26 +536,31 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_lp_pipe(
 
     const int d4 = tid % D4, kq = tid / D4;
     const int ntiles = (T + KT - 1) / KT;
-    const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Kg + base), 0, T * DH * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Vg + base), 0, T * DH * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc((char *)const_cast<float *>(Kg) + base * ES, 0, T * DH * ES, 0x00020000);
+    const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc((char *)const_cast<float *>(Vg) + base * ES, 0, T * DH * ES, 0x00020000);
     int voff[KPT];
 #pragma unroll
-    for (int i = 0; i < KPT; ++i) voff[i] = ((KPT * kq + i) * DH + 4 * d4) * 4;
+    for (int i = 0; i < KPT; ++i) voff[i] = ((KPT * kq + i) * DH + 4 * d4) * ES;
     f32x4 pk[KPT], pv[KPT];
+    u32x2 pk16[KPT], pv16[KPT];                       // IO16: 4 bf16 of one key
     float pm = 0.f;
     // the pipeline runs up to three tiles past the end: those loads re-read the last tile (their products are
     // never consumed); rows beyond T inside the last tile read as zeros (buffer bounds check) and are masked
     auto gload_k = [&](int tile) __attribute__((always_inline)) {
         tile = tile < ntiles ? tile : ntiles - 1;
 #pragma unroll
-        for (int i = 0; i < KPT; ++i)
-            pk[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(krs, voff[i], tile * (KT * DH * 4), 0));
+        for (int i = 0; i < KPT; ++i) {
+            if constexpr (IO16) pk16[i] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(krs, voff[i], tile * (KT * DH * ES), 0));
+            else pk[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(krs, voff[i], tile * (KT * DH * ES), 0));
+        }
     };
     auto gload_v = [&](int tile) __attribute__((always_inline)) {
         tile = tile < ntiles ? tile : ntiles - 1;
 #pragma unroll
-        for (int i = 0; i < KPT; ++i)
-            pv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(vrs, voff[i], tile * (KT * DH * 4), 0));
+        for (int i = 0; i < KPT; ++i) {
+            if constexpr (IO16) pv16[i] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(vrs, voff[i], tile * (KT * DH * ES), 0));
+            else pv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(vrs, voff[i], tile * (KT * DH * ES), 0));
+        }
     };
     auto gload_m = [&](int tile) __attribute__((always_inline)) {
         if (tid < KT) {
@@ -557,6 +571,10 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_lp_pipe(
         }
     };
     auto stage_k1 = [&](int i, int buf) __attribute__((always_inline)) {
+        if constexpr (IO16) {
+            *(u32x2 *)&Kb[buf][0][(KPT * kq + i) * LDK + 4 * d4] = pk16[i];
+            return;
+        }
         unsigned p0[NP], p1[NP];
         pack(pk[i][0], pk[i][1], p0);
         pack(pk[i][2], pk[i][3], p1);
@@ -567,6 +585,19 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_lp_pipe(
         }
     };
     auto stage_v1 = [&](int e, int buf) __attribute__((always_inline)) {
+        if constexpr (IO16) {
+            // element e of this lane's 4 d's, from two keys, into one dword: v_perm_b32 picks the (e & 1) halves
+            const unsigned sel = (e & 1) ? 0x07060302u : 0x05040100u;
+            if constexpr (KPT == 4) {
+                u32x2 u;
+                u[0] = __builtin_amdgcn_perm(pv16[1][e >> 1], pv16[0][e >> 1], sel);
+                u[1] = __builtin_amdgcn_perm(pv16[3][e >> 1], pv16[2][e >> 1], sel);
+                *(u32x2 *)&Vt[buf][0][(4 * d4 + e) * LDV + 4 * kq] = u;
+            } else {
+                *(unsigned *)&Vt[buf][0][(4 * d4 + e) * LDV + 2 * kq] = __builtin_amdgcn_perm(pv16[1][e >> 1], pv16[0][e >> 1], sel);
+            }
+            return;
+        }
         if constexpr (KPT == 4) {
             unsigned p0[NP], p1[NP];
             pack(pv[0][e], pv[1][e], p0);
@@ -747,6 +778,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_lp_pipe(
     if (q < T) {
         const float inv = 1.0f / o[ND][0];
         float *op = out + (orow0 + q) * (H * DH) + head * DH;
+        h16 *op16 = (h16 *)out + (orow0 + q) * (H * DH) + head * DH;
 #pragma unroll
         for (int d = 0; d < ND; ++d)
 #pragma unroll
@@ -754,6 +786,10 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_lp_pipe(
                 f32x4 v;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = o[d][4 * g + e] * inv;
+                if constexpr (IO16) {
+                    u32x2 u; u[0] = pack_bf16(v[0], v[1]); u[1] = pack_bf16(v[2], v[3]);
+                    *(u32x2 *)(op16 + 32 * d + 8 * g + 4 * h) = u;
+                } else
                 *(f32x4 *)(op + 32 * d + 8 * g + 4 * h) = v;
             }
     }
@@ -1066,9 +1102,11 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_pipe(
 
 }  // namespace
 
+float vsk_attention_qscale(float scale) { return scale * 1.4426950408889634f; }
+
 int vsk_attention(const float *q, const float *k, const float *v, const uint8_t *mask, float *out,
                   int B, int H, int T, int dh, float scale, hipStream_t st) {
-    const float sl2 = scale * 1.4426950408889634f;
+    const float sl2 = vsk_attention_qscale(scale);
     const int BH = B * H;
     dim3 grid(8 * ((BH + 7) / 8) * ((T + 127) / 128));
 #ifdef VS_WITH_DIAG     // A/B switch for tools/ (diagnostic library only): the non-pipelined kernel at head dim 32 / 64
@@ -1109,7 +1147,7 @@ int vsk_attention(const float *q, const float *k, const float *v, const uint8_t 
 // (video, query tile of 32*nw rows); exact fp32, head dim 32 / 64
 int vsk_attention_packed(const float *q, const float *k, const float *v, float *out, int H, int Mtot, int dh,
                          float scale, const int *cu, const int *work, int nwork, int nw, int prec, hipStream_t st) {
-    const float sl2 = scale * 1.4426950408889634f;
+    const float sl2 = vsk_attention_qscale(scale);
     if (nwork <= 0) return 0;
     dim3 grid(nwork, H);
     const int2 *wk = (const int2 *)work;
@@ -1117,7 +1155,14 @@ int vsk_attention_packed(const float *q, const float *k, const float *v, float *
     hipLaunchKernelGGL((attn_fwd_pipe<DH_, false, NW_, true>), grid, dim3(64 * NW_), 0, st, q, k, v, nullptr, out, H, 0, sl2, 0, cu, wk, Mtot)
 #define VSK_ATTN_PE(DH_, NW_, P_) \
     hipLaunchKernelGGL((attn_fwd_lp_pipe<DH_, NW_, P_, true>), grid, dim3(64 * NW_), 0, st, q, k, v, nullptr, out, H, 0, sl2, 0, cu, wk, Mtot)
-    if (prec == 2) {
+#define VSK_ATTN_P16(DH_, NW_) \
+    hipLaunchKernelGGL((attn_fwd_lp_pipe<DH_, NW_, 1, true, true>), grid, dim3(64 * NW_), 0, st, q, k, v, nullptr, out, H, 0, sl2, 0, cu, wk, Mtot)
+    if (prec == (1 | VSK_STORE16)) {      // bf16 q (pre-scaled) / k / v in, bf16 out
+        if (dh == 64 && nw == 8) VSK_ATTN_P16(64, 8);
+        else if (dh == 64 && nw == 4) VSK_ATTN_P16(64, 4);
+        else if (dh == 32 && nw == 4) VSK_ATTN_P16(32, 4);
+        else return -1;
+    } else if (prec == 2) {
         if (dh == 64 && nw == 8) VSK_ATTN_PE(64, 8, 2);
         else if (dh == 64 && nw == 4) VSK_ATTN_PE(64, 4, 2);
         else if (dh == 32 && nw == 4) VSK_ATTN_PE(32, 4, 2);
@@ -1136,13 +1181,14 @@ int vsk_attention_packed(const float *q, const float *k, const float *v, float *
     }
 #undef VSK_ATTN_PX
 #undef VSK_ATTN_PE
+#undef VSK_ATTN_P16
     VSK_CHECK_LAUNCH();
     return 0;
 }
 
 int vsk_attention_bf16(const float *q, const float *k, const float *v, const uint8_t *mask, float *out,
                        int B, int H, int T, int dh, float scale, int prec, hipStream_t st) {
-    const float sl2 = scale * 1.4426950408889634f;
+    const float sl2 = vsk_attention_qscale(scale);
     const int BH = B * H;
     // 8-wave blocks (256 query rows share one staged K/V tile) unless the ragged tail would waste too many rows
     const int r8 = (T + 255) / 256 * 256, r4 = (T + 127) / 128 * 128;
@@ -1158,6 +1204,16 @@ int vsk_attention_bf16(const float *q, const float *k, const float *v, const uin
         hipLaunchKernelGGL((KERN_<32, 4, P_>), grid, dim3(256), 0, st, q, k, v, mask, out, H, T, sl2, BH);               \
     else                                                                                                                 \
         return -1;
+    if (prec == (1 | VSK_STORE16)) {      // bf16 q (pre-scaled) / k / v in, bf16 out: the pipelined kernel only
+        if (dh == 64 && wide)
+            hipLaunchKernelGGL((attn_fwd_lp_pipe<64, 8, 1, false, true>), grid, dim3(512), 0, st, q, k, v, mask, out, H, T, sl2, BH);
+        else if (dh == 64)
+            hipLaunchKernelGGL((attn_fwd_lp_pipe<64, 4, 1, false, true>), grid, dim3(256), 0, st, q, k, v, mask, out, H, T, sl2, BH);
+        else if (dh == 32)
+            hipLaunchKernelGGL((attn_fwd_lp_pipe<32, 4, 1, false, true>), grid, dim3(256), 0, st, q, k, v, mask, out, H, T, sl2, BH);
+        else
+            return -1;
+    } else
     if (simple) { if (prec == 2) { VSK_ATTN_LP(attn_fwd_lp, 2) } else { VSK_ATTN_LP(attn_fwd_lp, 1) } }
     else        { if (prec == 2) { VSK_ATTN_LP(attn_fwd_lp_pipe, 2) } else { VSK_ATTN_LP(attn_fwd_lp_pipe, 1) } }
 #undef VSK_ATTN_LP

@@ -5,6 +5,10 @@
 #include <stdint.h>
 
 // bf16 != 0: operands rounded to bf16 for the matrix pipe (opt-in; fp32 storage, bias, accumulation, LayerNorm)
+// bf16 == (1 | VSK_STORE16): additionally the tensors that are ONLY ever consumed as bf16 matrix operands live in HBM
+// as bf16: C of vsk_qkv and of vsk_linear(relu), A of vsk_linear_res_ln, q/k/v/out of the bf16 attention.  The
+// rounding happens in the producer instead of the consumer: same bits, half the bytes.
+enum { VSK_STORE16 = 16 };
 // Wf: the weight in fragment-major order (vsk_pack_fragments) or nullptr; enables the packed latency kernels
 int vsk_linear(const float *A, const float *W, const float *Wf, const float *bias, float *C, int M, int N, int K,
                int relu, const float *pe, int T, int bf16, hipStream_t st);
@@ -17,11 +21,13 @@ int vsk_pack_fragments(const float *W, float *Wf, int N, int K, hipStream_t st);
 // the fp16x3 counterpart (hi|lo f16 halves of 2^10 * W, same size): pass it as `Wf` together with bf16 == 2
 int vsk_pack_fragments_f16x3(const float *W, float *Wh, int N, int K, hipStream_t st);
 int vsk_qkv(const float *h, const float *Wqkv, const float *Wf, const float *bqkv, float *qkv, int B, int T, int d,
-            int H, int bf16, hipStream_t st);
+            int H, int bf16, hipStream_t st, float qscale = 1.0f);
 int vsk_attention(const float *q, const float *k, const float *v, const uint8_t *mask, float *out,
                   int B, int H, int T, int dh, float scale, hipStream_t st);
 int vsk_attention_packed(const float *q, const float *k, const float *v, float *out, int H, int Mtot, int dh,
                          float scale, const int *cu, const int *work, int nwork, int nw, int prec, hipStream_t st);
+// the factor the bf16-storage QKV epilogue folds into q (the attention kernels' scale * log2 e, computed in one place)
+float vsk_attention_qscale(float scale);
 // prec 1: bf16 operands; 2: fp32 emulated with f16 hi+lo operand halves ("fp16x3")
 int vsk_attention_bf16(const float *q, const float *k, const float *v, const uint8_t *mask, float *out,
                        int B, int H, int T, int dh, float scale, int prec, hipStream_t st);
@@ -40,6 +46,16 @@ int vsk_mlp_fused(const float *H1, const float *W1, const float *b1, const float
                   const float *gamma, const float *beta, float *out, int M, int d,
                   const float *score_w, const float *score_b, int num_classes, int sigmoid, float *scores,
                   hipStream_t st);
+// bf16 mode, d_model == 256: fc1 + ReLU + fc2 + residual + LayerNorm (+ score head) as one kernel whose hidden
+// activations stay in registers (vs_mlp_fused.hip).  img: the per-chunk LDS images made by vsk_pack_mlp_bf16
+// (vsk_mlp_bf16_image_bytes(d) bytes, 256-byte aligned; 0 = this d_model has no fused kernel).
+bool vsk_mlp_bf16_supported(int d);
+size_t vsk_mlp_bf16_image_bytes(int d);
+int vsk_pack_mlp_bf16(const float *W1, const float *W2, void *img, int d, hipStream_t st);
+int vsk_mlp_bf16(const float *H1, const void *img, const float *b1, const float *b2,
+                 const float *gamma, const float *beta, float *out, int M, int d,
+                 const float *score_w, const float *score_b, int num_classes, int sigmoid, float *scores,
+                 hipStream_t st);
 // packed ragged batches: row offsets cu[B+1] and the (video, query tile) work list from device lengths; gather of
 // the positional rows pe[t] of every frame into rows[Mtot, d]
 int vsk_plan_packed(const int *lengths_dev, int B, int qb, int *cu, int *work, int work_cap, hipStream_t st);   // work_cap: (video, tile) pairs `work` can hold
@@ -55,6 +71,8 @@ struct VskOptions {
     int gemm_nj2;         // VS_GEMM_NJ2      128-column GEMM tiles only
     int attn_nw4;         // VS_ATTN_NW4      4-wave attention blocks only
     int attn_lp_simple;   // VS_ATTN_LP_SIMPLE phase-aligned low-precision attention
+    int lp_store32;       // VS_LP_STORE32    bf16 mode keeps q/k/v, the attention output and the MLP hidden tensor fp32 in HBM (A/B)
+    int lp_mlp_unfused;   // VS_LP_MLP_UNFUSED bf16 mode runs fc1 and fc2 + LayerNorm as two kernels (A/B)
     int mlp_fusion;       // VS_MLP_FUSION    (diagnostic builds only)
     int mlp_abl;          // VS_MLP_ABL       (diagnostic builds only)
     int attn_legacy;      // VS_ATTN_LEGACY   (diagnostic builds only)

@@ -66,7 +66,10 @@ __device__ __forceinline__ unsigned long long stamp() {
 // fragment reads); bias, accumulation and the epilogue are the fp32 ones.
 // PREC 2 (opt-in, VS_FLAG_F16X3_LINEAR): fp32 emulated on the f16 pipe (split_f16): an LDS row holds the 32 hi
 // halves then the 32 lo halves (128 B + 16 B pad = the fp32 row stride), three MFMAs per fragment pair.
-template <int EPI, int NWM = 2, int DIAG = 0, int NJ = 2, int PREC = 0>     // DIAG (tools/diag_gemm.py only) 2: epilogue skipped (wrong output) + per-wave cycles/wall clock; 1, 3: the same with the epilogue
+// C16 (PREC 1 only; fc1 and QKV): C is stored as bf16 - its only consumers (attention, fc2) round it to bf16 on entry
+// anyway, so the results are bit-identical and the tensor costs half the HBM bytes.  EPI_QKV then also pre-multiplies
+// q by ea.scale (the attention's scale * log2 e), which the bf16-input attention kernel no longer does.
+template <int EPI, int NWM = 2, int DIAG = 0, int NJ = 2, int PREC = 0, int C16 = 0>     // DIAG (tools/diag_gemm.py only) 2: epilogue skipped (wrong output) + per-wave cycles/wall clock; 1, 3: the same with the epilogue
 __global__ __launch_bounds__(128 * NWM, 2) void gemm_nt_128(
     const float *__restrict__ A, const float *__restrict__ W, const float *__restrict__ bias,
     float *__restrict__ C, int M, int N, int K, const float *__restrict__ pe, int T, int H, int dh,
@@ -374,7 +377,15 @@ __global__ __launch_bounds__(128 * NWM, 2) void gemm_nt_128(
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] = drop_keep(dsite, rk, (unsigned)(c32 + tc4 + e)) ? v[e] * dsite.scale : 0.f;
                         }
-                        if (EPI == EPI_QKV)
+                        if constexpr (C16 != 0) {
+                            if (EPI == EPI_QKV && which == 0) v *= ea.scale;
+                            u32x2 u; u[0] = pack_bf16(v[0], v[1]); u[1] = pack_bf16(v[2], v[3]);
+                            unsigned short *C2 = (unsigned short *)C;
+                            if (EPI == EPI_QKV)
+                                *(u32x2 *)(C2 + (size_t)which * M * (H * dh) + (((size_t)bb * H + head) * T + tt) * dh + e0 + tc4) = u;
+                            else
+                                *(u32x2 *)(C2 + (size_t)row * N + c32 + tc4) = u;
+                        } else if (EPI == EPI_QKV)
                             *(f32x4 *)(C + (size_t)which * M * (H * dh) + (((size_t)bb * H + head) * T + tt) * dh + e0 + tc4) = v;
                         else
                             *(f32x4 *)(C + (size_t)row * N + c32 + tc4) = v;
@@ -591,7 +602,8 @@ __global__ __launch_bounds__(256) void gemm_res_ln(
 //   epilogue issues no loads from HBM at all; gamma/beta/score_w sit in LDS.
 //   Block = 4 waves = 128 rows, BK = 16 (LDS rows padded to 20 floats), 2 blocks per CU.
 // ------------------------------------------------------------------------------------------
-template <int NT, int PREC = 0>     // PREC 1: bf16 MFMA operands (see gemm_nt_128), LDS rows of 16 bf16 padded to 48 B; 2: f16 hi|lo rows (80 B)
+// A16 (PREC 1 only): A lives in HBM as bf16 (written so by the bf16 attention / the C16 fc1 epilogue)
+template <int NT, int PREC = 0, int A16 = 0>     // PREC 1: bf16 MFMA operands (see gemm_nt_128), LDS rows of 16 bf16 padded to 48 B; 2: f16 hi|lo rows (80 B)
 __global__ __launch_bounds__(256, 2) void gemm_ln_rows(
     const float *__restrict__ A, const float *__restrict__ W, const float *__restrict__ bias,
     const float *__restrict__ res, const float *__restrict__ gamma, const float *__restrict__ beta,
@@ -614,7 +626,9 @@ __global__ __launch_bounds__(256, 2) void gemm_ln_rows(
     // staging map: A 128 rows x 4 float4 (2 per thread), W N rows x 4 float4 (WL per thread)
     const int lrow = tid >> 2, lc4 = (tid & 3) * 4;
     f32x4 pa[2], pw[WL];
+    u32x2 pa16[2];                                     // A16: 4 bf16 per thread and k-tile
     const float *aptr[2], *wptr[WL];
+    const unsigned short *aptr16[2];
 #pragma unroll
     for (int i = 0; i < WL; ++i) {
         int wrow = lrow + 64 * i; wrow = wrow < N ? wrow : N - 1;
@@ -643,7 +657,9 @@ __global__ __launch_bounds__(256, 2) void gemm_ln_rows(
         } else if constexpr (PREC == 1) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                u32x2 u; u[0] = pack_bf16(pa[i][0], pa[i][1]); u[1] = pack_bf16(pa[i][2], pa[i][3]);
+                u32x2 u;
+                if constexpr (A16 != 0) u = pa16[i];
+                else { u[0] = pack_bf16(pa[i][0], pa[i][1]); u[1] = pack_bf16(pa[i][2], pa[i][3]); }
                 *(u32x2 *)&As[(lrow + 64 * i) * LDB + lc4 / 2] = u;
             }
 #pragma unroll
@@ -670,8 +686,13 @@ __global__ __launch_bounds__(256, 2) void gemm_ln_rows(
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             int ar = m0 + lrow + 64 * i; ar = ar < M ? ar : M - 1;
-            aptr[i] = A + (size_t)ar * K + lc4;
-            pa[i] = *(const f32x4 *)aptr[i];
+            if constexpr (A16 != 0) {
+                aptr16[i] = (const unsigned short *)A + (size_t)ar * K + lc4;
+                pa16[i] = *(const u32x2 *)aptr16[i];
+            } else {
+                aptr[i] = A + (size_t)ar * K + lc4;
+                pa[i] = *(const f32x4 *)aptr[i];
+            }
         }
 #pragma unroll
         for (int i = 0; i < WL; ++i) pw[i] = *(const f32x4 *)wptr[i];
@@ -720,7 +741,10 @@ __global__ __launch_bounds__(256, 2) void gemm_ln_rows(
                 // one k-step of 16: lane (r,h) supplies k = 8h .. 8h+7
                 const bf16x8 fa = __builtin_bit_cast(bf16x8, *(const u32x4 *)(As + (32 * wave + r) * LDB + 4 * h));
 #pragma unroll
-                for (int i = 0; i < 2; ++i) pa[i] = *(const f32x4 *)(aptr[i] + kn * BK);
+                for (int i = 0; i < 2; ++i) {
+                    if constexpr (A16 != 0) pa16[i] = *(const u32x2 *)(aptr16[i] + kn * BK);
+                    else pa[i] = *(const f32x4 *)(aptr[i] + kn * BK);
+                }
 #pragma unroll
                 for (int i = 0; i < WL; ++i) pw[i] = *(const f32x4 *)(wptr[i] + kn * BK);
 #pragma unroll
@@ -1757,6 +1781,22 @@ static int launch_gemm(const float *A, const float *W, const float *Wf, const fl
         VSK_CHECK_LAUNCH();
         return 0;
     }
+    if constexpr (EPI == EPI_RELU || EPI == EPI_QKV) {
+        if (bf16 == (1 | VSK_STORE16)) {      // bf16 matrix pipe, C stored as bf16 (fc1, QKV)
+            if (N % 256 == 0 && M > 128) {
+                const int blocks = persistent_blocks(((M + 255) / 256) * (N / 256), 1);
+                if (blocks < 0) return (int)hipErrorInvalidDevice;
+                hipLaunchKernelGGL((gemm_nt_128<EPI, 4, 0, 4, 1, 1>), dim3(blocks), dim3(512), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr, ea);
+            } else {
+                const int blocks = persistent_blocks(((M + 127) / 128) * ((N + 127) / 128), 2);
+                if (blocks < 0) return (int)hipErrorInvalidDevice;
+                hipLaunchKernelGGL((gemm_nt_128<EPI, 2, 0, 2, 1, 1>), dim3(blocks), dim3(256), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr, ea);
+            }
+            VSK_CHECK_LAUNCH();
+            return 0;
+        }
+    }
+    if (bf16 & VSK_STORE16) return -1;       // only the two producers above have a bf16-output form
     if (bf16) {          // bf16 matrix pipe (opt-in): always the LDS-tiled kernels
         if (N % 256 == 0 && M > 128) {
             const int blocks = persistent_blocks(((M + 255) / 256) * (N / 256), 1);
@@ -1863,7 +1903,17 @@ int vsk_diag_gemm(const float *A, const float *W, const float *bias, float *C, i
                           : persistent_blocks(((M + 127) / 128) * ((N + 127) / 128), 2);
     if (blocks < 0) return (int)hipErrorInvalidDevice;
     if (grid > 0) blocks = grid;
-    if (getenv("VS_DIAG_PREC")) {         // the fp16x3 instantiation (256x256 tiles): 2 = without, else with the epilogue
+    const char *dprec = getenv("VS_DIAG_PREC");
+    if (dprec && atoi(dprec) == 1) {      // the bf16 instantiation (256x256 tiles): mode 2 = without, else with the epilogue
+        blocks = grid > 0 ? grid : persistent_blocks(((M + 255) / 256) * (N / 256), 1);
+        if (m == 2)
+            hipLaunchKernelGGL((gemm_nt_128<EPI_RELU, 4, 2, 4, 1>), dim3(blocks), dim3(512), 0, st, A, W, bias, C, M, N, K, nullptr, 1, 0, 0, diag);
+        else
+            hipLaunchKernelGGL((gemm_nt_128<EPI_RELU, 4, 3, 4, 1>), dim3(blocks), dim3(512), 0, st, A, W, bias, C, M, N, K, nullptr, 1, 0, 0, diag);
+        VSK_CHECK_LAUNCH();
+        return 0;
+    }
+    if (dprec) {                          // the fp16x3 instantiation (256x256 tiles): 2 = without, else with the epilogue
         blocks = grid > 0 ? grid : persistent_blocks(((M + 255) / 256) * (N / 256), 1);
         if (m == 2)
             hipLaunchKernelGGL((gemm_nt_128<EPI_RELU, 4, 2, 4, 2>), dim3(blocks), dim3(512), 0, st, A, W, bias, C, M, N, K, nullptr, 1, 0, 0, diag);
@@ -1883,9 +1933,11 @@ int vsk_diag_gemm(const float *A, const float *W, const float *bias, float *C, i
 }
 #endif  // VS_WITH_DIAG
 
+// bf16 | VSK_STORE16: q (times qscale), k, v are written as bf16, three [B,H,T,dh] planes of M*d 2-byte elements
 int vsk_qkv(const float *h, const float *Wqkv, const float *Wf, const float *bqkv, float *qkv, int B, int T, int d,
-            int H, int bf16, hipStream_t st) {
-    return launch_gemm<EPI_QKV>(h, Wqkv, Wf, bqkv, qkv, B * T, 3 * d, d, nullptr, T, H, d / H, bf16, st);
+            int H, int bf16, hipStream_t st, float qscale) {
+    return launch_gemm<EPI_QKV>(h, Wqkv, Wf, bqkv, qkv, B * T, 3 * d, d, nullptr, T, H, d / H, bf16, st,
+                                EpiArgs{0ull, 0u, 0.f, qscale});
 }
 
 int vsk_linear_res_ln(const float *A, const float *W, const float *Wf, const float *bias, const float *res,
@@ -1909,6 +1961,8 @@ int vsk_linear_res_ln(const float *A, const float *W, const float *Wf, const flo
         VSK_CHECK_LAUNCH();
         return 0;
     }
+    const bool a16 = bf16 == (1 | VSK_STORE16);           // A stored as bf16 (bf16 mode only)
+    if (a16) bf16 = 1;
     if (bf16 == 1 && (N > 256 || N % 32)) return -1;      // bf16: d_model <= 256 only
     if (bf16 && N <= 256) {          // low-precision lane-owns-a-row kernels (wider fp16x3: gemm_res_ln<NB, 2> below)
         if (N % 32) return -1;
@@ -1919,6 +1973,9 @@ int vsk_linear_res_ln(const float *A, const float *W, const float *Wf, const flo
     case NT_:                                                                                               \
         if (bf16 == 2)                                                                                      \
             hipLaunchKernelGGL((gemm_ln_rows<NT_, 2>), dim3(blocks), dim3(256), 0, st, A, W, bias, res, gamma, \
+                               beta, out, M, K, score_w, score_b, num_classes, sigmoid, scores);            \
+        else if (a16)                                                                                       \
+            hipLaunchKernelGGL((gemm_ln_rows<NT_, 1, 1>), dim3(blocks), dim3(256), 0, st, A, W, bias, res, gamma, \
                                beta, out, M, K, score_w, score_b, num_classes, sigmoid, scores);            \
         else                                                                                                \
             hipLaunchKernelGGL((gemm_ln_rows<NT_, 1>), dim3(blocks), dim3(256), 0, st, A, W, bias, res, gamma, \

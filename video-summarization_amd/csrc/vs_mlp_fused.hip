@@ -1,0 +1,318 @@
+// vs_mlp_fused.hip — the MLP block of one encoder layer as ONE kernel on the bf16 matrix pipe (opt-in bf16 mode,
+// d_model = 256, hidden = 1024):
+//     out = LayerNorm( relu(h1 W1^T + b1) W2^T + b2 + h1 ) * gamma + beta      (+ score head)
+// (reference simnet.py:109-110 EncoderBlock, 180-183 MLP, 42 final_layer).
+//
+// Why: as two kernels (fc1 + ReLU, fc2 + residual + LayerNorm) the [M, 1024] hidden tensor makes a round trip
+// through HBM and both kernels are bound by it and by their store bursts / load latency (stamped build: fc1 spends
+// 55 % of its time in the store epilogue and 3 200 cycles per 32-k tile waiting for loads; MFMA busy 0.06-0.14),
+// 209 us per layer at M = 65 536 against an MFMA floor of 27 us.  Here the hidden activations never leave registers.
+//
+// Layout.  Block = 8 waves = 256 rows, one block per CU; wave w owns rows 32w .. 32w+31 (lane (r, h) = row r):
+//   Y[8]   fp32 accumulators of the output row block, started at the residual h1 (C-in), 128 registers;
+//   X[16]  the same h1 values rounded to bf16, as the B operands of fc1 (64 registers) - they come out of the
+//          residual load for free: lane (r, h) holds columns 32j + 8q + 4h + e, and taking registers 8qq .. 8qq+7 of a
+//          32-column block as ONE 16-k step only permutes k inside the step (position 8h + i <-> column
+//          8(i>>2) + 4h + (i&3): bits 2 and 3 swapped);
+//   per 32 hidden units:  U = W1[32 rows] X^T (16 MFMAs, one dependent chain: gfx950 issues it back to back),
+//          ReLU + round to bf16 in place (the U accumulator registers 8qq .. 8qq+7 ARE the next B operand, the same
+//          permutation), Y += W2[:, 32 columns] U^T (16 MFMAs).
+//   The weights are pre-packed once per vs_weights_pack/update (vsk_pack_mlp_bf16) into the exact LDS IMAGE of every
+//   32-hidden-unit chunk: bf16, the permutation applied, rows padded (528 B / 80 B: conflict-free ds_read_b128), 40 KiB
+//   per chunk.  Staging is therefore LDS-DMA (global_load_lds_dwordx4: a wave instruction copies 1 KiB verbatim, no
+//   staging registers, no LDS-write instructions): every wave issues 5 pieces per chunk, TWO chunks ahead, into a ring of
+//   three LDS buffers; a counted s_waitcnt vmcnt(5) + one raw s_barrier per chunk retire the chunk needed next and
+//   leave the one after it in flight (the loop contains no other vector-memory instruction - the kernel must compile
+//   without scratch, which tests/test_host.py checks).  Per MFMA: one 1-KiB fragment read per wave, i.e. LDS reads
+//   (128 B/clk/CU) and the matrix pipe are co-limiting by construction.
+// Rounding points equal those of the two-kernel path (h1, the weights and relu(fc1) to bf16; fp32 everything else);
+// only the order of the 16 products inside an MFMA step differs, so the results agree to fp32 rounding, not bitwise.
+#include "vs_device.h"
+#include "vs_kernels.h"
+
+#include <atomic>
+
+namespace {
+
+typedef unsigned short h16;
+
+constexpr int MLP_D = 256, MLP_HID = 1024, MLP_CH = 32, MLP_NCH = MLP_HID / MLP_CH;
+constexpr int MLP_LD1 = 528;                    // bytes per W1 row in the image (256 bf16 + 16: stride = 4 mod 64 dwords)
+constexpr int MLP_LD2 = 80;                     // bytes per W2 row (32 bf16 + 16: 20 dwords, conflict-free b128)
+constexpr int MLP_W2OFF = 17408;                // W1 part: 32 * 528 = 16896, rounded up to a 1-KiB piece boundary
+constexpr int MLP_IMG = 40960;                  // W2 part: 256 * 80 = 20480 -> 37 pieces, padded to 40 (5 per wave)
+
+__device__ __forceinline__ int swap23(int p) { return (p & 3) | ((p & 4) << 1) | ((p & 8) >> 1); }
+
+// W1 [1024][256], W2 [256][1024] fp32 -> img [32 chunks][MLP_IMG bytes] (pad bytes are left as the caller zeroed them)
+__global__ void pack_mlp_bf16(const float *__restrict__ W1, const float *__restrict__ W2, unsigned char *__restrict__ img) {
+    const int n = MLP_D * MLP_HID / 2;          // bf16 pairs per matrix
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        {   // W1: pair at row = hidden unit, position p (even) of the permuted k order
+            const int row = (2 * i) / MLP_D, p = (2 * i) % MLP_D, b16 = p & ~15;
+            const float *src = W1 + (size_t)row * MLP_D + b16;
+            unsigned *dst = (unsigned *)(img + (size_t)(row / MLP_CH) * MLP_IMG + (row % MLP_CH) * MLP_LD1 + 2 * p);
+            *dst = pack_bf16(src[swap23(p & 15)], src[swap23((p & 15) + 1)]);
+        }
+        {   // W2: pair at row = output column, hidden unit 32c + position p32 (even) of the permuted order
+            const int row = (2 * i) / MLP_HID, hcol = (2 * i) % MLP_HID, c = hcol / MLP_CH, p32 = hcol % MLP_CH;
+            const float *src = W2 + (size_t)row * MLP_HID + MLP_CH * c + (p32 & 16);
+            unsigned *dst = (unsigned *)(img + (size_t)c * MLP_IMG + MLP_W2OFF + row * MLP_LD2 + 2 * p32);
+            *dst = pack_bf16(src[swap23(p32 & 15)], src[swap23((p32 & 15) + 1)]);
+        }
+    }
+}
+
+// one wave instruction: lane l copies 16 bytes from its `g` to lds_wave_base + 16 l (asynchronous, counted by vmcnt)
+__device__ __forceinline__ void glds16(const void *g, void *lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+}
+
+// ABL (diagnostic library only, timing runs with wrong results): 1 no weight staging, 2 no barrier / wait in the chunk
+// loop, 4 fragment reads replaced by register moves, 8 no chunk loop at all (prologue + epilogue only)
+template <int ABL = 0>
+__global__ __launch_bounds__(512, 1) void mlp_fused_bf16(
+    const float *__restrict__ H1, const unsigned char *__restrict__ Wimg, const float *__restrict__ b1,
+    const float *__restrict__ b2, const float *__restrict__ gamma,
+    const float *__restrict__ beta, float *__restrict__ out, int M,
+    const float *__restrict__ score_w, const float *__restrict__ score_b, int num_classes,
+    int sigmoid, float *__restrict__ scores) {
+    constexpr int D = MLP_D, HID = MLP_HID, NT = 8, NCH = MLP_NCH, IMG = MLP_IMG;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char dyn_smem[];      // ONE LDS object (see the header)
+    unsigned char *ring = dyn_smem;                              // [3][IMG]
+    float *b1s = (float *)(dyn_smem + 3 * IMG);                  // [HID]
+    float *gam_s = b1s + HID, *bet_s = gam_s + D, *sw_s = bet_s + D, *bias_s = sw_s + D;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    for (int i = tid; i < HID; i += 512) b1s[i] = b1[i];
+    for (int i = tid; i < D; i += 512) { gam_s[i] = gamma[i]; bet_s[i] = beta[i]; bias_s[i] = b2[i]; }
+
+    // chunk image -> ring buffer: 40 pieces of 1 KiB, 5 per wave
+    auto dma_chunk = [&](int chunk, int bufoff) __attribute__((always_inline)) {
+        const unsigned char *src = Wimg + (size_t)chunk * IMG + wave * 1024 + lane * 16;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) glds16(src + 8192 * i, ring + bufoff + wave * 1024 + 8192 * i);
+    };
+
+    f32x16 Y[NT];
+    u32x4 X[2 * NT];
+    const int ntiles = (M + 255) / 256;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int m0 = tile * 256 + 32 * wave;
+        int row = m0 + r;
+        const bool row_ok = row < M;
+        row = row_ok ? row : M - 1;
+        __syncthreads();                        // the previous tile's epilogue is done with the ring
+        if constexpr (!(ABL & 1)) { dma_chunk(0, 0); dma_chunk(1, IMG); }
+        {
+            const float *rp = H1 + (size_t)row * D + 4 * h;
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 rv = *(const f32x4 *)(rp + 32 * j + 8 * q);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) Y[j][4 * q + e] = rv[e];
+                    X[2 * j + (q >> 1)][2 * (q & 1)] = pack_bf16(rv[0], rv[1]);
+                    X[2 * j + (q >> 1)][2 * (q & 1) + 1] = pack_bf16(rv[2], rv[3]);
+                }
+        }
+        __syncthreads();                        // (waits for every outstanding load, the two DMA'd chunks included)
+
+        int cur = 0, nx1 = IMG, nx2 = 2 * IMG;  // ring offsets of chunk c, c+1, c+2
+        for (int c = 0; c < ((ABL & 8) ? 0 : NCH); ++c) {
+            if constexpr (!(ABL & 1)) dma_chunk(c + 2 < NCH ? c + 2 : NCH - 1, nx2);      // past the end: a harmless re-copy
+            const unsigned char *w1base = ring + cur + r * MLP_LD1 + 16 * h;
+            const unsigned char *w2base = ring + cur + MLP_W2OFF + r * MLP_LD2 + 16 * h;
+            // fragment f: f < 16: fc1 k-step f (W1 row r); f >= 16: fc2 k-step qq = (f-16)/8 of output block
+            // j = (f-16)%8 (W2 row 32j + r).  A ring of three registers sets: two reads in flight.
+            u32x4 fw[3];
+            auto frag = [&](auto fc) __attribute__((always_inline)) {
+                constexpr int f = decltype(fc)::value;
+                if constexpr ((ABL & 4) != 0) { fw[f % 3] = X[f % 16]; return; }
+                if constexpr (f < 16) fw[f % 3] = *(const u32x4 *)(w1base + 32 * f);
+                else fw[f % 3] = *(const u32x4 *)(w2base + 32 * ((f - 16) % 8) * MLP_LD2 + 32 * ((f - 16) / 8));
+            };
+            f32x16 U;
+            {
+                const float *bp = b1s + MLP_CH * c + 4 * h;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 bv = *(const f32x4 *)(bp + 8 * q);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) U[4 * q + e] = bv[e];
+                }
+            }
+            frag(std::integral_constant<int, 0>{});
+            frag(std::integral_constant<int, 1>{});
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- fc1: U = b1 + W1[32 rows] X^T (one dependent chain: issues back to back on gfx950) ----
+            static_for<16>([&](auto fc) {
+                constexpr int f = decltype(fc)::value;
+                frag(std::integral_constant<int, f + 2>{});
+                U = MFMA_BF16(__builtin_bit_cast(bf16x8, fw[f % 3]), __builtin_bit_cast(bf16x8, X[f]), U);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            // ---- ReLU, round to bf16: registers 8qq .. 8qq+7 are the B operand of k-step qq ----
+            u32x4 P[2];
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii)
+                    P[qq][ii] = pack_bf16(relu1(U[8 * qq + 2 * ii]), relu1(U[8 * qq + 2 * ii + 1]));
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- fc2: Y += W2[:, these 32 hidden units] P^T ----
+            static_for<16>([&](auto gc) {
+                constexpr int g = decltype(gc)::value, f = 16 + g;
+                if constexpr (f + 2 < 32) frag(std::integral_constant<int, f + 2>{});
+                Y[g % 8] = MFMA_BF16(__builtin_bit_cast(bf16x8, fw[f % 3]), __builtin_bit_cast(bf16x8, P[g / 8]), Y[g % 8]);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            if constexpr (!(ABL & 2)) {
+                // chunk c+1 (5 pieces, issued one iteration ago) has landed; chunk c+2's 5 stay in flight.  Its data
+                // is read only after the barrier every wave passes behind its own wait.
+                if constexpr (!(ABL & 1)) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+            const int t = cur; cur = nx1; nx1 = nx2; nx2 = t;
+        }
+        __syncthreads();                        // drains the DMAs still in flight before the ring is reused below
+
+        // ---- epilogue (that of gemm_ln_rows): + b2, LayerNorm over the row (lane-local + one lane^32 exchange),
+        // stores transposed through a wave-private corner of the now idle ring, score head ----
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            float pj = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 bv = *(const f32x4 *)&bias_s[32 * j + 8 * q + 4 * h];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { Y[j][4 * q + e] += bv[e]; pj += Y[j][4 * q + e]; }
+            }
+            sum += pj;
+        }
+        sum = pair_sum(sum);
+        const float mean = sum * (1.0f / D);
+        float sq = 0.f;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            float pj = 0.f;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) { const float cv = Y[j][t] - mean; Y[j][t] = cv; pj += cv * cv; }
+            sq += pj;
+        }
+        sq = pair_sum(sq);
+        const float rstd = 1.0f / sqrtf(sq * (1.0f / D) + 1e-5f);
+        float *tp = (float *)dyn_smem + wave * (32 * 36);
+        const int trow = lane >> 3, tc4 = (lane & 7) * 4;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 gv = *(const f32x4 *)&gam_s[32 * j + 8 * q + 4 * h];
+                const f32x4 bv = *(const f32x4 *)&bet_s[32 * j + 8 * q + 4 * h];
+                f32x4 y;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { y[e] = Y[j][4 * q + e] * rstd * gv[e] + bv[e]; Y[j][4 * q + e] = y[e]; }
+                *(f32x4 *)&tp[r * 36 + 8 * q + 4 * h] = y;
+            }
+#pragma unroll
+            for (int pq = 0; pq < 4; ++pq) {
+                const f32x4 v = *(const f32x4 *)&tp[(trow + 8 * pq) * 36 + tc4];
+                const int orow = m0 + trow + 8 * pq;
+                if (orow < M) *(f32x4 *)(out + (size_t)orow * D + 32 * j + tc4) = v;
+            }
+        }
+        if (score_w != nullptr) {
+            for (int cc = 0; cc < num_classes; ++cc) {
+                __syncthreads();
+                for (int i = tid; i < D; i += 512) sw_s[i] = score_w[(size_t)cc * D + i];
+                __syncthreads();
+                float dot = 0.f;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    float pj = 0.f;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 wv = *(const f32x4 *)&sw_s[32 * j + 8 * q + 4 * h];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) pj += Y[j][4 * q + e] * wv[e];
+                    }
+                    dot += pj;
+                }
+                dot = pair_sum(dot);
+                if (h == 0 && row_ok) {
+                    float sc = dot + score_b[cc];
+                    if (sigmoid) sc = 1.0f / (1.0f + expf(-sc));
+                    scores[(size_t)row * num_classes + cc] = sc;
+                }
+            }
+        }
+    }
+}
+
+constexpr size_t MLP_LDS = (size_t)3 * MLP_IMG + (MLP_HID + 4 * MLP_D) * sizeof(float);      // 128 KiB
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is per DEVICE: set once per (kernel instantiation, device)
+template <int ABL>
+int allow_lds() {
+    static std::atomic<unsigned char> done[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return (int)hipErrorInvalidDevice;
+    if (dev >= 0 && dev < 64 && done[dev].load(std::memory_order_acquire)) return 0;
+    const int rc = (int)hipFuncSetAttribute((const void *)mlp_fused_bf16<ABL>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)MLP_LDS);
+    if (rc == 0 && dev >= 0 && dev < 64) done[dev].store(1, std::memory_order_release);
+    return rc;
+}
+
+}  // namespace
+
+size_t vsk_mlp_bf16_image_bytes(int d) { return d == MLP_D ? (size_t)MLP_NCH * MLP_IMG : 0; }
+
+int vsk_pack_mlp_bf16(const float *W1, const float *W2, void *img, int d, hipStream_t st) {
+    if (d != MLP_D) return -1;
+    if (hipMemsetAsync(img, 0, vsk_mlp_bf16_image_bytes(d), st) != hipSuccess) return (int)hipGetLastError();
+    hipLaunchKernelGGL(pack_mlp_bf16, dim3(256), dim3(256), 0, st, W1, W2, (unsigned char *)img);
+    VSK_CHECK_LAUNCH();
+    return 0;
+}
+
+bool vsk_mlp_bf16_supported(int d) { return d == MLP_D; }
+
+int vsk_mlp_bf16(const float *H1, const void *img, const float *b1, const float *b2,
+                 const float *gamma, const float *beta, float *out, int M, int d,
+                 const float *score_w, const float *score_b, int num_classes, int sigmoid, float *scores,
+                 hipStream_t st) {
+    if (!vsk_mlp_bf16_supported(d) || M <= 0) return -1;
+    const int cus = vsk_device_cus();
+    if (cus <= 0) return (int)hipErrorInvalidDevice;
+    const int ntiles = (M + 255) / 256;
+    const int blocks = ntiles < cus ? ntiles : cus;
+#define VSK_MLP_LAUNCH(A_)                                                                                             \
+    do {                                                                                                               \
+        if (const int rc = allow_lds<A_>()) return rc;                                                                 \
+        hipLaunchKernelGGL((mlp_fused_bf16<A_>), dim3(blocks), dim3(512), MLP_LDS, st, H1, (const unsigned char *)img, b1, \
+                           b2, gamma, beta, out, M, score_w, score_b, num_classes, sigmoid, scores);                   \
+    } while (0)
+#ifdef VS_WITH_DIAG
+    switch (vsk_options().mlp_abl) {       // timing-only ablations (tools/bench_mlp_fused.py)
+        case 0: break;
+        case 1: VSK_MLP_LAUNCH(1); VSK_CHECK_LAUNCH(); return 0;
+        case 2: VSK_MLP_LAUNCH(2); VSK_CHECK_LAUNCH(); return 0;
+        case 3: VSK_MLP_LAUNCH(3); VSK_CHECK_LAUNCH(); return 0;
+        case 4: VSK_MLP_LAUNCH(4); VSK_CHECK_LAUNCH(); return 0;
+        case 5: VSK_MLP_LAUNCH(5); VSK_CHECK_LAUNCH(); return 0;
+        case 7: VSK_MLP_LAUNCH(7); VSK_CHECK_LAUNCH(); return 0;
+        default: VSK_MLP_LAUNCH(8); VSK_CHECK_LAUNCH(); return 0;
+    }
+#endif
+    VSK_MLP_LAUNCH(0);
+#undef VSK_MLP_LAUNCH
+    VSK_CHECK_LAUNCH();
+    return 0;
+}

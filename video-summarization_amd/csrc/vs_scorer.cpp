@@ -114,7 +114,8 @@ const OptionName kOptions[] = {
     {"VS_GEMM_NWM2", &VskOptions::gemm_nwm2, 0},         {"VS_GEMM_NJ2", &VskOptions::gemm_nj2, 0},
     {"VS_ATTN_NW4", &VskOptions::attn_nw4, 0},           {"VS_ATTN_LP_SIMPLE", &VskOptions::attn_lp_simple, 0},
     {"VS_MLP_FUSION", &VskOptions::mlp_fusion, 0},       {"VS_MLP_ABL", &VskOptions::mlp_abl, 0},
-    {"VS_ATTN_LEGACY", &VskOptions::attn_legacy, 0},
+    {"VS_ATTN_LEGACY", &VskOptions::attn_legacy, 0},     {"VS_LP_STORE32", &VskOptions::lp_store32, 0},
+    {"VS_LP_MLP_UNFUSED", &VskOptions::lp_mlp_unfused, 0},
 };
 int option_from_env(const OptionName &o) {
     const char *e = getenv(o.name);
@@ -206,6 +207,9 @@ static int fill_weights(vs_weights *w, const vs_model_params *params, hipStream_
         pk &= vsk_pack_fragments_f16x3(w->blob + L.w1, w->blob + L.h_w1, (int)(4 * d), (int)d, st) == 0;
         pk &= vsk_pack_fragments_f16x3(w->blob + L.w2, w->blob + L.h_w2, (int)d, (int)(4 * d), st) == 0;
     }
+    if (vsk_mlp_bf16_supported((int)d))
+        for (const auto &L : w->layers)
+            pk &= vsk_pack_mlp_bf16(w->blob + L.w1, w->blob + L.w2, w->blob + L.b_mlp, (int)d, st) == 0;
     if (!pk) return fail(VS_ERR_HIP, "weight fragment packing failed: %s", hipGetErrorString(hipGetLastError()));
     return VS_OK;
 }
@@ -243,6 +247,8 @@ int vs_weights_pack(const vs_model_desc *desc, const vs_model_params *params, vo
     for (auto &L : w->layers) {
         L.h_wqkv = take(3 * d * d); L.h_wo = take(d * d); L.h_w1 = take(4 * d * d); L.h_w2 = take(4 * d * d);
     }
+    if (vsk_mlp_bf16_supported((int)d))
+        for (auto &L : w->layers) L.b_mlp = take(vsk_mlp_bf16_image_bytes((int)d) / sizeof(float));
     w->blob_floats = off;
     if (hipGetDevice(&w->device) != hipSuccess) { delete w; return fail(VS_ERR_HIP, "hipGetDevice failed"); }
     hipError_t e = hipMalloc((void **)&w->blob, off * sizeof(float));
@@ -329,6 +335,13 @@ int forward_core(const vs_weights *w, const float *x, const uint8_t *key_pad_mas
     const int lbf = (flags & VS_FLAG_F16X3_LINEAR) ? 2 : ((flags & VS_FLAG_BF16_LINEAR) && M > lp_min_rows) ? 1 : 0;
     // the bf16 Linear + LayerNorm kernels stop at d_model 256 (validated above); fp16x3 has a wide variant too
     const int lnbf = lbf;
+    // bf16 mode: the tensors that are only ever read as bf16 matrix operands are WRITTEN as bf16 by their producers
+    // (q * scale * log2 e, k, v; the attention output; the MLP hidden tensor) - same bits, half the HBM bytes
+    const int aprec = pk ? pk->prec : (flags & VS_FLAG_F16X3_ATTENTION) ? 2 : (flags & VS_FLAG_BF16_ATTENTION) ? 1 : 0;
+    const bool qkv16 = lbf == 1 && aprec == 1 && !vsk_options().lp_store32 && !vsk_options().attn_lp_simple;
+    const bool ffn16 = lbf == 1 && !vsk_options().lp_store32;
+    const bool mlp16 = lbf == 1 && vsk_mlp_bf16_supported(d) && !vsk_options().lp_mlp_unfused && !vsk_options().lp_store32;
+    const size_t kv_stride = qkv16 ? (size_t)M * d / 2 : (size_t)M * d;      // floats between the q, k and v planes
 
     // Embedding + positional table (simnet.py:211, 237-238)
     {
@@ -341,16 +354,17 @@ int forward_core(const vs_weights *w, const float *x, const uint8_t *key_pad_mas
         const bool last = l == L - 1;
         {
             StageScope ps(VS_STAGE_QKV, st);
-            VS_LAUNCH(vsk_qkv(h0, w->p(P.wqkv), w->p(lbf == 2 ? P.h_wqkv : P.f_wqkv), w->p(P.bqkv), qkv, B, T, d, H, lbf, st));
+            VS_LAUNCH(vsk_qkv(h0, w->p(P.wqkv), w->p(lbf == 2 ? P.h_wqkv : P.f_wqkv), w->p(P.bqkv), qkv, B, T, d, H,
+                              qkv16 ? (1 | VSK_STORE16) : lbf, st, qkv16 ? vsk_attention_qscale(scale) : 1.0f));
         }
         {
             StageScope ps(VS_STAGE_ATTENTION, st);
             if (pk)
-                VS_LAUNCH(vsk_attention_packed(qkv, qkv + (size_t)M * d, qkv + 2 * (size_t)M * d, att, H, M, d / H, scale,
-                                               pk->cu, pk->work, pk->nwork, pk->nw, pk->prec, st));
-            else if (flags & (VS_FLAG_BF16_ATTENTION | VS_FLAG_F16X3_ATTENTION))
-                VS_LAUNCH(vsk_attention_bf16(qkv, qkv + (size_t)M * d, qkv + 2 * (size_t)M * d, key_pad_mask, att,
-                                             B, H, T, d / H, scale, (flags & VS_FLAG_F16X3_ATTENTION) ? 2 : 1, st));
+                VS_LAUNCH(vsk_attention_packed(qkv, qkv + kv_stride, qkv + 2 * kv_stride, att, H, M, d / H, scale,
+                                               pk->cu, pk->work, pk->nwork, pk->nw, qkv16 ? (1 | VSK_STORE16) : pk->prec, st));
+            else if (aprec)
+                VS_LAUNCH(vsk_attention_bf16(qkv, qkv + kv_stride, qkv + 2 * kv_stride, key_pad_mask, att,
+                                             B, H, T, d / H, scale, qkv16 ? (1 | VSK_STORE16) : aprec, st));
             else
                 VS_LAUNCH(vsk_attention(qkv, qkv + (size_t)M * d, qkv + 2 * (size_t)M * d, key_pad_mask, att, B, H,
                                         T, d / H, scale, st));
@@ -365,7 +379,7 @@ int forward_core(const vs_weights *w, const float *x, const uint8_t *key_pad_mas
                 VS_LAUNCH(vsk_rows_res_ln(qkv, h0, w->p(P.ln1g), w->p(P.ln1b), h1, M, d, nullptr, nullptr, 0, 0, nullptr, st));
             } else
             VS_LAUNCH(vsk_linear_res_ln(att, w->p(P.wo), w->p(lnbf == 2 ? P.h_wo : P.f_wo), w->p(P.bo), h0, w->p(P.ln1g), w->p(P.ln1b), h1, M, d, d,
-                                        nullptr, nullptr, 0, 0, nullptr, lnbf, st));
+                                        nullptr, nullptr, 0, 0, nullptr, qkv16 ? (1 | VSK_STORE16) : lnbf, st));
         }
         float *dst = (last && hidden) ? hidden : h0;
 #ifdef VS_WITH_DIAG     // diagnostic library only (tools/): the measured-slower fused MLP kernel
@@ -382,9 +396,18 @@ int forward_core(const vs_weights *w, const float *x, const uint8_t *key_pad_mas
             continue;
         }
 #endif
+        // bf16 mode, d_model 256, throughput batches: the whole MLP block as one kernel (hidden activations in registers)
+        if (mlp16) {
+            StageScope ps(VS_STAGE_FC2_LN, st);
+            VS_LAUNCH(vsk_mlp_bf16(h1, w->p(P.b_mlp), w->p(P.b1), w->p(P.b2), w->p(P.ln2g), w->p(P.ln2b), dst, M, d,
+                                   last ? w->p(w->final_w) : nullptr, last ? w->p(w->final_b) : nullptr,
+                                   D.num_classes, sig, last ? scores : nullptr, st));
+            continue;
+        }
         {
             StageScope ps(VS_STAGE_FC1, st);
-            VS_LAUNCH(vsk_linear(h1, w->p(P.w1), w->p(lbf == 2 ? P.h_w1 : P.f_w1), w->p(P.b1), ffn, M, 4 * d, d, 1, nullptr, 1, lbf, st));
+            VS_LAUNCH(vsk_linear(h1, w->p(P.w1), w->p(lbf == 2 ? P.h_w1 : P.f_w1), w->p(P.b1), ffn, M, 4 * d, d, 1, nullptr, 1,
+                                 ffn16 ? (1 | VSK_STORE16) : lbf, st));
         }
         if (split_ln) {
             StageScope ps(VS_STAGE_FC2_LN, st);
@@ -396,7 +419,7 @@ int forward_core(const vs_weights *w, const float *x, const uint8_t *key_pad_mas
             VS_LAUNCH(vsk_linear_res_ln(ffn, w->p(P.w2), w->p(lnbf == 2 ? P.h_w2 : P.f_w2), w->p(P.b2), h1, w->p(P.ln2g), w->p(P.ln2b), dst, M, d,
                                         4 * d, last ? w->p(w->final_w) : nullptr,
                                         last ? w->p(w->final_b) : nullptr, D.num_classes, sig,
-                                        last ? scores : nullptr, lnbf, st));
+                                        last ? scores : nullptr, ffn16 ? (1 | VSK_STORE16) : lnbf, st));
         }
     }
     return VS_OK;
@@ -562,6 +585,21 @@ int vs_linear_f32(const float *A, const float *W, const float *bias, float *C, i
 int vs_linear_bf16(const float *A, const float *W, const float *bias, float *C, int32_t M, int32_t N,
                    int32_t K, int32_t relu, const float *pe, int32_t T, void *stream) {
     return linear_entry(A, W, bias, C, M, N, K, relu, pe, T, 1, stream);
+}
+
+int vs_mlp_block_bf16(const vs_weights *w, int32_t layer, const float *h, float *out, int32_t M, int32_t with_head,
+                      int32_t sigmoid, float *scores, void *stream) {
+    if (!w || !h || !out) return fail(VS_ERR_INVALID, "NULL pointer");
+    if (layer < 0 || layer >= w->desc.num_layers || M <= 0) return fail(VS_ERR_INVALID, "layer=%d M=%d", layer, M);
+    if (!vsk_mlp_bf16_supported(w->desc.d_model))
+        return fail(VS_ERR_INVALID, "the fused bf16 MLP kernel needs d_model == 256 (got %d)", w->desc.d_model);
+    if (with_head && !scores) return fail(VS_ERR_INVALID, "scores is NULL");
+    if (((uintptr_t)h & 15) || ((uintptr_t)out & 15)) return fail(VS_ERR_INVALID, "h/out must be 16-byte aligned");
+    const LayerOff &P = w->layers[layer];
+    VS_LAUNCH(vsk_mlp_bf16(h, w->p(P.b_mlp), w->p(P.b1), w->p(P.b2), w->p(P.ln2g), w->p(P.ln2b), out, M,
+                           w->desc.d_model, with_head ? w->p(w->final_w) : nullptr, with_head ? w->p(w->final_b) : nullptr,
+                           w->desc.num_classes, sigmoid, with_head ? scores : nullptr, (hipStream_t)stream));
+    return VS_OK;
 }
 
 int vs_linear_f16x3(const float *A, const float *W, const float *bias, float *C, int32_t M, int32_t N,
