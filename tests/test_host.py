@@ -169,19 +169,20 @@ def test_fused_mlp_chunk_loop_has_only_its_counted_dma_on_the_vector_memory_coun
                         os.path.join(csrc, "vs_mlp_fused.hip"), "-o", asm], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     text = open(asm).read()
-    start = text.index("mlp_fused_bf16ILi0E")
-    body = text[text.index("mlp_fused_bf16ILi0E", start + 1):]
-    body = body[:body.index(".Lfunc_end")]
-    # basic blocks; the chunk loop is the one with the 32 MFMAs
-    blocks = re.split(r"\n\.LBB\d+_\d+:", body)
-    loops = [b for b in blocks if len(re.findall(r"\bv_mfma_f32_32x32x16_bf16\b", b)) == 32]
-    assert len(loops) == 1, [len(re.findall(r"v_mfma", b)) for b in blocks]
-    loop = loops[0]
-    loop = loop[:loop.index("s_cbranch")]           # up to the back edge; what follows is the epilogue's fall-through
-    assert len(re.findall(r"\bv_mfma_f32_32x32x16_bf16\b", loop)) == 32
-    assert len(re.findall(r"\bglobal_load_lds_dwordx4\b", loop)) == 5
-    vm = re.findall(r"\b(scratch_\w+|buffer_\w+|flat_\w+|global_(?!load_lds_dwordx4)\w+)\b", loop)
-    assert vm == [], vm
-    waits = re.findall(r"s_waitcnt[^\n]*vmcnt\((\d+)\)", loop)
-    assert waits == ["5"], waits
-    assert len(re.findall(r"\bs_barrier\b", loop)) == 1
+    for rg in (1,):                                 # the product instantiation (8 waves x 32 rows)
+        name = "mlp_fused_bf16ILi%dELi0E" % rg
+        body = text[text.index(name, text.index(name) + 1):]
+        body = body[:body.index(".Lfunc_end")]
+        # basic blocks; the chunk loop is the one with the 32 * rg MFMAs
+        blocks = re.split(r"\n\.LBB\d+_\d+:", body)
+        loops = [b for b in blocks if len(re.findall(r"\bv_mfma_f32_32x32x16_bf16\b", b)) == 32 * rg]
+        assert len(loops) == 1, [len(re.findall(r"v_mfma", b)) for b in blocks]
+        loop = loops[0]
+        loop = loop[:loop.index("s_cbranch")]       # up to the back edge; what follows is the epilogue's fall-through
+        assert len(re.findall(r"\bv_mfma_f32_32x32x16_bf16\b", loop)) == 32 * rg
+        assert len(re.findall(r"\bglobal_load_lds_dwordx4\b", loop)) == 5 * rg
+        vm = re.findall(r"\b(scratch_\w+|buffer_\w+|flat_\w+|global_(?!load_lds_dwordx4)\w+)\b", loop)
+        assert vm == [], vm
+        waits = re.findall(r"s_waitcnt[^\n]*vmcnt\((\d+)\)", loop)
+        assert waits == [str(5 * rg)], waits
+        assert len(re.findall(r"\bs_barrier\b", loop)) == 1

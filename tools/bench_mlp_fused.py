@@ -38,7 +38,11 @@ def run(tag):
     print("%-28s M=%d: %7.1f us  %6.1f TFLOP/s" % (tag, M, us, 4.0 * M * 1024 * 256 / us / 1e6))
 
 
-run("product kernel")
-for a in abls:
-    pkg._lib.set_option("VS_MLP_ABL", a)
-    run("ablation %d" % a)
+for rows64 in [int(a) for a in os.environ.get("VS_MLP_SHAPES", "0,1").split(",")]:
+    pkg._lib.set_option("VS_MLP_ROWS64", rows64)
+    pkg._lib.set_option("VS_MLP_ABL", 0)
+    tag = "4 waves x 64 rows" if rows64 else "8 waves x 32 rows"
+    run(tag)
+    for a in abls:
+        pkg._lib.set_option("VS_MLP_ABL", a)
+        run(tag + ", ablation %d" % a)

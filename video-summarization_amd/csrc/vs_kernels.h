@@ -73,6 +73,7 @@ struct VskOptions {
     int attn_lp_simple;   // VS_ATTN_LP_SIMPLE phase-aligned low-precision attention
     int lp_store32;       // VS_LP_STORE32    bf16 mode keeps q/k/v, the attention output and the MLP hidden tensor fp32 in HBM (A/B)
     int lp_mlp_unfused;   // VS_LP_MLP_UNFUSED bf16 mode runs fc1 and fc2 + LayerNorm as two kernels (A/B)
+    int mlp_rows64;       // VS_MLP_ROWS64    (diagnostic builds only) fused bf16 MLP as 4 waves x 64 rows
     int mlp_fusion;       // VS_MLP_FUSION    (diagnostic builds only)
     int mlp_abl;          // VS_MLP_ABL       (diagnostic builds only)
     int attn_legacy;      // VS_ATTN_LEGACY   (diagnostic builds only)

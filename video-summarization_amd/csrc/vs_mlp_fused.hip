@@ -71,14 +71,19 @@ __device__ __forceinline__ void glds16(const void *g, void *lds_wave_base) {
 
 // ABL (diagnostic library only, timing runs with wrong results): 1 no weight staging, 2 no barrier / wait in the chunk
 // loop, 4 fragment reads replaced by register moves, 8 no chunk loop at all (prologue + epilogue only)
-template <int ABL = 0>
-__global__ __launch_bounds__(512, 1) void mlp_fused_bf16(
+// RG = 32-row groups per wave.  1 (the product kernel): 8 waves x 32 rows, two waves per SIMD, 256 registers each.
+// 2 (diagnostic library only - a measured negative result): 4 waves x 64 rows, ONE wave per SIMD with
+// the whole 512-register file, so that every weight fragment read from LDS feeds two MFMAs.  Correct, but as hipcc
+// compiles it (accumulators in AGPRs, 96 v_accvgpr moves per chunk) it runs 3.6x slower (291 vs 82 us, MFMA busy 0.10).
+template <int RG, int ABL = 0>
+__global__ __launch_bounds__(512 / RG, 1) void mlp_fused_bf16(
     const float *__restrict__ H1, const unsigned char *__restrict__ Wimg, const float *__restrict__ b1,
     const float *__restrict__ b2, const float *__restrict__ gamma,
     const float *__restrict__ beta, float *__restrict__ out, int M,
     const float *__restrict__ score_w, const float *__restrict__ score_b, int num_classes,
     int sigmoid, float *__restrict__ scores) {
-    constexpr int D = MLP_D, HID = MLP_HID, NT = 8, NCH = MLP_NCH, IMG = MLP_IMG;
+    constexpr int D = MLP_D, HID = MLP_HID, NT = 8, NCH = MLP_NCH, IMG = MLP_IMG, NTHR = 512 / RG, NWV = 8 / RG;
+    constexpr int NDMA = 40 / NWV;                               // 1-KiB pieces per wave and chunk (5 or 10)
     extern __shared__ __attribute__((aligned(1024))) unsigned char dyn_smem[];      // ONE LDS object (see the header)
     unsigned char *ring = dyn_smem;                              // [3][IMG]
     float *b1s = (float *)(dyn_smem + 3 * IMG);                  // [HID]
@@ -86,37 +91,45 @@ __global__ __launch_bounds__(512, 1) void mlp_fused_bf16(
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    for (int i = tid; i < HID; i += 512) b1s[i] = b1[i];
-    for (int i = tid; i < D; i += 512) { gam_s[i] = gamma[i]; bet_s[i] = beta[i]; bias_s[i] = b2[i]; }
+    for (int i = tid; i < HID; i += NTHR) b1s[i] = b1[i];
+    for (int i = tid; i < D; i += NTHR) { gam_s[i] = gamma[i]; bet_s[i] = beta[i]; bias_s[i] = b2[i]; }
 
-    // chunk image -> ring buffer: 40 pieces of 1 KiB, 5 per wave
+    // chunk image -> ring buffer: 40 pieces of 1 KiB, NDMA per wave.  Source = wave-uniform base (scalar registers) +
+    // one per-lane byte offset: no per-piece address registers.
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const unsigned lane16 = (unsigned)lane * 16u;
     auto dma_chunk = [&](int chunk, int bufoff) __attribute__((always_inline)) {
-        const unsigned char *src = Wimg + (size_t)chunk * IMG + wave * 1024 + lane * 16;
+        const unsigned char *src = Wimg + (size_t)chunk * IMG + wave_u * 1024;
 #pragma unroll
-        for (int i = 0; i < 5; ++i) glds16(src + 8192 * i, ring + bufoff + wave * 1024 + 8192 * i);
+        for (int i = 0; i < NDMA; ++i) glds16(src + 1024 * NWV * i + lane16, ring + bufoff + wave_u * 1024 + 1024 * NWV * i);
     };
 
-    f32x16 Y[NT];
-    u32x4 X[2 * NT];
+    f32x16 Y[RG][NT];
+    u32x4 X[RG][2 * NT];
     const int ntiles = (M + 255) / 256;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int m0 = tile * 256 + 32 * wave;
-        int row = m0 + r;
-        const bool row_ok = row < M;
-        row = row_ok ? row : M - 1;
+        const int m0 = tile * 256 + 32 * RG * wave;              // this wave's rows: m0 + 32 g + r
         __syncthreads();                        // the previous tile's epilogue is done with the ring
         if constexpr (!(ABL & 1)) { dma_chunk(0, 0); dma_chunk(1, IMG); }
-        {
-            const float *rp = H1 + (size_t)row * D + 4 * h;
+        // (lane-derived addresses are recomputed per tile from an opaque copy of the thread index: left to the compiler
+        // they are hoisted to kernel entry - ~100 registers of loop-invariant addresses - and spilled around the loop)
+        int lp = tid;
+        asm volatile("" : "+v"(lp));
+        const int rp_r = lp & 31, rp_h = (lp >> 5) & 1;
+#pragma unroll
+        for (int g = 0; g < RG; ++g) {
+            int row = m0 + 32 * g + rp_r;
+            row = row < M ? row : M - 1;
+            const float *rp = H1 + (size_t)row * D + 4 * rp_h;
 #pragma unroll
             for (int j = 0; j < NT; ++j)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const f32x4 rv = *(const f32x4 *)(rp + 32 * j + 8 * q);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) Y[j][4 * q + e] = rv[e];
-                    X[2 * j + (q >> 1)][2 * (q & 1)] = pack_bf16(rv[0], rv[1]);
-                    X[2 * j + (q >> 1)][2 * (q & 1) + 1] = pack_bf16(rv[2], rv[3]);
+                    for (int e = 0; e < 4; ++e) Y[g][j][4 * q + e] = rv[e];
+                    X[g][2 * j + (q >> 1)][2 * (q & 1)] = pack_bf16(rv[0], rv[1]);
+                    X[g][2 * j + (q >> 1)][2 * (q & 1) + 1] = pack_bf16(rv[2], rv[3]);
                 }
         }
         __syncthreads();                        // (waits for every outstanding load, the two DMA'd chunks included)
@@ -127,53 +140,64 @@ __global__ __launch_bounds__(512, 1) void mlp_fused_bf16(
             const unsigned char *w1base = ring + cur + r * MLP_LD1 + 16 * h;
             const unsigned char *w2base = ring + cur + MLP_W2OFF + r * MLP_LD2 + 16 * h;
             // fragment f: f < 16: fc1 k-step f (W1 row r); f >= 16: fc2 k-step qq = (f-16)/8 of output block
-            // j = (f-16)%8 (W2 row 32j + r).  A ring of three registers sets: two reads in flight.
-            u32x4 fw[3];
+            // j = (f-16)%8 (W2 row 32j + r).  A ring of FR register sets: FR - 1 reads in flight.
+            constexpr int FR = 4;
+            u32x4 fw[FR];
             auto frag = [&](auto fc) __attribute__((always_inline)) {
                 constexpr int f = decltype(fc)::value;
-                if constexpr ((ABL & 4) != 0) { fw[f % 3] = X[f % 16]; return; }
-                if constexpr (f < 16) fw[f % 3] = *(const u32x4 *)(w1base + 32 * f);
-                else fw[f % 3] = *(const u32x4 *)(w2base + 32 * ((f - 16) % 8) * MLP_LD2 + 32 * ((f - 16) / 8));
+                if constexpr ((ABL & 4) != 0) { fw[f % FR] = X[0][f % 16]; return; }
+                if constexpr (f < 16) fw[f % FR] = *(const u32x4 *)(w1base + 32 * f);
+                else fw[f % FR] = *(const u32x4 *)(w2base + 32 * ((f - 16) % 8) * MLP_LD2 + 32 * ((f - 16) / 8));
             };
-            f32x16 U;
+            f32x16 U[RG];
             {
                 const float *bp = b1s + MLP_CH * c + 4 * h;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const f32x4 bv = *(const f32x4 *)(bp + 8 * q);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) U[4 * q + e] = bv[e];
+                    for (int g = 0; g < RG; ++g)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) U[g][4 * q + e] = bv[e];
                 }
             }
-            frag(std::integral_constant<int, 0>{});
-            frag(std::integral_constant<int, 1>{});
+            static_for<FR - 1>([&](auto fc) { frag(fc); });
             __builtin_amdgcn_sched_barrier(0);
-            // ---- fc1: U = b1 + W1[32 rows] X^T (one dependent chain: issues back to back on gfx950) ----
+            // ---- fc1: U = b1 + W1[32 rows] X^T (one dependent chain per row group: issues back to back on gfx950) ----
             static_for<16>([&](auto fc) {
                 constexpr int f = decltype(fc)::value;
-                frag(std::integral_constant<int, f + 2>{});
-                U = MFMA_BF16(__builtin_bit_cast(bf16x8, fw[f % 3]), __builtin_bit_cast(bf16x8, X[f]), U);
+                frag(std::integral_constant<int, f + FR - 1>{});
+#pragma unroll
+                for (int g = 0; g < RG; ++g)
+                    U[g] = MFMA_BF16(__builtin_bit_cast(bf16x8, fw[f % FR]), __builtin_bit_cast(bf16x8, X[g][f]), U[g]);
                 __builtin_amdgcn_sched_barrier(0);
             });
             // ---- ReLU, round to bf16: registers 8qq .. 8qq+7 are the B operand of k-step qq ----
-            u32x4 P[2];
+            u32x4 P[RG][2];
 #pragma unroll
-            for (int qq = 0; qq < 2; ++qq)
+            for (int g = 0; g < RG; ++g)
 #pragma unroll
-                for (int ii = 0; ii < 4; ++ii)
-                    P[qq][ii] = pack_bf16(relu1(U[8 * qq + 2 * ii]), relu1(U[8 * qq + 2 * ii + 1]));
+                for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+                    for (int ii = 0; ii < 4; ++ii)
+                        P[g][qq][ii] = pack_bf16(relu1(U[g][8 * qq + 2 * ii]), relu1(U[g][8 * qq + 2 * ii + 1]));
             __builtin_amdgcn_sched_barrier(0);
             // ---- fc2: Y += W2[:, these 32 hidden units] P^T ----
             static_for<16>([&](auto gc) {
-                constexpr int g = decltype(gc)::value, f = 16 + g;
-                if constexpr (f + 2 < 32) frag(std::integral_constant<int, f + 2>{});
-                Y[g % 8] = MFMA_BF16(__builtin_bit_cast(bf16x8, fw[f % 3]), __builtin_bit_cast(bf16x8, P[g / 8]), Y[g % 8]);
+                constexpr int k = decltype(gc)::value, f = 16 + k;
+                if constexpr (f + FR - 1 < 32) frag(std::integral_constant<int, f + FR - 1>{});
+#pragma unroll
+                for (int g = 0; g < RG; ++g)
+                    Y[g][k % 8] = MFMA_BF16(__builtin_bit_cast(bf16x8, fw[f % FR]), __builtin_bit_cast(bf16x8, P[g][k / 8]), Y[g][k % 8]);
                 __builtin_amdgcn_sched_barrier(0);
             });
             if constexpr (!(ABL & 2)) {
-                // chunk c+1 (5 pieces, issued one iteration ago) has landed; chunk c+2's 5 stay in flight.  Its data
+                // chunk c+1 (NDMA pieces, issued one iteration ago) has landed; chunk c+2's stay in flight.  Its data
                 // is read only after the barrier every wave passes behind its own wait.
-                if constexpr (!(ABL & 1)) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+                if constexpr (!(ABL & 1)) {
+                    if constexpr (NDMA == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+                }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
             }
@@ -181,74 +205,89 @@ __global__ __launch_bounds__(512, 1) void mlp_fused_bf16(
         }
         __syncthreads();                        // drains the DMAs still in flight before the ring is reused below
 
-        // ---- epilogue (that of gemm_ln_rows): + b2, LayerNorm over the row (lane-local + one lane^32 exchange),
-        // stores transposed through a wave-private corner of the now idle ring, score head ----
-        float sum = 0.f;
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            float pj = 0.f;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 bv = *(const f32x4 *)&bias_s[32 * j + 8 * q + 4 * h];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { Y[j][4 * q + e] += bv[e]; pj += Y[j][4 * q + e]; }
-            }
-            sum += pj;
-        }
-        sum = pair_sum(sum);
-        const float mean = sum * (1.0f / D);
-        float sq = 0.f;
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            float pj = 0.f;
-#pragma unroll
-            for (int t = 0; t < 16; ++t) { const float cv = Y[j][t] - mean; Y[j][t] = cv; pj += cv * cv; }
-            sq += pj;
-        }
-        sq = pair_sum(sq);
-        const float rstd = 1.0f / sqrtf(sq * (1.0f / D) + 1e-5f);
+        // ---- epilogue (that of gemm_ln_rows), one row group at a time: + b2, LayerNorm over the row (lane-local + one
+        // lane^32 exchange), stores transposed through a wave-private corner of the now idle ring, score head ----
+        int le = tid;
+        asm volatile("" : "+v"(le));
+        const int r = le & 31, h = (le >> 5) & 1;                // (shadow the kernel-scope copies: see the prologue)
         float *tp = (float *)dyn_smem + wave * (32 * 36);
-        const int trow = lane >> 3, tc4 = (lane & 7) * 4;
+        const int trow = (le & 63) >> 3, tc4 = (le & 7) * 4;
+        float dots[RG];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
+        for (int g = 0; g < RG; ++g) {
+            f32x16 (&Yg)[NT] = Y[g];
+            float sum = 0.f;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 gv = *(const f32x4 *)&gam_s[32 * j + 8 * q + 4 * h];
-                const f32x4 bv = *(const f32x4 *)&bet_s[32 * j + 8 * q + 4 * h];
-                f32x4 y;
+            for (int j = 0; j < NT; ++j) {
+                float pj = 0.f;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { y[e] = Y[j][4 * q + e] * rstd * gv[e] + bv[e]; Y[j][4 * q + e] = y[e]; }
-                *(f32x4 *)&tp[r * 36 + 8 * q + 4 * h] = y;
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 bv = *(const f32x4 *)&bias_s[32 * j + 8 * q + 4 * h];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { Yg[j][4 * q + e] += bv[e]; pj += Yg[j][4 * q + e]; }
+                }
+                sum += pj;
             }
+            sum = pair_sum(sum);
+            const float mean = sum * (1.0f / D);
+            float sq = 0.f;
 #pragma unroll
-            for (int pq = 0; pq < 4; ++pq) {
-                const f32x4 v = *(const f32x4 *)&tp[(trow + 8 * pq) * 36 + tc4];
-                const int orow = m0 + trow + 8 * pq;
-                if (orow < M) *(f32x4 *)(out + (size_t)orow * D + 32 * j + tc4) = v;
+            for (int j = 0; j < NT; ++j) {
+                float pj = 0.f;
+#pragma unroll
+                for (int t = 0; t < 16; ++t) { const float cv = Yg[j][t] - mean; Yg[j][t] = cv; pj += cv * cv; }
+                sq += pj;
+            }
+            sq = pair_sum(sq);
+            const float rstd = 1.0f / sqrtf(sq * (1.0f / D) + 1e-5f);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 gv = *(const f32x4 *)&gam_s[32 * j + 8 * q + 4 * h];
+                    const f32x4 bv = *(const f32x4 *)&bet_s[32 * j + 8 * q + 4 * h];
+                    f32x4 y;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { y[e] = Yg[j][4 * q + e] * rstd * gv[e] + bv[e]; Yg[j][4 * q + e] = y[e]; }
+                    *(f32x4 *)&tp[r * 36 + 8 * q + 4 * h] = y;
+                }
+#pragma unroll
+                for (int pq = 0; pq < 4; ++pq) {
+                    const f32x4 v = *(const f32x4 *)&tp[(trow + 8 * pq) * 36 + tc4];
+                    const int orow = m0 + 32 * g + trow + 8 * pq;
+                    if (orow < M) *(f32x4 *)(out + (size_t)orow * D + 32 * j + tc4) = v;
+                }
             }
         }
         if (score_w != nullptr) {
             for (int cc = 0; cc < num_classes; ++cc) {
                 __syncthreads();
-                for (int i = tid; i < D; i += 512) sw_s[i] = score_w[(size_t)cc * D + i];
+                for (int i = tid; i < D; i += NTHR) sw_s[i] = score_w[(size_t)cc * D + i];
                 __syncthreads();
-                float dot = 0.f;
 #pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    float pj = 0.f;
+                for (int g = 0; g < RG; ++g) {
+                    float dot = 0.f;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const f32x4 wv = *(const f32x4 *)&sw_s[32 * j + 8 * q + 4 * h];
+                    for (int j = 0; j < NT; ++j) {
+                        float pj = 0.f;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) pj += Y[j][4 * q + e] * wv[e];
+                        for (int q = 0; q < 4; ++q) {
+                            const f32x4 wv = *(const f32x4 *)&sw_s[32 * j + 8 * q + 4 * h];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) pj += Y[g][j][4 * q + e] * wv[e];
+                        }
+                        dot += pj;
                     }
-                    dot += pj;
+                    dots[g] = pair_sum(dot);
                 }
-                dot = pair_sum(dot);
-                if (h == 0 && row_ok) {
-                    float sc = dot + score_b[cc];
-                    if (sigmoid) sc = 1.0f / (1.0f + expf(-sc));
-                    scores[(size_t)row * num_classes + cc] = sc;
+#pragma unroll
+                for (int g = 0; g < RG; ++g) {
+                    const int row = m0 + 32 * g + r;
+                    if (h == 0 && row < M) {
+                        float sc = dots[g] + score_b[cc];
+                        if (sigmoid) sc = 1.0f / (1.0f + expf(-sc));
+                        scores[(size_t)row * num_classes + cc] = sc;
+                    }
                 }
             }
         }
@@ -258,13 +297,13 @@ __global__ __launch_bounds__(512, 1) void mlp_fused_bf16(
 constexpr size_t MLP_LDS = (size_t)3 * MLP_IMG + (MLP_HID + 4 * MLP_D) * sizeof(float);      // 128 KiB
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is per DEVICE: set once per (kernel instantiation, device)
-template <int ABL>
+template <int RG, int ABL>
 int allow_lds() {
     static std::atomic<unsigned char> done[64];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return (int)hipErrorInvalidDevice;
     if (dev >= 0 && dev < 64 && done[dev].load(std::memory_order_acquire)) return 0;
-    const int rc = (int)hipFuncSetAttribute((const void *)mlp_fused_bf16<ABL>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    const int rc = (int)hipFuncSetAttribute((const void *)mlp_fused_bf16<RG, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                             (int)MLP_LDS);
     if (rc == 0 && dev >= 0 && dev < 64) done[dev].store(1, std::memory_order_release);
     return rc;
@@ -293,25 +332,26 @@ int vsk_mlp_bf16(const float *H1, const void *img, const float *b1, const float 
     if (cus <= 0) return (int)hipErrorInvalidDevice;
     const int ntiles = (M + 255) / 256;
     const int blocks = ntiles < cus ? ntiles : cus;
-#define VSK_MLP_LAUNCH(A_)                                                                                             \
+#define VSK_MLP_LAUNCH(R_, A_)                                                                                         \
     do {                                                                                                               \
-        if (const int rc = allow_lds<A_>()) return rc;                                                                 \
-        hipLaunchKernelGGL((mlp_fused_bf16<A_>), dim3(blocks), dim3(512), MLP_LDS, st, H1, (const unsigned char *)img, b1, \
+        if (const int rc = allow_lds<R_, A_>()) return rc;                                                             \
+        hipLaunchKernelGGL((mlp_fused_bf16<R_, A_>), dim3(blocks), dim3(512 / R_), MLP_LDS, st, H1, (const unsigned char *)img, b1, \
                            b2, gamma, beta, out, M, score_w, score_b, num_classes, sigmoid, scores);                   \
     } while (0)
 #ifdef VS_WITH_DIAG
+    const bool two = vsk_options().mlp_rows64 != 0;
     switch (vsk_options().mlp_abl) {       // timing-only ablations (tools/bench_mlp_fused.py)
-        case 0: break;
-        case 1: VSK_MLP_LAUNCH(1); VSK_CHECK_LAUNCH(); return 0;
-        case 2: VSK_MLP_LAUNCH(2); VSK_CHECK_LAUNCH(); return 0;
-        case 3: VSK_MLP_LAUNCH(3); VSK_CHECK_LAUNCH(); return 0;
-        case 4: VSK_MLP_LAUNCH(4); VSK_CHECK_LAUNCH(); return 0;
-        case 5: VSK_MLP_LAUNCH(5); VSK_CHECK_LAUNCH(); return 0;
-        case 7: VSK_MLP_LAUNCH(7); VSK_CHECK_LAUNCH(); return 0;
-        default: VSK_MLP_LAUNCH(8); VSK_CHECK_LAUNCH(); return 0;
+        case 0: if (two) { VSK_MLP_LAUNCH(2, 0); VSK_CHECK_LAUNCH(); return 0; } break;
+        case 1: if (two) VSK_MLP_LAUNCH(2, 1); else VSK_MLP_LAUNCH(1, 1); VSK_CHECK_LAUNCH(); return 0;
+        case 2: if (two) VSK_MLP_LAUNCH(2, 2); else VSK_MLP_LAUNCH(1, 2); VSK_CHECK_LAUNCH(); return 0;
+        case 3: if (two) VSK_MLP_LAUNCH(2, 3); else VSK_MLP_LAUNCH(1, 3); VSK_CHECK_LAUNCH(); return 0;
+        case 4: if (two) VSK_MLP_LAUNCH(2, 4); else VSK_MLP_LAUNCH(1, 4); VSK_CHECK_LAUNCH(); return 0;
+        case 5: if (two) VSK_MLP_LAUNCH(2, 5); else VSK_MLP_LAUNCH(1, 5); VSK_CHECK_LAUNCH(); return 0;
+        case 7: if (two) VSK_MLP_LAUNCH(2, 7); else VSK_MLP_LAUNCH(1, 7); VSK_CHECK_LAUNCH(); return 0;
+        default: if (two) VSK_MLP_LAUNCH(2, 8); else VSK_MLP_LAUNCH(1, 8); VSK_CHECK_LAUNCH(); return 0;
     }
 #endif
-    VSK_MLP_LAUNCH(0);
+    VSK_MLP_LAUNCH(1, 0);
 #undef VSK_MLP_LAUNCH
     VSK_CHECK_LAUNCH();
     return 0;

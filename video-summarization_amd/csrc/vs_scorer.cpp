@@ -115,7 +115,7 @@ const OptionName kOptions[] = {
     {"VS_ATTN_NW4", &VskOptions::attn_nw4, 0},           {"VS_ATTN_LP_SIMPLE", &VskOptions::attn_lp_simple, 0},
     {"VS_MLP_FUSION", &VskOptions::mlp_fusion, 0},       {"VS_MLP_ABL", &VskOptions::mlp_abl, 0},
     {"VS_ATTN_LEGACY", &VskOptions::attn_legacy, 0},     {"VS_LP_STORE32", &VskOptions::lp_store32, 0},
-    {"VS_LP_MLP_UNFUSED", &VskOptions::lp_mlp_unfused, 0},
+    {"VS_LP_MLP_UNFUSED", &VskOptions::lp_mlp_unfused, 0}, {"VS_MLP_ROWS64", &VskOptions::mlp_rows64, 0},
 };
 int option_from_env(const OptionName &o) {
     const char *e = getenv(o.name);
