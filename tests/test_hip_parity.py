@@ -734,7 +734,7 @@ def test_bf16_storage_is_bit_identical_to_fp32_storage(vsa, lp_linear_everywhere
         return [t.clone() for t in (*a, *b, c)]
 
     try:
-        vsa._lib.set_option("VS_LP_MLP_UNFUSED", 1)      # (the fused MLP kernel has its own test below)
+        vsa._lib.set_option("VS_LP_MLP_UNFUSED", 1)      # (the fused MLP / layer-tail kernels have their own tests below)
         vsa._lib.set_option("VS_LP_STORE32", 1)
         ref = run()
         vsa._lib.set_option("VS_LP_STORE32", -1)
@@ -784,6 +784,43 @@ def test_mlp_block_bf16_kernel(vsa, M, nc, sig):
     assert err.max().item() < 2e-3 and err.median().item() < 1e-5
     if nc:
         assert (scores.cpu().double() - sc).abs().max().item() < 2e-3
+
+
+@pytest.mark.parametrize("cfg", ["M-A", "M-B8", "M-A-ragged"])
+def test_bf16_layer_tail_kernel_is_bit_identical_to_outproj_then_mlp_kernel(vsa, lp_linear_everywhere, cfg):
+    """With the attention output stored as bf16, the bf16 mode runs out-projection + residual + norm1 + MLP block + norm2
+    (+ score head) as ONE kernel (vs_mlp_fused.hip, TAIL).  Its out-projection multiplies in the same order as the
+    stand-alone kernel (gemm_ln_rows) and shares the LayerNorm arithmetic, so against VS_LP_TAIL_UNFUSED=1 (that kernel,
+    h1 through HBM, then the fused MLP kernel) logits, scores and hidden state must agree BIT FOR BIT - padded, masked and
+    packed batches, in-place (middle layers) and out-of-place (last layer with `hidden`) outputs."""
+    synth = vsa.synth
+    d, H, L = (256, 8, 3) if cfg == "M-B8" else (256, 4, 3)
+    sd = synth.make_state_dict(d, L, 371, trained_like=True)
+    lengths = [257, 1, 100, 513, 7] if cfg == "M-A-ragged" else [512, 333, 256, 31]
+    x = synth.make_features(len(lengths), max(lengths), 372, "pool5", lengths=lengths)
+    mask = synth.padding_mask(x)
+    m = vsa.SimNet(num_heads=H, d_model=d, num_layers=L, sparsity=0.0, dropout=0.3)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(_dev()).eval().set_compute_dtype("bf16")
+    dx, dm = x.to(_dev()), mask.to(_dev())
+    packed = torch.cat([x[i, :t] for i, t in enumerate(lengths)]).to(_dev())
+    lens = torch.tensor(lengths, dtype=torch.int32)
+
+    def run():
+        with torch.no_grad():
+            a = m(dx, dm)
+            b = m.score(dx, dm)
+            c = m.score_packed(packed, lens)
+        return [t.clone() for t in (*a, b, c)]
+
+    try:
+        vsa._lib.set_option("VS_LP_TAIL_UNFUSED", 1)
+        ref = run()
+    finally:
+        vsa._lib.set_option("VS_LP_TAIL_UNFUSED", -1)
+    got = run()
+    for g, r in zip(got, ref):
+        assert torch.isfinite(g).all() and torch.equal(g, r)
 
 
 @pytest.mark.parametrize("cfg", ["M-A", "M-A-ragged"])

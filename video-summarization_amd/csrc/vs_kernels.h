@@ -47,12 +47,15 @@ int vsk_mlp_fused(const float *H1, const float *W1, const float *b1, const float
                   const float *score_w, const float *score_b, int num_classes, int sigmoid, float *scores,
                   hipStream_t st);
 // bf16 mode, d_model == 256: fc1 + ReLU + fc2 + residual + LayerNorm (+ score head) as one kernel whose hidden
-// activations stay in registers (vs_mlp_fused.hip).  img: the per-chunk LDS images made by vsk_pack_mlp_bf16
-// (vsk_mlp_bf16_image_bytes(d) bytes, 256-byte aligned; 0 = this d_model has no fused kernel).
+// activations stay in registers (vs_mlp_fused.hip) - and, when the attention output is stored as bf16 (att16 != nullptr),
+// the out-projection + residual + norm1 in front of it as well (h is then the layer input, else h = h1).
+// img: the per-chunk LDS images of Wo, W1, W2 made by vsk_pack_mlp_bf16 (vsk_mlp_bf16_image_bytes(d) bytes, 256-byte
+// aligned; 0 = this d_model has no fused kernel).
 bool vsk_mlp_bf16_supported(int d);
 size_t vsk_mlp_bf16_image_bytes(int d);
-int vsk_pack_mlp_bf16(const float *W1, const float *W2, void *img, int d, hipStream_t st);
-int vsk_mlp_bf16(const float *H1, const void *img, const float *b1, const float *b2,
+int vsk_pack_mlp_bf16(const float *Wo, const float *W1, const float *W2, void *img, int d, hipStream_t st);
+int vsk_mlp_bf16(const float *h, const void *att16, const float *bo, const float *gamma1, const float *beta1,
+                 const void *img, const float *b1, const float *b2,
                  const float *gamma, const float *beta, float *out, int M, int d,
                  const float *score_w, const float *score_b, int num_classes, int sigmoid, float *scores,
                  hipStream_t st);
@@ -73,7 +76,7 @@ struct VskOptions {
     int attn_lp_simple;   // VS_ATTN_LP_SIMPLE phase-aligned low-precision attention
     int lp_store32;       // VS_LP_STORE32    bf16 mode keeps q/k/v, the attention output and the MLP hidden tensor fp32 in HBM (A/B)
     int lp_mlp_unfused;   // VS_LP_MLP_UNFUSED bf16 mode runs fc1 and fc2 + LayerNorm as two kernels (A/B)
-    int mlp_rows64;       // VS_MLP_ROWS64    (diagnostic builds only) fused bf16 MLP as 4 waves x 64 rows
+    int lp_tail_unfused;  // VS_LP_TAIL_UNFUSED bf16 mode runs the out-projection + norm1 as its own kernel in front of the fused MLP (A/B)
     int mlp_fusion;       // VS_MLP_FUSION    (diagnostic builds only)
     int mlp_abl;          // VS_MLP_ABL       (diagnostic builds only)
     int attn_legacy;      // VS_ATTN_LEGACY   (diagnostic builds only)

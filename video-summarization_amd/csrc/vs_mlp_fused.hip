@@ -41,24 +41,35 @@ constexpr int MLP_LD1 = 528;                    // bytes per W1 row in the image
 constexpr int MLP_LD2 = 80;                     // bytes per W2 row (32 bf16 + 16: 20 dwords, conflict-free b128)
 constexpr int MLP_W2OFF = 17408;                // W1 part: 32 * 528 = 16896, rounded up to a 1-KiB piece boundary
 constexpr int MLP_IMG = 40960;                  // W2 part: 256 * 80 = 20480 -> 37 pieces, padded to 40 (5 per wave)
+// the out-projection in front (TAIL kernels): Wo [256][256] as 4 chunks of 64 k, rows of 64 bf16 + 16 B (144 B = 36 dwords:
+// conflict-free b128), 256 * 144 = 36 864 B = 36 pieces, padded to the same 40-piece chunk
+constexpr int MLP_LDO = 144, MLP_NCHO = 4;
+constexpr int MLP_CHUNKS = MLP_NCHO + MLP_NCH;  // image = [4 Wo chunks][32 MLP chunks]
 
 __device__ __forceinline__ int swap23(int p) { return (p & 3) | ((p & 4) << 1) | ((p & 8) >> 1); }
 
-// W1 [1024][256], W2 [256][1024] fp32 -> img [32 chunks][MLP_IMG bytes] (pad bytes are left as the caller zeroed them)
-__global__ void pack_mlp_bf16(const float *__restrict__ W1, const float *__restrict__ W2, unsigned char *__restrict__ img) {
-    const int n = MLP_D * MLP_HID / 2;          // bf16 pairs per matrix
+// Wo [256][256], W1 [1024][256], W2 [256][1024] fp32 -> img [36 chunks][MLP_IMG bytes] (pad bytes stay as zeroed)
+__global__ void pack_mlp_bf16(const float *__restrict__ Wo, const float *__restrict__ W1, const float *__restrict__ W2,
+                              unsigned char *__restrict__ img) {
+    const int n = MLP_D * MLP_HID / 2;          // bf16 pairs per MLP matrix
+    unsigned char *mlp = img + (size_t)MLP_NCHO * MLP_IMG;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         {   // W1: pair at row = hidden unit, position p (even) of the permuted k order
             const int row = (2 * i) / MLP_D, p = (2 * i) % MLP_D, b16 = p & ~15;
             const float *src = W1 + (size_t)row * MLP_D + b16;
-            unsigned *dst = (unsigned *)(img + (size_t)(row / MLP_CH) * MLP_IMG + (row % MLP_CH) * MLP_LD1 + 2 * p);
+            unsigned *dst = (unsigned *)(mlp + (size_t)(row / MLP_CH) * MLP_IMG + (row % MLP_CH) * MLP_LD1 + 2 * p);
             *dst = pack_bf16(src[swap23(p & 15)], src[swap23((p & 15) + 1)]);
         }
         {   // W2: pair at row = output column, hidden unit 32c + position p32 (even) of the permuted order
             const int row = (2 * i) / MLP_HID, hcol = (2 * i) % MLP_HID, c = hcol / MLP_CH, p32 = hcol % MLP_CH;
             const float *src = W2 + (size_t)row * MLP_HID + MLP_CH * c + (p32 & 16);
-            unsigned *dst = (unsigned *)(img + (size_t)c * MLP_IMG + MLP_W2OFF + row * MLP_LD2 + 2 * p32);
+            unsigned *dst = (unsigned *)(mlp + (size_t)c * MLP_IMG + MLP_W2OFF + row * MLP_LD2 + 2 * p32);
             *dst = pack_bf16(src[swap23(p32 & 15)], src[swap23((p32 & 15) + 1)]);
+        }
+        if (i < MLP_D * MLP_D / 2) {   // Wo: natural k order (its B operand is read from HBM in that order), 64 k per chunk
+            const int row = (2 * i) / MLP_D, k = (2 * i) % MLP_D;
+            unsigned *dst = (unsigned *)(img + (size_t)(k / 64) * MLP_IMG + row * MLP_LDO + 2 * (k % 64));
+            *dst = pack_bf16(Wo[(size_t)row * MLP_D + k], Wo[(size_t)row * MLP_D + k + 1]);
         }
     }
 }
@@ -69,162 +80,137 @@ __device__ __forceinline__ void glds16(const void *g, void *lds_wave_base) {
                                      (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
 }
 
+struct TailArgs {            // TAIL kernels: the out-projection + norm1 in front of the MLP block
+    const h16 *att;          // [M, 256] bf16 attention output
+    const float *res;        // [M, 256] fp32 residual (the layer input)
+    const float *bo, *gamma1, *beta1;
+};
+
+// TAIL: the kernel starts one step earlier in the encoder layer: H1 is not read but computed,
+//     h1 = LayerNorm(att Wo^T + bo + res) * gamma1 + beta1          (reference simnet.py:107 norm1(x + sa(x)))
+// by four more chunks through the same ring (Wo in 64-k slabs; the bf16 attention rows are the B operands straight from HBM,
+// the residual is the C-in of Y, bias and LayerNorm in registers exactly as gemm_ln_rows does them), and the
+// result is at once the X / Y input of the MLP part: h1 never exists in HBM, one launch and one prologue fewer per layer.
 // ABL (diagnostic library only, timing runs with wrong results): 1 no weight staging, 2 no barrier / wait in the chunk
 // loop, 4 fragment reads replaced by register moves, 8 no chunk loop at all (prologue + epilogue only)
-// RG = 32-row groups per wave.  1 (the product kernel): 8 waves x 32 rows, two waves per SIMD, 256 registers each.
-// 2 (diagnostic library only - a measured negative result): 4 waves x 64 rows, ONE wave per SIMD with
-// the whole 512-register file, so that every weight fragment read from LDS feeds two MFMAs.  Correct, but as hipcc
-// compiles it (accumulators in AGPRs, 96 v_accvgpr moves per chunk) it runs 3.6x slower (291 vs 82 us, MFMA busy 0.10).
-template <int RG, int ABL = 0>
-__global__ __launch_bounds__(512 / RG, 1) void mlp_fused_bf16(
-    const float *__restrict__ H1, const unsigned char *__restrict__ Wimg, const float *__restrict__ b1,
+template <bool TAIL, int ABL = 0>
+__global__ __launch_bounds__(512, 1) void mlp_fused_bf16(
+    const float *H1, TailArgs ta, const unsigned char *__restrict__ Wimg, const float *__restrict__ b1,
     const float *__restrict__ b2, const float *__restrict__ gamma,
-    const float *__restrict__ beta, float *__restrict__ out, int M,
-    const float *__restrict__ score_w, const float *__restrict__ score_b, int num_classes,
+    const float *__restrict__ beta, float *out /* may be the residual buffer: every block rewrites only rows it has read */,
+    int M, const float *__restrict__ score_w, const float *__restrict__ score_b, int num_classes,
     int sigmoid, float *__restrict__ scores) {
-    constexpr int D = MLP_D, HID = MLP_HID, NT = 8, NCH = MLP_NCH, IMG = MLP_IMG, NTHR = 512 / RG, NWV = 8 / RG;
-    constexpr int NDMA = 40 / NWV;                               // 1-KiB pieces per wave and chunk (5 or 10)
+    constexpr int D = MLP_D, HID = MLP_HID, NT = 8, IMG = MLP_IMG;
+    constexpr int C0 = TAIL ? 0 : MLP_NCHO;                      // first chunk of the image this kernel consumes
     extern __shared__ __attribute__((aligned(1024))) unsigned char dyn_smem[];      // ONE LDS object (see the header)
     unsigned char *ring = dyn_smem;                              // [3][IMG]
     float *b1s = (float *)(dyn_smem + 3 * IMG);                  // [HID]
     float *gam_s = b1s + HID, *bet_s = gam_s + D, *sw_s = bet_s + D, *bias_s = sw_s + D;
+    float *gam1_s = bias_s + D, *bet1_s = gam1_s + D, *bo_s = bet1_s + D;     // TAIL only
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    for (int i = tid; i < HID; i += NTHR) b1s[i] = b1[i];
-    for (int i = tid; i < D; i += NTHR) { gam_s[i] = gamma[i]; bet_s[i] = beta[i]; bias_s[i] = b2[i]; }
+    for (int i = tid; i < HID; i += 512) b1s[i] = b1[i];
+    for (int i = tid; i < D; i += 512) {
+        gam_s[i] = gamma[i]; bet_s[i] = beta[i]; bias_s[i] = b2[i];
+        if constexpr (TAIL) { gam1_s[i] = ta.gamma1[i]; bet1_s[i] = ta.beta1[i]; bo_s[i] = ta.bo[i]; }
+    }
 
-    // chunk image -> ring buffer: 40 pieces of 1 KiB, NDMA per wave.  Source = wave-uniform base (scalar registers) +
+    // chunk image -> ring buffer: 40 pieces of 1 KiB, 5 per wave.  Source = wave-uniform base (scalar registers) +
     // one per-lane byte offset: no per-piece address registers.
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const unsigned lane16 = (unsigned)lane * 16u;
     auto dma_chunk = [&](int chunk, int bufoff) __attribute__((always_inline)) {
         const unsigned char *src = Wimg + (size_t)chunk * IMG + wave_u * 1024;
+        unsigned l16 = lane16;
+        asm volatile("" : "+v"(l16));           // (opaque: else five per-lane 64-bit pointers are precomputed and spilled)
 #pragma unroll
-        for (int i = 0; i < NDMA; ++i) glds16(src + 1024 * NWV * i + lane16, ring + bufoff + wave_u * 1024 + 1024 * NWV * i);
+        for (int i = 0; i < 5; ++i) glds16(src + 8192 * i + l16, ring + bufoff + wave_u * 1024 + 8192 * i);
     };
+    // end of a chunk: the next chunk (5 pieces, issued one iteration ago) has landed, the one after it stays in flight;
+    // its data is read only after the barrier every wave passes behind its own wait
+    auto chunk_done = [&]() __attribute__((always_inline)) {
+        if constexpr (!(ABL & 2)) {
+            if constexpr (!(ABL & 1)) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+    };
+    constexpr int FR = 4;                                        // fragment ring: FR - 1 LDS reads in flight
 
-    f32x16 Y[RG][NT];
-    u32x4 X[RG][2 * NT];
+    f32x16 Y[NT];
+    u32x4 X[2 * NT];
     const int ntiles = (M + 255) / 256;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int m0 = tile * 256 + 32 * RG * wave;              // this wave's rows: m0 + 32 g + r
+        const int m0 = tile * 256 + 32 * wave;                   // this wave's rows: m0 + r
         __syncthreads();                        // the previous tile's epilogue is done with the ring
-        if constexpr (!(ABL & 1)) { dma_chunk(0, 0); dma_chunk(1, IMG); }
+        if constexpr (!(ABL & 1)) { dma_chunk(C0, 0); dma_chunk(C0 + 1, IMG); }
         // (lane-derived addresses are recomputed per tile from an opaque copy of the thread index: left to the compiler
         // they are hoisted to kernel entry - ~100 registers of loop-invariant addresses - and spilled around the loop)
         int lp = tid;
         asm volatile("" : "+v"(lp));
         const int rp_r = lp & 31, rp_h = (lp >> 5) & 1;
-#pragma unroll
-        for (int g = 0; g < RG; ++g) {
-            int row = m0 + 32 * g + rp_r;
+        {
+            int row = m0 + rp_r;
             row = row < M ? row : M - 1;
-            const float *rp = H1 + (size_t)row * D + 4 * rp_h;
+            const float *rp = (TAIL ? ta.res : H1) + (size_t)row * D + 4 * rp_h;
 #pragma unroll
             for (int j = 0; j < NT; ++j)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const f32x4 rv = *(const f32x4 *)(rp + 32 * j + 8 * q);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) Y[g][j][4 * q + e] = rv[e];
-                    X[g][2 * j + (q >> 1)][2 * (q & 1)] = pack_bf16(rv[0], rv[1]);
-                    X[g][2 * j + (q >> 1)][2 * (q & 1) + 1] = pack_bf16(rv[2], rv[3]);
+                    for (int e = 0; e < 4; ++e) Y[j][4 * q + e] = rv[e];
+                    if constexpr (!TAIL) {
+                        X[2 * j + (q >> 1)][2 * (q & 1)] = pack_bf16(rv[0], rv[1]);
+                        X[2 * j + (q >> 1)][2 * (q & 1) + 1] = pack_bf16(rv[2], rv[3]);
+                    }
                 }
+            if constexpr (TAIL) {               // B operands of the out-projection: k-step ks = att[row][16 ks + 8 h .. + 7]
+                const h16 *ap = ta.att + (size_t)row * D + 8 * rp_h;
+#pragma unroll
+                for (int ks = 0; ks < 2 * NT; ++ks) X[ks] = *(const u32x4 *)(ap + 16 * ks);
+            }
         }
         __syncthreads();                        // (waits for every outstanding load, the two DMA'd chunks included)
 
         int cur = 0, nx1 = IMG, nx2 = 2 * IMG;  // ring offsets of chunk c, c+1, c+2
-        for (int c = 0; c < ((ABL & 8) ? 0 : NCH); ++c) {
-            if constexpr (!(ABL & 1)) dma_chunk(c + 2 < NCH ? c + 2 : NCH - 1, nx2);      // past the end: a harmless re-copy
-            const unsigned char *w1base = ring + cur + r * MLP_LD1 + 16 * h;
-            const unsigned char *w2base = ring + cur + MLP_W2OFF + r * MLP_LD2 + 16 * h;
-            // fragment f: f < 16: fc1 k-step f (W1 row r); f >= 16: fc2 k-step qq = (f-16)/8 of output block
-            // j = (f-16)%8 (W2 row 32j + r).  A ring of FR register sets: FR - 1 reads in flight.
-            constexpr int FR = 4;
-            u32x4 fw[FR];
-            auto frag = [&](auto fc) __attribute__((always_inline)) {
-                constexpr int f = decltype(fc)::value;
-                if constexpr ((ABL & 4) != 0) { fw[f % FR] = X[0][f % 16]; return; }
-                if constexpr (f < 16) fw[f % FR] = *(const u32x4 *)(w1base + 32 * f);
-                else fw[f % FR] = *(const u32x4 *)(w2base + 32 * ((f - 16) % 8) * MLP_LD2 + 32 * ((f - 16) / 8));
-            };
-            f32x16 U[RG];
-            {
-                const float *bp = b1s + MLP_CH * c + 4 * h;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x4 bv = *(const f32x4 *)(bp + 8 * q);
-#pragma unroll
-                    for (int g = 0; g < RG; ++g)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) U[g][4 * q + e] = bv[e];
-                }
-            }
-            static_for<FR - 1>([&](auto fc) { frag(fc); });
-            __builtin_amdgcn_sched_barrier(0);
-            // ---- fc1: U = b1 + W1[32 rows] X^T (one dependent chain per row group: issues back to back on gfx950) ----
-            static_for<16>([&](auto fc) {
-                constexpr int f = decltype(fc)::value;
-                frag(std::integral_constant<int, f + FR - 1>{});
-#pragma unroll
-                for (int g = 0; g < RG; ++g)
-                    U[g] = MFMA_BF16(__builtin_bit_cast(bf16x8, fw[f % FR]), __builtin_bit_cast(bf16x8, X[g][f]), U[g]);
+        if constexpr (TAIL && !(ABL & 8)) {
+            // ---- out-projection: 4 chunks of 64 k; fragment f: k-step f / 8 of the chunk, output block f % 8 ----
+            static_for<MLP_NCHO>([&](auto cc) {                    // (unrolled: the B operands X[4c + ..] are registers)
+                constexpr int c = decltype(cc)::value;
+                if constexpr (!(ABL & 1)) dma_chunk(c + 2, nx2);
+                const unsigned char *wbase = ring + cur + r * MLP_LDO + 16 * h;
+                u32x4 fw[FR];
+                auto frag = [&](auto fc) __attribute__((always_inline)) {
+                    constexpr int f = decltype(fc)::value;
+                    if constexpr ((ABL & 4) != 0) { fw[f % FR] = X[f % 16]; return; }
+                    fw[f % FR] = *(const u32x4 *)(wbase + 32 * (f % 8) * MLP_LDO + 32 * (f / 8));
+                };
+                static_for<FR - 1>([&](auto fc) { frag(fc); });
                 __builtin_amdgcn_sched_barrier(0);
+                static_for<32>([&](auto fc) {
+                    constexpr int f = decltype(fc)::value;
+                    if constexpr (f + FR - 1 < 32) frag(std::integral_constant<int, f + FR - 1>{});
+                    Y[f % 8] = MFMA_BF16(__builtin_bit_cast(bf16x8, fw[f % FR]), __builtin_bit_cast(bf16x8, X[4 * c + f / 8]), Y[f % 8]);
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+                chunk_done();
+                const int t = cur; cur = nx1; nx1 = nx2; nx2 = t;
             });
-            // ---- ReLU, round to bf16: registers 8qq .. 8qq+7 are the B operand of k-step qq ----
-            u32x4 P[RG][2];
-#pragma unroll
-            for (int g = 0; g < RG; ++g)
-#pragma unroll
-                for (int qq = 0; qq < 2; ++qq)
-#pragma unroll
-                    for (int ii = 0; ii < 4; ++ii)
-                        P[g][qq][ii] = pack_bf16(relu1(U[g][8 * qq + 2 * ii]), relu1(U[g][8 * qq + 2 * ii + 1]));
-            __builtin_amdgcn_sched_barrier(0);
-            // ---- fc2: Y += W2[:, these 32 hidden units] P^T ----
-            static_for<16>([&](auto gc) {
-                constexpr int k = decltype(gc)::value, f = 16 + k;
-                if constexpr (f + FR - 1 < 32) frag(std::integral_constant<int, f + FR - 1>{});
-#pragma unroll
-                for (int g = 0; g < RG; ++g)
-                    Y[g][k % 8] = MFMA_BF16(__builtin_bit_cast(bf16x8, fw[f % FR]), __builtin_bit_cast(bf16x8, P[g][k / 8]), Y[g][k % 8]);
-                __builtin_amdgcn_sched_barrier(0);
-            });
-            if constexpr (!(ABL & 2)) {
-                // chunk c+1 (NDMA pieces, issued one iteration ago) has landed; chunk c+2's stay in flight.  Its data
-                // is read only after the barrier every wave passes behind its own wait.
-                if constexpr (!(ABL & 1)) {
-                    if constexpr (NDMA == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-            }
-            const int t = cur; cur = nx1; nx1 = nx2; nx2 = t;
-        }
-        __syncthreads();                        // drains the DMAs still in flight before the ring is reused below
-
-        // ---- epilogue (that of gemm_ln_rows), one row group at a time: + b2, LayerNorm over the row (lane-local + one
-        // lane^32 exchange), stores transposed through a wave-private corner of the now idle ring, score head ----
-        int le = tid;
-        asm volatile("" : "+v"(le));
-        const int r = le & 31, h = (le >> 5) & 1;                // (shadow the kernel-scope copies: see the prologue)
-        float *tp = (float *)dyn_smem + wave * (32 * 36);
-        const int trow = (le & 63) >> 3, tc4 = (le & 7) * 4;
-        float dots[RG];
-#pragma unroll
-        for (int g = 0; g < RG; ++g) {
-            f32x16 (&Yg)[NT] = Y[g];
+            // ---- + bo, norm1 (the arithmetic of gemm_ln_rows' epilogue), then h1 is both X (bf16) and Y (residual) ----
+            int l1 = tid;
+            asm volatile("" : "+v"(l1));
+            const int h = (l1 >> 5) & 1;        // (opaque copy: see the prologue)
             float sum = 0.f;
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 float pj = 0.f;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const f32x4 bv = *(const f32x4 *)&bias_s[32 * j + 8 * q + 4 * h];
+                    const f32x4 bv = *(const f32x4 *)&bo_s[32 * j + 8 * q + 4 * h];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { Yg[j][4 * q + e] += bv[e]; pj += Yg[j][4 * q + e]; }
+                    for (int e = 0; e < 4; ++e) { Y[j][4 * q + e] += bv[e]; pj += Y[j][4 * q + e]; }
                 }
                 sum += pj;
             }
@@ -235,75 +221,165 @@ __global__ __launch_bounds__(512 / RG, 1) void mlp_fused_bf16(
             for (int j = 0; j < NT; ++j) {
                 float pj = 0.f;
 #pragma unroll
-                for (int t = 0; t < 16; ++t) { const float cv = Yg[j][t] - mean; Yg[j][t] = cv; pj += cv * cv; }
+                for (int t = 0; t < 16; ++t) { const float cv = Y[j][t] - mean; Y[j][t] = cv; pj += cv * cv; }
                 sq += pj;
             }
             sq = pair_sum(sq);
             const float rstd = 1.0f / sqrtf(sq * (1.0f / D) + 1e-5f);
 #pragma unroll
-            for (int j = 0; j < NT; ++j) {
+            for (int j = 0; j < NT; ++j)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const f32x4 gv = *(const f32x4 *)&gam_s[32 * j + 8 * q + 4 * h];
-                    const f32x4 bv = *(const f32x4 *)&bet_s[32 * j + 8 * q + 4 * h];
+                    const f32x4 gv = *(const f32x4 *)&gam1_s[32 * j + 8 * q + 4 * h];
+                    const f32x4 bv = *(const f32x4 *)&bet1_s[32 * j + 8 * q + 4 * h];
                     f32x4 y;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { y[e] = Yg[j][4 * q + e] * rstd * gv[e] + bv[e]; Yg[j][4 * q + e] = y[e]; }
-                    *(f32x4 *)&tp[r * 36 + 8 * q + 4 * h] = y;
+                    for (int e = 0; e < 4; ++e) { y[e] = Y[j][4 * q + e] * rstd * gv[e] + bv[e]; Y[j][4 * q + e] = y[e]; }
+                    X[2 * j + (q >> 1)][2 * (q & 1)] = pack_bf16(y[0], y[1]);
+                    X[2 * j + (q >> 1)][2 * (q & 1) + 1] = pack_bf16(y[2], y[3]);
                 }
+        }
+        for (int c = 0; c < ((ABL & 8) ? 0 : MLP_NCH); ++c) {
+            const int g = MLP_NCHO + c;                          // chunk index in the image
+            if constexpr (!(ABL & 1)) dma_chunk(g + 2 < MLP_CHUNKS ? g + 2 : MLP_CHUNKS - 1, nx2);      // past the end: a harmless re-copy
+            const unsigned char *w1base = ring + cur + r * MLP_LD1 + 16 * h;
+            const unsigned char *w2base = ring + cur + MLP_W2OFF + r * MLP_LD2 + 16 * h;
+            // fragment f: f < 16: fc1 k-step f (W1 row r); f >= 16: fc2 k-step qq = (f-16)/8 of output block
+            // j = (f-16)%8 (W2 row 32j + r)
+            u32x4 fw[FR];
+            auto frag = [&](auto fc) __attribute__((always_inline)) {
+                constexpr int f = decltype(fc)::value;
+                if constexpr ((ABL & 4) != 0) { fw[f % FR] = X[f % 16]; return; }
+                if constexpr (f < 16) fw[f % FR] = *(const u32x4 *)(w1base + 32 * f);
+                else fw[f % FR] = *(const u32x4 *)(w2base + 32 * ((f - 16) % 8) * MLP_LD2 + 32 * ((f - 16) / 8));
+            };
+            f32x16 U;
+            {
+                const float *bp = b1s + MLP_CH * c + 4 * h;
 #pragma unroll
-                for (int pq = 0; pq < 4; ++pq) {
-                    const f32x4 v = *(const f32x4 *)&tp[(trow + 8 * pq) * 36 + tc4];
-                    const int orow = m0 + 32 * g + trow + 8 * pq;
-                    if (orow < M) *(f32x4 *)(out + (size_t)orow * D + 32 * j + tc4) = v;
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 bv = *(const f32x4 *)(bp + 8 * q);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) U[4 * q + e] = bv[e];
                 }
+            }
+            static_for<FR - 1>([&](auto fc) { frag(fc); });
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- fc1: U = b1 + W1[32 rows] X^T (one dependent chain: issues back to back on gfx950) ----
+            static_for<16>([&](auto fc) {
+                constexpr int f = decltype(fc)::value;
+                frag(std::integral_constant<int, f + FR - 1>{});
+                U = MFMA_BF16(__builtin_bit_cast(bf16x8, fw[f % FR]), __builtin_bit_cast(bf16x8, X[f]), U);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            // ---- ReLU, round to bf16: registers 8qq .. 8qq+7 are the B operand of k-step qq ----
+            u32x4 P[2];
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii)
+                    P[qq][ii] = pack_bf16(relu1(U[8 * qq + 2 * ii]), relu1(U[8 * qq + 2 * ii + 1]));
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- fc2: Y += W2[:, these 32 hidden units] P^T ----
+            static_for<16>([&](auto gc) {
+                constexpr int k = decltype(gc)::value, f = 16 + k;
+                if constexpr (f + FR - 1 < 32) frag(std::integral_constant<int, f + FR - 1>{});
+                Y[k % 8] = MFMA_BF16(__builtin_bit_cast(bf16x8, fw[f % FR]), __builtin_bit_cast(bf16x8, P[k / 8]), Y[k % 8]);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            chunk_done();
+            const int t = cur; cur = nx1; nx1 = nx2; nx2 = t;
+        }
+        __syncthreads();                        // drains the DMAs still in flight before the ring is reused below
+
+        // ---- epilogue (that of gemm_ln_rows): + b2, LayerNorm over the row (lane-local + one lane^32 exchange), stores
+        // transposed through a wave-private corner of the now idle ring, score head ----
+        int le = tid;
+        asm volatile("" : "+v"(le));
+        const int er = le & 31, eh = (le >> 5) & 1;              // (opaque copies of r, h: see the prologue)
+        float *tp = (float *)dyn_smem + wave * (32 * 36);
+        const int trow = (le & 63) >> 3, tc4 = (le & 7) * 4;
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            float pj = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 bv = *(const f32x4 *)&bias_s[32 * j + 8 * q + 4 * eh];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { Y[j][4 * q + e] += bv[e]; pj += Y[j][4 * q + e]; }
+            }
+            sum += pj;
+        }
+        sum = pair_sum(sum);
+        const float mean = sum * (1.0f / D);
+        float sq = 0.f;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            float pj = 0.f;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) { const float cv = Y[j][t] - mean; Y[j][t] = cv; pj += cv * cv; }
+            sq += pj;
+        }
+        sq = pair_sum(sq);
+        const float rstd = 1.0f / sqrtf(sq * (1.0f / D) + 1e-5f);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 gv = *(const f32x4 *)&gam_s[32 * j + 8 * q + 4 * eh];
+                const f32x4 bv = *(const f32x4 *)&bet_s[32 * j + 8 * q + 4 * eh];
+                f32x4 y;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { y[e] = Y[j][4 * q + e] * rstd * gv[e] + bv[e]; Y[j][4 * q + e] = y[e]; }
+                *(f32x4 *)&tp[er * 36 + 8 * q + 4 * eh] = y;
+            }
+#pragma unroll
+            for (int pq = 0; pq < 4; ++pq) {
+                const f32x4 v = *(const f32x4 *)&tp[(trow + 8 * pq) * 36 + tc4];
+                const int orow = m0 + trow + 8 * pq;
+                if (orow < M) *(f32x4 *)(out + (size_t)orow * D + 32 * j + tc4) = v;
             }
         }
         if (score_w != nullptr) {
             for (int cc = 0; cc < num_classes; ++cc) {
                 __syncthreads();
-                for (int i = tid; i < D; i += NTHR) sw_s[i] = score_w[(size_t)cc * D + i];
+                for (int i = tid; i < D; i += 512) sw_s[i] = score_w[(size_t)cc * D + i];
                 __syncthreads();
+                float dot = 0.f;
 #pragma unroll
-                for (int g = 0; g < RG; ++g) {
-                    float dot = 0.f;
+                for (int j = 0; j < NT; ++j) {
+                    float pj = 0.f;
 #pragma unroll
-                    for (int j = 0; j < NT; ++j) {
-                        float pj = 0.f;
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 wv = *(const f32x4 *)&sw_s[32 * j + 8 * q + 4 * eh];
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const f32x4 wv = *(const f32x4 *)&sw_s[32 * j + 8 * q + 4 * h];
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) pj += Y[g][j][4 * q + e] * wv[e];
-                        }
-                        dot += pj;
+                        for (int e = 0; e < 4; ++e) pj += Y[j][4 * q + e] * wv[e];
                     }
-                    dots[g] = pair_sum(dot);
+                    dot += pj;
                 }
-#pragma unroll
-                for (int g = 0; g < RG; ++g) {
-                    const int row = m0 + 32 * g + r;
-                    if (h == 0 && row < M) {
-                        float sc = dots[g] + score_b[cc];
-                        if (sigmoid) sc = 1.0f / (1.0f + expf(-sc));
-                        scores[(size_t)row * num_classes + cc] = sc;
-                    }
+                dot = pair_sum(dot);
+                const int row = m0 + er;
+                if (eh == 0 && row < M) {
+                    float sc = dot + score_b[cc];
+                    if (sigmoid) sc = 1.0f / (1.0f + expf(-sc));
+                    scores[(size_t)row * num_classes + cc] = sc;
                 }
             }
         }
     }
 }
 
-constexpr size_t MLP_LDS = (size_t)3 * MLP_IMG + (MLP_HID + 4 * MLP_D) * sizeof(float);      // 128 KiB
+constexpr size_t MLP_LDS = (size_t)3 * MLP_IMG + (MLP_HID + 7 * MLP_D) * sizeof(float);      // 131 KiB
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is per DEVICE: set once per (kernel instantiation, device)
-template <int RG, int ABL>
+template <bool TAIL, int ABL>
 int allow_lds() {
     static std::atomic<unsigned char> done[64];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return (int)hipErrorInvalidDevice;
     if (dev >= 0 && dev < 64 && done[dev].load(std::memory_order_acquire)) return 0;
-    const int rc = (int)hipFuncSetAttribute((const void *)mlp_fused_bf16<RG, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    const int rc = (int)hipFuncSetAttribute((const void *)mlp_fused_bf16<TAIL, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                             (int)MLP_LDS);
     if (rc == 0 && dev >= 0 && dev < 64) done[dev].store(1, std::memory_order_release);
     return rc;
@@ -311,19 +387,22 @@ int allow_lds() {
 
 }  // namespace
 
-size_t vsk_mlp_bf16_image_bytes(int d) { return d == MLP_D ? (size_t)MLP_NCH * MLP_IMG : 0; }
+size_t vsk_mlp_bf16_image_bytes(int d) { return d == MLP_D ? (size_t)MLP_CHUNKS * MLP_IMG : 0; }
 
-int vsk_pack_mlp_bf16(const float *W1, const float *W2, void *img, int d, hipStream_t st) {
+int vsk_pack_mlp_bf16(const float *Wo, const float *W1, const float *W2, void *img, int d, hipStream_t st) {
     if (d != MLP_D) return -1;
     if (hipMemsetAsync(img, 0, vsk_mlp_bf16_image_bytes(d), st) != hipSuccess) return (int)hipGetLastError();
-    hipLaunchKernelGGL(pack_mlp_bf16, dim3(256), dim3(256), 0, st, W1, W2, (unsigned char *)img);
+    hipLaunchKernelGGL(pack_mlp_bf16, dim3(256), dim3(256), 0, st, Wo, W1, W2, (unsigned char *)img);
     VSK_CHECK_LAUNCH();
     return 0;
 }
 
 bool vsk_mlp_bf16_supported(int d) { return d == MLP_D; }
 
-int vsk_mlp_bf16(const float *H1, const void *img, const float *b1, const float *b2,
+// att16 != nullptr: the layer tail (out-projection + norm1 + MLP block): h = the residual (layer input), att16 the bf16
+// attention output;  att16 == nullptr: the MLP block alone on h = h1
+int vsk_mlp_bf16(const float *h, const void *att16, const float *bo, const float *gamma1, const float *beta1,
+                 const void *img, const float *b1, const float *b2,
                  const float *gamma, const float *beta, float *out, int M, int d,
                  const float *score_w, const float *score_b, int num_classes, int sigmoid, float *scores,
                  hipStream_t st) {
@@ -332,26 +411,26 @@ int vsk_mlp_bf16(const float *H1, const void *img, const float *b1, const float 
     if (cus <= 0) return (int)hipErrorInvalidDevice;
     const int ntiles = (M + 255) / 256;
     const int blocks = ntiles < cus ? ntiles : cus;
-#define VSK_MLP_LAUNCH(R_, A_)                                                                                         \
+    const TailArgs ta{(const h16 *)att16, h, bo, gamma1, beta1};
+#define VSK_MLP_LAUNCH(T_, A_)                                                                                         \
     do {                                                                                                               \
-        if (const int rc = allow_lds<R_, A_>()) return rc;                                                             \
-        hipLaunchKernelGGL((mlp_fused_bf16<R_, A_>), dim3(blocks), dim3(512 / R_), MLP_LDS, st, H1, (const unsigned char *)img, b1, \
+        if (const int rc = allow_lds<T_, A_>()) return rc;                                                             \
+        hipLaunchKernelGGL((mlp_fused_bf16<T_, A_>), dim3(blocks), dim3(512), MLP_LDS, st, h, ta, (const unsigned char *)img, b1, \
                            b2, gamma, beta, out, M, score_w, score_b, num_classes, sigmoid, scores);                   \
     } while (0)
 #ifdef VS_WITH_DIAG
-    const bool two = vsk_options().mlp_rows64 != 0;
-    switch (vsk_options().mlp_abl) {       // timing-only ablations (tools/bench_mlp_fused.py)
-        case 0: if (two) { VSK_MLP_LAUNCH(2, 0); VSK_CHECK_LAUNCH(); return 0; } break;
-        case 1: if (two) VSK_MLP_LAUNCH(2, 1); else VSK_MLP_LAUNCH(1, 1); VSK_CHECK_LAUNCH(); return 0;
-        case 2: if (two) VSK_MLP_LAUNCH(2, 2); else VSK_MLP_LAUNCH(1, 2); VSK_CHECK_LAUNCH(); return 0;
-        case 3: if (two) VSK_MLP_LAUNCH(2, 3); else VSK_MLP_LAUNCH(1, 3); VSK_CHECK_LAUNCH(); return 0;
-        case 4: if (two) VSK_MLP_LAUNCH(2, 4); else VSK_MLP_LAUNCH(1, 4); VSK_CHECK_LAUNCH(); return 0;
-        case 5: if (two) VSK_MLP_LAUNCH(2, 5); else VSK_MLP_LAUNCH(1, 5); VSK_CHECK_LAUNCH(); return 0;
-        case 7: if (two) VSK_MLP_LAUNCH(2, 7); else VSK_MLP_LAUNCH(1, 7); VSK_CHECK_LAUNCH(); return 0;
-        default: if (two) VSK_MLP_LAUNCH(2, 8); else VSK_MLP_LAUNCH(1, 8); VSK_CHECK_LAUNCH(); return 0;
+    switch (vsk_options().mlp_abl) {       // timing-only ablations of the MLP-block kernel (tools/bench_mlp_fused.py)
+        case 0: break;
+        case 1: VSK_MLP_LAUNCH(false, 1); VSK_CHECK_LAUNCH(); return 0;
+        case 2: VSK_MLP_LAUNCH(false, 2); VSK_CHECK_LAUNCH(); return 0;
+        case 3: VSK_MLP_LAUNCH(false, 3); VSK_CHECK_LAUNCH(); return 0;
+        case 4: VSK_MLP_LAUNCH(false, 4); VSK_CHECK_LAUNCH(); return 0;
+        case 5: VSK_MLP_LAUNCH(false, 5); VSK_CHECK_LAUNCH(); return 0;
+        case 7: VSK_MLP_LAUNCH(false, 7); VSK_CHECK_LAUNCH(); return 0;
+        default: VSK_MLP_LAUNCH(false, 8); VSK_CHECK_LAUNCH(); return 0;
     }
 #endif
-    VSK_MLP_LAUNCH(1, 0);
+    if (att16 != nullptr) VSK_MLP_LAUNCH(true, 0); else VSK_MLP_LAUNCH(false, 0);
 #undef VSK_MLP_LAUNCH
     VSK_CHECK_LAUNCH();
     return 0;

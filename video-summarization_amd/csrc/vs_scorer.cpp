@@ -115,7 +115,7 @@ const OptionName kOptions[] = {
     {"VS_ATTN_NW4", &VskOptions::attn_nw4, 0},           {"VS_ATTN_LP_SIMPLE", &VskOptions::attn_lp_simple, 0},
     {"VS_MLP_FUSION", &VskOptions::mlp_fusion, 0},       {"VS_MLP_ABL", &VskOptions::mlp_abl, 0},
     {"VS_ATTN_LEGACY", &VskOptions::attn_legacy, 0},     {"VS_LP_STORE32", &VskOptions::lp_store32, 0},
-    {"VS_LP_MLP_UNFUSED", &VskOptions::lp_mlp_unfused, 0}, {"VS_MLP_ROWS64", &VskOptions::mlp_rows64, 0},
+    {"VS_LP_MLP_UNFUSED", &VskOptions::lp_mlp_unfused, 0}, {"VS_LP_TAIL_UNFUSED", &VskOptions::lp_tail_unfused, 0},
 };
 int option_from_env(const OptionName &o) {
     const char *e = getenv(o.name);
@@ -209,7 +209,7 @@ static int fill_weights(vs_weights *w, const vs_model_params *params, hipStream_
     }
     if (vsk_mlp_bf16_supported((int)d))
         for (const auto &L : w->layers)
-            pk &= vsk_pack_mlp_bf16(w->blob + L.w1, w->blob + L.w2, w->blob + L.b_mlp, (int)d, st) == 0;
+            pk &= vsk_pack_mlp_bf16(w->blob + L.wo, w->blob + L.w1, w->blob + L.w2, w->blob + L.b_mlp, (int)d, st) == 0;
     if (!pk) return fail(VS_ERR_HIP, "weight fragment packing failed: %s", hipGetErrorString(hipGetLastError()));
     return VS_OK;
 }
@@ -369,6 +369,16 @@ int forward_core(const vs_weights *w, const float *x, const uint8_t *key_pad_mas
                 VS_LAUNCH(vsk_attention(qkv, qkv + (size_t)M * d, qkv + 2 * (size_t)M * d, key_pad_mask, att, B, H,
                                         T, d / H, scale, st));
         }
+        float *dst = (last && hidden) ? hidden : h0;
+        // bf16 mode, d_model 256, bf16 attention output: out-projection + norm1 + the whole MLP block + norm2 (+ score
+        // head) as ONE kernel; h1 never exists in HBM
+        if (mlp16 && qkv16 && !vsk_options().lp_tail_unfused) {
+            StageScope ps(VS_STAGE_FC2_LN, st);
+            VS_LAUNCH(vsk_mlp_bf16(h0, att, w->p(P.bo), w->p(P.ln1g), w->p(P.ln1b), w->p(P.b_mlp), w->p(P.b1), w->p(P.b2),
+                                   w->p(P.ln2g), w->p(P.ln2b), dst, M, d, last ? w->p(w->final_w) : nullptr,
+                                   last ? w->p(w->final_b) : nullptr, D.num_classes, sig, last ? scores : nullptr, st));
+            continue;
+        }
         // d_model > 256: plain GEMM + the row LayerNorm pass (faster than the fused wide kernel at every M; the
         // GEMM's output goes to a region of the workspace that is free at that point: q after the attention, att after fc1)
         const bool split_ln = d > 256 && lnbf != 1;
@@ -381,7 +391,6 @@ int forward_core(const vs_weights *w, const float *x, const uint8_t *key_pad_mas
             VS_LAUNCH(vsk_linear_res_ln(att, w->p(P.wo), w->p(lnbf == 2 ? P.h_wo : P.f_wo), w->p(P.bo), h0, w->p(P.ln1g), w->p(P.ln1b), h1, M, d, d,
                                         nullptr, nullptr, 0, 0, nullptr, qkv16 ? (1 | VSK_STORE16) : lnbf, st));
         }
-        float *dst = (last && hidden) ? hidden : h0;
 #ifdef VS_WITH_DIAG     // diagnostic library only (tools/): the measured-slower fused MLP kernel
         // Opt-in alternative (VS_MLP_FUSION=1, d_model = 256): fc1 + ReLU + fc2 + residual + norm2 (+ score head)
         // as ONE kernel with the activations kept in registers (reported under the fc2 stage).  Bit-identical
@@ -399,7 +408,7 @@ int forward_core(const vs_weights *w, const float *x, const uint8_t *key_pad_mas
         // bf16 mode, d_model 256, throughput batches: the whole MLP block as one kernel (hidden activations in registers)
         if (mlp16) {
             StageScope ps(VS_STAGE_FC2_LN, st);
-            VS_LAUNCH(vsk_mlp_bf16(h1, w->p(P.b_mlp), w->p(P.b1), w->p(P.b2), w->p(P.ln2g), w->p(P.ln2b), dst, M, d,
+            VS_LAUNCH(vsk_mlp_bf16(h1, nullptr, nullptr, nullptr, nullptr, w->p(P.b_mlp), w->p(P.b1), w->p(P.b2), w->p(P.ln2g), w->p(P.ln2b), dst, M, d,
                                    last ? w->p(w->final_w) : nullptr, last ? w->p(w->final_b) : nullptr,
                                    D.num_classes, sig, last ? scores : nullptr, st));
             continue;
@@ -596,7 +605,7 @@ int vs_mlp_block_bf16(const vs_weights *w, int32_t layer, const float *h, float 
     if (with_head && !scores) return fail(VS_ERR_INVALID, "scores is NULL");
     if (((uintptr_t)h & 15) || ((uintptr_t)out & 15)) return fail(VS_ERR_INVALID, "h/out must be 16-byte aligned");
     const LayerOff &P = w->layers[layer];
-    VS_LAUNCH(vsk_mlp_bf16(h, w->p(P.b_mlp), w->p(P.b1), w->p(P.b2), w->p(P.ln2g), w->p(P.ln2b), out, M,
+    VS_LAUNCH(vsk_mlp_bf16(h, nullptr, nullptr, nullptr, nullptr, w->p(P.b_mlp), w->p(P.b1), w->p(P.b2), w->p(P.ln2g), w->p(P.ln2b), out, M,
                            w->desc.d_model, with_head ? w->p(w->final_w) : nullptr, with_head ? w->p(w->final_b) : nullptr,
                            w->desc.num_classes, sigmoid, with_head ? scores : nullptr, (hipStream_t)stream));
     return VS_OK;
