@@ -789,10 +789,11 @@ def test_mlp_block_bf16_kernel(vsa, M, nc, sig):
 @pytest.mark.parametrize("cfg", ["M-A", "M-B8", "M-A-ragged"])
 def test_bf16_layer_tail_kernel_is_bit_identical_to_outproj_then_mlp_kernel(vsa, lp_linear_everywhere, cfg):
     """With the attention output stored as bf16, the bf16 mode runs out-projection + residual + norm1 + MLP block + norm2
-    (+ score head) as ONE kernel (vs_mlp_fused.hip, TAIL).  Its out-projection multiplies in the same order as the
-    stand-alone kernel (gemm_ln_rows) and shares the LayerNorm arithmetic, so against VS_LP_TAIL_UNFUSED=1 (that kernel,
-    h1 through HBM, then the fused MLP kernel) logits, scores and hidden state must agree BIT FOR BIT - padded, masked and
-    packed batches, in-place (middle layers) and out-of-place (last layer with `hidden`) outputs."""
+    (+ score head) as ONE kernel (vs_mlp_fused.hip, TAIL), which then also projects its rows to the NEXT layer's q/k/v
+    (QKV epilogue).  Both additions multiply in the same order as the stand-alone kernels they replace (gemm_ln_rows;
+    gemm_nt_128<EPI_QKV, C16>) and share their epilogue arithmetic, so against VS_LP_TAIL_UNFUSED=1 / VS_LP_QKV_UNFUSED=1
+    (those kernels, h1 and the layer output re-read from HBM) logits, scores and hidden state must agree BIT FOR BIT -
+    padded, masked and packed batches, head dim 64 and 32, in-place (middle layers) and out-of-place (last layer)."""
     synth = vsa.synth
     d, H, L = (256, 8, 3) if cfg == "M-B8" else (256, 4, 3)
     sd = synth.make_state_dict(d, L, 371, trained_like=True)
@@ -815,12 +816,19 @@ def test_bf16_layer_tail_kernel_is_bit_identical_to_outproj_then_mlp_kernel(vsa,
 
     try:
         vsa._lib.set_option("VS_LP_TAIL_UNFUSED", 1)
-        ref = run()
+        vsa._lib.set_option("VS_LP_QKV_UNFUSED", 1)
+        ref = run()                                      # out-projection kernel, MLP kernel, QKV kernel per layer
+        vsa._lib.set_option("VS_LP_TAIL_UNFUSED", -1)
+        mid = run()                                      # layer-tail kernel, QKV kernel per layer
+        vsa._lib.set_option("VS_LP_QKV_UNFUSED", -1)
+        vsa._lib.set_option("VS_LP_TAIL_UNFUSED", 1)
+        mid2 = run()                                     # out-projection kernel, MLP kernel with the next layer's QKV behind it
     finally:
         vsa._lib.set_option("VS_LP_TAIL_UNFUSED", -1)
-    got = run()
-    for g, r in zip(got, ref):
-        assert torch.isfinite(g).all() and torch.equal(g, r)
+        vsa._lib.set_option("VS_LP_QKV_UNFUSED", -1)
+    got = run()                                          # the default: layer-tail kernel with the next layer's QKV behind it
+    for g, a, b, r in zip(got, mid, mid2, ref):
+        assert torch.isfinite(g).all() and torch.equal(a, r) and torch.equal(b, r) and torch.equal(g, r)
 
 
 @pytest.mark.parametrize("cfg", ["M-A", "M-A-ragged"])

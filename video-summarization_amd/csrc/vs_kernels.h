@@ -54,11 +54,22 @@ int vsk_mlp_fused(const float *H1, const float *W1, const float *b1, const float
 bool vsk_mlp_bf16_supported(int d);
 size_t vsk_mlp_bf16_image_bytes(int d);
 int vsk_pack_mlp_bf16(const float *Wo, const float *W1, const float *W2, void *img, int d, hipStream_t st);
+// next != nullptr: the kernel also projects the rows it produced to the NEXT layer's q * qscale / k / v (bf16, head-major:
+// three [M / T, H, T, d / H] planes of M * d elements at qkv16; M a multiple of T) - bit-identical to vsk_qkv(.. STORE16)
+struct VskNextQkv {
+    const void *img;            // vsk_pack_qkv_bf16 image of that layer's Wqkv (vsk_qkv_bf16_image_bytes(d) bytes)
+    const float *bqkv;
+    void *qkv16;
+    int T, H;
+    float qscale;
+};
+size_t vsk_qkv_bf16_image_bytes(int d);
+int vsk_pack_qkv_bf16(const float *Wqkv, void *img, int d, hipStream_t st);
 int vsk_mlp_bf16(const float *h, const void *att16, const float *bo, const float *gamma1, const float *beta1,
                  const void *img, const float *b1, const float *b2,
                  const float *gamma, const float *beta, float *out, int M, int d,
                  const float *score_w, const float *score_b, int num_classes, int sigmoid, float *scores,
-                 hipStream_t st);
+                 const VskNextQkv *next, hipStream_t st);
 // packed ragged batches: row offsets cu[B+1] and the (video, query tile) work list from device lengths; gather of
 // the positional rows pe[t] of every frame into rows[Mtot, d]
 int vsk_plan_packed(const int *lengths_dev, int B, int qb, int *cu, int *work, int work_cap, hipStream_t st);   // work_cap: (video, tile) pairs `work` can hold
@@ -77,6 +88,7 @@ struct VskOptions {
     int lp_store32;       // VS_LP_STORE32    bf16 mode keeps q/k/v, the attention output and the MLP hidden tensor fp32 in HBM (A/B)
     int lp_mlp_unfused;   // VS_LP_MLP_UNFUSED bf16 mode runs fc1 and fc2 + LayerNorm as two kernels (A/B)
     int lp_tail_unfused;  // VS_LP_TAIL_UNFUSED bf16 mode runs the out-projection + norm1 as its own kernel in front of the fused MLP (A/B)
+    int lp_qkv_unfused;   // VS_LP_QKV_UNFUSED  bf16 mode runs every layer's QKV projection as its own kernel (A/B)
     int mlp_fusion;       // VS_MLP_FUSION    (diagnostic builds only)
     int mlp_abl;          // VS_MLP_ABL       (diagnostic builds only)
     int attn_legacy;      // VS_ATTN_LEGACY   (diagnostic builds only)

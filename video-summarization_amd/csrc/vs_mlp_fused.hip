@@ -45,6 +45,9 @@ constexpr int MLP_IMG = 40960;                  // W2 part: 256 * 80 = 20480 -> 
 // conflict-free b128), 256 * 144 = 36 864 B = 36 pieces, padded to the same 40-piece chunk
 constexpr int MLP_LDO = 144, MLP_NCHO = 4;
 constexpr int MLP_CHUNKS = MLP_NCHO + MLP_NCH;  // image = [4 Wo chunks][32 MLP chunks]
+// the NEXT layer's QKV projection behind (QKV epilogue): Wqkv [768][256] as 12 chunks of 64 output columns, rows of 256 bf16
+// + 16 B like W1 (64 * 528 = 33 792 B = 33 pieces, padded to 40), natural k order; its own image
+constexpr int MLP_NCHQ = 12;
 
 __device__ __forceinline__ int swap23(int p) { return (p & 3) | ((p & 4) << 1) | ((p & 8) >> 1); }
 
@@ -74,6 +77,16 @@ __global__ void pack_mlp_bf16(const float *__restrict__ Wo, const float *__restr
     }
 }
 
+// Wqkv [768][256] fp32 -> img [12 chunks][MLP_IMG bytes]
+__global__ void pack_qkv_bf16(const float *__restrict__ Wqkv, unsigned char *__restrict__ img) {
+    const int n = 3 * MLP_D * MLP_D / 2;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int row = (2 * i) / MLP_D, k = (2 * i) % MLP_D;
+        unsigned *dst = (unsigned *)(img + (size_t)(row / 64) * MLP_IMG + (row % 64) * MLP_LD1 + 2 * k);
+        *dst = pack_bf16(Wqkv[(size_t)row * MLP_D + k], Wqkv[(size_t)row * MLP_D + k + 1]);
+    }
+}
+
 // one wave instruction: lane l copies 16 bytes from its `g` to lds_wave_base + 16 l (asynchronous, counted by vmcnt)
 __device__ __forceinline__ void glds16(const void *g, void *lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
@@ -86,16 +99,33 @@ struct TailArgs {            // TAIL kernels: the out-projection + norm1 in fron
     const float *bo, *gamma1, *beta1;
 };
 
+struct QkvArgs {             // QKV epilogue: the next layer's q / k / v projection of the rows this block just produced
+    const unsigned char *img;    // vsk_pack_qkv_bf16 image of the NEXT layer's Wqkv, or nullptr (no epilogue)
+    const float *bqkv;           // [768]
+    h16 *qkv;                    // out: three [B, H, T, dh] bf16 planes of M * 256 elements (q pre-multiplied by qscale)
+    int T, H, dh;
+    float qscale;
+};
+
 // TAIL: the kernel starts one step earlier in the encoder layer: H1 is not read but computed,
 //     h1 = LayerNorm(att Wo^T + bo + res) * gamma1 + beta1          (reference simnet.py:107 norm1(x + sa(x)))
 // by four more chunks through the same ring (Wo in 64-k slabs; the bf16 attention rows are the B operands straight from HBM,
 // the residual is the C-in of Y, bias and LayerNorm in registers exactly as gemm_ln_rows does them), and the
 // result is at once the X / Y input of the MLP part: h1 never exists in HBM, one launch and one prologue fewer per layer.
+// QKV epilogue (qa.img != nullptr; every layer but the last): the rows this block has just normalised are the next
+// layer's input, so its q / k / v projection runs here, on registers: X = bf16(out rows) brought into natural k order by
+// one v_permlane32_swap per dword (lanes l and l^32 hold the two halves of every 8-column group), 12 more chunks of
+// 64 output columns through the ring, two 16-MFMA chains per chunk in the k order of the stand-alone QKV kernel
+// (gemm_nt_128<EPI_QKV, .., C16>: bit-identical q * qscale, k, v), and the results leave as 16-byte pieces per lane
+// (again one permlane swap per dword) straight into the head-major bf16 planes - no LDS round trip.  A chunk's stores are
+// issued after its barrier, at the top of the next iteration and BEFORE that iteration's 5 DMA pieces: the counted
+// vmcnt(5) at its end then still proves that the chunk needed next has landed (loads retire in order among loads; at
+// worst it also waits for stores that are a whole chunk old).
 // ABL (diagnostic library only, timing runs with wrong results): 1 no weight staging, 2 no barrier / wait in the chunk
 // loop, 4 fragment reads replaced by register moves, 8 no chunk loop at all (prologue + epilogue only)
 template <bool TAIL, int ABL = 0>
 __global__ __launch_bounds__(512, 1) void mlp_fused_bf16(
-    const float *H1, TailArgs ta, const unsigned char *__restrict__ Wimg, const float *__restrict__ b1,
+    const float *H1, TailArgs ta, QkvArgs qa, const unsigned char *__restrict__ Wimg, const float *__restrict__ b1,
     const float *__restrict__ b2, const float *__restrict__ gamma,
     const float *__restrict__ beta, float *out /* may be the residual buffer: every block rewrites only rows it has read */,
     int M, const float *__restrict__ score_w, const float *__restrict__ score_b, int num_classes,
@@ -107,6 +137,7 @@ __global__ __launch_bounds__(512, 1) void mlp_fused_bf16(
     float *b1s = (float *)(dyn_smem + 3 * IMG);                  // [HID]
     float *gam_s = b1s + HID, *bet_s = gam_s + D, *sw_s = bet_s + D, *bias_s = sw_s + D;
     float *gam1_s = bias_s + D, *bet1_s = gam1_s + D, *bo_s = bet1_s + D;     // TAIL only
+    float *bqkv_s = bo_s + D;                                    // [3 D], QKV epilogue only
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -115,18 +146,21 @@ __global__ __launch_bounds__(512, 1) void mlp_fused_bf16(
         gam_s[i] = gamma[i]; bet_s[i] = beta[i]; bias_s[i] = b2[i];
         if constexpr (TAIL) { gam1_s[i] = ta.gamma1[i]; bet1_s[i] = ta.beta1[i]; bo_s[i] = ta.bo[i]; }
     }
+    if (qa.img != nullptr)
+        for (int i = tid; i < 3 * D; i += 512) bqkv_s[i] = qa.bqkv[i];
 
     // chunk image -> ring buffer: 40 pieces of 1 KiB, 5 per wave.  Source = wave-uniform base (scalar registers) +
     // one per-lane byte offset: no per-piece address registers.
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const unsigned lane16 = (unsigned)lane * 16u;
-    auto dma_chunk = [&](int chunk, int bufoff) __attribute__((always_inline)) {
-        const unsigned char *src = Wimg + (size_t)chunk * IMG + wave_u * 1024;
+    auto dma_from = [&](const unsigned char *image, int chunk, int bufoff) __attribute__((always_inline)) {
+        const unsigned char *src = image + (size_t)chunk * IMG + wave_u * 1024;
         unsigned l16 = lane16;
         asm volatile("" : "+v"(l16));           // (opaque: else five per-lane 64-bit pointers are precomputed and spilled)
 #pragma unroll
         for (int i = 0; i < 5; ++i) glds16(src + 8192 * i + l16, ring + bufoff + wave_u * 1024 + 8192 * i);
     };
+    auto dma_chunk = [&](int chunk, int bufoff) __attribute__((always_inline)) { dma_from(Wimg, chunk, bufoff); };
     // end of a chunk: the next chunk (5 pieces, issued one iteration ago) has landed, the one after it stays in flight;
     // its data is read only after the barrier every wave passes behind its own wait
     auto chunk_done = [&]() __attribute__((always_inline)) {
@@ -367,10 +401,94 @@ __global__ __launch_bounds__(512, 1) void mlp_fused_bf16(
                 }
             }
         }
+        if (qa.img != nullptr) {
+            // ---- QKV epilogue (see the header of this kernel) ----
+            // X[ks] = this lane's 8 natural-order k of the normalised row: k-step ks = 2j + qq covers columns 32j + 16qq ..
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int qq = 0; qq < 2; ++qq) {
+                    const unsigned e0 = pack_bf16(Y[j][8 * qq + 0], Y[j][8 * qq + 1]), e1 = pack_bf16(Y[j][8 * qq + 2], Y[j][8 * qq + 3]);
+                    const unsigned o0 = pack_bf16(Y[j][8 * qq + 4], Y[j][8 * qq + 5]), o1 = pack_bf16(Y[j][8 * qq + 6], Y[j][8 * qq + 7]);
+                    auto s0 = __builtin_amdgcn_permlane32_swap(e0, o0, false, false);
+                    auto s1 = __builtin_amdgcn_permlane32_swap(e1, o1, false, false);
+                    X[2 * j + qq][0] = s0[0]; X[2 * j + qq][1] = s1[0]; X[2 * j + qq][2] = s0[1]; X[2 * j + qq][3] = s1[1];
+                }
+            __syncthreads();                    // every wave is done with its transposition corner of the ring
+            dma_from(qa.img, 0, 0);
+            dma_from(qa.img, 1, IMG);
+            const int row = m0 + er;
+            const int vb = row / qa.T, vt = row - vb * qa.T;      // (video, frame) of this lane's row
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            int qcur = 0, qn1 = IMG, qn2 = 2 * IMG;
+            u32x4 pend[4];                      // the previous chunk's packed results, stored after its barrier
+            for (int c = 0; c <= MLP_NCHQ; ++c) {
+                if (c > 0) {                    // stores of chunk c - 1: 16 bytes per lane = 8 consecutive columns of its row
+                    const int n0 = 64 * (c - 1), which = n0 >> 8;
+                    if (row < M) {
+#pragma unroll
+                        for (int t = 0; t < 2; ++t)
+#pragma unroll
+                            for (int pp = 0; pp < 2; ++pp) {
+                                const int cd = (n0 & 255) + 32 * t + 16 * pp + 8 * eh, head = cd / qa.dh, e = cd - head * qa.dh;
+                                h16 *dst = qa.qkv + (size_t)which * M * D + (((size_t)vb * qa.H + head) * qa.T + vt) * qa.dh + e;
+                                *(u32x4 *)dst = pend[2 * t + pp];
+                            }
+                    }
+                    if (c == MLP_NCHQ) break;
+                }
+                dma_from(qa.img, c + 2 < MLP_NCHQ ? c + 2 : MLP_NCHQ - 1, qn2);      // past the end: a harmless re-copy
+                const unsigned char *wbase = ring + qcur + er * MLP_LD1 + 16 * eh;
+                u32x4 fw[FR];
+                auto frag = [&](auto fc) __attribute__((always_inline)) {       // fragment f: k-step f / 2, column block f % 2
+                    constexpr int f = decltype(fc)::value;
+                    fw[f % FR] = *(const u32x4 *)(wbase + 32 * (f % 2) * MLP_LD1 + 32 * (f / 2));
+                };
+                f32x16 U[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const float *bp = bqkv_s + 64 * c + 32 * t + 4 * eh;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 bv = *(const f32x4 *)(bp + 8 * q);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) U[t][4 * q + e] = bv[e];
+                    }
+                }
+                static_for<FR - 1>([&](auto fc) { frag(fc); });
+                __builtin_amdgcn_sched_barrier(0);
+                static_for<32>([&](auto fc) {
+                    constexpr int f = decltype(fc)::value;
+                    if constexpr (f + FR - 1 < 32) frag(std::integral_constant<int, f + FR - 1>{});
+                    U[f % 2] = MFMA_BF16(__builtin_bit_cast(bf16x8, fw[f % FR]), __builtin_bit_cast(bf16x8, X[f / 2]), U[f % 2]);
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+                const float osc = c < 4 ? qa.qscale : 1.0f;       // chunks 0..3 are q
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int pp = 0; pp < 2; ++pp) {
+                        const float *u = (const float *)&U[t] + 8 * pp;       // registers 8pp .. 8pp+7: q = 2pp (even), 2pp+1 (odd)
+                        const unsigned e0 = pack_bf16(U[t][8 * pp + 0] * osc, U[t][8 * pp + 1] * osc), e1 = pack_bf16(U[t][8 * pp + 2] * osc, U[t][8 * pp + 3] * osc);
+                        const unsigned o0 = pack_bf16(U[t][8 * pp + 4] * osc, U[t][8 * pp + 5] * osc), o1 = pack_bf16(U[t][8 * pp + 6] * osc, U[t][8 * pp + 7] * osc);
+                        (void)u;
+                        auto s0 = __builtin_amdgcn_permlane32_swap(e0, o0, false, false);
+                        auto s1 = __builtin_amdgcn_permlane32_swap(e1, o1, false, false);
+                        pend[2 * t + pp][0] = s0[0]; pend[2 * t + pp][1] = s1[0]; pend[2 * t + pp][2] = s0[1]; pend[2 * t + pp][3] = s1[1];
+                    }
+                // <= 5 operations outstanding: loads retire in order among themselves, so chunk c+1's pieces (older than the 5
+                // of chunk c+2) have landed whatever the stores issued at the top of this iteration are doing
+                asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                const int t = qcur; qcur = qn1; qn1 = qn2; qn2 = t;
+            }
+        }
     }
 }
 
-constexpr size_t MLP_LDS = (size_t)3 * MLP_IMG + (MLP_HID + 7 * MLP_D) * sizeof(float);      // 131 KiB
+constexpr size_t MLP_LDS = (size_t)3 * MLP_IMG + (MLP_HID + 10 * MLP_D) * sizeof(float);      // 134 KiB
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is per DEVICE: set once per (kernel instantiation, device)
 template <bool TAIL, int ABL>
@@ -399,23 +517,36 @@ int vsk_pack_mlp_bf16(const float *Wo, const float *W1, const float *W2, void *i
 
 bool vsk_mlp_bf16_supported(int d) { return d == MLP_D; }
 
+size_t vsk_qkv_bf16_image_bytes(int d) { return d == MLP_D ? (size_t)MLP_NCHQ * MLP_IMG : 0; }
+
+int vsk_pack_qkv_bf16(const float *Wqkv, void *img, int d, hipStream_t st) {
+    if (d != MLP_D) return -1;
+    if (hipMemsetAsync(img, 0, vsk_qkv_bf16_image_bytes(d), st) != hipSuccess) return (int)hipGetLastError();
+    hipLaunchKernelGGL(pack_qkv_bf16, dim3(256), dim3(256), 0, st, Wqkv, (unsigned char *)img);
+    VSK_CHECK_LAUNCH();
+    return 0;
+}
+
 // att16 != nullptr: the layer tail (out-projection + norm1 + MLP block): h = the residual (layer input), att16 the bf16
 // attention output;  att16 == nullptr: the MLP block alone on h = h1
 int vsk_mlp_bf16(const float *h, const void *att16, const float *bo, const float *gamma1, const float *beta1,
                  const void *img, const float *b1, const float *b2,
                  const float *gamma, const float *beta, float *out, int M, int d,
                  const float *score_w, const float *score_b, int num_classes, int sigmoid, float *scores,
-                 hipStream_t st) {
+                 const VskNextQkv *next, hipStream_t st) {
     if (!vsk_mlp_bf16_supported(d) || M <= 0) return -1;
+    if (next && (next->T <= 0 || M % next->T || next->H <= 0 || d % next->H || (d / next->H) % 16)) return -1;
     const int cus = vsk_device_cus();
     if (cus <= 0) return (int)hipErrorInvalidDevice;
     const int ntiles = (M + 255) / 256;
     const int blocks = ntiles < cus ? ntiles : cus;
     const TailArgs ta{(const h16 *)att16, h, bo, gamma1, beta1};
+    const QkvArgs qa = next ? QkvArgs{(const unsigned char *)next->img, next->bqkv, (h16 *)next->qkv16, next->T, next->H, d / next->H, next->qscale}
+                            : QkvArgs{nullptr, nullptr, nullptr, 1, 1, d, 1.0f};
 #define VSK_MLP_LAUNCH(T_, A_)                                                                                         \
     do {                                                                                                               \
         if (const int rc = allow_lds<T_, A_>()) return rc;                                                             \
-        hipLaunchKernelGGL((mlp_fused_bf16<T_, A_>), dim3(blocks), dim3(512), MLP_LDS, st, h, ta, (const unsigned char *)img, b1, \
+        hipLaunchKernelGGL((mlp_fused_bf16<T_, A_>), dim3(blocks), dim3(512), MLP_LDS, st, h, ta, qa, (const unsigned char *)img, b1, \
                            b2, gamma, beta, out, M, score_w, score_b, num_classes, sigmoid, scores);                   \
     } while (0)
 #ifdef VS_WITH_DIAG

@@ -116,6 +116,7 @@ const OptionName kOptions[] = {
     {"VS_MLP_FUSION", &VskOptions::mlp_fusion, 0},       {"VS_MLP_ABL", &VskOptions::mlp_abl, 0},
     {"VS_ATTN_LEGACY", &VskOptions::attn_legacy, 0},     {"VS_LP_STORE32", &VskOptions::lp_store32, 0},
     {"VS_LP_MLP_UNFUSED", &VskOptions::lp_mlp_unfused, 0}, {"VS_LP_TAIL_UNFUSED", &VskOptions::lp_tail_unfused, 0},
+    {"VS_LP_QKV_UNFUSED", &VskOptions::lp_qkv_unfused, 0},
 };
 int option_from_env(const OptionName &o) {
     const char *e = getenv(o.name);
@@ -209,7 +210,10 @@ static int fill_weights(vs_weights *w, const vs_model_params *params, hipStream_
     }
     if (vsk_mlp_bf16_supported((int)d))
         for (const auto &L : w->layers)
+        {
             pk &= vsk_pack_mlp_bf16(w->blob + L.wo, w->blob + L.w1, w->blob + L.w2, w->blob + L.b_mlp, (int)d, st) == 0;
+            pk &= vsk_pack_qkv_bf16(w->blob + L.wqkv, w->blob + L.b_qkv, (int)d, st) == 0;
+        }
     if (!pk) return fail(VS_ERR_HIP, "weight fragment packing failed: %s", hipGetErrorString(hipGetLastError()));
     return VS_OK;
 }
@@ -248,7 +252,10 @@ int vs_weights_pack(const vs_model_desc *desc, const vs_model_params *params, vo
         L.h_wqkv = take(3 * d * d); L.h_wo = take(d * d); L.h_w1 = take(4 * d * d); L.h_w2 = take(4 * d * d);
     }
     if (vsk_mlp_bf16_supported((int)d))
-        for (auto &L : w->layers) L.b_mlp = take(vsk_mlp_bf16_image_bytes((int)d) / sizeof(float));
+        for (auto &L : w->layers) {
+            L.b_mlp = take(vsk_mlp_bf16_image_bytes((int)d) / sizeof(float));
+            L.b_qkv = take(vsk_qkv_bf16_image_bytes((int)d) / sizeof(float));
+        }
     w->blob_floats = off;
     if (hipGetDevice(&w->device) != hipSuccess) { delete w; return fail(VS_ERR_HIP, "hipGetDevice failed"); }
     hipError_t e = hipMalloc((void **)&w->blob, off * sizeof(float));
@@ -349,10 +356,19 @@ int forward_core(const vs_weights *w, const float *x, const uint8_t *key_pad_mas
         VS_LAUNCH(vsk_linear(x, w->p(w->embed_w), w->p(lbf == 2 ? w->h_embed_w : w->f_embed_w), w->p(w->embed_b), h0, M, d, D.in_features, 0,
                              pk ? pk->pe_rows : (w->has_pe ? w->p(w->pe) : nullptr), T, lbf, st));
     }
+    // bf16 mode with bf16 q/k/v: every layer's tail kernel also projects its output rows to the NEXT layer's q/k/v
+    const bool qkv_fused = mlp16 && qkv16 && !vsk_options().lp_qkv_unfused;
+    bool have_qkv = false;                  // q/k/v of the layer about to run were written by the previous layer's tail
     for (int l = 0; l < L; ++l) {
         const LayerOff &P = w->layers[l];
         const bool last = l == L - 1;
-        {
+        VskNextQkv nq{}, *next = nullptr;
+        if (qkv_fused && !last) {
+            const LayerOff &N = w->layers[l + 1];
+            nq = VskNextQkv{w->p(N.b_qkv), w->p(N.bqkv), qkv, T, H, vsk_attention_qscale(scale)};
+            next = &nq;
+        }
+        if (!have_qkv) {
             StageScope ps(VS_STAGE_QKV, st);
             VS_LAUNCH(vsk_qkv(h0, w->p(P.wqkv), w->p(lbf == 2 ? P.h_wqkv : P.f_wqkv), w->p(P.bqkv), qkv, B, T, d, H,
                               qkv16 ? (1 | VSK_STORE16) : lbf, st, qkv16 ? vsk_attention_qscale(scale) : 1.0f));
@@ -376,9 +392,11 @@ int forward_core(const vs_weights *w, const float *x, const uint8_t *key_pad_mas
             StageScope ps(VS_STAGE_FC2_LN, st);
             VS_LAUNCH(vsk_mlp_bf16(h0, att, w->p(P.bo), w->p(P.ln1g), w->p(P.ln1b), w->p(P.b_mlp), w->p(P.b1), w->p(P.b2),
                                    w->p(P.ln2g), w->p(P.ln2b), dst, M, d, last ? w->p(w->final_w) : nullptr,
-                                   last ? w->p(w->final_b) : nullptr, D.num_classes, sig, last ? scores : nullptr, st));
+                                   last ? w->p(w->final_b) : nullptr, D.num_classes, sig, last ? scores : nullptr, next, st));
+            have_qkv = next != nullptr;
             continue;
         }
+        have_qkv = false;
         // d_model > 256: plain GEMM + the row LayerNorm pass (faster than the fused wide kernel at every M; the
         // GEMM's output goes to a region of the workspace that is free at that point: q after the attention, att after fc1)
         const bool split_ln = d > 256 && lnbf != 1;
@@ -410,7 +428,8 @@ int forward_core(const vs_weights *w, const float *x, const uint8_t *key_pad_mas
             StageScope ps(VS_STAGE_FC2_LN, st);
             VS_LAUNCH(vsk_mlp_bf16(h1, nullptr, nullptr, nullptr, nullptr, w->p(P.b_mlp), w->p(P.b1), w->p(P.b2), w->p(P.ln2g), w->p(P.ln2b), dst, M, d,
                                    last ? w->p(w->final_w) : nullptr, last ? w->p(w->final_b) : nullptr,
-                                   D.num_classes, sig, last ? scores : nullptr, st));
+                                   D.num_classes, sig, last ? scores : nullptr, next, st));
+            have_qkv = next != nullptr;
             continue;
         }
         {
@@ -607,7 +626,7 @@ int vs_mlp_block_bf16(const vs_weights *w, int32_t layer, const float *h, float 
     const LayerOff &P = w->layers[layer];
     VS_LAUNCH(vsk_mlp_bf16(h, nullptr, nullptr, nullptr, nullptr, w->p(P.b_mlp), w->p(P.b1), w->p(P.b2), w->p(P.ln2g), w->p(P.ln2b), out, M,
                            w->desc.d_model, with_head ? w->p(w->final_w) : nullptr, with_head ? w->p(w->final_b) : nullptr,
-                           w->desc.num_classes, sigmoid, with_head ? scores : nullptr, (hipStream_t)stream));
+                           w->desc.num_classes, sigmoid, with_head ? scores : nullptr, nullptr, (hipStream_t)stream));
     return VS_OK;
 }
 

@@ -11,7 +11,8 @@ struct LayerOff {
     size_t wqkv, bqkv, wo, bo, ln1g, ln1b, w1, b1, w2, b2, ln2g, ln2b;
     size_t f_wqkv, f_wo, f_w1, f_w2;        // fragment-major copies for the latency kernels
     size_t h_wqkv, h_wo, h_w1, h_w2;        // their fp16x3 counterparts (hi|lo f16 halves, same size)
-    size_t b_mlp;                           // W1 and W2 as the LDS images of the fused bf16 MLP (vsk_pack_mlp_bf16)
+    size_t b_mlp;                           // Wo, W1, W2 as the LDS images of the fused bf16 layer-tail kernel (vsk_pack_mlp_bf16)
+    size_t b_qkv;                           // Wqkv as the LDS images of that kernel's QKV epilogue (vsk_pack_qkv_bf16)
 };
 
 // transposed weights for the dgrad GEMMs of the training backward (dX = dY W is an NT GEMM against W^T); built
