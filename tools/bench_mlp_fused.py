@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""The fused bf16 MLP block kernel (vs_mlp_block_bf16) alone: time per launch and TFLOP/s at M rows (default 65536),
+"""The fused bf16 MLP block kernel (vs_mlp_block_bf16: the layer-tail kernel without its out-projection and QKV parts)
+alone: time per launch and TFLOP/s at M rows (default 65536),
 and with VS_MLP_ABLS=1,2,.. (diagnostic library; bit 1 no weight staging, 2 no chunk barrier, 4 no fragment LDS
 reads, 8 no chunk loop at all) the timing-only ablations that say where the time goes.  Usage: python tools/bench_mlp_fused.py [M]"""
 import importlib
@@ -38,11 +39,7 @@ def run(tag):
     print("%-28s M=%d: %7.1f us  %6.1f TFLOP/s" % (tag, M, us, 4.0 * M * 1024 * 256 / us / 1e6))
 
 
-for rows64 in [int(a) for a in os.environ.get("VS_MLP_SHAPES", "0,1").split(",")]:
-    pkg._lib.set_option("VS_MLP_ROWS64", rows64)
-    pkg._lib.set_option("VS_MLP_ABL", 0)
-    tag = "4 waves x 64 rows" if rows64 else "8 waves x 32 rows"
-    run(tag)
-    for a in abls:
-        pkg._lib.set_option("VS_MLP_ABL", a)
-        run(tag + ", ablation %d" % a)
+run("MLP block kernel")
+for a in abls:
+    pkg._lib.set_option("VS_MLP_ABL", a)
+    run("ablation %d" % a)

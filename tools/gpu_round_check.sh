@@ -19,4 +19,11 @@ python tools/bench_train.py --model B --shapes 4x320,64x1024 >> gpurun_out/$TAG/
 bash tools/pmc_cmd.sh gpurun_out/$TAG/pmc_summary.txt bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-extras > /dev/null 2>&1
 bash tools/pmc_cmd.sh gpurun_out/$TAG/pmc_summary_mb.txt bench.py --model B --steps 6 --warmup 2 --no-cpu-baseline --no-extras --no-emulated > /dev/null 2>&1
 python tools/bench_configs.py > gpurun_out/$TAG/bench_configs.txt 2>&1
+# the opt-in modes: configs[4] (8 x 8192 x 2048) and the headline shape in fp32 / bf16 / fp16x3, the layer-tail kernel's
+# ablations, kernel trace + PMC summary of the bf16 mode at configs[4]
+python tools/bench_long.py 8 8192 fp32,bf16,fp16x3 > gpurun_out/$TAG/bench_long.txt 2>&1
+VS_BENCH_D=1024 python tools/bench_long.py 64 1024 fp32,bf16,fp16x3 > gpurun_out/$TAG/bench_headline_modes.txt 2>&1
+VS_MLP_ABLS=1,2,4,7,8 python tools/bench_mlp_fused.py > gpurun_out/$TAG/mlp_fused_ablations.txt 2>&1
+( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/$TAG/prof_long_bf16 -- python3 $GRAFT_REPO_ROOT/tools/bench_long.py 8 8192 bf16 > /dev/null 2>&1 )
+bash tools/pmc_cmd.sh gpurun_out/$TAG/pmc_summary_long_bf16.txt tools/bench_long.py 8 8192 bf16 > /dev/null 2>&1
 echo done

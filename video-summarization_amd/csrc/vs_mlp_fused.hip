@@ -1,12 +1,14 @@
-// vs_mlp_fused.hip — the MLP block of one encoder layer as ONE kernel on the bf16 matrix pipe (opt-in bf16 mode,
-// d_model = 256, hidden = 1024):
+// vs_mlp_fused.hip — the tail of one encoder layer as ONE kernel on the bf16 matrix pipe (opt-in bf16 mode,
+// d_model = 256, hidden = 1024).  The core is the MLP block
 //     out = LayerNorm( relu(h1 W1^T + b1) W2^T + b2 + h1 ) * gamma + beta      (+ score head)
-// (reference simnet.py:109-110 EncoderBlock, 180-183 MLP, 42 final_layer).
+// (reference simnet.py:109-110 EncoderBlock, 180-183 MLP, 42 final_layer); in front of it, when the attention output is
+// stored as bf16, the out-projection + residual + norm1 that produces h1 (simnet.py:107, 163; "TAIL"), and behind it the
+// NEXT layer's q / k / v projection of the rows just produced (simnet.py:148-153; "QKV epilogue").  One launch per layer
+// besides the attention; h1, the hidden activations and the re-read of the layer output never touch HBM.
 //
-// Why: as two kernels (fc1 + ReLU, fc2 + residual + LayerNorm) the [M, 1024] hidden tensor makes a round trip
-// through HBM and both kernels are bound by it and by their store bursts / load latency (stamped build: fc1 spends
-// 55 % of its time in the store epilogue and 3 200 cycles per 32-k tile waiting for loads; MFMA busy 0.06-0.14),
-// 209 us per layer at M = 65 536 against an MFMA floor of 27 us.  Here the hidden activations never leave registers.
+// Why: as separate kernels every stage is bound by its HBM round trip, store bursts and load latency, not by the matrix
+// pipe (stamped build: fc1 spends 55 % of its time in the store epilogue and 3 200 cycles per 32-k tile waiting for loads;
+// MFMA busy 0.06-0.14): fc1 + fc2 took 209 us per layer at M = 65 536 against an MFMA floor of 27 us.
 //
 // Layout.  Block = 8 waves = 256 rows, one block per CU; wave w owns rows 32w .. 32w+31 (lane (r, h) = row r):
 //   Y[8]   fp32 accumulators of the output row block, started at the residual h1 (C-in), 128 registers;
@@ -17,16 +19,24 @@
 //   per 32 hidden units:  U = W1[32 rows] X^T (16 MFMAs, one dependent chain: gfx950 issues it back to back),
 //          ReLU + round to bf16 in place (the U accumulator registers 8qq .. 8qq+7 ARE the next B operand, the same
 //          permutation), Y += W2[:, 32 columns] U^T (16 MFMAs).
-//   The weights are pre-packed once per vs_weights_pack/update (vsk_pack_mlp_bf16) into the exact LDS IMAGE of every
-//   32-hidden-unit chunk: bf16, the permutation applied, rows padded (528 B / 80 B: conflict-free ds_read_b128), 40 KiB
-//   per chunk.  Staging is therefore LDS-DMA (global_load_lds_dwordx4: a wave instruction copies 1 KiB verbatim, no
-//   staging registers, no LDS-write instructions): every wave issues 5 pieces per chunk, TWO chunks ahead, into a ring of
-//   three LDS buffers; a counted s_waitcnt vmcnt(5) + one raw s_barrier per chunk retire the chunk needed next and
-//   leave the one after it in flight (the loop contains no other vector-memory instruction - the kernel must compile
-//   without scratch, which tests/test_host.py checks).  Per MFMA: one 1-KiB fragment read per wave, i.e. LDS reads
-//   (128 B/clk/CU) and the matrix pipe are co-limiting by construction.
-// Rounding points equal those of the two-kernel path (h1, the weights and relu(fc1) to bf16; fp32 everything else);
-// only the order of the 16 products inside an MFMA step differs, so the results agree to fp32 rounding, not bitwise.
+//   The weights are pre-packed once per vs_weights_pack/update (vsk_pack_mlp_bf16 / vsk_pack_qkv_bf16) into the exact LDS
+//   IMAGE of every chunk: bf16, the permutation applied where the B operand is permuted, rows padded (528 / 144 / 80 B:
+//   conflict-free ds_read_b128), 40 KiB per chunk.  Staging is therefore LDS-DMA (global_load_lds_dwordx4: a wave
+//   instruction copies 1 KiB verbatim, no staging registers, no LDS-write instructions): every wave issues 5 pieces per
+//   chunk, TWO chunks ahead, into a ring of three LDS buffers; a counted s_waitcnt vmcnt(5) + one raw s_barrier per chunk
+//   retire the chunk needed next and leave the one after it in flight.  That count is only right if nothing else sits on
+//   the vector-memory counter inside a chunk: tests/test_host.py checks the ISA of every chunk at build time (and lane-
+//   derived addresses are recomputed per tile from an opaque copy of the thread index - left to the compiler they are
+//   hoisted to kernel entry, ~100 registers of them, and spilled around the loops).  Per MFMA: one 1-KiB fragment read per
+//   wave and nothing else.
+// Numerics.  Rounding points equal those of the separate kernels (activations, weights and relu(fc1) to bf16; fp32
+// everything else).  The out-projection and the QKV epilogue multiply in the k order of the kernels they replace:
+// bit-identical.  The MLP part permutes k inside an MFMA step: equal to fp32 rounding, not bitwise.
+// Measured (MI355X, M = 65 536): MLP block alone 79 us (two kernels: 209), of which 25 us are the exposed prologue +
+// epilogue of the single tile each CU owns; + out-projection/norm1 93 us (was 44 + 79); + next QKV 116-120 us (was + 66).
+// Tried and dropped: 4 waves x 64 rows with the whole 512-register file per wave (one fragment read feeds two MFMAs):
+// correct, but as hipcc compiles it (accumulators in AGPRs, 96 v_accvgpr moves per chunk) 291 us against 82, MFMA busy
+// 0.10, with no waiting on any counter - cause not found.
 #include "vs_device.h"
 #include "vs_kernels.h"
 
