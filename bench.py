@@ -25,6 +25,7 @@ Prints ONE JSON line on rank 0 with the contract fields plus
   latency       configs[1]: one T=320 video, GPU ms per forward (same model), beside the CPU's
   emulated_f32  the same K steps again with every product EMULATED on the f16 matrix pipe ("fp16x3"): reported
                 beside `value`, never as `value`: the headline is the exact-fp32 MFMA path (--compute to change).
+  bf16_mode     the same K steps on the bf16 matrix pipe (reduced precision, opt-in): context only.
 """
 import argparse
 import hashlib
@@ -245,6 +246,19 @@ def main():
             diff = (model(x)[0] - exact_logits).abs().max().item()
             model.set_compute_dtype("fp32")
             emu = (dt_emu, diff)
+        # secondary: the same K steps with every product on the bf16 matrix pipe (reduced precision: never `value`)
+        low = None
+        if args.compute == "fp32" and not args.no_emulated and d <= 256 and d // H in (32, 64):
+            exact_logits = model(x)[0].clone()
+            model.set_compute_dtype("bf16")
+            for _ in range(max(2, args.warmup // 2)):
+                w = step()
+                if w is not None:
+                    w.wait()
+            dt_low = timed(args.steps)
+            diff = (model(x)[0] - exact_logits).abs().max().item()
+            model.set_compute_dtype("fp32")
+            low = (dt_low, diff)
 
         pcie_fps = pcie_overlap_fps = lat_ms = None
         if not args.no_extras:
@@ -353,6 +367,14 @@ def main():
                 "value": round(ev, 1), "unit": "frames/s", "ms_per_step": round(emu[0] / args.steps * 1e3, 4),
                 "speedup_vs_value": round(ev / value, 3), "max_abs_logit_diff_vs_exact": emu[1],
                 "f32_equivalent_tflops": round(ev / world * flops_per_frame / 1e12, 2)}
+        if low:
+            lv = frames / low[0]
+            out["bf16_mode"] = {
+                "mode": "bf16: every product on the bf16 matrix pipe, fp32 accumulation / residual / LayerNorm / softmax "
+                        "statistics (opt-in SimNet.set_compute_dtype('bf16'); REDUCED precision: logits within ~4e-3, "
+                        "outside the 1e-4 parity bar - context, not the headline)",
+                "value": round(lv, 1), "unit": "frames/s", "ms_per_step": round(low[0] / args.steps * 1e3, 4),
+                "speedup_vs_value": round(lv / value, 3), "max_abs_logit_diff_vs_exact": low[1]}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
