@@ -790,8 +790,9 @@ def test_mlp_block_bf16_kernel(vsa, M, nc, sig):
 def test_bf16_layer_tail_kernel_is_bit_identical_to_outproj_then_mlp_kernel(vsa, lp_linear_everywhere, cfg):
     """With the attention output stored as bf16, the bf16 mode runs out-projection + residual + norm1 + MLP block + norm2
     (+ score head) as ONE kernel (vs_mlp_fused.hip, TAIL), which then also projects its rows to the NEXT layer's q/k/v
-    (QKV epilogue).  Both additions multiply in the same order as the stand-alone kernels they replace (gemm_ln_rows;
-    gemm_nt_128<EPI_QKV, C16>) and share their epilogue arithmetic, so against VS_LP_TAIL_UNFUSED=1 / VS_LP_QKV_UNFUSED=1
+    (QKV epilogue); the embedding runs on the same design with the first layer's QKV behind it (embed_qkv_bf16).  All
+    three multiply in the same order as the stand-alone kernels they replace (gemm_ln_rows; gemm_nt_128<EPI_QKV, C16>;
+    gemm_nt_128<EPI_PE>) and share their epilogue arithmetic, so against VS_LP_TAIL_UNFUSED=1 / VS_LP_QKV_UNFUSED=1 / VS_LP_EMBED_UNFUSED=1
     (those kernels, h1 and the layer output re-read from HBM) logits, scores and hidden state must agree BIT FOR BIT -
     padded, masked and packed batches, head dim 64 and 32, in-place (middle layers) and out-of-place (last layer)."""
     synth = vsa.synth
@@ -823,12 +824,16 @@ def test_bf16_layer_tail_kernel_is_bit_identical_to_outproj_then_mlp_kernel(vsa,
         vsa._lib.set_option("VS_LP_QKV_UNFUSED", -1)
         vsa._lib.set_option("VS_LP_TAIL_UNFUSED", 1)
         mid2 = run()                                     # out-projection kernel, MLP kernel with the next layer's QKV behind it
+        vsa._lib.set_option("VS_LP_TAIL_UNFUSED", -1)
+        vsa._lib.set_option("VS_LP_EMBED_UNFUSED", 1)
+        mid3 = run()                                     # generic embedding GEMM + first QKV kernel, then layer-tail kernels
     finally:
         vsa._lib.set_option("VS_LP_TAIL_UNFUSED", -1)
         vsa._lib.set_option("VS_LP_QKV_UNFUSED", -1)
-    got = run()                                          # the default: layer-tail kernel with the next layer's QKV behind it
-    for g, a, b, r in zip(got, mid, mid2, ref):
-        assert torch.isfinite(g).all() and torch.equal(a, r) and torch.equal(b, r) and torch.equal(g, r)
+        vsa._lib.set_option("VS_LP_EMBED_UNFUSED", -1)
+    got = run()                                          # the default: embedding + QKV kernel, layer-tail kernels with the next QKV
+    for g, a, b, c, r in zip(got, mid, mid2, mid3, ref):
+        assert torch.isfinite(g).all() and torch.equal(a, r) and torch.equal(b, r) and torch.equal(c, r) and torch.equal(g, r)
 
 
 @pytest.mark.parametrize("cfg", ["M-A", "M-A-ragged"])

@@ -173,24 +173,30 @@ def test_fused_mlp_chunk_loop_has_only_its_counted_dma_on_the_vector_memory_coun
         name = "mlp_fused_bf16ILb%dELi0E" % tail
         body = text[text.index(name, text.index(name) + 1):]
         body = body[:body.index(".Lfunc_end")]
-        # every barrier-to-barrier segment that multiplies is one chunk of 32 MFMAs and ends in the COUNTED wait: exactly
-        # its 5 DMA pieces on the counter - plus, in the QKV-epilogue chunks, the previous chunk's 4 stores, which are
-        # issued BEFORE the DMA pieces (so that "<= 5 outstanding" still proves the older chunk has landed)
+        # every barrier-to-barrier segment that multiplies is one chunk of 32 MFMAs and ends in the COUNTED wait with
+        # exactly its 5 DMA pieces as the only LOADS on the counter (loads retire in order among themselves, so
+        # "<= 5 outstanding" proves that the chunk issued one iteration earlier has landed; the QKV epilogue's stores may
+        # sit anywhere - they can only make the wait longer, not shorter).  No spill reloads, no other loads.
         chunks = [seg for seg in body.split("s_barrier") if "v_mfma" in seg]
-        plain = 0
-        for seg in chunks:
+        assert len(chunks) >= (6 if tail else 2)        # out-projection x4 (unrolled), MLP loop, QKV epilogue loop
+        for idx, seg in enumerate(chunks):
             assert len(re.findall(r"\bv_mfma_f32_32x32x16_bf16\b", seg)) == 32
-            stores = [m.start() for m in re.finditer(r"\bglobal_store_dwordx4\b", seg)]
-            dmas = [m.start() for m in re.finditer(r"\bglobal_load_lds_dwordx4\b", seg)]
-            assert len(dmas) == 5
-            if stores:
-                assert len(stores) == 4 and max(stores) < min(dmas)
-            else:
-                plain += 1
-            seg = seg[min(stores + dmas):]                                  # (what precedes is the previous wait's tail)
-            vm = re.findall(r"\b(scratch_\w+|buffer_\w+|flat_\w+|global_(?!load_lds_dwordx4|store_dwordx4)\w+)\b", seg)
-            assert vm == [], vm
-            assert re.findall(r"s_waitcnt[^\n]*vmcnt\((\d+)\)", seg) == ["5"]
-        base = 5 if tail else 1                                             # 4 unrolled out-projection chunks + the MLP loop
-        assert plain in (base, base + 1), plain                             # (+ a peeled first QKV chunk, which has no stores yet)
-        assert len(chunks) > plain                                          # the QKV epilogue is there
+            seg = seg[seg.index("global_load_lds_dwordx4"):]                # (what precedes is the previous wait's tail)
+            assert len(re.findall(r"\bglobal_load_lds_dwordx4\b", seg)) == 5
+            assert "5" in re.findall(r"s_waitcnt[^\n]*vmcnt\((\d+)\)", seg)
+            if idx < (5 if tail else 1):                # out-projection and MLP chunks (99 % of the MFMAs): nothing else at all
+                vm = re.findall(r"\b(scratch_\w+|buffer_\w+|flat_\w+|global_(?!load_lds_dwordx4)\w+)\b", seg)
+                assert vm == [], vm
+                assert re.findall(r"s_waitcnt[^\n]*vmcnt\((\d+)\)", seg) == ["5"]
+    # the embedding kernel: per chunk 5 DMA pieces + this lane's 8 x-loads (two chunks ahead), 32 MFMAs, vmcnt(13)
+    body = text[text.index("embed_qkv_bf16", text.index("embed_qkv_bf16") + 1):]
+    body = body[:body.index(".Lfunc_end")]
+    embed = [seg for seg in body.split("s_barrier") if "v_mfma" in seg and re.findall(r"s_waitcnt[^\n]*vmcnt\(13\)", seg)]
+    full = 0
+    for seg in embed:
+        seg = seg[seg.index("global_load_lds_dwordx4"):]
+        ops = re.findall(r"\b(global_load_lds_dwordx4|global_load_dwordx4|scratch_\w+|buffer_\w+|flat_\w+|global_store\w+|global_load_dword\b)", seg)
+        assert len(re.findall(r"\bv_mfma_f32_32x32x16_bf16\b", seg)) == 32
+        assert ops.count("global_load_lds_dwordx4") == 5 and set(ops) <= {"global_load_lds_dwordx4", "global_load_dwordx4"}, ops
+        full += ops.count("global_load_dwordx4") == 8          # (the peeled last chunk of an odd count loads no x)
+    assert full >= 2

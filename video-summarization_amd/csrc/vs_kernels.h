@@ -63,6 +63,11 @@ struct VskNextQkv {
     int T, H;
     float qscale;
 };
+// embedding + positional rows (+ the first layer's QKV) on the same design; 0 bytes = shape not supported (d != 256, K % 64)
+size_t vsk_embed_bf16_image_bytes(int d, int K);
+int vsk_pack_embed_bf16(const float *W, void *img, int d, int K, hipStream_t st);
+int vsk_embed_bf16(const float *x, const void *img, const float *bias, const float *pe, int T, float *out, int M, int d, int K,
+                   const VskNextQkv *next, hipStream_t st);
 size_t vsk_qkv_bf16_image_bytes(int d);
 int vsk_pack_qkv_bf16(const float *Wqkv, void *img, int d, hipStream_t st);
 int vsk_mlp_bf16(const float *h, const void *att16, const float *bo, const float *gamma1, const float *beta1,
@@ -89,6 +94,7 @@ struct VskOptions {
     int lp_mlp_unfused;   // VS_LP_MLP_UNFUSED bf16 mode runs fc1 and fc2 + LayerNorm as two kernels (A/B)
     int lp_tail_unfused;  // VS_LP_TAIL_UNFUSED bf16 mode runs the out-projection + norm1 as its own kernel in front of the fused MLP (A/B)
     int lp_qkv_unfused;   // VS_LP_QKV_UNFUSED  bf16 mode runs every layer's QKV projection as its own kernel (A/B)
+    int lp_embed_unfused; // VS_LP_EMBED_UNFUSED bf16 mode runs the embedding as the generic GEMM + the first QKV kernel (A/B)
     int mlp_fusion;       // VS_MLP_FUSION    (diagnostic builds only)
     int mlp_abl;          // VS_MLP_ABL       (diagnostic builds only)
     int attn_legacy;      // VS_ATTN_LEGACY   (diagnostic builds only)

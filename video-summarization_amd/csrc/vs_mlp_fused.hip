@@ -117,6 +117,111 @@ struct QkvArgs {             // QKV epilogue: the next layer's q / k / v project
     float qscale;
 };
 
+// LDS ring + the LDS-DMA copy of one 40-KiB chunk image into it (40 pieces of 1 KiB, 5 per wave): source = wave-uniform
+// base (scalar registers) + one per-lane byte offset, no per-piece address registers
+struct RingDma {
+    unsigned char *ring;
+    int wave_u;
+    unsigned lane16;
+    __device__ __forceinline__ void dma(const unsigned char *image, int chunk, int bufoff) const {
+        const unsigned char *src = image + (size_t)chunk * MLP_IMG + wave_u * 1024;
+        unsigned l16 = lane16;
+        asm volatile("" : "+v"(l16));           // (opaque: else five per-lane 64-bit pointers are precomputed and spilled)
+#pragma unroll
+        for (int i = 0; i < 5; ++i) glds16(src + 8192 * i + l16, ring + bufoff + wave_u * 1024 + 8192 * i);
+    }
+};
+
+// QKV epilogue shared by the layer-tail and the embedding kernels (see the header of mlp_fused_bf16): Y = this wave's 32
+// finished rows (fp32, lane (er, eh) = row er, columns 32j + 8q + 4eh + e), X = scratch for their bf16 B operands.
+template <int FR>
+__device__ __forceinline__ void qkv_epilogue(f32x16 (&Y)[8], u32x4 (&X)[16], const QkvArgs &qa, const RingDma &rd,
+                                             const float *bqkv_s, int m0, int er, int eh, int M) {
+    constexpr int NT = 8, D = MLP_D;
+        // ---- QKV epilogue (see the header of this kernel) ----
+        // X[ks] = this lane's 8 natural-order k of the normalised row: k-step ks = 2j + qq covers columns 32j + 16qq ..
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) {
+                const unsigned e0 = pack_bf16(Y[j][8 * qq + 0], Y[j][8 * qq + 1]), e1 = pack_bf16(Y[j][8 * qq + 2], Y[j][8 * qq + 3]);
+                const unsigned o0 = pack_bf16(Y[j][8 * qq + 4], Y[j][8 * qq + 5]), o1 = pack_bf16(Y[j][8 * qq + 6], Y[j][8 * qq + 7]);
+                auto s0 = __builtin_amdgcn_permlane32_swap(e0, o0, false, false);
+                auto s1 = __builtin_amdgcn_permlane32_swap(e1, o1, false, false);
+                X[2 * j + qq][0] = s0[0]; X[2 * j + qq][1] = s1[0]; X[2 * j + qq][2] = s0[1]; X[2 * j + qq][3] = s1[1];
+            }
+        __syncthreads();                    // every wave is done with its transposition corner of the ring
+        rd.dma(qa.img, 0, 0);
+        rd.dma(qa.img, 1, MLP_IMG);
+        const int row = m0 + er;
+        const int vb = row / qa.T, vt = row - vb * qa.T;      // (video, frame) of this lane's row
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        int qcur = 0, qn1 = MLP_IMG, qn2 = 2 * MLP_IMG;
+        u32x4 pend[4];                      // the previous chunk's packed results, stored after its barrier
+        for (int c = 0; c <= MLP_NCHQ; ++c) {
+            if (c > 0) {                    // stores of chunk c - 1: 16 bytes per lane = 8 consecutive columns of its row
+                const int n0 = 64 * (c - 1), which = n0 >> 8;
+                if (row < M) {
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int pp = 0; pp < 2; ++pp) {
+                            const int cd = (n0 & 255) + 32 * t + 16 * pp + 8 * eh, head = cd / qa.dh, e = cd - head * qa.dh;
+                            h16 *dst = qa.qkv + (size_t)which * M * D + (((size_t)vb * qa.H + head) * qa.T + vt) * qa.dh + e;
+                            *(u32x4 *)dst = pend[2 * t + pp];
+                        }
+                }
+                if (c == MLP_NCHQ) break;
+            }
+            rd.dma(qa.img, c + 2 < MLP_NCHQ ? c + 2 : MLP_NCHQ - 1, qn2);      // past the end: a harmless re-copy
+            const unsigned char *wbase = rd.ring + qcur + er * MLP_LD1 + 16 * eh;
+            u32x4 fw[FR];
+            auto frag = [&](auto fc) __attribute__((always_inline)) {       // fragment f: k-step f / 2, column block f % 2
+                constexpr int f = decltype(fc)::value;
+                fw[f % FR] = *(const u32x4 *)(wbase + 32 * (f % 2) * MLP_LD1 + 32 * (f / 2));
+            };
+            f32x16 U[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const float *bp = bqkv_s + 64 * c + 32 * t + 4 * eh;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 bv = *(const f32x4 *)(bp + 8 * q);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) U[t][4 * q + e] = bv[e];
+                }
+            }
+            static_for<FR - 1>([&](auto fc) { frag(fc); });
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<32>([&](auto fc) {
+                constexpr int f = decltype(fc)::value;
+                if constexpr (f + FR - 1 < 32) frag(std::integral_constant<int, f + FR - 1>{});
+                U[f % 2] = MFMA_BF16(__builtin_bit_cast(bf16x8, fw[f % FR]), __builtin_bit_cast(bf16x8, X[f / 2]), U[f % 2]);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            const float osc = c < 4 ? qa.qscale : 1.0f;       // chunks 0..3 are q
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int pp = 0; pp < 2; ++pp) {
+                    const float *u = (const float *)&U[t] + 8 * pp;       // registers 8pp .. 8pp+7: q = 2pp (even), 2pp+1 (odd)
+                    const unsigned e0 = pack_bf16(U[t][8 * pp + 0] * osc, U[t][8 * pp + 1] * osc), e1 = pack_bf16(U[t][8 * pp + 2] * osc, U[t][8 * pp + 3] * osc);
+                    const unsigned o0 = pack_bf16(U[t][8 * pp + 4] * osc, U[t][8 * pp + 5] * osc), o1 = pack_bf16(U[t][8 * pp + 6] * osc, U[t][8 * pp + 7] * osc);
+                    (void)u;
+                    auto s0 = __builtin_amdgcn_permlane32_swap(e0, o0, false, false);
+                    auto s1 = __builtin_amdgcn_permlane32_swap(e1, o1, false, false);
+                    pend[2 * t + pp][0] = s0[0]; pend[2 * t + pp][1] = s1[0]; pend[2 * t + pp][2] = s0[1]; pend[2 * t + pp][3] = s1[1];
+                }
+            // <= 5 operations outstanding: loads retire in order among themselves, so chunk c+1's pieces (older than the 5
+            // of chunk c+2) have landed whatever the stores issued at the top of this iteration are doing
+            asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            const int t = qcur; qcur = qn1; qn1 = qn2; qn2 = t;
+        }
+}
+
 // TAIL: the kernel starts one step earlier in the encoder layer: H1 is not read but computed,
 //     h1 = LayerNorm(att Wo^T + bo + res) * gamma1 + beta1          (reference simnet.py:107 norm1(x + sa(x)))
 // by four more chunks through the same ring (Wo in 64-k slabs; the bf16 attention rows are the B operands straight from HBM,
@@ -128,9 +233,10 @@ struct QkvArgs {             // QKV epilogue: the next layer's q / k / v project
 // 64 output columns through the ring, two 16-MFMA chains per chunk in the k order of the stand-alone QKV kernel
 // (gemm_nt_128<EPI_QKV, .., C16>: bit-identical q * qscale, k, v), and the results leave as 16-byte pieces per lane
 // (again one permlane swap per dword) straight into the head-major bf16 planes - no LDS round trip.  A chunk's stores are
-// issued after its barrier, at the top of the next iteration and BEFORE that iteration's 5 DMA pieces: the counted
-// vmcnt(5) at its end then still proves that the chunk needed next has landed (loads retire in order among loads; at
-// worst it also waits for stores that are a whole chunk old).
+// issued after its barrier, at the top of the next iteration: the counted vmcnt(5) at that iteration's end still proves
+// that the chunk needed next has landed (loads retire in order among loads, so "<= 5 outstanding" cannot hold while a
+// piece older than the newest five is pending, whatever the stores do); at worst it also waits for those stores, which
+// are a whole chunk old by then.
 // ABL (diagnostic library only, timing runs with wrong results): 1 no weight staging, 2 no barrier / wait in the chunk
 // loop, 4 fragment reads replaced by register moves, 8 no chunk loop at all (prologue + epilogue only)
 template <bool TAIL, int ABL = 0>
@@ -159,18 +265,8 @@ __global__ __launch_bounds__(512, 1) void mlp_fused_bf16(
     if (qa.img != nullptr)
         for (int i = tid; i < 3 * D; i += 512) bqkv_s[i] = qa.bqkv[i];
 
-    // chunk image -> ring buffer: 40 pieces of 1 KiB, 5 per wave.  Source = wave-uniform base (scalar registers) +
-    // one per-lane byte offset: no per-piece address registers.
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    const unsigned lane16 = (unsigned)lane * 16u;
-    auto dma_from = [&](const unsigned char *image, int chunk, int bufoff) __attribute__((always_inline)) {
-        const unsigned char *src = image + (size_t)chunk * IMG + wave_u * 1024;
-        unsigned l16 = lane16;
-        asm volatile("" : "+v"(l16));           // (opaque: else five per-lane 64-bit pointers are precomputed and spilled)
-#pragma unroll
-        for (int i = 0; i < 5; ++i) glds16(src + 8192 * i + l16, ring + bufoff + wave_u * 1024 + 8192 * i);
-    };
-    auto dma_chunk = [&](int chunk, int bufoff) __attribute__((always_inline)) { dma_from(Wimg, chunk, bufoff); };
+    const RingDma rd{ring, __builtin_amdgcn_readfirstlane(wave), (unsigned)lane * 16u};
+    auto dma_chunk = [&](int chunk, int bufoff) __attribute__((always_inline)) { rd.dma(Wimg, chunk, bufoff); };
     // end of a chunk: the next chunk (5 pieces, issued one iteration ago) has landed, the one after it stays in flight;
     // its data is read only after the barrier every wave passes behind its own wait
     auto chunk_done = [&]() __attribute__((always_inline)) {
@@ -411,92 +507,170 @@ __global__ __launch_bounds__(512, 1) void mlp_fused_bf16(
                 }
             }
         }
-        if (qa.img != nullptr) {
-            // ---- QKV epilogue (see the header of this kernel) ----
-            // X[ks] = this lane's 8 natural-order k of the normalised row: k-step ks = 2j + qq covers columns 32j + 16qq ..
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-#pragma unroll
-                for (int qq = 0; qq < 2; ++qq) {
-                    const unsigned e0 = pack_bf16(Y[j][8 * qq + 0], Y[j][8 * qq + 1]), e1 = pack_bf16(Y[j][8 * qq + 2], Y[j][8 * qq + 3]);
-                    const unsigned o0 = pack_bf16(Y[j][8 * qq + 4], Y[j][8 * qq + 5]), o1 = pack_bf16(Y[j][8 * qq + 6], Y[j][8 * qq + 7]);
-                    auto s0 = __builtin_amdgcn_permlane32_swap(e0, o0, false, false);
-                    auto s1 = __builtin_amdgcn_permlane32_swap(e1, o1, false, false);
-                    X[2 * j + qq][0] = s0[0]; X[2 * j + qq][1] = s1[0]; X[2 * j + qq][2] = s0[1]; X[2 * j + qq][3] = s1[1];
-                }
-            __syncthreads();                    // every wave is done with its transposition corner of the ring
-            dma_from(qa.img, 0, 0);
-            dma_from(qa.img, 1, IMG);
-            const int row = m0 + er;
-            const int vb = row / qa.T, vt = row - vb * qa.T;      // (video, frame) of this lane's row
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            int qcur = 0, qn1 = IMG, qn2 = 2 * IMG;
-            u32x4 pend[4];                      // the previous chunk's packed results, stored after its barrier
-            for (int c = 0; c <= MLP_NCHQ; ++c) {
-                if (c > 0) {                    // stores of chunk c - 1: 16 bytes per lane = 8 consecutive columns of its row
-                    const int n0 = 64 * (c - 1), which = n0 >> 8;
-                    if (row < M) {
-#pragma unroll
-                        for (int t = 0; t < 2; ++t)
-#pragma unroll
-                            for (int pp = 0; pp < 2; ++pp) {
-                                const int cd = (n0 & 255) + 32 * t + 16 * pp + 8 * eh, head = cd / qa.dh, e = cd - head * qa.dh;
-                                h16 *dst = qa.qkv + (size_t)which * M * D + (((size_t)vb * qa.H + head) * qa.T + vt) * qa.dh + e;
-                                *(u32x4 *)dst = pend[2 * t + pp];
-                            }
-                    }
-                    if (c == MLP_NCHQ) break;
-                }
-                dma_from(qa.img, c + 2 < MLP_NCHQ ? c + 2 : MLP_NCHQ - 1, qn2);      // past the end: a harmless re-copy
-                const unsigned char *wbase = ring + qcur + er * MLP_LD1 + 16 * eh;
-                u32x4 fw[FR];
-                auto frag = [&](auto fc) __attribute__((always_inline)) {       // fragment f: k-step f / 2, column block f % 2
-                    constexpr int f = decltype(fc)::value;
-                    fw[f % FR] = *(const u32x4 *)(wbase + 32 * (f % 2) * MLP_LD1 + 32 * (f / 2));
-                };
-                f32x16 U[2];
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const float *bp = bqkv_s + 64 * c + 32 * t + 4 * eh;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const f32x4 bv = *(const f32x4 *)(bp + 8 * q);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) U[t][4 * q + e] = bv[e];
-                    }
-                }
-                static_for<FR - 1>([&](auto fc) { frag(fc); });
-                __builtin_amdgcn_sched_barrier(0);
-                static_for<32>([&](auto fc) {
-                    constexpr int f = decltype(fc)::value;
-                    if constexpr (f + FR - 1 < 32) frag(std::integral_constant<int, f + FR - 1>{});
-                    U[f % 2] = MFMA_BF16(__builtin_bit_cast(bf16x8, fw[f % FR]), __builtin_bit_cast(bf16x8, X[f / 2]), U[f % 2]);
-                    __builtin_amdgcn_sched_barrier(0);
-                });
-                const float osc = c < 4 ? qa.qscale : 1.0f;       // chunks 0..3 are q
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-#pragma unroll
-                    for (int pp = 0; pp < 2; ++pp) {
-                        const float *u = (const float *)&U[t] + 8 * pp;       // registers 8pp .. 8pp+7: q = 2pp (even), 2pp+1 (odd)
-                        const unsigned e0 = pack_bf16(U[t][8 * pp + 0] * osc, U[t][8 * pp + 1] * osc), e1 = pack_bf16(U[t][8 * pp + 2] * osc, U[t][8 * pp + 3] * osc);
-                        const unsigned o0 = pack_bf16(U[t][8 * pp + 4] * osc, U[t][8 * pp + 5] * osc), o1 = pack_bf16(U[t][8 * pp + 6] * osc, U[t][8 * pp + 7] * osc);
-                        (void)u;
-                        auto s0 = __builtin_amdgcn_permlane32_swap(e0, o0, false, false);
-                        auto s1 = __builtin_amdgcn_permlane32_swap(e1, o1, false, false);
-                        pend[2 * t + pp][0] = s0[0]; pend[2 * t + pp][1] = s1[0]; pend[2 * t + pp][2] = s0[1]; pend[2 * t + pp][3] = s1[1];
-                    }
-                // <= 5 operations outstanding: loads retire in order among themselves, so chunk c+1's pieces (older than the 5
-                // of chunk c+2) have landed whatever the stores issued at the top of this iteration are doing
-                asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                const int t = qcur; qcur = qn1; qn1 = qn2; qn2 = t;
-            }
-        }
+        if (qa.img != nullptr) qkv_epilogue<FR>(Y, X, qa, rd, bqkv_s, m0, er, eh, M);
     }
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Embedding + positional table + the FIRST layer's QKV (reference simnet.py:211, 237-238, 148-153), same design: a wave
+// keeps its 32 output rows in Y (started at the bias), W_embed streams through the ring in 64-k chunks (the
+// out-projection's chunk format, natural k order), and the B operands are the wave's own rows of x: every lane reads
+// its row's 64 fp32 of a chunk straight from HBM TWO chunks ahead (2 x 8 x 16 bytes in registers - x is read exactly
+// once, an LDS stage would only add a barrier dependency) and rounds them to bf16 one chunk ahead.  A chunk issues its 5
+// DMA pieces and 8 x loads together, so the counted wait is vmcnt(13): loads retire in order, "<= 13 outstanding" =
+// everything issued before this iteration has landed.  Same k order and epilogue arithmetic as
+// gemm_nt_128<EPI_PE, .., bf16>: bit-identical rows, which then take the QKV epilogue above.
+// Measured (MI355X, M = 65 536): K = 1024: 139 us with the first QKV included (generic GEMM 139 + QKV kernel 67); the
+// embedding part itself (~100 us for 268 MB of x) is no faster than the generic kernel, and neither a deeper x prefetch
+// (one chunk ahead: the same) nor blocks starting their k loop at different chunks (132 us) moves it.
+struct EmbedArgs {
+    const float *x;          // [M, K] fp32 features
+    int K;                   // in_features, a multiple of 64
+    const float *bias;       // [256]
+    const float *pe;         // [T, 256] positional rows (row m takes pe[m % T]) or nullptr
+    int T;
+};
+
+__global__ __launch_bounds__(512, 1) void embed_qkv_bf16(EmbedArgs ea, QkvArgs qa, const unsigned char *__restrict__ Wimg,
+                                                         float *__restrict__ out, int M) {
+    constexpr int D = MLP_D, NT = 8, IMG = MLP_IMG, FR = 4;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char dyn_smem[];      // ONE LDS object
+    unsigned char *ring = dyn_smem;                              // [3][IMG]
+    float *bias_s = (float *)(dyn_smem + 3 * IMG);               // [D]
+    float *bqkv_s = bias_s + D;                                  // [3 D]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    for (int i = tid; i < D; i += 512) bias_s[i] = ea.bias[i];
+    if (qa.img != nullptr)
+        for (int i = tid; i < 3 * D; i += 512) bqkv_s[i] = qa.bqkv[i];
+    const RingDma rd{ring, __builtin_amdgcn_readfirstlane(wave), (unsigned)lane * 16u};
+    const int nch = ea.K / 64;
+    auto gch = [&](int c) __attribute__((always_inline)) { return c < nch ? c : nch - 1; };      // past the end: a harmless re-copy / reload
+
+    f32x16 Y[NT];
+    u32x4 X[2 * NT];
+    f32x4 xr[2][8];                                              // this lane's 64 fp32 of the next TWO chunks: k-step ks = [2ks], [2ks+1]
+    const int ntiles = (M + 255) / 256;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int m0 = tile * 256 + 32 * wave;
+        __syncthreads();                        // consts visible / the previous tile is done with the ring
+        rd.dma(Wimg, gch(0), 0);
+        rd.dma(Wimg, gch(1), IMG);
+        int lp = tid;
+        asm volatile("" : "+v"(lp));            // (lane-derived addresses recomputed per tile: see mlp_fused_bf16)
+        const int pr = lp & 31, ph = (lp >> 5) & 1;
+        int row = m0 + pr;
+        row = row < M ? row : M - 1;
+        const float *xp = ea.x + (size_t)row * ea.K + 8 * ph;
+        auto xload = [&](int set, int chunk) __attribute__((always_inline)) {
+            const float *xn = xp + 64 * gch(chunk);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) xr[set][i] = *(const f32x4 *)(xn + 16 * (i >> 1) + 4 * (i & 1));
+        };
+        xload(0, 0);
+        xload(1, 1);
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 bv = *(const f32x4 *)&bias_s[32 * j + 8 * q + 4 * ph];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) Y[j][4 * q + e] = bv[e];
+            }
+        __syncthreads();                        // (waits for every outstanding load, the two DMA'd chunks included)
+
+        int cur = 0, nx1 = IMG, nx2 = 2 * IMG;
+        u32x4 xb[4];                            // a chunk's four B operands: natural k order, 8 k per lane and step
+        auto convert = [&](int set) __attribute__((always_inline)) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                xb[ks][0] = pack_bf16(xr[set][2 * ks][0], xr[set][2 * ks][1]);         xb[ks][1] = pack_bf16(xr[set][2 * ks][2], xr[set][2 * ks][3]);
+                xb[ks][2] = pack_bf16(xr[set][2 * ks + 1][0], xr[set][2 * ks + 1][1]); xb[ks][3] = pack_bf16(xr[set][2 * ks + 1][2], xr[set][2 * ks + 1][3]);
+            }
+        };
+        convert(0);
+        // one chunk; `set` = the register set chunk c came from (free again: it takes chunk c + 2)
+        auto chunk = [&](int c, auto setc) __attribute__((always_inline)) {
+            constexpr int set = decltype(setc)::value;
+            rd.dma(Wimg, gch(c + 2), nx2);
+            xload(set, c + 2);
+            const unsigned char *wbase = ring + cur + r * MLP_LDO + 16 * h;
+            u32x4 fw[FR];
+            auto frag = [&](auto fc) __attribute__((always_inline)) {    // fragment f: k-step f / 8, output block f % 8
+                constexpr int f = decltype(fc)::value;
+                fw[f % FR] = *(const u32x4 *)(wbase + 32 * (f % 8) * MLP_LDO + 32 * (f / 8));
+            };
+            static_for<FR - 1>([&](auto fc) { frag(fc); });
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<32>([&](auto fc) {
+                constexpr int f = decltype(fc)::value;
+                if constexpr (f + FR - 1 < 32) frag(std::integral_constant<int, f + FR - 1>{});
+                Y[f % 8] = MFMA_BF16(__builtin_bit_cast(bf16x8, fw[f % FR]), __builtin_bit_cast(bf16x8, xb[f / 8]), Y[f % 8]);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            // <= 13 loads outstanding = this iteration's 5 DMA pieces + 8 x loads: everything older has landed - the
+            // chunk the ring serves next AND the x registers of the next chunk, which are converted right here
+            asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+            convert(set ^ 1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            const int t = cur; cur = nx1; nx1 = nx2; nx2 = t;
+        };
+        int c = 0;
+        for (; c + 1 < nch; c += 2) {
+            chunk(c, std::integral_constant<int, 0>{});
+            chunk(c + 1, std::integral_constant<int, 1>{});
+        }
+        if (c < nch) chunk(c, std::integral_constant<int, 0>{});
+        __syncthreads();                        // drains what is still in flight before the ring is reused below
+
+        // ---- + positional row, stores transposed through a wave-private corner of the idle ring (full 128-byte lines) ----
+        int le = tid;
+        asm volatile("" : "+v"(le));
+        const int er = le & 31, eh = (le >> 5) & 1;
+        float *tp = (float *)dyn_smem + wave * (32 * 36);
+        const int trow = (le & 63) >> 3, tc4 = (le & 7) * 4;
+        int prow = m0 + er;
+        prow = prow < M ? prow : M - 1;
+        const float *pp = ea.pe != nullptr ? ea.pe + (size_t)(prow % ea.T) * D + 4 * eh : nullptr;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 y;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[e] = Y[j][4 * q + e];
+                if (pp != nullptr) {
+                    const f32x4 pv = *(const f32x4 *)(pp + 32 * j + 8 * q);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) y[e] += pv[e];
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) Y[j][4 * q + e] = y[e];
+                *(f32x4 *)&tp[er * 36 + 8 * q + 4 * eh] = y;
+            }
+#pragma unroll
+            for (int pq = 0; pq < 4; ++pq) {
+                const f32x4 v = *(const f32x4 *)&tp[(trow + 8 * pq) * 36 + tc4];
+                const int orow = m0 + trow + 8 * pq;
+                if (orow < M) *(f32x4 *)(out + (size_t)orow * D + 32 * j + tc4) = v;
+            }
+        }
+        if (qa.img != nullptr) qkv_epilogue<FR>(Y, X, qa, rd, bqkv_s, m0, er, eh, M);
+    }
+}
+
+// W_embed [256][K] fp32 -> img [K / 64 chunks][MLP_IMG bytes]: rows of 64 bf16 + 16 B, natural k order
+__global__ void pack_embed_bf16(const float *__restrict__ W, unsigned char *__restrict__ img, int K) {
+    const int n = MLP_D * K / 2;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int row = (2 * i) / K, k = (2 * i) % K;
+        unsigned *dst = (unsigned *)(img + (size_t)(k / 64) * MLP_IMG + row * MLP_LDO + 2 * (k % 64));
+        *dst = pack_bf16(W[(size_t)row * K + k], W[(size_t)row * K + k + 1]);
+    }
+}
+
+constexpr size_t EMBED_LDS = (size_t)3 * MLP_IMG + 4 * MLP_D * sizeof(float);
 
 constexpr size_t MLP_LDS = (size_t)3 * MLP_IMG + (MLP_HID + 10 * MLP_D) * sizeof(float);      // 134 KiB
 
@@ -521,6 +695,44 @@ int vsk_pack_mlp_bf16(const float *Wo, const float *W1, const float *W2, void *i
     if (d != MLP_D) return -1;
     if (hipMemsetAsync(img, 0, vsk_mlp_bf16_image_bytes(d), st) != hipSuccess) return (int)hipGetLastError();
     hipLaunchKernelGGL(pack_mlp_bf16, dim3(256), dim3(256), 0, st, Wo, W1, W2, (unsigned char *)img);
+    VSK_CHECK_LAUNCH();
+    return 0;
+}
+
+size_t vsk_embed_bf16_image_bytes(int d, int K) { return d == MLP_D && K > 0 && K % 64 == 0 ? (size_t)(K / 64) * MLP_IMG : 0; }
+
+int vsk_pack_embed_bf16(const float *W, void *img, int d, int K, hipStream_t st) {
+    const size_t bytes = vsk_embed_bf16_image_bytes(d, K);
+    if (!bytes) return -1;
+    if (hipMemsetAsync(img, 0, bytes, st) != hipSuccess) return (int)hipGetLastError();
+    hipLaunchKernelGGL(pack_embed_bf16, dim3(256), dim3(256), 0, st, W, (unsigned char *)img, K);
+    VSK_CHECK_LAUNCH();
+    return 0;
+}
+
+// h0 = x W^T + bias + pe[row % T]  (fp32 out, bf16 matrix pipe), and - next != nullptr - the first layer's q / k / v
+int vsk_embed_bf16(const float *x, const void *img, const float *bias, const float *pe, int T, float *out, int M, int d, int K,
+                   const VskNextQkv *next, hipStream_t st) {
+    if (!vsk_embed_bf16_image_bytes(d, K) || M <= 0 || T <= 0) return -1;
+    if (next && (next->T <= 0 || M % next->T || next->H <= 0 || d % next->H || (d / next->H) % 16)) return -1;
+    const int cus = vsk_device_cus();
+    if (cus <= 0) return (int)hipErrorInvalidDevice;
+    const int ntiles = (M + 255) / 256;
+    const int blocks = ntiles < cus ? ntiles : cus;
+    {
+        static std::atomic<unsigned char> done[64];
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return (int)hipErrorInvalidDevice;
+        if (!(dev >= 0 && dev < 64 && done[dev].load(std::memory_order_acquire))) {
+            const int rc = (int)hipFuncSetAttribute((const void *)embed_qkv_bf16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)EMBED_LDS);
+            if (rc) return rc;
+            if (dev >= 0 && dev < 64) done[dev].store(1, std::memory_order_release);
+        }
+    }
+    const EmbedArgs ea{x, K, bias, pe, T};
+    const QkvArgs qa = next ? QkvArgs{(const unsigned char *)next->img, next->bqkv, (h16 *)next->qkv16, next->T, next->H, d / next->H, next->qscale}
+                            : QkvArgs{nullptr, nullptr, nullptr, 1, 1, d, 1.0f};
+    hipLaunchKernelGGL(embed_qkv_bf16, dim3(blocks), dim3(512), EMBED_LDS, st, ea, qa, (const unsigned char *)img, out, M);
     VSK_CHECK_LAUNCH();
     return 0;
 }

@@ -116,7 +116,7 @@ const OptionName kOptions[] = {
     {"VS_MLP_FUSION", &VskOptions::mlp_fusion, 0},       {"VS_MLP_ABL", &VskOptions::mlp_abl, 0},
     {"VS_ATTN_LEGACY", &VskOptions::attn_legacy, 0},     {"VS_LP_STORE32", &VskOptions::lp_store32, 0},
     {"VS_LP_MLP_UNFUSED", &VskOptions::lp_mlp_unfused, 0}, {"VS_LP_TAIL_UNFUSED", &VskOptions::lp_tail_unfused, 0},
-    {"VS_LP_QKV_UNFUSED", &VskOptions::lp_qkv_unfused, 0},
+    {"VS_LP_QKV_UNFUSED", &VskOptions::lp_qkv_unfused, 0}, {"VS_LP_EMBED_UNFUSED", &VskOptions::lp_embed_unfused, 0},
 };
 int option_from_env(const OptionName &o) {
     const char *e = getenv(o.name);
@@ -208,6 +208,7 @@ static int fill_weights(vs_weights *w, const vs_model_params *params, hipStream_
         pk &= vsk_pack_fragments_f16x3(w->blob + L.w1, w->blob + L.h_w1, (int)(4 * d), (int)d, st) == 0;
         pk &= vsk_pack_fragments_f16x3(w->blob + L.w2, w->blob + L.h_w2, (int)d, (int)(4 * d), st) == 0;
     }
+    if (w->has_b_embed) pk &= vsk_pack_embed_bf16(w->blob + w->embed_w, w->blob + w->b_embed, (int)d, (int)din, st) == 0;
     if (vsk_mlp_bf16_supported((int)d))
         for (const auto &L : w->layers)
         {
@@ -256,6 +257,8 @@ int vs_weights_pack(const vs_model_desc *desc, const vs_model_params *params, vo
             L.b_mlp = take(vsk_mlp_bf16_image_bytes((int)d) / sizeof(float));
             L.b_qkv = take(vsk_qkv_bf16_image_bytes((int)d) / sizeof(float));
         }
+    w->has_b_embed = vsk_embed_bf16_image_bytes((int)d, (int)din) != 0;
+    if (w->has_b_embed) w->b_embed = take(vsk_embed_bf16_image_bytes((int)d, (int)din) / sizeof(float));
     w->blob_floats = off;
     if (hipGetDevice(&w->device) != hipSuccess) { delete w; return fail(VS_ERR_HIP, "hipGetDevice failed"); }
     hipError_t e = hipMalloc((void **)&w->blob, off * sizeof(float));
@@ -350,15 +353,23 @@ int forward_core(const vs_weights *w, const float *x, const uint8_t *key_pad_mas
     const bool mlp16 = lbf == 1 && vsk_mlp_bf16_supported(d) && !vsk_options().lp_mlp_unfused && !vsk_options().lp_store32;
     const size_t kv_stride = qkv16 ? (size_t)M * d / 2 : (size_t)M * d;      // floats between the q, k and v planes
 
+    // bf16 mode with bf16 q/k/v: every layer's tail kernel also projects its output rows to the NEXT layer's q/k/v, and
+    // the embedding kernel to the first layer's
+    const bool qkv_fused = mlp16 && qkv16 && !vsk_options().lp_qkv_unfused;
+    bool have_qkv = false;                  // q/k/v of the layer about to run were written by the kernel before it
+    const float *pe_rows = pk ? pk->pe_rows : (w->has_pe ? w->p(w->pe) : nullptr);
     // Embedding + positional table (simnet.py:211, 237-238)
-    {
+    if (lbf == 1 && w->has_b_embed && qkv_fused && L > 0 && !vsk_options().lp_embed_unfused) {
+        StageScope ps(VS_STAGE_EMBED, st);
+        const LayerOff &N = w->layers[0];
+        const VskNextQkv nq{w->p(N.b_qkv), w->p(N.bqkv), qkv, T, H, vsk_attention_qscale(scale)};
+        VS_LAUNCH(vsk_embed_bf16(x, w->p(w->b_embed), w->p(w->embed_b), pe_rows, T, h0, M, d, D.in_features, &nq, st));
+        have_qkv = true;
+    } else {
         StageScope ps(VS_STAGE_EMBED, st);
         VS_LAUNCH(vsk_linear(x, w->p(w->embed_w), w->p(lbf == 2 ? w->h_embed_w : w->f_embed_w), w->p(w->embed_b), h0, M, d, D.in_features, 0,
-                             pk ? pk->pe_rows : (w->has_pe ? w->p(w->pe) : nullptr), T, lbf, st));
+                             pe_rows, T, lbf, st));
     }
-    // bf16 mode with bf16 q/k/v: every layer's tail kernel also projects its output rows to the NEXT layer's q/k/v
-    const bool qkv_fused = mlp16 && qkv16 && !vsk_options().lp_qkv_unfused;
-    bool have_qkv = false;                  // q/k/v of the layer about to run were written by the previous layer's tail
     for (int l = 0; l < L; ++l) {
         const LayerOff &P = w->layers[l];
         const bool last = l == L - 1;

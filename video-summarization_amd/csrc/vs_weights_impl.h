@@ -28,6 +28,8 @@ struct vs_weights {
     size_t blob_floats = 0;
     int device = 0;               // the device the blob lives on
     size_t embed_w = 0, embed_b = 0, pe = 0, final_w = 0, final_b = 0, f_embed_w = 0, h_embed_w = 0;
+    size_t b_embed = 0;           // W_embed as the LDS images of the bf16 embedding kernel (vsk_pack_embed_bf16), if supported
+    bool has_b_embed = false;
     bool has_pe = false;
     std::vector<LayerOff> layers;
     const float *p(size_t off) const { return blob + off; }
