@@ -138,88 +138,86 @@ template <int FR>
 __device__ __forceinline__ void qkv_epilogue(f32x16 (&Y)[8], u32x4 (&X)[16], const QkvArgs &qa, const RingDma &rd,
                                              const float *bqkv_s, int m0, int er, int eh, int M) {
     constexpr int NT = 8, D = MLP_D;
-        // ---- QKV epilogue (see the header of this kernel) ----
-        // X[ks] = this lane's 8 natural-order k of the normalised row: k-step ks = 2j + qq covers columns 32j + 16qq ..
+    // X[ks] = this lane's 8 natural-order k of the normalised row: k-step ks = 2j + qq covers columns 32j + 16qq ..
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
+    for (int j = 0; j < NT; ++j)
 #pragma unroll
-            for (int qq = 0; qq < 2; ++qq) {
-                const unsigned e0 = pack_bf16(Y[j][8 * qq + 0], Y[j][8 * qq + 1]), e1 = pack_bf16(Y[j][8 * qq + 2], Y[j][8 * qq + 3]);
-                const unsigned o0 = pack_bf16(Y[j][8 * qq + 4], Y[j][8 * qq + 5]), o1 = pack_bf16(Y[j][8 * qq + 6], Y[j][8 * qq + 7]);
+        for (int qq = 0; qq < 2; ++qq) {
+            const unsigned e0 = pack_bf16(Y[j][8 * qq + 0], Y[j][8 * qq + 1]), e1 = pack_bf16(Y[j][8 * qq + 2], Y[j][8 * qq + 3]);
+            const unsigned o0 = pack_bf16(Y[j][8 * qq + 4], Y[j][8 * qq + 5]), o1 = pack_bf16(Y[j][8 * qq + 6], Y[j][8 * qq + 7]);
+            auto s0 = __builtin_amdgcn_permlane32_swap(e0, o0, false, false);
+            auto s1 = __builtin_amdgcn_permlane32_swap(e1, o1, false, false);
+            X[2 * j + qq][0] = s0[0]; X[2 * j + qq][1] = s1[0]; X[2 * j + qq][2] = s0[1]; X[2 * j + qq][3] = s1[1];
+        }
+    __syncthreads();                    // every wave is done with its transposition corner of the ring
+    rd.dma(qa.img, 0, 0);
+    rd.dma(qa.img, 1, MLP_IMG);
+    const int row = m0 + er;
+    const int vb = row / qa.T, vt = row - vb * qa.T;      // (video, frame) of this lane's row
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    int qcur = 0, qn1 = MLP_IMG, qn2 = 2 * MLP_IMG;
+    u32x4 pend[4];                      // the previous chunk's packed results, stored after its barrier
+    for (int c = 0; c <= MLP_NCHQ; ++c) {
+        if (c > 0) {                    // stores of chunk c - 1: 16 bytes per lane = 8 consecutive columns of its row
+            const int n0 = 64 * (c - 1), which = n0 >> 8;
+            if (row < M) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int pp = 0; pp < 2; ++pp) {
+                        const int cd = (n0 & 255) + 32 * t + 16 * pp + 8 * eh, head = cd / qa.dh, e = cd - head * qa.dh;
+                        h16 *dst = qa.qkv + (size_t)which * M * D + (((size_t)vb * qa.H + head) * qa.T + vt) * qa.dh + e;
+                        *(u32x4 *)dst = pend[2 * t + pp];
+                    }
+            }
+            if (c == MLP_NCHQ) break;
+        }
+        rd.dma(qa.img, c + 2 < MLP_NCHQ ? c + 2 : MLP_NCHQ - 1, qn2);      // past the end: a harmless re-copy
+        const unsigned char *wbase = rd.ring + qcur + er * MLP_LD1 + 16 * eh;
+        u32x4 fw[FR];
+        auto frag = [&](auto fc) __attribute__((always_inline)) {       // fragment f: k-step f / 2, column block f % 2
+            constexpr int f = decltype(fc)::value;
+            fw[f % FR] = *(const u32x4 *)(wbase + 32 * (f % 2) * MLP_LD1 + 32 * (f / 2));
+        };
+        f32x16 U[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const float *bp = bqkv_s + 64 * c + 32 * t + 4 * eh;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 bv = *(const f32x4 *)(bp + 8 * q);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) U[t][4 * q + e] = bv[e];
+            }
+        }
+        static_for<FR - 1>([&](auto fc) { frag(fc); });
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<32>([&](auto fc) {
+            constexpr int f = decltype(fc)::value;
+            if constexpr (f + FR - 1 < 32) frag(std::integral_constant<int, f + FR - 1>{});
+            U[f % 2] = MFMA_BF16(__builtin_bit_cast(bf16x8, fw[f % FR]), __builtin_bit_cast(bf16x8, X[f / 2]), U[f % 2]);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        const float osc = c < 4 ? qa.qscale : 1.0f;       // chunks 0..3 are q
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int pp = 0; pp < 2; ++pp) {
+                // registers 8pp .. 8pp+7 of a tile: q = 2pp (even group), 2pp + 1 (odd group)
+                const unsigned e0 = pack_bf16(U[t][8 * pp + 0] * osc, U[t][8 * pp + 1] * osc), e1 = pack_bf16(U[t][8 * pp + 2] * osc, U[t][8 * pp + 3] * osc);
+                const unsigned o0 = pack_bf16(U[t][8 * pp + 4] * osc, U[t][8 * pp + 5] * osc), o1 = pack_bf16(U[t][8 * pp + 6] * osc, U[t][8 * pp + 7] * osc);
                 auto s0 = __builtin_amdgcn_permlane32_swap(e0, o0, false, false);
                 auto s1 = __builtin_amdgcn_permlane32_swap(e1, o1, false, false);
-                X[2 * j + qq][0] = s0[0]; X[2 * j + qq][1] = s1[0]; X[2 * j + qq][2] = s0[1]; X[2 * j + qq][3] = s1[1];
+                pend[2 * t + pp][0] = s0[0]; pend[2 * t + pp][1] = s1[0]; pend[2 * t + pp][2] = s0[1]; pend[2 * t + pp][3] = s1[1];
             }
-        __syncthreads();                    // every wave is done with its transposition corner of the ring
-        rd.dma(qa.img, 0, 0);
-        rd.dma(qa.img, 1, MLP_IMG);
-        const int row = m0 + er;
-        const int vb = row / qa.T, vt = row - vb * qa.T;      // (video, frame) of this lane's row
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // <= 5 operations outstanding: loads retire in order among themselves, so chunk c+1's pieces (older than the 5
+        // of chunk c+2) have landed whatever the stores issued at the top of this iteration are doing
+        asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        int qcur = 0, qn1 = MLP_IMG, qn2 = 2 * MLP_IMG;
-        u32x4 pend[4];                      // the previous chunk's packed results, stored after its barrier
-        for (int c = 0; c <= MLP_NCHQ; ++c) {
-            if (c > 0) {                    // stores of chunk c - 1: 16 bytes per lane = 8 consecutive columns of its row
-                const int n0 = 64 * (c - 1), which = n0 >> 8;
-                if (row < M) {
-#pragma unroll
-                    for (int t = 0; t < 2; ++t)
-#pragma unroll
-                        for (int pp = 0; pp < 2; ++pp) {
-                            const int cd = (n0 & 255) + 32 * t + 16 * pp + 8 * eh, head = cd / qa.dh, e = cd - head * qa.dh;
-                            h16 *dst = qa.qkv + (size_t)which * M * D + (((size_t)vb * qa.H + head) * qa.T + vt) * qa.dh + e;
-                            *(u32x4 *)dst = pend[2 * t + pp];
-                        }
-                }
-                if (c == MLP_NCHQ) break;
-            }
-            rd.dma(qa.img, c + 2 < MLP_NCHQ ? c + 2 : MLP_NCHQ - 1, qn2);      // past the end: a harmless re-copy
-            const unsigned char *wbase = rd.ring + qcur + er * MLP_LD1 + 16 * eh;
-            u32x4 fw[FR];
-            auto frag = [&](auto fc) __attribute__((always_inline)) {       // fragment f: k-step f / 2, column block f % 2
-                constexpr int f = decltype(fc)::value;
-                fw[f % FR] = *(const u32x4 *)(wbase + 32 * (f % 2) * MLP_LD1 + 32 * (f / 2));
-            };
-            f32x16 U[2];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const float *bp = bqkv_s + 64 * c + 32 * t + 4 * eh;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x4 bv = *(const f32x4 *)(bp + 8 * q);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) U[t][4 * q + e] = bv[e];
-                }
-            }
-            static_for<FR - 1>([&](auto fc) { frag(fc); });
-            __builtin_amdgcn_sched_barrier(0);
-            static_for<32>([&](auto fc) {
-                constexpr int f = decltype(fc)::value;
-                if constexpr (f + FR - 1 < 32) frag(std::integral_constant<int, f + FR - 1>{});
-                U[f % 2] = MFMA_BF16(__builtin_bit_cast(bf16x8, fw[f % FR]), __builtin_bit_cast(bf16x8, X[f / 2]), U[f % 2]);
-                __builtin_amdgcn_sched_barrier(0);
-            });
-            const float osc = c < 4 ? qa.qscale : 1.0f;       // chunks 0..3 are q
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int pp = 0; pp < 2; ++pp) {
-                    const float *u = (const float *)&U[t] + 8 * pp;       // registers 8pp .. 8pp+7: q = 2pp (even), 2pp+1 (odd)
-                    const unsigned e0 = pack_bf16(U[t][8 * pp + 0] * osc, U[t][8 * pp + 1] * osc), e1 = pack_bf16(U[t][8 * pp + 2] * osc, U[t][8 * pp + 3] * osc);
-                    const unsigned o0 = pack_bf16(U[t][8 * pp + 4] * osc, U[t][8 * pp + 5] * osc), o1 = pack_bf16(U[t][8 * pp + 6] * osc, U[t][8 * pp + 7] * osc);
-                    (void)u;
-                    auto s0 = __builtin_amdgcn_permlane32_swap(e0, o0, false, false);
-                    auto s1 = __builtin_amdgcn_permlane32_swap(e1, o1, false, false);
-                    pend[2 * t + pp][0] = s0[0]; pend[2 * t + pp][1] = s1[0]; pend[2 * t + pp][2] = s0[1]; pend[2 * t + pp][3] = s1[1];
-                }
-            // <= 5 operations outstanding: loads retire in order among themselves, so chunk c+1's pieces (older than the 5
-            // of chunk c+2) have landed whatever the stores issued at the top of this iteration are doing
-            asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            const int t = qcur; qcur = qn1; qn1 = qn2; qn2 = t;
-        }
+        const int t = qcur; qcur = qn1; qn1 = qn2; qn2 = t;
+    }
 }
 
 // TAIL: the kernel starts one step earlier in the encoder layer: H1 is not read but computed,
