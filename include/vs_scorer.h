@@ -186,7 +186,7 @@ int vs_attention_f32(const float *q, const float *k, const float *v, const uint8
                      float *out, int32_t B, int32_t H, int32_t T, int32_t dh, float scale,
                      void *stream);
 
-/* The same contract on the bf16 matrix pipe (see VS_FLAG_BF16_ATTENTION); dh in {32, 64}. */
+/* The same contract on the bf16 matrix pipe (see VS_FLAG_BF16_ATTENTION); dh in {32, 64, 128}. */
 int vs_attention_bf16(const float *q, const float *k, const float *v, const uint8_t *key_pad_mask,
                       float *out, int32_t B, int32_t H, int32_t T, int32_t dh, float scale,
                       void *stream);

@@ -496,7 +496,8 @@ def _run_attn_bf16(vsa, q, k, v, mask, scale):
 @pytest.mark.gpu
 @pytest.mark.parametrize("B,H,T,dh,masked", [(2, 4, 320, 64, False), (1, 4, 1024, 64, False), (2, 4, 200, 64, True),
                                              (1, 8, 65, 32, True), (1, 4, 31, 64, False), (3, 8, 257, 32, False),
-                                             (1, 1, 1, 64, False)])
+                                             (1, 1, 1, 64, False),
+                                             (2, 4, 320, 128, False), (1, 2, 700, 128, True), (1, 4, 1, 128, False)])
 def test_attention_bf16_kernel(vsa, B, H, T, dh, masked):
     g = torch.Generator().manual_seed(T + dh)
     q, k, v = (torch.randn(B, H, T, dh, generator=g) * 2.0 for _ in range(3))
@@ -511,7 +512,7 @@ def test_attention_bf16_kernel(vsa, B, H, T, dh, masked):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("T,dh", [(64, 64), (200, 64), (513, 64), (300, 32)])
+@pytest.mark.parametrize("T,dh", [(64, 64), (200, 64), (513, 64), (300, 32), (257, 128), (640, 128)])
 def test_attention_bf16_operand_layout_is_exact_on_a_permutation(vsa, T, dh):
     """Every index map of both bf16 products, checked exactly: keys are +-1 vectors (exact in bf16) and query i is
     a scaled copy of key pi(i), so softmax row i is one-hot at pi(i) to ~e^-30 and the output must be
@@ -546,11 +547,12 @@ def test_attention_bf16_rescale_branch(vsa):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cfg", ["M-A", "M-B"])
+@pytest.mark.parametrize("cfg", ["M-A", "M-B", "M-B512"])
 def test_bf16_attention_mode_end_to_end(vsa, cfg):
-    """SimNet.attention_dtype = 'bf16' against the fp32 oracle, ragged batch, both architectures."""
+    """SimNet.attention_dtype = 'bf16' against the fp32 oracle, ragged batch; head dim 64, 32 and 128 (BASELINE's M-B:
+    4 heads, d_model 512 - bf16 attention with exact Linear kernels)."""
     synth = vsa.synth
-    d, H, L = (256, 4, 4) if cfg == "M-A" else (256, 8, 6)
+    d, H, L = {"M-A": (256, 4, 4), "M-B": (256, 8, 6), "M-B512": (512, 4, 3)}[cfg]
     sd = synth.make_state_dict(d, L, 71, trained_like=True)
     lengths = [400, 333, 64, 1]
     x = synth.make_features(4, 400, 72, "pool5", lengths=lengths)

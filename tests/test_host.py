@@ -110,9 +110,13 @@ def test_attention_dtype_is_validated(vsa):
     m.attention_dtype = "bf16"
     with pytest.raises(ValueError):
         m.attention_dtype = "fp16"
-    wide = vsa.SimNet(num_heads=4, d_model=512, num_layers=1)      # head_dim 128: fp32 kernels only
+    wide = vsa.SimNet(num_heads=4, d_model=512, num_layers=1)      # head_dim 128: exact and bf16 attention kernels only
+    wide.attention_dtype = "bf16"
     with pytest.raises(ValueError):
-        wide.attention_dtype = "bf16"
+        wide.attention_dtype = "fp16x3"
+    huge = vsa.SimNet(num_heads=2, d_model=512, num_layers=1)      # head_dim 256: nothing
+    with pytest.raises(ValueError):
+        huge.attention_dtype = "bf16"
 
 
 def test_compute_dtype_switches_are_validated(vsa):

@@ -322,8 +322,9 @@ int forward_core(const vs_weights *w, const float *x, const uint8_t *key_pad_mas
         return fail(VS_ERR_INVALID, "VS_FLAG_BF16_LINEAR needs d_model <= 256 (got %d)", D.d_model);
     if ((flags & VS_FLAG_BF16_LINEAR) && (flags & VS_FLAG_F16X3_LINEAR))
         return fail(VS_ERR_INVALID, "VS_FLAG_BF16_LINEAR and VS_FLAG_F16X3_LINEAR are exclusive");
-    if ((flags & (VS_FLAG_BF16_ATTENTION | VS_FLAG_F16X3_ATTENTION)) && D.d_model / D.num_heads != 32 && D.d_model / D.num_heads != 64)
-        return fail(VS_ERR_INVALID, "VS_FLAG_BF16_ATTENTION / VS_FLAG_F16X3_ATTENTION need head_dim 32 or 64 (got %d)", D.d_model / D.num_heads);
+    if ((flags & (VS_FLAG_BF16_ATTENTION | VS_FLAG_F16X3_ATTENTION)) && D.d_model / D.num_heads != 32 && D.d_model / D.num_heads != 64 &&
+        !((flags & VS_FLAG_BF16_ATTENTION) && D.d_model / D.num_heads == 128))
+        return fail(VS_ERR_INVALID, "VS_FLAG_BF16_ATTENTION needs head_dim 32, 64 or 128, VS_FLAG_F16X3_ATTENTION 32 or 64 (got %d)", D.d_model / D.num_heads);
     if ((flags & VS_FLAG_BF16_ATTENTION) && (flags & VS_FLAG_F16X3_ATTENTION))
         return fail(VS_ERR_INVALID, "VS_FLAG_BF16_ATTENTION and VS_FLAG_F16X3_ATTENTION are exclusive");
     const size_t need = vs_scorer_workspace_bytes(w, B, T);
@@ -675,7 +676,8 @@ static int attention_lp_entry(const float *q, const float *k, const float *v, co
                               float *out, int32_t B, int32_t H, int32_t T, int32_t dh, float scale, int prec, void *stream) {
     if (!q || !k || !v || !out) return fail(VS_ERR_INVALID, "NULL pointer");
     if (B <= 0 || H <= 0 || T <= 0) return fail(VS_ERR_INVALID, "B=%d H=%d T=%d", B, H, T);
-    if (dh != 32 && dh != 64) return fail(VS_ERR_INVALID, "head_dim=%d unsupported on the bf16 / f16x3 path", dh);
+    if (dh != 32 && dh != 64 && !(dh == 128 && prec == 1))
+        return fail(VS_ERR_INVALID, "head_dim=%d unsupported on the %s path", dh, prec == 1 ? "bf16" : "f16x3");
     VS_LAUNCH(vsk_attention_bf16(q, k, v, key_pad_mask, out, B, H, T, dh, scale, prec, (hipStream_t)stream));
     return VS_OK;
 }

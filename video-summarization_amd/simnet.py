@@ -442,8 +442,9 @@ class SimNet(nn.Module):
     def attention_dtype(self, value: str) -> None:
         if value not in ("fp32", "bf16", "fp16x3"):
             raise ValueError("attention_dtype must be 'fp32', 'bf16' or 'fp16x3', got %r" % (value,))
-        if value != "fp32" and self.d_model // self.num_heads not in (32, 64):
-            raise ValueError("%s attention needs head_dim 32 or 64, got %d" % (value, self.d_model // self.num_heads))
+        ok = (32, 64, 128) if value == "bf16" else (32, 64)
+        if value != "fp32" and self.d_model // self.num_heads not in ok:
+            raise ValueError("%s attention needs head_dim in %s, got %d" % (value, ok, self.d_model // self.num_heads))
         self._attention_dtype = value
 
     @property
