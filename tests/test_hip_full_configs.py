@@ -145,3 +145,35 @@ def test_three_times_the_bench_batch_scoring_and_training(vsa):
         grads.append([p.grad.clone() for p in m.parameters()])
     for a, b in zip(*grads):
         assert torch.isfinite(a).all() and torch.equal(a, b)
+
+
+def test_bf16_layer_kernels_with_more_row_tiles_than_cus(vsa):
+    """B=80, T=1024 (81 920 rows = 320 row tiles of 256: more than the 256 CUs, so some blocks of the persistent bf16
+    layer kernels - embedding + QKV, layer tail + next QKV - walk a second tile and restart their weight ring): the whole
+    forward must equal, bit for bit, the same mode with those kernels switched back to the stand-alone ones."""
+    B, T = 80, 1024
+    sd = vsa.synth.make_state_dict(256, 2, 17, trained_like=True)
+    m = vsa.SimNet(num_heads=4, d_model=256, num_layers=2, sparsity=0.0, dropout=0.3)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(_dev()).eval().set_compute_dtype("bf16")
+    g = torch.Generator(device="cpu").manual_seed(80)
+    x = (torch.randn(B, T, 1024, generator=g).abs() * 0.5).to(_dev())
+    mask = torch.zeros(B, T, dtype=torch.bool, device=_dev())
+    mask[7, 1000:] = True
+    mask[79, 500:] = True
+
+    def run():
+        with torch.no_grad():
+            return [t.clone() for t in m(x, mask)]
+
+    names = ("VS_LP_TAIL_UNFUSED", "VS_LP_QKV_UNFUSED", "VS_LP_EMBED_UNFUSED")
+    try:
+        for n in names:
+            vsa._lib.set_option(n, 1)
+        ref = run()
+    finally:
+        for n in names:
+            vsa._lib.set_option(n, -1)
+    got = run()
+    for a, b in zip(got, ref):
+        assert torch.isfinite(a).all() and torch.equal(a, b)
