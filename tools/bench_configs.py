@@ -40,7 +40,7 @@ with torch.no_grad():
         for B, T, it in ((1, 320, 200), (1, 1024, 200), (8, 1024, 50), (64, 1024, 20)):
             x = torch.randn(B, T, 1024, device=dev)
             F = 2 * 1024 * d + L * (24 * d * d + 4 * T * d) + 2 * d
-            for mode in ("fp32", "fp16x3"):
+            for mode in ("fp32", "fp16x3") + (("bf16",) if tag == "A" else ()):       # (bf16 Linears: d_model <= 256)
                 m.set_compute_dtype(mode)
                 dt = timed(lambda: m(x), it)
                 print("cfg M-%s %-6s B=%2d T=%4d: %8.3f ms/forward  %10.0f frames/s  %6.1f TFLOP/s(fp32-equivalent)" % (
@@ -61,7 +61,7 @@ with torch.no_grad():
     g = torch.Generator().manual_seed(7)
     lens = torch.randint(150, 650, (50,), generator=g).tolist() + torch.randint(100, 650, (25,), generator=g).tolist()
     vids = [torch.randn(t, 1024, generator=g).to(dev) for t in lens]
-    for mode in ("fp32", "fp16x3"):
+    for mode in ("fp32", "fp16x3", "bf16"):
         m.set_compute_dtype(mode)
         for mf in (16384, 65536):
             for packed in (False, True):
