@@ -52,3 +52,21 @@ def test_bench_runs_its_rccl_gather_on_one_gpu():
                 "--no-emulated", "--no-extras"], {"VS_BENCH_FORCE_DIST": "1"}, 600)
     assert out["n_gpus"] == 1 and out["collective_backend"] == "nccl" and out["value"] > 0
     assert "RCCL all_gather" in out["config"]["parallelism"]
+
+
+@pytest.mark.gpu
+def test_bench_line_carries_the_contract_fields_and_a_traceable_traffic_figure():
+    """One short run at the bench's own shape: every field the driver reads is there, `roofline.traffic` comes from the
+    committed PMC file (its source hash must match the loaded kernels - a stale file reads as null and fails here, so a
+    kernel edit without `tools/collect_traffic.sh` is caught), and the secondary legs (fp16x3, bf16) are printed beside,
+    never as, `value`."""
+    out = _run(["--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-extras"], {}, 900)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in out, key
+    assert out["dtype"] == "f32" and out["n_gpus"] == 1 and out["steps"] == 5 and "workload" in out["config"]
+    rf = out["roofline"]
+    assert rf["bound"] == "mfma" and 0.5 < rf["frac"] < 1.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert rf["traffic"] is not None and rf["traffic"] > 2.0e8, rf["traffic_source"]      # attention: ~268 MB per launch
+    assert out["emulated_f32"]["value"] > out["value"] and out["emulated_f32"]["max_abs_logit_diff_vs_exact"] < 1e-4
+    assert out["bf16_mode"]["value"] > out["emulated_f32"]["value"] and out["bf16_mode"]["max_abs_logit_diff_vs_exact"] < 3e-2
