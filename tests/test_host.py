@@ -204,3 +204,16 @@ def test_fused_mlp_chunk_loop_has_only_its_counted_dma_on_the_vector_memory_coun
         assert ops.count("global_load_lds_dwordx4") == 5 and set(ops) <= {"global_load_lds_dwordx4", "global_load_dwordx4"}, ops
         full += ops.count("global_load_dwordx4") == 8          # (the peeled last chunk of an odd count loads no x)
     assert full >= 2
+
+
+def test_every_documented_switch_is_a_known_option_and_unknown_names_are_refused(vsa):
+    """include/vs_scorer.h names the A/B switches vs_set_option accepts; each must be known to the library (value -1 =
+    back to the environment / built-in default: a no-op here), a misspelt one must be an error, not a silent no-op."""
+    hdr = open(os.path.join(ROOT, "include", "vs_scorer.h")).read()
+    block = hdr[hdr.index("A/B and test switches"):hdr.index("int vs_set_option")]
+    names = sorted(set(re.findall(r"\bVS_[A-Z0-9_]+\b", block)) - {"VS_SCORER_H"})
+    assert "VS_LP_STORE32" in names and "VS_LP_EMBED_UNFUSED" in names and "VS_LP_MIN_ROWS_FUSED" in names and len(names) >= 15
+    for n in names:
+        vsa._lib.set_option(n, -1)
+    with pytest.raises(RuntimeError, match="unknown option"):
+        vsa._lib.set_option("VS_LP_STORE_32", 1)
