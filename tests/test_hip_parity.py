@@ -788,8 +788,9 @@ def test_mlp_block_bf16_kernel(vsa, M, nc, sig):
         assert (scores.cpu().double() - sc).abs().max().item() < 2e-3
 
 
+@pytest.mark.parametrize("tile256", [0, 1])
 @pytest.mark.parametrize("cfg", ["M-A", "M-B8", "M-A-ragged"])
-def test_bf16_layer_tail_kernel_is_bit_identical_to_outproj_then_mlp_kernel(vsa, lp_linear_everywhere, cfg):
+def test_bf16_layer_tail_kernel_is_bit_identical_to_outproj_then_mlp_kernel(vsa, lp_linear_everywhere, cfg, tile256):
     """With the attention output stored as bf16, the bf16 mode runs out-projection + residual + norm1 + MLP block + norm2
     (+ score head) as ONE kernel (vs_mlp_fused.hip, TAIL), which then also projects its rows to the NEXT layer's q/k/v
     (QKV epilogue); the embedding runs on the same design with the first layer's QKV behind it (embed_qkv_bf16).  All
@@ -818,6 +819,8 @@ def test_bf16_layer_tail_kernel_is_bit_identical_to_outproj_then_mlp_kernel(vsa,
         return [t.clone() for t in (*a, b, c)]
 
     try:
+        # both block shapes of the fused kernels: 4 waves x 32 rows (the default at these row counts) and 8 waves (pinned)
+        vsa._lib.set_option("VS_LP_TILE256", tile256)
         vsa._lib.set_option("VS_LP_TAIL_UNFUSED", 1)
         vsa._lib.set_option("VS_LP_QKV_UNFUSED", 1)
         ref = run()                                      # out-projection kernel, MLP kernel, QKV kernel per layer
@@ -829,11 +832,13 @@ def test_bf16_layer_tail_kernel_is_bit_identical_to_outproj_then_mlp_kernel(vsa,
         vsa._lib.set_option("VS_LP_TAIL_UNFUSED", -1)
         vsa._lib.set_option("VS_LP_EMBED_UNFUSED", 1)
         mid3 = run()                                     # generic embedding GEMM + first QKV kernel, then layer-tail kernels
+        vsa._lib.set_option("VS_LP_EMBED_UNFUSED", -1)
+        got = run()                                      # all fused: embedding + QKV kernel, layer-tail kernels with the next QKV
     finally:
         vsa._lib.set_option("VS_LP_TAIL_UNFUSED", -1)
         vsa._lib.set_option("VS_LP_QKV_UNFUSED", -1)
         vsa._lib.set_option("VS_LP_EMBED_UNFUSED", -1)
-    got = run()                                          # the default: embedding + QKV kernel, layer-tail kernels with the next QKV
+        vsa._lib.set_option("VS_LP_TILE256", -1)
     for g, a, b, c, r in zip(got, mid, mid2, mid3, ref):
         assert torch.isfinite(g).all() and torch.equal(a, r) and torch.equal(b, r) and torch.equal(c, r) and torch.equal(g, r)
 

@@ -173,37 +173,40 @@ def test_fused_mlp_chunk_loop_has_only_its_counted_dma_on_the_vector_memory_coun
                         os.path.join(csrc, "vs_mlp_fused.hip"), "-o", asm], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     text = open(asm).read()
-    for tail in (0, 1):                             # MLP block alone; out-projection + norm1 + MLP block
-        name = "mlp_fused_bf16ILb%dELi0E" % tail
+    for nwv in (8, 4):                              # 8-wave blocks (256-row tiles) and 4-wave blocks (128-row tiles)
+        pieces = 40 // nwv
+        for tail in (0, 1):                         # MLP block alone; out-projection + norm1 + MLP block
+            name = "mlp_fused_bf16ILb%dELi%dELi0E" % (tail, nwv)
+            body = text[text.index(name, text.index(name) + 1):]
+            body = body[:body.index(".Lfunc_end")]
+            # every barrier-to-barrier segment that multiplies is one chunk of 32 MFMAs and ends in the COUNTED wait with
+            # exactly its DMA pieces as the only LOADS on the counter (loads retire in order among themselves, so
+            # "<= pieces outstanding" proves that the chunk issued one iteration earlier has landed; the QKV epilogue's
+            # stores may sit anywhere - they can only make the wait longer, not shorter).  No spill reloads, no other loads.
+            chunks = [seg for seg in body.split("s_barrier") if "v_mfma" in seg]
+            assert len(chunks) >= (6 if tail else 2)        # out-projection x4 (unrolled), MLP loop, QKV epilogue loop
+            for idx, seg in enumerate(chunks):
+                assert len(re.findall(r"\bv_mfma_f32_32x32x16_bf16\b", seg)) == 32
+                seg = seg[seg.index("global_load_lds_dwordx4"):]            # (what precedes is the previous wait's tail)
+                assert len(re.findall(r"\bglobal_load_lds_dwordx4\b", seg)) == pieces
+                assert str(pieces) in re.findall(r"s_waitcnt[^\n]*vmcnt\((\d+)\)", seg)
+                if idx < (5 if tail else 1):            # out-projection and MLP chunks (99 % of the MFMAs): nothing else at all
+                    vm = re.findall(r"\b(scratch_\w+|buffer_\w+|flat_\w+|global_(?!load_lds_dwordx4)\w+)\b", seg)
+                    assert vm == [], vm
+                    assert re.findall(r"s_waitcnt[^\n]*vmcnt\((\d+)\)", seg) == [str(pieces)]
+        # the embedding kernel: per chunk the DMA pieces + this lane's 8 x-loads (two chunks ahead), 32 MFMAs, counted wait
+        name = "embed_qkv_bf16ILi%dE" % nwv
         body = text[text.index(name, text.index(name) + 1):]
         body = body[:body.index(".Lfunc_end")]
-        # every barrier-to-barrier segment that multiplies is one chunk of 32 MFMAs and ends in the COUNTED wait with
-        # exactly its 5 DMA pieces as the only LOADS on the counter (loads retire in order among themselves, so
-        # "<= 5 outstanding" proves that the chunk issued one iteration earlier has landed; the QKV epilogue's stores may
-        # sit anywhere - they can only make the wait longer, not shorter).  No spill reloads, no other loads.
-        chunks = [seg for seg in body.split("s_barrier") if "v_mfma" in seg]
-        assert len(chunks) >= (6 if tail else 2)        # out-projection x4 (unrolled), MLP loop, QKV epilogue loop
-        for idx, seg in enumerate(chunks):
+        embed = [seg for seg in body.split("s_barrier") if "v_mfma" in seg and re.findall(r"s_waitcnt[^\n]*vmcnt\(%d\)" % (pieces + 8), seg)]
+        full = 0
+        for seg in embed:
+            seg = seg[seg.index("global_load_lds_dwordx4"):]
+            ops = re.findall(r"\b(global_load_lds_dwordx4|global_load_dwordx4|scratch_\w+|buffer_\w+|flat_\w+|global_store\w+|global_load_dword\b)", seg)
             assert len(re.findall(r"\bv_mfma_f32_32x32x16_bf16\b", seg)) == 32
-            seg = seg[seg.index("global_load_lds_dwordx4"):]                # (what precedes is the previous wait's tail)
-            assert len(re.findall(r"\bglobal_load_lds_dwordx4\b", seg)) == 5
-            assert "5" in re.findall(r"s_waitcnt[^\n]*vmcnt\((\d+)\)", seg)
-            if idx < (5 if tail else 1):                # out-projection and MLP chunks (99 % of the MFMAs): nothing else at all
-                vm = re.findall(r"\b(scratch_\w+|buffer_\w+|flat_\w+|global_(?!load_lds_dwordx4)\w+)\b", seg)
-                assert vm == [], vm
-                assert re.findall(r"s_waitcnt[^\n]*vmcnt\((\d+)\)", seg) == ["5"]
-    # the embedding kernel: per chunk 5 DMA pieces + this lane's 8 x-loads (two chunks ahead), 32 MFMAs, vmcnt(13)
-    body = text[text.index("embed_qkv_bf16", text.index("embed_qkv_bf16") + 1):]
-    body = body[:body.index(".Lfunc_end")]
-    embed = [seg for seg in body.split("s_barrier") if "v_mfma" in seg and re.findall(r"s_waitcnt[^\n]*vmcnt\(13\)", seg)]
-    full = 0
-    for seg in embed:
-        seg = seg[seg.index("global_load_lds_dwordx4"):]
-        ops = re.findall(r"\b(global_load_lds_dwordx4|global_load_dwordx4|scratch_\w+|buffer_\w+|flat_\w+|global_store\w+|global_load_dword\b)", seg)
-        assert len(re.findall(r"\bv_mfma_f32_32x32x16_bf16\b", seg)) == 32
-        assert ops.count("global_load_lds_dwordx4") == 5 and set(ops) <= {"global_load_lds_dwordx4", "global_load_dwordx4"}, ops
-        full += ops.count("global_load_dwordx4") == 8          # (the peeled last chunk of an odd count loads no x)
-    assert full >= 2
+            assert ops.count("global_load_lds_dwordx4") == pieces and set(ops) <= {"global_load_lds_dwordx4", "global_load_dwordx4"}, ops
+            full += ops.count("global_load_dwordx4") == 8          # (the peeled last chunk of an odd count loads no x)
+        assert full >= 2
 
 
 def test_every_documented_switch_is_a_known_option_and_unknown_names_are_refused(vsa):

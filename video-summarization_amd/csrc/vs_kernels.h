@@ -86,7 +86,7 @@ int vsk_skinny_max_rows();      // rows up to which the skinny (latency) kernels
 struct VskOptions {
     int skinny_rows;      // VS_SKINNY_ROWS   (default 16384)
     int lp_min_rows;      // VS_LP_MIN_ROWS   (default 8192)
-    int lp_min_rows_fused;// VS_LP_MIN_ROWS_FUSED (default 3072): the same threshold where the fused bf16 layer kernels apply
+    int lp_min_rows_fused;// VS_LP_MIN_ROWS_FUSED (default 256): the same threshold where the fused bf16 layer kernels apply
     int gemm_nwm2;        // VS_GEMM_NWM2     128x128 four-wave GEMM blocks only
     int gemm_nj2;         // VS_GEMM_NJ2      128-column GEMM tiles only
     int attn_nw4;         // VS_ATTN_NW4      4-wave attention blocks only
@@ -95,6 +95,7 @@ struct VskOptions {
     int lp_mlp_unfused;   // VS_LP_MLP_UNFUSED bf16 mode runs fc1 and fc2 + LayerNorm as two kernels (A/B)
     int lp_tail_unfused;  // VS_LP_TAIL_UNFUSED bf16 mode runs the out-projection + norm1 as its own kernel in front of the fused MLP (A/B)
     int lp_qkv_unfused;   // VS_LP_QKV_UNFUSED  bf16 mode runs every layer's QKV projection as its own kernel (A/B)
+    int lp_tile256;       // VS_LP_TILE256     the fused bf16 layer kernels always use 256-row tiles / 8-wave blocks (A/B)
     int lp_embed_unfused; // VS_LP_EMBED_UNFUSED bf16 mode runs the embedding as the generic GEMM + the first QKV kernel (A/B)
     int mlp_fusion;       // VS_MLP_FUSION    (diagnostic builds only)
     int mlp_abl;          // VS_MLP_ABL       (diagnostic builds only)

@@ -119,23 +119,35 @@ struct QkvArgs {             // QKV epilogue: the next layer's q / k / v project
 
 // LDS ring + the LDS-DMA copy of one 40-KiB chunk image into it (40 pieces of 1 KiB, 5 per wave): source = wave-uniform
 // base (scalar registers) + one per-lane byte offset, no per-piece address registers
+template <int NWV>              // waves per block: 8 (5 pieces per wave and chunk) or 4 (10)
 struct RingDma {
+    static constexpr int PIECES = 40 / NWV;
     unsigned char *ring;
     int wave_u;
     unsigned lane16;
     __device__ __forceinline__ void dma(const unsigned char *image, int chunk, int bufoff) const {
         const unsigned char *src = image + (size_t)chunk * MLP_IMG + wave_u * 1024;
         unsigned l16 = lane16;
-        asm volatile("" : "+v"(l16));           // (opaque: else five per-lane 64-bit pointers are precomputed and spilled)
+        asm volatile("" : "+v"(l16));           // (opaque: else per-piece per-lane 64-bit pointers are precomputed and spilled)
 #pragma unroll
-        for (int i = 0; i < 5; ++i) glds16(src + 8192 * i + l16, ring + bufoff + wave_u * 1024 + 8192 * i);
+        for (int i = 0; i < PIECES; ++i) glds16(src + 1024 * NWV * i + l16, ring + bufoff + wave_u * 1024 + 1024 * NWV * i);
     }
 };
+// the counted wait that leaves exactly the newest N vector-memory operations in flight (N a compile-time constant)
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_le() {
+    static_assert(N == 0 || N == 5 || N == 10 || N == 13 || N == 18, "counts this file uses");
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else if constexpr (N == 13) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+}
 
 // QKV epilogue shared by the layer-tail and the embedding kernels (see the header of mlp_fused_bf16): Y = this wave's 32
 // finished rows (fp32, lane (er, eh) = row er, columns 32j + 8q + 4eh + e), X = scratch for their bf16 B operands.
-template <int FR>
-__device__ __forceinline__ void qkv_epilogue(f32x16 (&Y)[8], u32x4 (&X)[16], const QkvArgs &qa, const RingDma &rd,
+template <int FR, int NWV>
+__device__ __forceinline__ void qkv_epilogue(f32x16 (&Y)[8], u32x4 (&X)[16], const QkvArgs &qa, const RingDma<NWV> &rd,
                                              const float *bqkv_s, int m0, int er, int eh, int M) {
     constexpr int NT = 8, D = MLP_D;
     // X[ks] = this lane's 8 natural-order k of the normalised row: k-step ks = 2j + qq covers columns 32j + 16qq ..
@@ -213,7 +225,7 @@ __device__ __forceinline__ void qkv_epilogue(f32x16 (&Y)[8], u32x4 (&X)[16], con
             }
         // <= 5 operations outstanding: loads retire in order among themselves, so chunk c+1's pieces (older than the 5
         // of chunk c+2) have landed whatever the stores issued at the top of this iteration are doing
-        asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        wait_vmcnt_le<40 / NWV>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         const int t = qcur; qcur = qn1; qn1 = qn2; qn2 = t;
@@ -237,14 +249,17 @@ __device__ __forceinline__ void qkv_epilogue(f32x16 (&Y)[8], u32x4 (&X)[16], con
 // are a whole chunk old by then.
 // ABL (diagnostic library only, timing runs with wrong results): 1 no weight staging, 2 no barrier / wait in the chunk
 // loop, 4 fragment reads replaced by register moves, 8 no chunk loop at all (prologue + epilogue only)
-template <bool TAIL, int ABL = 0>
+// NWV = waves per block: 8 (256-row tiles, two waves per SIMD: the throughput form) or 4 (128-row tiles, one wave per SIMD,
+// the same per-wave code and register budget - launch_bounds stays 512: 74 % of the two-wave throughput per CU, but twice
+// as many blocks, for row counts that would leave half the chip idle with 256-row tiles)
+template <bool TAIL, int NWV, int ABL = 0>
 __global__ __launch_bounds__(512, 1) void mlp_fused_bf16(
     const float *H1, TailArgs ta, QkvArgs qa, const unsigned char *__restrict__ Wimg, const float *__restrict__ b1,
     const float *__restrict__ b2, const float *__restrict__ gamma,
     const float *__restrict__ beta, float *out /* may be the residual buffer: every block rewrites only rows it has read */,
     int M, const float *__restrict__ score_w, const float *__restrict__ score_b, int num_classes,
     int sigmoid, float *__restrict__ scores) {
-    constexpr int D = MLP_D, HID = MLP_HID, NT = 8, IMG = MLP_IMG;
+    constexpr int D = MLP_D, HID = MLP_HID, NT = 8, IMG = MLP_IMG, NTHR = 64 * NWV, ROWS = 32 * NWV;
     constexpr int C0 = TAIL ? 0 : MLP_NCHO;                      // first chunk of the image this kernel consumes
     extern __shared__ __attribute__((aligned(1024))) unsigned char dyn_smem[];      // ONE LDS object (see the header)
     unsigned char *ring = dyn_smem;                              // [3][IMG]
@@ -255,21 +270,21 @@ __global__ __launch_bounds__(512, 1) void mlp_fused_bf16(
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    for (int i = tid; i < HID; i += 512) b1s[i] = b1[i];
-    for (int i = tid; i < D; i += 512) {
+    for (int i = tid; i < HID; i += NTHR) b1s[i] = b1[i];
+    for (int i = tid; i < D; i += NTHR) {
         gam_s[i] = gamma[i]; bet_s[i] = beta[i]; bias_s[i] = b2[i];
         if constexpr (TAIL) { gam1_s[i] = ta.gamma1[i]; bet1_s[i] = ta.beta1[i]; bo_s[i] = ta.bo[i]; }
     }
     if (qa.img != nullptr)
-        for (int i = tid; i < 3 * D; i += 512) bqkv_s[i] = qa.bqkv[i];
+        for (int i = tid; i < 3 * D; i += NTHR) bqkv_s[i] = qa.bqkv[i];
 
-    const RingDma rd{ring, __builtin_amdgcn_readfirstlane(wave), (unsigned)lane * 16u};
+    const RingDma<NWV> rd{ring, __builtin_amdgcn_readfirstlane(wave), (unsigned)lane * 16u};
     auto dma_chunk = [&](int chunk, int bufoff) __attribute__((always_inline)) { rd.dma(Wimg, chunk, bufoff); };
     // end of a chunk: the next chunk (5 pieces, issued one iteration ago) has landed, the one after it stays in flight;
     // its data is read only after the barrier every wave passes behind its own wait
     auto chunk_done = [&]() __attribute__((always_inline)) {
         if constexpr (!(ABL & 2)) {
-            if constexpr (!(ABL & 1)) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            if constexpr (!(ABL & 1)) wait_vmcnt_le<40 / NWV>();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
         }
@@ -278,9 +293,9 @@ __global__ __launch_bounds__(512, 1) void mlp_fused_bf16(
 
     f32x16 Y[NT];
     u32x4 X[2 * NT];
-    const int ntiles = (M + 255) / 256;
+    const int ntiles = (M + ROWS - 1) / ROWS;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int m0 = tile * 256 + 32 * wave;                   // this wave's rows: m0 + r
+        const int m0 = tile * ROWS + 32 * wave;                   // this wave's rows: m0 + r
         __syncthreads();                        // the previous tile's epilogue is done with the ring
         if constexpr (!(ABL & 1)) { dma_chunk(C0, 0); dma_chunk(C0 + 1, IMG); }
         // (lane-derived addresses are recomputed per tile from an opaque copy of the thread index: left to the compiler
@@ -482,7 +497,7 @@ __global__ __launch_bounds__(512, 1) void mlp_fused_bf16(
         if (score_w != nullptr) {
             for (int cc = 0; cc < num_classes; ++cc) {
                 __syncthreads();
-                for (int i = tid; i < D; i += 512) sw_s[i] = score_w[(size_t)cc * D + i];
+                for (int i = tid; i < D; i += NTHR) sw_s[i] = score_w[(size_t)cc * D + i];
                 __syncthreads();
                 float dot = 0.f;
 #pragma unroll
@@ -505,7 +520,7 @@ __global__ __launch_bounds__(512, 1) void mlp_fused_bf16(
                 }
             }
         }
-        if (qa.img != nullptr) qkv_epilogue<FR>(Y, X, qa, rd, bqkv_s, m0, er, eh, M);
+        if (qa.img != nullptr) qkv_epilogue<FR, NWV>(Y, X, qa, rd, bqkv_s, m0, er, eh, M);
     }
 }
 
@@ -529,28 +544,29 @@ struct EmbedArgs {
     int T;
 };
 
+template <int NWV>      // waves per block, see mlp_fused_bf16
 __global__ __launch_bounds__(512, 1) void embed_qkv_bf16(EmbedArgs ea, QkvArgs qa, const unsigned char *__restrict__ Wimg,
                                                          float *__restrict__ out, int M) {
-    constexpr int D = MLP_D, NT = 8, IMG = MLP_IMG, FR = 4;
+    constexpr int D = MLP_D, NT = 8, IMG = MLP_IMG, FR = 4, NTHR = 64 * NWV, ROWS = 32 * NWV;
     extern __shared__ __attribute__((aligned(1024))) unsigned char dyn_smem[];      // ONE LDS object
     unsigned char *ring = dyn_smem;                              // [3][IMG]
     float *bias_s = (float *)(dyn_smem + 3 * IMG);               // [D]
     float *bqkv_s = bias_s + D;                                  // [3 D]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    for (int i = tid; i < D; i += 512) bias_s[i] = ea.bias[i];
+    for (int i = tid; i < D; i += NTHR) bias_s[i] = ea.bias[i];
     if (qa.img != nullptr)
-        for (int i = tid; i < 3 * D; i += 512) bqkv_s[i] = qa.bqkv[i];
-    const RingDma rd{ring, __builtin_amdgcn_readfirstlane(wave), (unsigned)lane * 16u};
+        for (int i = tid; i < 3 * D; i += NTHR) bqkv_s[i] = qa.bqkv[i];
+    const RingDma<NWV> rd{ring, __builtin_amdgcn_readfirstlane(wave), (unsigned)lane * 16u};
     const int nch = ea.K / 64;
     auto gch = [&](int c) __attribute__((always_inline)) { return c < nch ? c : nch - 1; };      // past the end: a harmless re-copy / reload
 
     f32x16 Y[NT];
     u32x4 X[2 * NT];
     f32x4 xr[2][8];                                              // this lane's 64 fp32 of the next TWO chunks: k-step ks = [2ks], [2ks+1]
-    const int ntiles = (M + 255) / 256;
+    const int ntiles = (M + ROWS - 1) / ROWS;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int m0 = tile * 256 + 32 * wave;
+        const int m0 = tile * ROWS + 32 * wave;
         __syncthreads();                        // consts visible / the previous tile is done with the ring
         rd.dma(Wimg, gch(0), 0);
         rd.dma(Wimg, gch(1), IMG);
@@ -608,7 +624,7 @@ __global__ __launch_bounds__(512, 1) void embed_qkv_bf16(EmbedArgs ea, QkvArgs q
             });
             // <= 13 loads outstanding = this iteration's 5 DMA pieces + 8 x loads: everything older has landed - the
             // chunk the ring serves next AND the x registers of the next chunk, which are converted right here
-            asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+            wait_vmcnt_le<40 / NWV + 8>();
             convert(set ^ 1);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
@@ -654,7 +670,7 @@ __global__ __launch_bounds__(512, 1) void embed_qkv_bf16(EmbedArgs ea, QkvArgs q
                 if (orow < M) *(f32x4 *)(out + (size_t)orow * D + 32 * j + tc4) = v;
             }
         }
-        if (qa.img != nullptr) qkv_epilogue<FR>(Y, X, qa, rd, bqkv_s, m0, er, eh, M);
+        if (qa.img != nullptr) qkv_epilogue<FR, NWV>(Y, X, qa, rd, bqkv_s, m0, er, eh, M);
     }
 }
 
@@ -673,13 +689,13 @@ constexpr size_t EMBED_LDS = (size_t)3 * MLP_IMG + 4 * MLP_D * sizeof(float);
 constexpr size_t MLP_LDS = (size_t)3 * MLP_IMG + (MLP_HID + 10 * MLP_D) * sizeof(float);      // 134 KiB
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is per DEVICE: set once per (kernel instantiation, device)
-template <bool TAIL, int ABL>
+template <bool TAIL, int NWV, int ABL>
 int allow_lds() {
     static std::atomic<unsigned char> done[64];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return (int)hipErrorInvalidDevice;
     if (dev >= 0 && dev < 64 && done[dev].load(std::memory_order_acquire)) return 0;
-    const int rc = (int)hipFuncSetAttribute((const void *)mlp_fused_bf16<TAIL, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    const int rc = (int)hipFuncSetAttribute((const void *)mlp_fused_bf16<TAIL, NWV, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                             (int)MLP_LDS);
     if (rc == 0 && dev >= 0 && dev < 64) done[dev].store(1, std::memory_order_release);
     return rc;
@@ -696,6 +712,9 @@ int vsk_pack_mlp_bf16(const float *Wo, const float *W1, const float *W2, void *i
     VSK_CHECK_LAUNCH();
     return 0;
 }
+
+// 128-row tiles on 4-wave blocks (one wave per SIMD) when 256-row tiles would leave at least half the CUs without a block
+static bool vsk_fused_half_tiles(int M, int cus) { return !vsk_options().lp_tile256 && (M + 255) / 256 <= cus / 2; }
 
 size_t vsk_embed_bf16_image_bytes(int d, int K) { return d == MLP_D && K > 0 && K % 64 == 0 ? (size_t)(K / 64) * MLP_IMG : 0; }
 
@@ -715,22 +734,25 @@ int vsk_embed_bf16(const float *x, const void *img, const float *bias, const flo
     if (next && (next->T <= 0 || M % next->T || next->H <= 0 || d % next->H || (d / next->H) % 16)) return -1;
     const int cus = vsk_device_cus();
     if (cus <= 0) return (int)hipErrorInvalidDevice;
-    const int ntiles = (M + 255) / 256;
-    const int blocks = ntiles < cus ? ntiles : cus;
-    {
-        static std::atomic<unsigned char> done[64];
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess) return (int)hipErrorInvalidDevice;
-        if (!(dev >= 0 && dev < 64 && done[dev].load(std::memory_order_acquire))) {
-            const int rc = (int)hipFuncSetAttribute((const void *)embed_qkv_bf16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)EMBED_LDS);
-            if (rc) return rc;
-            if (dev >= 0 && dev < 64) done[dev].store(1, std::memory_order_release);
-        }
-    }
     const EmbedArgs ea{x, K, bias, pe, T};
     const QkvArgs qa = next ? QkvArgs{(const unsigned char *)next->img, next->bqkv, (h16 *)next->qkv16, next->T, next->H, d / next->H, next->qscale}
                             : QkvArgs{nullptr, nullptr, nullptr, 1, 1, d, 1.0f};
-    hipLaunchKernelGGL(embed_qkv_bf16, dim3(blocks), dim3(512), EMBED_LDS, st, ea, qa, (const unsigned char *)img, out, M);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return (int)hipErrorInvalidDevice;
+#define VSK_EMBED_LAUNCH(W_)                                                                                            \
+    do {                                                                                                                \
+        static std::atomic<unsigned char> done[64];      /* hipFuncAttributeMaxDynamicSharedMemorySize is per DEVICE */  \
+        if (!(dev >= 0 && dev < 64 && done[dev].load(std::memory_order_acquire))) {                                     \
+            const int rc = (int)hipFuncSetAttribute((const void *)embed_qkv_bf16<W_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)EMBED_LDS); \
+            if (rc) return rc;                                                                                          \
+            if (dev >= 0 && dev < 64) done[dev].store(1, std::memory_order_release);                                    \
+        }                                                                                                               \
+        const int ntiles = (M + 32 * W_ - 1) / (32 * W_);                                                               \
+        hipLaunchKernelGGL(embed_qkv_bf16<W_>, dim3(ntiles < cus ? ntiles : cus), dim3(64 * W_), EMBED_LDS, st, ea, qa,  \
+                           (const unsigned char *)img, out, M);                                                         \
+    } while (0)
+    if (vsk_fused_half_tiles(M, cus)) VSK_EMBED_LAUNCH(4); else VSK_EMBED_LAUNCH(8);
+#undef VSK_EMBED_LAUNCH
     VSK_CHECK_LAUNCH();
     return 0;
 }
@@ -758,30 +780,33 @@ int vsk_mlp_bf16(const float *h, const void *att16, const float *bo, const float
     if (next && (next->T <= 0 || M % next->T || next->H <= 0 || d % next->H || (d / next->H) % 16)) return -1;
     const int cus = vsk_device_cus();
     if (cus <= 0) return (int)hipErrorInvalidDevice;
-    const int ntiles = (M + 255) / 256;
-    const int blocks = ntiles < cus ? ntiles : cus;
     const TailArgs ta{(const h16 *)att16, h, bo, gamma1, beta1};
     const QkvArgs qa = next ? QkvArgs{(const unsigned char *)next->img, next->bqkv, (h16 *)next->qkv16, next->T, next->H, d / next->H, next->qscale}
                             : QkvArgs{nullptr, nullptr, nullptr, 1, 1, d, 1.0f};
-#define VSK_MLP_LAUNCH(T_, A_)                                                                                         \
+#define VSK_MLP_LAUNCH(T_, W_, A_)                                                                                     \
     do {                                                                                                               \
-        if (const int rc = allow_lds<T_, A_>()) return rc;                                                             \
-        hipLaunchKernelGGL((mlp_fused_bf16<T_, A_>), dim3(blocks), dim3(512), MLP_LDS, st, h, ta, qa, (const unsigned char *)img, b1, \
-                           b2, gamma, beta, out, M, score_w, score_b, num_classes, sigmoid, scores);                   \
+        if (const int rc = allow_lds<T_, W_, A_>()) return rc;                                                         \
+        const int ntiles = (M + 32 * W_ - 1) / (32 * W_);                                                              \
+        hipLaunchKernelGGL((mlp_fused_bf16<T_, W_, A_>), dim3(ntiles < cus ? ntiles : cus), dim3(64 * W_), MLP_LDS, st, h, ta, qa, \
+                           (const unsigned char *)img, b1, b2, gamma, beta, out, M, score_w, score_b, num_classes, sigmoid, scores); \
     } while (0)
 #ifdef VS_WITH_DIAG
     switch (vsk_options().mlp_abl) {       // timing-only ablations of the MLP-block kernel (tools/bench_mlp_fused.py)
         case 0: break;
-        case 1: VSK_MLP_LAUNCH(false, 1); VSK_CHECK_LAUNCH(); return 0;
-        case 2: VSK_MLP_LAUNCH(false, 2); VSK_CHECK_LAUNCH(); return 0;
-        case 3: VSK_MLP_LAUNCH(false, 3); VSK_CHECK_LAUNCH(); return 0;
-        case 4: VSK_MLP_LAUNCH(false, 4); VSK_CHECK_LAUNCH(); return 0;
-        case 5: VSK_MLP_LAUNCH(false, 5); VSK_CHECK_LAUNCH(); return 0;
-        case 7: VSK_MLP_LAUNCH(false, 7); VSK_CHECK_LAUNCH(); return 0;
-        default: VSK_MLP_LAUNCH(false, 8); VSK_CHECK_LAUNCH(); return 0;
+        case 1: VSK_MLP_LAUNCH(false, 8, 1); VSK_CHECK_LAUNCH(); return 0;
+        case 2: VSK_MLP_LAUNCH(false, 8, 2); VSK_CHECK_LAUNCH(); return 0;
+        case 3: VSK_MLP_LAUNCH(false, 8, 3); VSK_CHECK_LAUNCH(); return 0;
+        case 4: VSK_MLP_LAUNCH(false, 8, 4); VSK_CHECK_LAUNCH(); return 0;
+        case 5: VSK_MLP_LAUNCH(false, 8, 5); VSK_CHECK_LAUNCH(); return 0;
+        case 7: VSK_MLP_LAUNCH(false, 8, 7); VSK_CHECK_LAUNCH(); return 0;
+        default: VSK_MLP_LAUNCH(false, 8, 8); VSK_CHECK_LAUNCH(); return 0;
     }
 #endif
-    if (att16 != nullptr) VSK_MLP_LAUNCH(true, 0); else VSK_MLP_LAUNCH(false, 0);
+    if (vsk_fused_half_tiles(M, cus)) {
+        if (att16 != nullptr) VSK_MLP_LAUNCH(true, 4, 0); else VSK_MLP_LAUNCH(false, 4, 0);
+    } else {
+        if (att16 != nullptr) VSK_MLP_LAUNCH(true, 8, 0); else VSK_MLP_LAUNCH(false, 8, 0);
+    }
 #undef VSK_MLP_LAUNCH
     VSK_CHECK_LAUNCH();
     return 0;

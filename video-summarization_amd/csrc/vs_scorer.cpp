@@ -117,7 +117,7 @@ const OptionName kOptions[] = {
     {"VS_ATTN_LEGACY", &VskOptions::attn_legacy, 0},     {"VS_LP_STORE32", &VskOptions::lp_store32, 0},
     {"VS_LP_MLP_UNFUSED", &VskOptions::lp_mlp_unfused, 0}, {"VS_LP_TAIL_UNFUSED", &VskOptions::lp_tail_unfused, 0},
     {"VS_LP_QKV_UNFUSED", &VskOptions::lp_qkv_unfused, 0}, {"VS_LP_EMBED_UNFUSED", &VskOptions::lp_embed_unfused, 0},
-    {"VS_LP_MIN_ROWS_FUSED", &VskOptions::lp_min_rows_fused, 3072},
+    {"VS_LP_MIN_ROWS_FUSED", &VskOptions::lp_min_rows_fused, 256}, {"VS_LP_TILE256", &VskOptions::lp_tile256, 0},
 };
 int option_from_env(const OptionName &o) {
     const char *e = getenv(o.name);
@@ -343,8 +343,9 @@ int forward_core(const vs_weights *w, const float *x, const uint8_t *key_pad_mas
     // bf16 Linear kernels exist as LDS-tiled throughput kernels only: up to 8192 rows (measured crossover) the exact
     // fp32 latency kernels are faster and are used whatever that flag says.  fp16x3 has its own latency kernels
     // (same product order as its tiled kernels: a video's scores do not depend on the batch it is scored in).
-    // (measured crossover, T=1024: 8192 rows for the stand-alone bf16 GEMMs; 3072 where the fused layer kernels of
-    // vs_mlp_fused.hip apply - d_model 256 with bf16 attention - which cost ~0.55 ms per forward from 1k to 10k rows)
+    // (measured crossover, T=1024: 8192 rows for the stand-alone bf16 GEMMs; where the fused layer kernels of
+    // vs_mlp_fused.hip apply - d_model 256 with bf16 attention - they win from a single T=320 video on (128-row tiles on
+    // 4-wave blocks below half a chip of 256-row tiles: 0.36 ms at 320 rows, 0.43 ms from 1k to 8k rows): 256 rows)
     const VskOptions &opt = vsk_options();
     const bool fused_ok = vsk_mlp_bf16_supported(d) && (pk ? pk->prec == 1 : (flags & VS_FLAG_BF16_ATTENTION) != 0) &&
                           !opt.lp_store32 && !opt.lp_mlp_unfused && !opt.attn_lp_simple;
