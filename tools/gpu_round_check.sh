@@ -4,13 +4,15 @@ set -e
 TAG=${1:-r02b}
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/$TAG
+# HBM-traffic passes first: the bench contract test below wants a traffic file measured on the sources that are loaded
+bash tools/collect_traffic.sh > gpurun_out/$TAG/traffic.log 2>&1
+cp gpurun_out/traffic.json gpurun_out/$TAG/traffic.json
+cp gpurun_out/traffic.json profiles/r02_hbm_traffic.json      # (on the box; copy gpurun_out/$TAG/traffic.json home as well)
 python -m pytest tests -x -q -m gpu > gpurun_out/$TAG/gputest.log 2>&1 || { tail -40 gpurun_out/$TAG/gputest.log; exit 1; }
 tail -3 gpurun_out/$TAG/gputest.log
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
 python bench.py > gpurun_out/$TAG/bench.json 2> gpurun_out/$TAG/bench.err
 cat gpurun_out/$TAG/bench.json
-bash tools/collect_traffic.sh > gpurun_out/$TAG/traffic.log 2>&1
-cp gpurun_out/traffic.json gpurun_out/$TAG/traffic.json
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/$TAG/prof -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras > $GRAFT_REPO_ROOT/gpurun_out/$TAG/prof_bench.json 2>$GRAFT_REPO_ROOT/gpurun_out/$TAG/prof.err )
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/$TAG/prof_mb -- python3 $GRAFT_REPO_ROOT/bench.py --model B --steps 20 --warmup 5 --no-cpu-baseline --no-extras > $GRAFT_REPO_ROOT/gpurun_out/$TAG/prof_bench_mb.json 2>$GRAFT_REPO_ROOT/gpurun_out/$TAG/prof_mb.err )
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/$TAG/prof_train -- python3 $GRAFT_REPO_ROOT/tools/bench_train.py --shapes 64x1024 --iters 5 > /dev/null 2>&1 )
