@@ -10,7 +10,8 @@
 // pipe (stamped build: fc1 spends 55 % of its time in the store epilogue and 3 200 cycles per 32-k tile waiting for loads;
 // MFMA busy 0.06-0.14): fc1 + fc2 took 209 us per layer at M = 65 536 against an MFMA floor of 27 us.
 //
-// Layout.  Block = 8 waves = 256 rows, one block per CU; wave w owns rows 32w .. 32w+31 (lane (r, h) = row r):
+// Layout.  Block = 8 waves = 256 rows, one block per CU (or 4 waves = 128 rows when 256-row tiles would occupy at most
+// half the CUs: template parameter NWV); wave w owns rows 32w .. 32w+31 (lane (r, h) = row r):
 //   Y[8]   fp32 accumulators of the output row block, started at the residual h1 (C-in), 128 registers;
 //   X[16]  the same h1 values rounded to bf16, as the B operands of fc1 (64 registers) - they come out of the
 //          residual load for free: lane (r, h) holds columns 32j + 8q + 4h + e, and taking registers 8qq .. 8qq+7 of a
@@ -36,7 +37,8 @@
 // epilogue of the single tile each CU owns; + out-projection/norm1 93 us (was 44 + 79); + next QKV 116-120 us (was + 66).
 // Tried and dropped: 4 waves x 64 rows with the whole 512-register file per wave (one fragment read feeds two MFMAs):
 // correct, but as hipcc compiles it (accumulators in AGPRs, 96 v_accvgpr moves per chunk) 291 us against 82, MFMA busy
-// 0.10, with no waiting on any counter - cause not found.
+// 0.10, with no waiting on any counter - cause not found.  It is not the occupancy: this file's own code at one wave per
+// SIMD (NWV = 4, two 128-row tiles per CU) takes 106 us against 79.
 #include "vs_device.h"
 #include "vs_kernels.h"
 
