@@ -17,9 +17,10 @@ import torch
 
 from conftest import GOLDEN
 import torch_ref
+import tolerances as tol
 
 pytestmark = pytest.mark.gpu
-ATOL, RTOL = 1e-4, 1e-3
+ATOL, RTOL = tol.TRAIN_GRAD_ATOL, tol.TRAIN_GRAD_RTOL
 
 
 def _dev():

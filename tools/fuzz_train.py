@@ -22,7 +22,7 @@ import test_hip_train as tht      # noqa: E402  (_library_masks)
 
 ARCH = [(4, 256), (8, 256), (4, 128), (2, 128), (4, 512), (8, 512), (2, 64), (6, 192), (5, 320)]
 LENGTHS = [1, 2, 5, 17, 31, 32, 33, 63, 64, 65, 96, 127, 128, 129, 150, 200, 255, 256, 257, 320, 400, 511, 513, 700]
-ATOL, RTOL = 1e-4, 1e-3
+ATOL, RTOL = tht.ATOL, tht.RTOL          # tests/tolerances.py: TRAIN_GRAD_ATOL / TRAIN_GRAD_RTOL
 # The float64 checker differentiates the SAME piecewise-linear function as the implementation: it takes the ReLU-and-
 # dropout gate of every layer from the HIP forward's own activation record (a ReLU input within fp32 rounding of zero
 # may fall on the other side in float64, and with millions of activations per case some do).
