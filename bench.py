@@ -26,6 +26,15 @@ Prints ONE JSON line on rank 0 with the contract fields plus
   emulated_f32  the same K steps again with every product EMULATED on the f16 matrix pipe ("fp16x3"): reported
                 beside `value`, never as `value`: the headline is the exact-fp32 MFMA path (--compute to change).
   bf16_mode     the same K steps on the bf16 matrix pipe (reduced precision, opt-in): context only.
+
+``--workload`` selects the BASELINE.json configuration (same launcher, same JSON contract, one rank-0 line):
+  batch  (default) configs[2]: B=64 x T=1024 x D=1024 per GPU, exact fp32, weak scaling - the headline metric
+  corpus configs[3]: the 75-video TVSum+SumMe-shaped ragged corpus (30 568 frames), STRONG scaling: the videos are dealt
+         to the ranks (corpus.plan_shards), each rank scores its shard as packed batches, one all_gather returns every
+         video's scores to every rank; a step = one pass over the corpus; `eval_ms` = the sharded keyshot evaluation
+         (four sums all-reduced) of the same scores, timed beside the step, never inside `value`
+  long   configs[4]: B=8 x T=8192 x D=2048 per GPU, every product on the bf16 matrix pipe (the config names bf16), weak
+         scaling; `roofline.peak` is the dense bf16 MFMA peak
 """
 import argparse
 import hashlib
@@ -135,16 +144,23 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=64, help="videos per GPU per step")
-    ap.add_argument("--frames", type=int, default=1024)
+    ap.add_argument("--workload", default="batch", choices=["batch", "corpus", "long"],
+                    help="batch: configs[2] (headline); corpus: configs[3] (strong scaling); long: configs[4] (bf16)")
+    ap.add_argument("--batch", type=int, default=None, help="videos per GPU per step (batch: 64, long: 8)")
+    ap.add_argument("--frames", type=int, default=None, help="frames per video (batch: 1024, long: 8192)")
     ap.add_argument("--model", default="A", choices=["A", "B"], help="A: H4 d256 L4 (run scripts); B: H4 d512 L3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--compute", default="fp32", choices=["fp32", "fp16x3", "bf16"],
-                    help="matrix-product arithmetic of the timed path (default: exact fp32 MFMA)")
+    ap.add_argument("--compute", default=None, choices=["fp32", "fp16x3", "bf16"],
+                    help="matrix-product arithmetic of the timed path (default: exact fp32 MFMA; workload long: bf16)")
     ap.add_argument("--no-emulated", action="store_true", help="skip the secondary fp16x3 measurement")
     ap.add_argument("--no-extras", action="store_true", help="skip the PCIe-inclusive and latency legs")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline sample length")
-    return ap.parse_args()
+    args = ap.parse_args()
+    long_ = args.workload == "long"
+    args.batch = args.batch or (8 if long_ else 64)
+    args.frames = args.frames or (8192 if long_ else 1024)
+    args.compute = args.compute or ("bf16" if long_ else "fp32")
+    return args
 
 
 def main():
@@ -185,25 +201,56 @@ def main():
         backend = dist.get_backend()
         assert dist.get_world_size() == world and dist.get_rank() == rank
         assert rehearse or backend == "nccl", "multi-GPU runs gather over RCCL (torch backend 'nccl'), got %r" % backend
+    ranks_seen = [0]
+    if dist is not None:      # every rank's id through the collective transport itself (RCCL on a GPU node): all present, once each
+        ids = torch.empty(world, dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
+        dist.all_gather_into_tensor(ids, torch.tensor([rank], dtype=torch.int64, device=ids.device))
+        ranks_seen = ids.cpu().tolist()
+        assert sorted(ranks_seen) == list(range(world)), ranks_seen
 
     pkg = importlib.import_module("video-summarization_amd")
     lib = pkg._lib.load()
     H, d, L = (4, 256, 4) if args.model == "A" else (4, 512, 3)
-    B, T, Din = args.batch, args.frames, 1024
-    sd = pkg.synth.make_state_dict(d, L, seed=1234)
-    model = pkg.SimNet(num_heads=H, d_model=d, num_layers=L, sparsity=0.0, dropout=0.3)
+    wl = args.workload
+    B, T, Din = args.batch, args.frames, (2048 if wl == "long" else 1024)
+    if wl == "long":       # configs[4]: outside the reference's envelope (in_features 1024, 2000-row table): re-parameterised
+        sd = pkg.synth.make_state_dict(d, L, seed=1234, in_features=Din, max_len=max(T, 2000))
+        model = pkg.SimNet(num_heads=H, d_model=d, num_layers=L, sparsity=0.0, dropout=0.3, in_features=Din, pe_len=max(T, 2000))
+    else:
+        sd = pkg.synth.make_state_dict(d, L, seed=1234)
+        model = pkg.SimNet(num_heads=H, d_model=d, num_layers=L, sparsity=0.0, dropout=0.3)
     model.load_state_dict(sd, strict=True)
     model = model.to(dev).eval().set_compute_dtype(args.compute)
-    g = torch.Generator(device="cpu").manual_seed(1234 + rank)       # disjoint videos per rank
-    x_host = torch.randn(B, T, Din, generator=g).pin_memory()
-    x = x_host.to(dev)
-    gathered = torch.empty((world * B, T), dtype=torch.float32, device=dev) if dist is not None else None   # rank-major rows
+    corpus_mod = importlib.import_module("video-summarization_amd.corpus")
+    if wl == "corpus":
+        # configs[3]: 50 + 25 ragged videos (tools/eval_corpus.py: lengths U[150,650] / U[100,650]),
+        # the SAME corpus on every rank; a rank's shard is resident on its GPU, scores return to every rank
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        feats, targets, users = importlib.import_module("eval_corpus").corpus(seed=7)
+        lengths = [int(f.shape[0]) for f in feats]
+        mine = corpus_mod.plan_shards(lengths, world)[rank]
+        videos = [f.to(dev) if i in set(mine) else f for i, f in enumerate(feats)]
+        frames_per_step = sum(lengths)                       # whole job, fixed: strong scaling
+        can_pack = d // H in (32, 64)
+        gathered = None
 
-    def step():
-        logits, _hidden = model(x)
-        if dist is not None:
-            return dist.all_gather_into_tensor(gathered, logits.view(B, T), async_op=True)
-        return None
+        def step():
+            corpus_mod.score_corpus(lambda xx, mm: model.score(xx, mm), videos, rank=rank, world=world, device=dev,
+                                    max_frames=16384, packed_fn=(lambda xx, ll: model.score_packed(xx, ll)) if can_pack else None,
+                                    force_collective=dist is not None)
+            return None
+    else:
+        g = torch.Generator(device="cpu").manual_seed(1234 + rank)       # disjoint videos per rank
+        x_host = torch.randn(B, T, Din, generator=g).pin_memory()
+        x = x_host.to(dev)
+        frames_per_step = B * T * world                      # whole job, grows with the ranks: weak scaling
+        gathered = torch.empty((world * B, T), dtype=torch.float32, device=dev) if dist is not None else None   # rank-major rows
+
+        def step():
+            logits, _hidden = model(x)
+            if dist is not None:
+                return dist.all_gather_into_tensor(gathered, logits.view(B, T), async_op=True)
+            return None
 
     def fence():
         if dist is not None:
@@ -235,7 +282,7 @@ def main():
 
         # secondary: the same K steps with fp32 emulated on the f16 pipe (never `value`)
         emu = None
-        if args.compute == "fp32" and not args.no_emulated and d // H in (32, 64, 128):
+        if wl == "batch" and args.compute == "fp32" and not args.no_emulated and d // H in (32, 64, 128):
             exact_logits = model(x)[0].clone()
             model.set_compute_dtype("fp16x3")
             for _ in range(max(2, args.warmup // 2)):
@@ -248,7 +295,7 @@ def main():
             emu = (dt_emu, diff)
         # secondary: the same K steps with every product on the bf16 matrix pipe (reduced precision: never `value`)
         low = None
-        if args.compute == "fp32" and not args.no_emulated and d <= 256 and d // H in (32, 64):
+        if wl == "batch" and args.compute == "fp32" and not args.no_emulated and d <= 256 and d // H in (32, 64):
             exact_logits = model(x)[0].clone()
             model.set_compute_dtype("bf16")
             for _ in range(max(2, args.warmup // 2)):
@@ -261,7 +308,15 @@ def main():
             low = (dt_low, diff)
 
         pcie_fps = pcie_overlap_fps = lat_ms = None
-        if not args.no_extras:
+        eval_ms = None
+        if wl == "corpus":           # the consumer of the gathered scores: sharded keyshot evaluation + all_reduce of four sums
+            harness = importlib.import_module("video-summarization_amd.harness")
+            fence()
+            t1 = time.perf_counter()
+            harness.val_step_batched(model, videos, targets, users, dev, rank, world)
+            torch.cuda.synchronize()
+            eval_ms = (time.perf_counter() - t1) * 1e3 - dt / args.steps * 1e3      # minus one scoring pass
+        if wl == "batch" and not args.no_extras:
             # PCIe-inclusive rates (never `value`): pinned host batches -> device -> forward.  Serial = copy then
             # kernels on one stream; overlapped = corpus.score_host_batches (copy stream + compute stream).
             fence()
@@ -294,12 +349,23 @@ def main():
         dt = t[0].item()
         if emu:
             emu = (t[1].item(), t[2].item())
-    frames = B * T * world * args.steps
+    frames = frames_per_step * args.steps
     value = frames / dt
 
     out = None
     if rank == 0:
-        fl = stage_flops(B, T, Din, d, H, L)
+        if wl == "corpus":
+            # ragged shard: per-stage FLOPs of ONE pass over rank 0's videos, divided by the launches that pass made
+            # (one per packed batch and layer) = the average launch the event durations are averaged over
+            mine_t = [lengths[i] for i in mine]
+            Msh, Q = float(sum(mine_t)), float(sum(t * t for t in mine_t))
+            per_pass = {"embed_pe": 2.0 * Msh * Din * d, "qkv_proj": L * 2.0 * Msh * d * 3 * d, "attention": L * 4.0 * Q * d,
+                        "outproj_ln": L * 2.0 * Msh * d * d, "fc1_relu": L * 2.0 * Msh * d * 4 * d,
+                        "fc2_ln_score": L * 2.0 * Msh * 4 * d * d + 2.0 * Msh * d}
+            fl = {k: per_pass[k] / max(stages.get(k, (0, 0))[1] / args.steps, 1e-9) if stages.get(k, (0, 0))[1] else 0.0
+                  for k in per_pass}
+        else:
+            fl = stage_flops(B, T, Din, d, H, L)
         # the bf16 mode folds stages into fewer kernels: a stage that was never launched did its
         # work inside another - the layer tail (reported as fc2_ln_score) carries the out-projection, fc1 and all but the
         # first QKV, the embedding kernel the first QKV; FLOPs per launch follow the work
@@ -326,10 +392,12 @@ def main():
             v["share"] = round(v["avg_ms"] * v["launches"] / tot, 3)
         dom = max(table, key=lambda k: table[k]["share"])
         flops_per_frame = 2 * Din * d + L * (24 * d * d + 4 * T * d) + 2 * d
+        if wl == "corpus":            # corpus average: sum over videos of T (2 Din d + L (24 d^2 + 4 T d) + 2 d) / sum T
+            flops_per_frame = sum(t * (2 * Din * d + L * (24 * d * d + 4 * t * d) + 2 * d) for t in lengths) / float(sum(lengths))
         # peak of the arithmetic the timed path used: fp32 MFMA, or f16 MFMA / 3 products (fp16x3), or bf16 MFMA
         peak = {"fp32": PEAK_F32_MFMA_TFLOPS, "fp16x3": PEAK_F16_MFMA_TFLOPS / 3, "bf16": PEAK_F16_MFMA_TFLOPS}[args.compute]
         traffic, traffic_src = (None, "not the measured configuration")
-        if (B, T, args.model, args.compute) == (64, 1024, "A", "fp32"):
+        if (wl, B, T, args.model, args.compute) == ("batch", 64, 1024, "A", "fp32"):
             traffic, traffic_src = measured_traffic(dom)
         roofline = {"bound": "mfma", "kernel": dom, "achieved": table[dom]["tflops"], "peak": round(peak, 1),
                     "unit": "TFLOP/s", "frac": round(table[dom]["tflops"] / peak, 4),
@@ -345,35 +413,57 @@ def main():
         cpu = None
         latency = None
         if world == 1 and not args.no_cpu_baseline:
-            from oracle.simnet_oracle import time_cpu_baseline      # the checker, timed as the CPU "port"
-            fps, cores, sample = time_cpu_baseline(sd, H, 8, T, args.cpu_seconds)
-            fps1, cores1, sample1 = time_cpu_baseline(sd, H, 1, 320, 0.0, iters=20)
-            cpu = {"value": round(fps, 1), "unit": "frames/s", "cores": cores, "kind": "port",
-                   "sample": "oracle/simnet_oracle.py (materialised [B,H,T,T] softmax, torch CPU fp32), " + sample,
-                   "single_video": {"value": round(fps1, 1), "unit": "frames/s", "ms_per_video": round(320 / fps1 * 1e3, 3),
-                                    "cores": cores1, "sample": sample1}}
+            from oracle.simnet_oracle import time_cpu_baseline, usable_cpus      # the checker, timed as the CPU "port"
+            # `cores` = the host cores this job may use on the box (affinity / cgroup share); `threads` = the torch
+            # thread count the sweep found fastest for the oracle (never more than `cores`)
+            box_cores = usable_cpus()
+            if wl == "long":         # one T=8192 video, one pass: four materialised [4, 8192, 8192] fp32 score tensors
+                fps, threads, sample = time_cpu_baseline(sd, H, 1, T, 0.0, iters=1)
+            elif wl == "corpus":     # three videos of the corpus' median length
+                tm = sorted(lengths)[len(lengths) // 2]
+                fps, threads, sample = time_cpu_baseline(sd, H, 3, tm, args.cpu_seconds)
+            else:
+                fps, threads, sample = time_cpu_baseline(sd, H, 8, T, args.cpu_seconds)
+            cpu = {"value": round(fps, 1), "unit": "frames/s", "cores": box_cores, "threads": threads, "kind": "port",
+                   "sample": "oracle/simnet_oracle.py (materialised [B,H,T,T] softmax, torch CPU fp32), " + sample}
+            if wl == "batch":
+                fps1, threads1, sample1 = time_cpu_baseline(sd, H, 1, 320, 0.0, iters=20)
+                cpu["single_video"] = {"value": round(fps1, 1), "unit": "frames/s", "ms_per_video": round(320 / fps1 * 1e3, 3),
+                                       "cores": box_cores, "threads": threads1, "sample": sample1}
         if lat_ms is not None:
             latency = {"workload": "configs[1]: one video, T=320, D=1024, M-%s" % args.model, "gpu_ms": round(lat_ms, 4),
                        "gpu_frames_per_s": round(320 / lat_ms * 1e3, 1),
                        "cpu_ms": cpu["single_video"]["ms_per_video"] if cpu else None}
+        par = "%s all_gather of scores" % ("RCCL" if backend == "nccl" else (backend or "no"))
+        if wl == "corpus":
+            workload = ("configs[3]: TVSum+SumMe-shaped corpus, %d ragged videos / %d frames (T 100..650, D=1024) dealt to %d "
+                        "GPU(s) by cost, packed batches, scorer cfg M-%s (heads %d, d_model %d, layers %d), sigmoid scores "
+                        "returned to every rank" % (len(lengths), sum(lengths), world, args.model, H, d, L))
+            cfg = {"workload": workload, "videos": len(lengths), "frames_per_step": frames_per_step,
+                   "parallelism": "videos sharded over %d GPU(s) (strong scaling), %s" % (world, par)}
+            metric = "frames/sec scored (whole node), synthetic TVSum+SumMe-shaped ragged corpus [75 videos, D=1024]"
+        else:
+            workload = ("configs[%d]: B=%d videos x T=%d frames x D=%d per GPU, scorer cfg M-%s (heads %d, d_model %d, layers %d), "
+                        "logits + hidden state" % (4 if wl == "long" else 2, B, T, Din, args.model, H, d, L))
+            cfg = {"workload": workload, "global_batch": B * world, "frames_per_step": frames_per_step,
+                   "parallelism": "videos sharded over %d GPU(s), %s" % (world, par)}
+            metric = "frames/sec scored (whole node), synthetic [B,T=%d,D=%d]" % (T, Din)
         out = {
-            "metric": "frames/sec scored (whole node), synthetic [B,T=1024,D=1024]",
+            "metric": metric,
             "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None,
+            "scaling": "strong" if wl == "corpus" else "weak", "vs_baseline": None,
             "dtype": {"fp32": "f32", "fp16x3": "f32 emulated as 3 x f16 MFMA (hi+lo operand split), f32 accumulate",
                       "bf16": "bf16 MFMA operands, f32 accumulate"}[args.compute],
             "data": "synthetic",
-            "config": {"workload": "configs[2]: B=%d videos x T=%d frames x D=%d per GPU, scorer cfg M-%s "
-                                   "(heads %d, d_model %d, layers %d), logits + hidden state" % (B, T, Din, args.model, H, d, L),
-                       "global_batch": B * world, "frames_per_step": B * T * world,
-                       "parallelism": "videos sharded over %d GPU(s), %s all_gather of scores"
-                                      % (world, "RCCL" if backend == "nccl" else (backend or "no"))},
-            "collective_backend": backend,
+            "config": cfg,
+            "collective_backend": backend, "ranks_seen": ranks_seen,
             "pcie_inclusive_value": round(pcie_fps * world, 1) if pcie_fps else None,
             "pcie_inclusive_overlapped_value": round(pcie_overlap_fps * world, 1) if pcie_overlap_fps else None,
             "roofline": roofline, "cpu_baseline": cpu, "latency": latency,
         }
+        if eval_ms is not None:
+            out["eval_ms"] = round(eval_ms, 3)
         if emu:
             ev = frames / emu[0]
             out["emulated_f32"] = {

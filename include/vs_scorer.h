@@ -103,7 +103,11 @@ void vs_weights_free(vs_weights *w);
 
 /* Replaces: the parameter writes of an optimizer step / load_state_dict on an existing module (train.py:127,
  * 42-43).  Re-copies every parameter into the handle's existing device storage (same desc, same device as
- * vs_weights_pack; no allocation, no free) and rebuilds the kernel-layout copies, stream-ordered on `stream`. */
+ * vs_weights_pack; no allocation, no free), stream-ordered on `stream`: one batched copy launch per encoder layer.
+ * params->pos_embedding may be NULL here: the table already packed is kept (it is a buffer, not a parameter).  The
+ * kernel-layout copies (fragment-major, fp16x3, bf16 images, transposes) are NOT rebuilt here: each family is rebuilt
+ * by the first forward / backward that reads it after the update, on that call's stream - so a handle's calls must be
+ * issued on ONE stream at a time or be ordered by the caller. */
 int vs_weights_update(vs_weights *w, const vs_model_params *params, void *stream);
 
 /* Bytes of scratch vs_scorer_forward needs for a [B,T] batch (0 on invalid arguments). */
@@ -122,6 +126,18 @@ int vs_scorer_forward(const vs_weights *w, const float *x, const uint8_t *key_pa
                       int32_t B, int32_t T, uint32_t flags,
                       float *scores, float *hidden,
                       void *workspace, size_t workspace_bytes, void *stream);
+
+/* Replaces: SimNet.forward of a module built with use_cls=True (simnet.py:205-206, 214-216, process_mask :47-51; no
+ * reference caller enables it): `cls_token` [d_model] fp32 (16-byte aligned) is prepended to every video AFTER the
+ * positional encoding, the encoder sees T + 1 positions (the token is never padding), and
+ *   scores [B, T+1, num_classes], hidden [B, T+1, d_model] (or NULL)
+ * carry the token's row first.  x, key_pad_mask, flags, stream as vs_scorer_forward (x has T frames per video, the
+ * mask T entries); workspace >= vs_scorer_workspace_bytes_cls(w, B, T).  Every compute mode of vs_scorer_forward. */
+size_t vs_scorer_workspace_bytes_cls(const vs_weights *w, int32_t B, int32_t T);
+int vs_scorer_forward_cls(const vs_weights *w, const float *x, const uint8_t *key_pad_mask,
+                          const float *cls_token, int32_t B, int32_t T, uint32_t flags,
+                          float *scores, float *hidden,
+                          void *workspace, size_t workspace_bytes, void *stream);
 
 /* Packed ragged batch (no reference counterpart: the reference pads with the 1000.0 sentinel and masks,
  * data/dataset.py:157-161, train.py:118): the frames of B videos concatenated, x [Mtot, in_features] with

@@ -5,8 +5,11 @@
  *                                                        reference src/train.py:111-131, src/pretrain.py:49-86
  * The reference has no FFI; what a binding binds is torch.autograd's contract for this nn.Module: a forward that
  * keeps what the backward needs, and a backward from (d_scores, d_hidden) to the gradients of every parameter
- * (and of the input).  Same conventions as vs_scorer.h: device pointers, no allocation, work enqueued on the
- * caller's stream, int status + vs_last_error().  All arithmetic is exact fp32 (v_mfma_f32_32x32x2_f32); every
+ * (and of the input).  Same conventions as vs_scorer.h: device pointers, work enqueued on the caller's stream, int
+ * status + vs_last_error().  ONE allocation exists on this path: the transposed weights of the dgrad GEMMs, made by
+ * vs_train_prepare() (or, if that was never called, by the first vs_train_backward).  A handle's calls (forward,
+ * backward, vs_weights_update) must be issued on ONE stream at a time, or be ordered by the caller: the lazily rebuilt
+ * weight images are ordered on the stream of the call that rebuilds them.  All arithmetic is exact fp32 (v_mfma_f32_32x32x2_f32); every
  * reduction runs in a fixed order, so a step is bitwise reproducible for a given dropout seed.
  */
 #ifndef VS_TRAIN_H
@@ -46,6 +49,11 @@ typedef struct vs_model_grads {
     const vs_layer_grads *layers;               /* HOST array of num_layers entries */
     float *final_w, *final_b;
 } vs_model_grads;
+
+/* Allocates (first call per handle: hipMalloc, synchronises the device - call it OUTSIDE the training loop and outside
+ * any stream capture) and (re)builds the transposed weight copies the backward's dgrad GEMMs read, stream-ordered on
+ * `stream`.  Later calls - and the backward itself - only rebuild them after a vs_weights_update: no allocation. */
+int vs_train_prepare(vs_weights *w, void *stream);
 
 /* Bytes of the activation record one forward leaves for its backward, and of the scratch either call needs. */
 size_t vs_train_saved_bytes(const vs_weights *w, int32_t B, int32_t T);

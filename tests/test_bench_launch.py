@@ -72,3 +72,25 @@ def test_bench_line_carries_the_contract_fields_and_a_traceable_traffic_figure()
     assert rf["traffic"] is not None and rf["traffic"] > 2.0e8, rf["traffic_source"]      # attention: ~268 MB per launch
     assert out["emulated_f32"]["value"] > out["value"] and out["emulated_f32"]["max_abs_logit_diff_vs_exact"] < 1e-4
     assert out["bf16_mode"]["value"] > out["emulated_f32"]["value"] and out["bf16_mode"]["max_abs_logit_diff_vs_exact"] < tol.BF16_LOGIT_TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload", ["corpus", "long"])
+def test_two_rank_rehearsal_of_the_other_workloads(workload):
+    """configs[3] (`--workload corpus`: strong scaling of the 75-video corpus, scores gathered to every rank, sharded
+    evaluation timed beside) and configs[4] (`--workload long`: bf16) under the same self-launcher and JSON contract;
+    two ranks on the one GPU over gloo (numbers meaningless), plus the one-rank form."""
+    extra = ["--workload", workload, "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    if workload == "long":
+        extra += ["--batch", "1", "--frames", "512"]
+    two = _run(["--gpus", "2"] + extra, {"VS_BENCH_REHEARSE": "1"}, 900)
+    one = _run(["--gpus", "1"] + extra, {}, 900)
+    for out, n in ((two, 2), (one, 1)):
+        assert out["n_gpus"] == n and out["value"] > 0 and out["ranks_seen"] == list(range(n))
+        assert out["roofline"]["frac"] > 0 and out["roofline"]["stages"]["attention"]["launches"] > 0
+        if workload == "corpus":
+            assert out["scaling"] == "strong" and out["config"]["videos"] == 75 and out["config"]["frames_per_step"] == 30568
+            assert out["eval_ms"] is not None and "configs[3]" in out["config"]["workload"]
+        else:
+            assert out["scaling"] == "weak" and out["dtype"].startswith("bf16") and "configs[4]" in out["config"]["workload"]
+            assert out["config"]["frames_per_step"] == 512 * n and out["roofline"]["peak"] == 2500.0

@@ -138,6 +138,30 @@ def test_feeder_errors_reach_the_consumer(data):
             feeder.done(slot, None)
 
 
+def test_feeder_producer_exits_when_the_consumer_stops_early(data):
+    """a consumer that raises (or breaks) mid-iteration must not leave the producer blocked on the ring with
+    the pinned buffers alive: the iterator's ``finally`` / ``close()`` / ``with`` stop and join the thread."""
+    import time
+    videos = [np.zeros((60, 32), np.float32) for _ in range(40)]               # 40 one-video batches, 2 slots
+    feeder = data.RaggedFeeder(videos, max_frames=60, slots=2)
+    with pytest.raises(RuntimeError, match="consumer failed"):
+        for slot, *_ in feeder:                                                 # never hands the slot back
+            raise RuntimeError("consumer failed")
+    deadline = time.time() + 5
+    while feeder.alive and time.time() < deadline:
+        time.sleep(0.01)
+    assert not feeder.alive
+    # break + with-statement: same guarantee
+    with data.RaggedFeeder(videos, max_frames=60, slots=2) as f2:
+        for slot, *_ in f2:
+            break
+    assert not f2.alive
+    # an untouched feeder can be closed too
+    f3 = data.RaggedFeeder(videos, max_frames=60, slots=2)
+    f3.close()
+    assert not f3.alive
+
+
 @pytest.mark.gpu
 def test_val_step_from_files_matches_the_reference_golden(vsa, data, tmp_path):
     """The reference's val_step on split-0-shaped records (tests/golden/make_golden_valstep.py: reference model +

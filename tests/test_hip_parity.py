@@ -1219,3 +1219,39 @@ def test_class_token_model_matches_reference_golden_and_oracle(vsa):
             m.train()(x.to(_dev()))                          # training with a class token is not offered
         with pytest.raises(NotImplementedError):
             m.score_packed(x[0].to(_dev()), [c["T"]])
+
+
+def test_class_token_scoring_launches_no_torch_kernels_after_the_first_call(vsa):
+    """``use_cls`` scoring goes through ONE C call (``vs_scorer_forward_cls``) on the cached packed
+    weights - after the first call (which packs them) a forward launches no ``at::native`` kernel (no per-call weight
+    cast / ``torch.cat``) and no device-to-device memcpy: only kernels of libvsscore.so.  Also: the low-precision modes
+    run with a class token (they did not before the token moved into the library)."""
+    from torch.profiler import ProfilerActivity, profile
+    sd = vsa.synth.make_state_dict(256, 2, 21, use_cls=True)
+    m = vsa.SimNet(num_heads=4, d_model=256, num_layers=2, sparsity=0.0, use_cls=True, dropout=0.0)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(_dev()).eval()
+    x = vsa.synth.make_features(2, 150, 7, "randn").to(_dev())
+    mask = vsa.synth.random_mask(2, 150, 5).to(_dev())
+    with torch.no_grad():
+        ref_l, ref_h = m(x, mask)                             # first call: packs the weights
+        torch.cuda.synchronize()
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+            l2, h2 = m(x, mask)
+            s2 = m.score(x, mask)
+            torch.cuda.synchronize()
+    names = [e.name for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA]
+    assert names, "no device activity recorded"
+    bad = [n for n in names if "at::native" in n or "Memcpy" in n or "Memset" in n]
+    assert not bad, bad
+    assert torch.equal(l2, ref_l) and torch.equal(h2, ref_h)
+    assert (s2 - torch.sigmoid(ref_l.squeeze(-1))).abs().max().item() < 1e-6
+    rl, rh = oracle_forward(sd, x.cpu(), mask.cpu(), 4)
+    assert (ref_l.cpu() - rl).abs().max().item() < TOL and (ref_h.cpu() - rh).abs().max().item() < TOL
+    with torch.no_grad():
+        m.set_compute_dtype("fp16x3")
+        lf, _ = m(x, mask)
+        assert (lf.cpu() - rl).abs().max().item() < TOL
+        m.set_compute_dtype("bf16")
+        lb, _ = m(x, mask)
+        assert (lb.cpu() - rl).abs().max().item() < tol.BF16_LOGIT_TOL

@@ -121,6 +121,81 @@ def test_train_mode_without_dropout_equals_the_scoring_path(vsa):
     assert (a.detach() - b)[valid].abs().max().item() < 2e-5 and (ha.detach() - hb)[valid].abs().max().item() < 5e-5
 
 
+def test_embedding_dropout_does_not_exist_without_a_positional_table(vsa):
+    """the reference's embedding dropout lives INSIDE PositionalEncoding (simnet.py:224,237), so a
+    ``use_pos=False`` model has none.  The C ABI (``vs_train_forward`` / ``_backward``) ignores ``p_embed`` for a
+    handle packed without a positional table; with one, the same ``p_embed`` does change the result."""
+    lib = vsa._lib.load()
+    x = vsa.synth.make_features(2, 70, 4, "randn").to(_dev())
+    for use_pos in (False, True):
+        sd = vsa.synth.make_state_dict(256, 1, 5, use_pos=use_pos)
+        m = vsa.SimNet(num_heads=4, d_model=256, num_layers=1, sparsity=0.5, dropout=0.0, use_pos=use_pos)
+        m.load_state_dict(sd)
+        m = m.to(_dev())
+        packed = m._packed_weights(_dev())
+        outs = []
+        for p_embed in (0.0, 0.5):
+            cfg = vsa._lib.DropoutCfg(p_embed, 0.0, 77)
+            scores = torch.empty((2, 70, 1), device=_dev())
+            saved = torch.empty((lib.vs_train_saved_bytes(packed.handle, 2, 70),), dtype=torch.uint8, device=_dev())
+            ws = torch.empty((lib.vs_train_workspace_bytes(packed.handle, 2, 70),), dtype=torch.uint8, device=_dev())
+            vsa._lib.check(lib.vs_train_forward(packed.handle, x.data_ptr(), None, 2, 70, C.byref(cfg), scores.data_ptr(), None,
+                                                saved.data_ptr(), saved.numel(), ws.data_ptr(), ws.numel(), _stream()))
+            torch.cuda.synchronize()
+            outs.append(scores.clone())
+        if use_pos:
+            assert not torch.equal(outs[0], outs[1])
+        else:
+            assert torch.equal(outs[0], outs[1])
+        # and the module's own train-mode forward (sparsity 0.5) equals eval for the use_pos=False model
+        if not use_pos:
+            a, _ = m.train()(x)
+            with torch.no_grad():
+                b, _ = m.eval()(x)
+            assert (a.detach() - b).abs().max().item() < 2e-5
+
+
+def test_parameter_updates_reach_every_kernel_layout_copy(vsa):
+    """Since round 3 the kernel-layout weight images (fragment-major fp32 / fp16x3, bf16 LDS images, dgrad transposes)
+    are rebuilt LAZILY, per family, by the first call that reads them after a ``vs_weights_update``: every compute mode
+    and the backward must see an in-place parameter write (optimizer step) exactly like a freshly packed module does."""
+    sd = vsa.synth.make_state_dict(256, 2, 9)
+    x_small = vsa.synth.make_features(1, 90, 3, "randn").to(_dev())          # latency kernels (fragment-major copies)
+    x_big = vsa.synth.make_features(20, 1024, 4, "randn").to(_dev())        # 20480 rows: LDS-tiled kernels
+
+    def fresh(state):
+        mm = vsa.SimNet(num_heads=4, d_model=256, num_layers=2, sparsity=0.0, dropout=0.0)
+        mm.load_state_dict(state)
+        return mm.to(_dev()).eval()
+
+    m = fresh(sd)
+    with torch.no_grad():
+        for mode in ("fp32", "fp16x3", "bf16"):                                 # build every family once
+            m.set_compute_dtype(mode)
+            m(x_small); m(x_big)
+        for name, prm in m.named_parameters():                                  # an "optimizer step": in-place writes
+            prm.add_(0.01 * torch.randn_like(prm))
+        sd2 = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+        ref = fresh(sd2)
+        for mode in ("fp32", "fp16x3", "bf16"):
+            m.set_compute_dtype(mode); ref.set_compute_dtype(mode)
+            for xx in (x_small, x_big):
+                a, ha = m(xx)
+                b, hb = ref(xx)
+                assert torch.equal(a, b) and torch.equal(ha, hb), mode
+    # backward after an update: gradients equal a fresh module's
+    m.set_compute_dtype("fp32"); ref.set_compute_dtype("fp32")
+    grads = []
+    for mod in (m, ref):
+        mod.train()
+        mod.zero_grad(set_to_none=True)
+        p1, _ = mod(x_small)
+        p1.square().mean().backward()
+        grads.append([p.grad.clone() for p in mod.parameters()])
+    for ga, gb in zip(*grads):
+        assert torch.equal(ga, gb)
+
+
 def test_training_has_no_cpu_fallback(vsa):
     m = vsa.SimNet(num_heads=4, d_model=256, num_layers=1).train()
     with pytest.raises(RuntimeError, match="HIP"):

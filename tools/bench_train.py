@@ -59,6 +59,20 @@ for shape in args.shapes.split(","):
         m.zero_grad(set_to_none=True)
         loss.backward()
 
+    # the reference's whole train_step (train.py:111-131): autocast forward, masked MSE, GradScaler, Adam - every step
+    # re-packs the parameters the optimizer wrote (vs_weights_update) and rebuilds the dgrad transposes
+    optim = torch.optim.Adam(m.parameters(), lr=1e-5, weight_decay=1e-5)
+    scaler = torch.amp.GradScaler("cuda")
+
+    def full_step():
+        with torch.autocast("cuda"):
+            pred, _ = m(x, mask)
+            loss = pkg.mse_with_mask_loss(pred, target, mask)
+        optim.zero_grad(set_to_none=True)
+        scaler.scale(loss).backward()
+        scaler.step(optim)
+        scaler.update()
+
     def fwd_only():
         pred, _ = m(x, mask)
         return pred
@@ -68,11 +82,12 @@ for shape in args.shapes.split(","):
     m.train()
     f = timed(fwd_only, args.iters)
     s = timed(step, args.iters)
+    fs = timed(full_step, args.iters)
     flops_f = B * T * (2 * 1024 * d + L * (24 * d * d + 4 * T * d))
     # backward: 2x the Linear flops (dgrad + wgrad) + 3.5x the attention flops (7 products for the forward's 2)
     flops_b = B * T * (2 * 2 * 1024 * d + L * (2 * 24 * d * d + 14 * T * d)) - B * T * 2 * 1024 * d   # no input gradient
-    line = "B=%3d T=%4d  scoring fwd %.3f ms | train fwd %.3f ms | fwd+loss+bwd %.3f ms (bwd %.3f ms) | %.1f TF fwd, %.1f TF bwd, %.0f frames/s trained" % (
-        B, T, ev, f, s, s - f, flops_f / f / 1e9, flops_b / (s - f) / 1e9, B * T / s * 1e3)
+    line = "B=%3d T=%4d  scoring fwd %.3f ms | train fwd %.3f ms | fwd+loss+bwd %.3f ms (bwd %.3f ms) | %.1f TF fwd, %.1f TF bwd, %.0f frames/s | WHOLE train_step (autocast + GradScaler + Adam + re-pack) %.3f ms = %.0f frames/s trained" % (
+        B, T, ev, f, s, s - f, flops_f / f / 1e9, flops_b / (s - f) / 1e9, B * T / s * 1e3, fs, B * T / fs * 1e3)
     if args.torch:
         import torch_ref
         params = {k: v.to(dev).clone().requires_grad_(v.dtype.is_floating_point and "pos_embedding" not in k) for k, v in sd.items()}

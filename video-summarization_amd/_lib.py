@@ -31,7 +31,7 @@ VS_FLAG_F16X3_ATTENTION = 16
 # every symbol include/vs_scorer.h declares
 EXPORTS = ("vs_abi_version", "vs_last_error", "vs_weights_pack", "vs_weights_free", "vs_weights_update", "vs_set_option",
            "vs_scorer_workspace_bytes", "vs_scorer_forward", "vs_scorer_workspace_bytes_packed",
-           "vs_scorer_forward_packed", "vs_linear_f32", "vs_qkv_proj_f32",
+           "vs_scorer_forward_packed", "vs_scorer_workspace_bytes_cls", "vs_scorer_forward_cls", "vs_linear_f32", "vs_qkv_proj_f32",
            "vs_attention_f32", "vs_attention_bf16", "vs_attention_f16x3", "vs_linear_residual_layernorm_f32",
            "vs_linear_bf16", "vs_linear_residual_layernorm_bf16", "vs_linear_f16x3",
            "vs_linear_residual_layernorm_f16x3", "vs_mlp_block_bf16",
@@ -40,7 +40,7 @@ EXPORTS = ("vs_abi_version", "vs_last_error", "vs_weights_pack", "vs_weights_fre
 EVAL_EXPORTS = ("vs_eval_upsample", "vs_eval_knapsack", "vs_eval_generate_summary", "vs_eval_fscore",
                 "vs_eval_rank_correlation")
 # include/vs_train.h
-TRAIN_EXPORTS = ("vs_train_saved_bytes", "vs_train_workspace_bytes", "vs_train_forward", "vs_train_backward",
+TRAIN_EXPORTS = ("vs_train_prepare", "vs_train_saved_bytes", "vs_train_workspace_bytes", "vs_train_forward", "vs_train_backward",
                  "vs_mse_mask_loss_forward", "vs_mse_mask_loss_backward", "vs_train_attention_forward",
                  "vs_train_attention_backward", "vs_train_wgrad_scratch_floats", "vs_train_wgrad",
                  "vs_train_dropout_mask_attention", "vs_train_dropout_mask_rows", "vs_train_dropout_site", "vs_train_saved_field",
@@ -183,6 +183,11 @@ def load() -> C.CDLL:
         lib.vs_scorer_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                           C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                           C.c_void_p]
+        lib.vs_scorer_workspace_bytes_cls.restype = C.c_size_t
+        lib.vs_scorer_workspace_bytes_cls.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+        lib.vs_scorer_forward_cls.restype = C.c_int
+        lib.vs_scorer_forward_cls.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                              C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         lib.vs_scorer_workspace_bytes_packed.restype = C.c_size_t
         lib.vs_scorer_workspace_bytes_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
         lib.vs_scorer_forward_packed.restype = C.c_int
@@ -223,6 +228,8 @@ def load() -> C.CDLL:
         lib.vs_eval_rank_correlation.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_double),
                                                  C.POINTER(C.c_double)]
         # include/vs_train.h
+        lib.vs_train_prepare.restype = C.c_int
+        lib.vs_train_prepare.argtypes = [C.c_void_p, C.c_void_p]
         lib.vs_train_saved_bytes.restype = C.c_size_t
         lib.vs_train_saved_bytes.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
         lib.vs_train_workspace_bytes.restype = C.c_size_t

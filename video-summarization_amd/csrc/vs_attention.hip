@@ -817,11 +817,21 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_lp_pipe(
 // VARLEN (packed ragged batches, vs_scorer_forward_packed): the videos' frames are concatenated ([Mtot, .] rows,
 // video b = rows cu[b] .. cu[b+1]), q/k/v are head-major over the packed rows ([H][Mtot][DH]) and the grid is
 // (work items, heads) with work[w] = (video, query tile): T, the operand bases and the output rows are per block.
-template <int DH, bool HAS_MASK, int NW, bool VARLEN = false>
+// DIAG (diagnostic library only, tools/diag_attention.py): per-wave s_memtime stamps around the phases of a tile ->
+// diag[(block * NW + wave) * 16 + ..]: 0 prologue, 1 barrier A, 2 half-step A (S' of block 1 || softmax of block 0),
+// 3 P.V of block 0, 4 barrier B, 5 half-step B, 6 P.V of block 1, 7 epilogue, 8 total cycles, 9 / 10 wall clock
+// (100 MHz) at wave start / end, 11 tiles, 12 Q fetch (inside 0)
+template <int DH, bool HAS_MASK, int NW, bool VARLEN = false, int DIAG = 0>
 __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_pipe(
     const float *__restrict__ Q, const float *__restrict__ Kg, const float *__restrict__ Vg,
     const uint8_t *__restrict__ mask, float *__restrict__ out, int H, int T, float scale_log2e, int BH,
-    const int *__restrict__ cu = nullptr, const int2 *__restrict__ work = nullptr, int Mtot = 0) {
+    const int *__restrict__ cu = nullptr, const int2 *__restrict__ work = nullptr, int Mtot = 0,
+    unsigned long long *__restrict__ diag = nullptr) {
+    unsigned long long dg[13] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull}, tbeg = 0, tl = 0;
+    if constexpr (DIAG != 0) { dg[9] = __builtin_amdgcn_s_memrealtime(); tbeg = vs_stamp(); tl = tbeg; }
+    auto lap = [&](int slot) __attribute__((always_inline)) {
+        if constexpr (DIAG != 0) { const unsigned long long t = vs_stamp(); dg[slot] += t - tl; tl = t; }
+    };
     constexpr int KT = 64, LD = DH + 4, NJ = DH / 8, ND = DH / 32;
     constexpr int NT = 64 * NW;                     // threads per block
     constexpr int F4 = KT * DH / 4 / NT;            // float4 per thread per operand tile
@@ -874,6 +884,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_pipe(
             for (int s = 0; s < 4; ++s) qreg[4 * j + s] = v[s] * scale_log2e;
         }
     }
+    lap(12);
     __syncthreads();                                 // Q corners are read; K/V staging may overwrite them
     f32x16 o[ND];
 #pragma unroll
@@ -1055,12 +1066,16 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_pipe(
         const float *Ks = smem + buf * 2 * TILE, *Vs = Ks + TILE;
         const float *Kn = smem + (buf ^ 1) * 2 * TILE;
         __syncthreads();                       // everyone is done with buffer buf^1 (tile t-1)
+        lap(1);
         // S' of block (t,1)  ||  softmax of block (t,0), LDS writes of tile t+1, loads of tile t+2
         mb_nxt = (m_run == NEG_INF) ? 0.f : m_run;
         half_step(Ks, 1, s_nxt, mb_nxt, s_cur, mb_cur, mbs + buf * KT, Vs, 0, masked_tag, std::integral_constant<bool, !LAST>{},
                   buf ^ 1, t + 2 < ntiles ? t + 2 : ntiles - 1);
+        lap(2);
         pv_acc(s_cur);
+        lap(3);
         __syncthreads();                       // tile t+1 is visible in buffer buf^1
+        lap(4);
         if constexpr (!LAST) {
             // S' of block (t+1,0)  ||  softmax of block (t,1)
             mb_cur = (m_run == NEG_INF) ? 0.f : m_run;
@@ -1068,8 +1083,11 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_pipe(
         } else {
             softmax_only(s_nxt, mb_nxt, mbs + buf * KT + 32, Vs, 1, masked_tag);
         }
+        lap(5);
         pv_acc(s_nxt);
+        lap(6);
     };
+    lap(0);
     // without a mask only the ragged last tile carries dead keys
     for (int t = 0; t + 1 < ntiles; ++t) tile_step(t, std::integral_constant<bool, HAS_MASK>{}, std::false_type{});
     if (HAS_MASK || (T % KT) != 0) tile_step(ntiles - 1, std::true_type{}, std::true_type{});
@@ -1098,9 +1116,33 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_pipe(
             if (q < T) *(f32x4 *)(out + (orow0 + q) * (H * DH) + head * DH + oc4) = v;
         }
     }
+    if constexpr (DIAG != 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the stores have left the wave
+        lap(7);
+        dg[8] = tl - tbeg; dg[10] = __builtin_amdgcn_s_memrealtime(); dg[11] = (unsigned long long)ntiles;
+        dg[0] -= dg[12];
+        if (diag != nullptr && lane == 0) {
+            unsigned long long *o = diag + ((size_t)blockIdx.x * NW + wave) * 16;
+#pragma unroll
+            for (int i = 0; i < 13; ++i) o[i] = dg[i];
+        }
+    }
 }
 
 }  // namespace
+
+#ifdef VS_WITH_DIAG
+// tools/diag_attention.py: the stamped instantiation of the exact head-dim-64 kernel (8-wave blocks, no mask)
+int vsk_diag_attention(const float *q, const float *k, const float *v, float *out, int B, int H, int T, float scale,
+                       unsigned long long *diag, hipStream_t st) {
+    const int BH = B * H, nq = (T + 255) / 256;
+    dim3 g(8 * ((BH + 7) / 8) * nq);
+    hipLaunchKernelGGL((attn_fwd_pipe<64, false, 8, false, 1>), g, dim3(512), 0, st, q, k, v, nullptr, out, H, T,
+                       scale * 1.4426950408889634f, BH, nullptr, nullptr, 0, diag);
+    VSK_CHECK_LAUNCH();
+    return (int)g.x;     // > 0: blocks launched (the caller sizes / reads diag[blocks * 8 * 16])
+}
+#endif
 
 float vsk_attention_qscale(float scale) { return scale * 1.4426950408889634f; }
 
@@ -1125,7 +1167,7 @@ int vsk_attention(const float *q, const float *k, const float *v, const uint8_t 
         const int nq = wide ? r8 / 256 : r4 / 128;
         dim3 g(8 * ((BH + 7) / 8) * nq), blk(wide ? 512 : 256);
 #define VSK_ATTN(DH_, MASK_, NW_) \
-    hipLaunchKernelGGL((attn_fwd_pipe<DH_, MASK_, NW_, false>), g, blk, 0, st, q, k, v, mask, out, H, T, sl2, BH, nullptr, nullptr, 0)
+    hipLaunchKernelGGL((attn_fwd_pipe<DH_, MASK_, NW_, false>), g, blk, 0, st, q, k, v, mask, out, H, T, sl2, BH, nullptr, nullptr, 0, nullptr)
         if (dh == 32) {
             if (mask) { if (wide) VSK_ATTN(32, true, 8); else VSK_ATTN(32, true, 4); }
             else      { if (wide) VSK_ATTN(32, false, 8); else VSK_ATTN(32, false, 4); }
@@ -1152,7 +1194,7 @@ int vsk_attention_packed(const float *q, const float *k, const float *v, float *
     dim3 grid(nwork, H);
     const int2 *wk = (const int2 *)work;
 #define VSK_ATTN_PX(DH_, NW_) \
-    hipLaunchKernelGGL((attn_fwd_pipe<DH_, false, NW_, true>), grid, dim3(64 * NW_), 0, st, q, k, v, nullptr, out, H, 0, sl2, 0, cu, wk, Mtot)
+    hipLaunchKernelGGL((attn_fwd_pipe<DH_, false, NW_, true>), grid, dim3(64 * NW_), 0, st, q, k, v, nullptr, out, H, 0, sl2, 0, cu, wk, Mtot, nullptr)
 #define VSK_ATTN_PE(DH_, NW_, P_) \
     hipLaunchKernelGGL((attn_fwd_lp_pipe<DH_, NW_, P_, true>), grid, dim3(64 * NW_), 0, st, q, k, v, nullptr, out, H, 0, sl2, 0, cu, wk, Mtot)
 #define VSK_ATTN_P16(DH_, NW_) \

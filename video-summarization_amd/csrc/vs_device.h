@@ -117,4 +117,16 @@ __device__ __forceinline__ float half_sum(float v) {   // sum over the 32 lanes 
 
 }  // namespace
 
+// Diagnostic stamps (cdna guide section 7 "In-kernel stamps"): used only by the DIAG instantiations of the diagnostic
+// library (-DVS_WITH_DIAG, tools/); no product launch executes a stamp.  The wait also drains the wave's LDS reads.
+namespace {
+__device__ __forceinline__ unsigned long long vs_stamp() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+}  // namespace
+
 #define VSK_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)

@@ -39,6 +39,8 @@ int vsk_linear_res_ln(const float *A, const float *W, const float *Wf, const flo
 int vsk_rows_res_ln(const float *a, const float *res, const float *gamma, const float *beta, float *out, int M, int d,
                     const float *score_w, const float *score_b, int num_classes, int sigmoid, float *scores,
                     hipStream_t st);
+int vsk_diag_attention(const float *q, const float *k, const float *v, float *out, int B, int H, int T, float scale,
+                       unsigned long long *diag, hipStream_t st);      // diagnostic library only; returns the blocks launched
 int vsk_diag_gemm(const float *A, const float *W, const float *bias, float *C, int M, int N, int K,
                   int grid, unsigned long long *diag, hipStream_t st);
 // fc1 + ReLU + fc2 + residual + LayerNorm (+ score head) in one kernel; d_model == 256 only (-1 otherwise)
@@ -79,6 +81,18 @@ int vsk_mlp_bf16(const float *h, const void *att16, const float *bo, const float
 // the positional rows pe[t] of every frame into rows[Mtot, d]
 int vsk_plan_packed(const int *lengths_dev, int B, int qb, int *cu, int *work, int work_cap, hipStream_t st);   // work_cap: (video, tile) pairs `work` can hold
 int vsk_gather_rows(const float *pe, const int *cu, int B, int tmax, int d, float *rows, hipStream_t st);
+// up to VSK_COPY_MAX_SEGS device-to-device float copies in ONE launch (vs_weights_pack / _update)
+enum { VSK_COPY_MAX_SEGS = 20 };
+struct VskCopySegs {
+    const float *src[VSK_COPY_MAX_SEGS];
+    float *dst[VSK_COPY_MAX_SEGS];
+    unsigned n[VSK_COPY_MAX_SEGS];       // floats
+    int count;
+};
+int vsk_copy_segments(const VskCopySegs &segs, hipStream_t st);
+// use_cls=True: h [B, T+1, d] = class token row + the embedded frames e [B, T, d]; mask1 [B, T+1] (or both nullptr)
+int vsk_insert_cls(const float *e, const float *cls, const uint8_t *mask, float *h, uint8_t *mask1, int B, int T, int d,
+                   hipStream_t st);
 int vsk_skinny_max_rows();      // rows up to which the skinny (latency) kernels are used
 
 // A/B and test switches (DESIGN.md "Environment switches").  Read from the environment ONCE, when the library is

@@ -45,15 +45,9 @@ struct EpiArgs {              // extra epilogue operands of EPI_GATE / EPI_RELU_
     float scale;
 };
 
-// Diagnostic stamps (cdna guide §7 "In-kernel stamps"): compiled only into the DIAG instantiation,
-// which is reachable only through vs_diag_gemm(); no product launch executes a stamp.
-__device__ __forceinline__ unsigned long long stamp() {
-    unsigned long long t;
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-    __builtin_amdgcn_sched_barrier(0);
-    return t;
-}
+// Diagnostic stamps: vs_stamp() of vs_device.h; compiled only into the DIAG instantiation, which is reachable only
+// through vs_diag_gemm(); no product launch executes a stamp.
+__device__ __forceinline__ unsigned long long stamp() { return vs_stamp(); }
 
 // NWM = waves along M (block = NWM x 2 waves, tile = 64*NWM x 128).  NWM = 4: one 8-wave block per CU -
 // the two waves of every SIMD then belong to the same block and are coupled by its barriers, so neither
@@ -1678,6 +1672,38 @@ __global__ __launch_bounds__(256) void gather_rows(const float *__restrict__ pe,
     }
 }
 
+// segment blockIdx.y of a batch of plain float copies; 16-byte accesses where both ends and the length allow
+__global__ __launch_bounds__(256) void copy_segments(const VskCopySegs s) {
+    const int g = blockIdx.y;
+    const float *src = s.src[g];
+    float *dst = s.dst[g];
+    const unsigned n = s.n[g];
+    if ((((uintptr_t)src | (uintptr_t)dst) & 15) == 0 && (n & 3) == 0) {
+        for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < n / 4; i += gridDim.x * 256)
+            ((f32x4 *)dst)[i] = ((const f32x4 *)src)[i];
+    } else {
+        for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) dst[i] = src[i];
+    }
+}
+
+// use_cls=True (reference simnet.py:214-216, 47-51): h[b, 0, :] = class token, h[b, 1 + t, :] = e[b, t, :], and the key
+// mask gets a leading "not padding" entry per video.  grid = (ceil((T + 1) / 64), B)
+__global__ __launch_bounds__(256) void insert_cls(const float *__restrict__ e, const float *__restrict__ cls,
+                                                   const uint8_t *__restrict__ mask, float *__restrict__ h,
+                                                   uint8_t *__restrict__ mask1, int T, int d) {
+    const int b = blockIdx.y, f4 = d / 4, T1 = T + 1;
+    for (int idx = threadIdx.x; idx < 64 * f4; idx += 256) {
+        const int t = blockIdx.x * 64 + idx / f4, c = (idx % f4) * 4;
+        if (t < T1)
+            *(f32x4 *)(h + ((size_t)b * T1 + t) * d + c) =
+                t == 0 ? *(const f32x4 *)(cls + c) : *(const f32x4 *)(e + ((size_t)b * T + t - 1) * d + c);
+    }
+    if (mask1 != nullptr && threadIdx.x < 64) {
+        const int t = blockIdx.x * 64 + threadIdx.x;
+        if (t < T1) mask1[(size_t)b * T1 + t] = t == 0 ? 0 : mask[(size_t)b * T + t - 1];
+    }
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------
@@ -1714,6 +1740,21 @@ int vsk_plan_packed(const int *lengths_dev, int B, int qb, int *cu, int *work, i
 
 int vsk_gather_rows(const float *pe, const int *cu, int B, int tmax, int d, float *rows, hipStream_t st) {
     hipLaunchKernelGGL(gather_rows, dim3((tmax + 63) / 64, B), dim3(256), 0, st, pe, cu, d, rows);
+    VSK_CHECK_LAUNCH();
+    return 0;
+}
+
+int vsk_copy_segments(const VskCopySegs &segs, hipStream_t st) {
+    if (segs.count <= 0 || segs.count > VSK_COPY_MAX_SEGS) return -1;
+    hipLaunchKernelGGL(copy_segments, dim3(64, segs.count), dim3(256), 0, st, segs);
+    VSK_CHECK_LAUNCH();
+    return 0;
+}
+
+int vsk_insert_cls(const float *e, const float *cls, const uint8_t *mask, float *h, uint8_t *mask1, int B, int T, int d,
+                   hipStream_t st) {
+    if (d % 4) return -1;
+    hipLaunchKernelGGL(insert_cls, dim3((T + 1 + 63) / 64, B), dim3(256), 0, st, e, cls, mask, h, mask1, T, d);
     VSK_CHECK_LAUNCH();
     return 0;
 }

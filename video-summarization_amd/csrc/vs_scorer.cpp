@@ -152,73 +152,95 @@ int vs_abi_version(void) { return VS_ABI_VERSION; }
 
 const char *vs_last_error(void) { return g_err.c_str(); }
 
-// copies the parameters into w->blob and rebuilds the fragment-major copies (all stream-ordered on `st`)
-static int fill_weights(vs_weights *w, const vs_model_params *params, hipStream_t st) {
+// copies the parameters into w->blob (stream-ordered on `st`): one batched copy kernel for the embedding / head and
+// one per encoder layer instead of 16 hipMemcpyAsync per layer (an optimizer step re-packs on every iteration).
+// params->pos_embedding == NULL on an UPDATE keeps the table already packed (it is a buffer: an optimizer never writes it).
+static int fill_weights(vs_weights *w, const vs_model_params *params, hipStream_t st, bool update) {
     const vs_model_desc *desc = &w->desc;
     const size_t d = desc->d_model, din = desc->in_features, nc = desc->num_classes;
     if (!params->embed_w || !params->embed_b || !params->final_w || !params->final_b ||
         (desc->num_layers > 0 && !params->layers))
         return fail(VS_ERR_INVALID, "a required parameter pointer is NULL");
-    if ((params->pos_embedding != nullptr) != (desc->max_len > 0))
+    if ((params->pos_embedding != nullptr) != (desc->max_len > 0) && !(update && !params->pos_embedding))
         return fail(VS_ERR_INVALID, "pos_embedding / max_len mismatch");
-    auto copy = [&](size_t dst, const float *src, size_t n) -> hipError_t {
-        if (!src) return hipErrorInvalidValue;
-        return hipMemcpyAsync(w->blob + dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, st);
-    };
+    VskCopySegs segs{};
     bool ok = true;
-    ok &= copy(w->embed_w, params->embed_w, d * din) == hipSuccess;
-    ok &= copy(w->embed_b, params->embed_b, d) == hipSuccess;
-    if (w->has_pe) ok &= copy(w->pe, params->pos_embedding, (size_t)desc->max_len * d) == hipSuccess;
-    for (int l = 0; l < desc->num_layers; ++l) {
+    auto add = [&](size_t dst, const float *src, size_t n) {
+        if (!src || segs.count >= VSK_COPY_MAX_SEGS) { ok = false; return; }
+        segs.src[segs.count] = src; segs.dst[segs.count] = w->blob + dst; segs.n[segs.count] = (unsigned)n; ++segs.count;
+    };
+    auto flush = [&]() { if (ok && segs.count) ok = vsk_copy_segments(segs, st) == 0; segs.count = 0; };
+    add(w->embed_w, params->embed_w, d * din);
+    add(w->embed_b, params->embed_b, d);
+    add(w->final_w, params->final_w, nc * d);
+    add(w->final_b, params->final_b, nc);
+    flush();
+    if (w->has_pe && params->pos_embedding)
+        ok &= hipMemcpyAsync(w->blob + w->pe, params->pos_embedding, (size_t)desc->max_len * d * sizeof(float),
+                             hipMemcpyDeviceToDevice, st) == hipSuccess;
+    for (int l = 0; l < desc->num_layers && ok; ++l) {
         const vs_layer_params &P = params->layers[l];
         const LayerOff &L = w->layers[l];
-        ok &= copy(L.wqkv, P.wq, d * d) == hipSuccess;
-        ok &= copy(L.wqkv + d * d, P.wk, d * d) == hipSuccess;
-        ok &= copy(L.wqkv + 2 * d * d, P.wv, d * d) == hipSuccess;
-        ok &= copy(L.bqkv, P.bq, d) == hipSuccess;
-        ok &= copy(L.bqkv + d, P.bk, d) == hipSuccess;
-        ok &= copy(L.bqkv + 2 * d, P.bv, d) == hipSuccess;
-        ok &= copy(L.wo, P.wo, d * d) == hipSuccess;
-        ok &= copy(L.bo, P.bo, d) == hipSuccess;
-        ok &= copy(L.ln1g, P.ln1_g, d) == hipSuccess;
-        ok &= copy(L.ln1b, P.ln1_b, d) == hipSuccess;
-        ok &= copy(L.w1, P.w1, 4 * d * d) == hipSuccess;
-        ok &= copy(L.b1, P.b1, 4 * d) == hipSuccess;
-        ok &= copy(L.w2, P.w2, 4 * d * d) == hipSuccess;
-        ok &= copy(L.b2, P.b2, d) == hipSuccess;
-        ok &= copy(L.ln2g, P.ln2_g, d) == hipSuccess;
-        ok &= copy(L.ln2b, P.ln2_b, d) == hipSuccess;
+        add(L.wqkv, P.wq, d * d); add(L.wqkv + d * d, P.wk, d * d); add(L.wqkv + 2 * d * d, P.wv, d * d);
+        add(L.bqkv, P.bq, d);     add(L.bqkv + d, P.bk, d);         add(L.bqkv + 2 * d, P.bv, d);
+        add(L.wo, P.wo, d * d);   add(L.bo, P.bo, d);
+        add(L.ln1g, P.ln1_g, d);  add(L.ln1b, P.ln1_b, d);
+        add(L.w1, P.w1, 4 * d * d); add(L.b1, P.b1, 4 * d);
+        add(L.w2, P.w2, 4 * d * d); add(L.b2, P.b2, d);
+        add(L.ln2g, P.ln2_g, d);  add(L.ln2b, P.ln2_b, d);
+        flush();
     }
-    ok &= copy(w->final_w, params->final_w, nc * d) == hipSuccess;
-    ok &= copy(w->final_b, params->final_b, nc) == hipSuccess;
     if (!ok)
-        return fail(VS_ERR_HIP, "parameter copy failed (NULL pointer or hipMemcpyAsync error: %s)",
+        return fail(VS_ERR_HIP, "parameter copy failed (NULL pointer or launch error: %s)",
                     hipGetErrorString(hipGetLastError()));
-    // fragment-major copies (stream-ordered after the copies above)
-    bool pk = vsk_pack_fragments(w->blob + w->embed_w, w->blob + w->f_embed_w, (int)d, (int)din, st) == 0;
-    for (const auto &L : w->layers) {
-        pk &= vsk_pack_fragments(w->blob + L.wqkv, w->blob + L.f_wqkv, (int)(3 * d), (int)d, st) == 0;
-        pk &= vsk_pack_fragments(w->blob + L.wo, w->blob + L.f_wo, (int)d, (int)d, st) == 0;
-        pk &= vsk_pack_fragments(w->blob + L.w1, w->blob + L.f_w1, (int)(4 * d), (int)d, st) == 0;
-        pk &= vsk_pack_fragments(w->blob + L.w2, w->blob + L.f_w2, (int)d, (int)(4 * d), st) == 0;
-    }
-    pk &= vsk_pack_fragments_f16x3(w->blob + w->embed_w, w->blob + w->h_embed_w, (int)d, (int)din, st) == 0;
-    for (const auto &L : w->layers) {
-        pk &= vsk_pack_fragments_f16x3(w->blob + L.wqkv, w->blob + L.h_wqkv, (int)(3 * d), (int)d, st) == 0;
-        pk &= vsk_pack_fragments_f16x3(w->blob + L.wo, w->blob + L.h_wo, (int)d, (int)d, st) == 0;
-        pk &= vsk_pack_fragments_f16x3(w->blob + L.w1, w->blob + L.h_w1, (int)(4 * d), (int)d, st) == 0;
-        pk &= vsk_pack_fragments_f16x3(w->blob + L.w2, w->blob + L.h_w2, (int)d, (int)(4 * d), st) == 0;
-    }
-    if (w->has_b_embed) pk &= vsk_pack_embed_bf16(w->blob + w->embed_w, w->blob + w->b_embed, (int)d, (int)din, st) == 0;
-    if (vsk_mlp_bf16_supported((int)d))
-        for (const auto &L : w->layers)
-        {
-            pk &= vsk_pack_mlp_bf16(w->blob + L.wo, w->blob + L.w1, w->blob + L.w2, w->blob + L.b_mlp, (int)d, st) == 0;
-            pk &= vsk_pack_qkv_bf16(w->blob + L.wqkv, w->blob + L.b_qkv, (int)d, st) == 0;
-        }
-    if (!pk) return fail(VS_ERR_HIP, "weight fragment packing failed: %s", hipGetErrorString(hipGetLastError()));
     return VS_OK;
 }
+
+}  // extern "C"
+
+namespace { std::mutex g_wmu; }
+
+// kernel-layout images, built on first use after each pack / update (see vs_weights_impl.h)
+int vsw_ensure(const vs_weights *w, unsigned families, void *stream) {
+    hipStream_t st = (hipStream_t)stream;
+    std::lock_guard<std::mutex> lk(g_wmu);
+    const size_t d = w->desc.d_model, din = w->desc.in_features;
+    float *blob = w->blob;
+    bool pk = true;
+    if ((families & VSW_FRAGMENTS) && w->f_version != w->version) {
+        pk &= vsk_pack_fragments(blob + w->embed_w, blob + w->f_embed_w, (int)d, (int)din, st) == 0;
+        for (const auto &L : w->layers) {
+            pk &= vsk_pack_fragments(blob + L.wqkv, blob + L.f_wqkv, (int)(3 * d), (int)d, st) == 0;
+            pk &= vsk_pack_fragments(blob + L.wo, blob + L.f_wo, (int)d, (int)d, st) == 0;
+            pk &= vsk_pack_fragments(blob + L.w1, blob + L.f_w1, (int)(4 * d), (int)d, st) == 0;
+            pk &= vsk_pack_fragments(blob + L.w2, blob + L.f_w2, (int)d, (int)(4 * d), st) == 0;
+        }
+        if (pk) w->f_version = w->version;
+    }
+    if ((families & VSW_F16X3) && w->h_version != w->version) {
+        pk &= vsk_pack_fragments_f16x3(blob + w->embed_w, blob + w->h_embed_w, (int)d, (int)din, st) == 0;
+        for (const auto &L : w->layers) {
+            pk &= vsk_pack_fragments_f16x3(blob + L.wqkv, blob + L.h_wqkv, (int)(3 * d), (int)d, st) == 0;
+            pk &= vsk_pack_fragments_f16x3(blob + L.wo, blob + L.h_wo, (int)d, (int)d, st) == 0;
+            pk &= vsk_pack_fragments_f16x3(blob + L.w1, blob + L.h_w1, (int)(4 * d), (int)d, st) == 0;
+            pk &= vsk_pack_fragments_f16x3(blob + L.w2, blob + L.h_w2, (int)d, (int)(4 * d), st) == 0;
+        }
+        if (pk) w->h_version = w->version;
+    }
+    if ((families & VSW_BF16) && w->b_version != w->version) {
+        if (w->has_b_embed) pk &= vsk_pack_embed_bf16(blob + w->embed_w, blob + w->b_embed, (int)d, (int)din, st) == 0;
+        if (vsk_mlp_bf16_supported((int)d))
+            for (const auto &L : w->layers) {
+                pk &= vsk_pack_mlp_bf16(blob + L.wo, blob + L.w1, blob + L.w2, blob + L.b_mlp, (int)d, st) == 0;
+                pk &= vsk_pack_qkv_bf16(blob + L.wqkv, blob + L.b_qkv, (int)d, st) == 0;
+            }
+        if (pk) w->b_version = w->version;
+    }
+    if (!pk) return fail(VS_ERR_HIP, "weight image packing failed: %s", hipGetErrorString(hipGetLastError()));
+    return VS_OK;
+}
+
+extern "C" {
 
 int vs_weights_pack(const vs_model_desc *desc, const vs_model_params *params, void *stream,
                     vs_weights **out) {
@@ -264,7 +286,7 @@ int vs_weights_pack(const vs_model_desc *desc, const vs_model_params *params, vo
     if (hipGetDevice(&w->device) != hipSuccess) { delete w; return fail(VS_ERR_HIP, "hipGetDevice failed"); }
     hipError_t e = hipMalloc((void **)&w->blob, off * sizeof(float));
     if (e != hipSuccess) { delete w; return fail(VS_ERR_HIP, "hipMalloc(%zu): %s", off * sizeof(float), hipGetErrorString(e)); }
-    if (int rc = fill_weights(w, params, (hipStream_t)stream)) {
+    if (int rc = fill_weights(w, params, (hipStream_t)stream, false)) {
         (void)hipFree(w->blob);
         delete w;
         return rc;
@@ -279,8 +301,8 @@ int vs_weights_update(vs_weights *w, const vs_model_params *params, void *stream
     int dev = -1;
     if (hipGetDevice(&dev) != hipSuccess || dev != w->device)
         return fail(VS_ERR_INVALID, "vs_weights_update on device %d, handle was packed on device %d", dev, w->device);
-    ++w->version;        // the training side rebuilds its transposed copies on next use
-    return fill_weights(w, params, (hipStream_t)stream);
+    ++w->version;        // every image family (and the training side's transposes) is rebuilt on its next use
+    return fill_weights(w, params, (hipStream_t)stream, true);
 }
 
 void vs_weights_free(vs_weights *w) {
@@ -309,14 +331,20 @@ struct PackedInfo {
     int prec;                // attention arithmetic: 0 exact fp32, 2 fp16x3
 };
 
+// cls != nullptr (use_cls=True, reference simnet.py:205-206, 214-216, 47-51): x has T frames per video, a class token
+// [d_model] is prepended AFTER the positional encoding, so the encoder sees T + 1 positions (the token is never
+// padding) and scores / hidden have T + 1 rows per video.
 int forward_core(const vs_weights *w, const float *x, const uint8_t *key_pad_mask, int32_t B,
                  int32_t T, uint32_t flags, float *scores, float *hidden, void *workspace,
-                 size_t workspace_bytes, void *stream, const PackedInfo *pk) {
+                 size_t workspace_bytes, void *stream, const PackedInfo *pk, const float *cls = nullptr) {
     if (!w || !x || !scores) return fail(VS_ERR_INVALID, "weights/x/scores is NULL");
     if (B <= 0 || T <= 0) return fail(VS_ERR_INVALID, "B=%d T=%d", B, T);
     const vs_model_desc &D = w->desc;
     if (!pk && w->has_pe && T > D.max_len)
         return fail(VS_ERR_INVALID, "T=%d exceeds the positional table (max_len=%d)", T, D.max_len);
+    if (cls && pk) return fail(VS_ERR_INVALID, "packed batches have no class-token form");
+    const int Tf = T;                   // frames per video (rows of x, positional rows)
+    if (cls) T += 1;                    // sequence length the encoder sees
     if ((long long)B * T > (1ll << 30)) return fail(VS_ERR_INVALID, "B*T too large");
     if ((flags & VS_FLAG_BF16_LINEAR) && D.d_model > 256)
         return fail(VS_ERR_INVALID, "VS_FLAG_BF16_LINEAR needs d_model <= 256 (got %d)", D.d_model);
@@ -327,11 +355,12 @@ int forward_core(const vs_weights *w, const float *x, const uint8_t *key_pad_mas
         return fail(VS_ERR_INVALID, "VS_FLAG_BF16_ATTENTION needs head_dim 32, 64 or 128, VS_FLAG_F16X3_ATTENTION 32 or 64 (got %d)", D.d_model / D.num_heads);
     if ((flags & VS_FLAG_BF16_ATTENTION) && (flags & VS_FLAG_F16X3_ATTENTION))
         return fail(VS_ERR_INVALID, "VS_FLAG_BF16_ATTENTION and VS_FLAG_F16X3_ATTENTION are exclusive");
-    const size_t need = vs_scorer_workspace_bytes(w, B, T);
+    const size_t need_core = vs_scorer_workspace_bytes(w, B, T);
+    const size_t need = need_core + (cls ? align_up((size_t)B * T, 256) : 0);       // + the [B, T+1] key mask
     if (!workspace || workspace_bytes < need)
         return fail(VS_ERR_WORKSPACE, "workspace %zu bytes < %zu needed", workspace_bytes, need);
-    if (((uintptr_t)workspace & 255) || ((uintptr_t)x & 15) || (hidden && ((uintptr_t)hidden & 15)))
-        return fail(VS_ERR_INVALID, "workspace must be 256-byte, x/hidden 16-byte aligned");
+    if (((uintptr_t)workspace & 255) || ((uintptr_t)x & 15) || (hidden && ((uintptr_t)hidden & 15)) || (cls && ((uintptr_t)cls & 15)))
+        return fail(VS_ERR_INVALID, "workspace must be 256-byte, x/hidden/cls_token 16-byte aligned");
 
     hipStream_t st = (hipStream_t)stream;
     const int d = D.d_model, H = D.num_heads, L = D.num_layers, M = B * T;
@@ -354,6 +383,11 @@ int forward_core(const vs_weights *w, const float *x, const uint8_t *key_pad_mas
     const int lbf = (flags & VS_FLAG_F16X3_LINEAR) ? 2 : ((flags & VS_FLAG_BF16_LINEAR) && M > lp_min_rows) ? 1 : 0;
     // the bf16 Linear + LayerNorm kernels stop at d_model 256 (validated above); fp16x3 has a wide variant too
     const int lnbf = lbf;
+    {   // kernel-layout weight images this forward reads, (re)built only if the parameters changed since their last use
+        const int rows_min = cls ? B * Tf : M;
+        const unsigned fam = lbf == 1 ? VSW_BF16 : rows_min > vsk_skinny_max_rows() ? 0u : lbf == 2 ? VSW_F16X3 : VSW_FRAGMENTS;
+        if (fam) if (int rc = vsw_ensure(w, fam, stream)) return rc;
+    }
     // bf16 mode: the tensors that are only ever read as bf16 matrix operands are WRITTEN as bf16 by their producers
     // (q * scale * log2 e, k, v; the attention output; the MLP hidden tensor) - same bits, half the HBM bytes
     const int aprec = pk ? pk->prec : (flags & VS_FLAG_F16X3_ATTENTION) ? 2 : (flags & VS_FLAG_BF16_ATTENTION) ? 1 : 0;
@@ -368,7 +402,15 @@ int forward_core(const vs_weights *w, const float *x, const uint8_t *key_pad_mas
     bool have_qkv = false;                  // q/k/v of the layer about to run were written by the kernel before it
     const float *pe_rows = pk ? pk->pe_rows : (w->has_pe ? w->p(w->pe) : nullptr);
     // Embedding + positional table (simnet.py:211, 237-238)
-    if (lbf == 1 && w->has_b_embed && qkv_fused && L > 0 && !vsk_options().lp_embed_unfused) {
+    if (cls) {
+        // frames through the embedding GEMM into a free region (h1), then token row + frames -> h0, mask -> mask'
+        StageScope ps(VS_STAGE_EMBED, st);
+        VS_LAUNCH(vsk_linear(x, w->p(w->embed_w), w->p(lbf == 2 ? w->h_embed_w : w->f_embed_w), w->p(w->embed_b), h1, B * Tf, d,
+                             D.in_features, 0, pe_rows, Tf, lbf, st));
+        uint8_t *mask1 = key_pad_mask ? (uint8_t *)workspace + need_core : nullptr;
+        VS_LAUNCH(vsk_insert_cls(h1, cls, key_pad_mask, h0, mask1, B, Tf, d, st));
+        key_pad_mask = mask1;
+    } else if (lbf == 1 && w->has_b_embed && qkv_fused && L > 0 && !vsk_options().lp_embed_unfused) {
         StageScope ps(VS_STAGE_EMBED, st);
         const LayerOff &N = w->layers[0];
         const VskNextQkv nq{w->p(N.b_qkv), w->p(N.bqkv), qkv, T, H, vsk_attention_qscale(scale)};
@@ -480,6 +522,18 @@ int vs_scorer_forward(const vs_weights *w, const float *x, const uint8_t *key_pa
                       int32_t T, uint32_t flags, float *scores, float *hidden, void *workspace,
                       size_t workspace_bytes, void *stream) {
     return forward_core(w, x, key_pad_mask, B, T, flags, scores, hidden, workspace, workspace_bytes, stream, nullptr);
+}
+
+size_t vs_scorer_workspace_bytes_cls(const vs_weights *w, int32_t B, int32_t T) {
+    if (!w || B <= 0 || T <= 0) return 0;
+    return vs_scorer_workspace_bytes(w, B, T + 1) + align_up((size_t)B * (T + 1), 256);
+}
+
+int vs_scorer_forward_cls(const vs_weights *w, const float *x, const uint8_t *key_pad_mask, const float *cls_token,
+                          int32_t B, int32_t T, uint32_t flags, float *scores, float *hidden, void *workspace,
+                          size_t workspace_bytes, void *stream) {
+    if (!cls_token) return fail(VS_ERR_INVALID, "cls_token is NULL");
+    return forward_core(w, x, key_pad_mask, B, T, flags, scores, hidden, workspace, workspace_bytes, stream, nullptr, cls_token);
 }
 
 // ---- packed ragged batches ----
@@ -613,6 +667,13 @@ int vs_diag_gemm(const float *A, const float *W, const float *bias, float *C, in
     VS_LAUNCH(vsk_diag_gemm(A, W, bias, C, M, N, K, grid, diag, (hipStream_t)stream));
     return VS_OK;
 }
+// Diagnostic entry: exact head-dim-64 attention with per-phase s_memtime stamps; returns the number of blocks (> 0) or
+// -status.  diag: [blocks * 8 waves][16] u64 (layout: vs_attention.hip, attn_fwd_pipe DIAG).
+int vs_diag_attention(const float *q, const float *k, const float *v, float *out, int32_t B, int32_t H, int32_t T,
+                      float scale, unsigned long long *diag, void *stream) {
+    const int blocks = vsk_diag_attention(q, k, v, out, B, H, T, scale, diag, (hipStream_t)stream);
+    return blocks;
+}
 #endif  // VS_WITH_DIAG
 
 static int linear_entry(const float *A, const float *W, const float *bias, float *C, int32_t M, int32_t N,
@@ -644,6 +705,7 @@ int vs_mlp_block_bf16(const vs_weights *w, int32_t layer, const float *h, float 
     if (with_head && !scores) return fail(VS_ERR_INVALID, "scores is NULL");
     if (((uintptr_t)h & 15) || ((uintptr_t)out & 15)) return fail(VS_ERR_INVALID, "h/out must be 16-byte aligned");
     const LayerOff &P = w->layers[layer];
+    if (int rc = vsw_ensure(w, VSW_BF16, stream)) return rc;
     VS_LAUNCH(vsk_mlp_bf16(h, nullptr, nullptr, nullptr, nullptr, w->p(P.b_mlp), w->p(P.b1), w->p(P.b2), w->p(P.ln2g), w->p(P.ln2b), out, M,
                            w->desc.d_model, with_head ? w->p(w->final_w) : nullptr, with_head ? w->p(w->final_b) : nullptr,
                            w->desc.num_classes, sigmoid, with_head ? scores : nullptr, nullptr, (hipStream_t)stream));

@@ -107,8 +107,10 @@ int check_common(const vs_weights *w, const float *x, int B, int T, const vs_dro
 
 std::mutex g_tmu;
 
-// W^T copies for the dgrad GEMMs + a zero "bias"; rebuilt when the handle's parameters changed
-int ensure_transposed(vs_weights *w, hipStream_t st) {
+// W^T copies for the dgrad GEMMs + a zero "bias"; rebuilt when the handle's parameters changed.  `frags`: also the
+// fragment-major copies of W^T (only the latency kernels, rows <= VS_SKINNY_ROWS, read them).  The buffer is allocated
+// by the first call: vs_train_prepare() lets a caller do that outside its backward pass.
+int ensure_transposed(vs_weights *w, hipStream_t st, bool frags) {
     std::lock_guard<std::mutex> lk(g_tmu);
     const size_t d = w->desc.d_model, din = w->desc.in_features;
     if (!w->tblob) {
@@ -126,12 +128,15 @@ int ensure_transposed(vs_weights *w, hipStream_t st) {
         VST_HIP(hipMalloc((void **)&w->tblob, off * sizeof(float)));
         VST_HIP(hipMemsetAsync(w->tblob + w->zeros, 0, nz * sizeof(float), st));
         w->t_version = ~0ull;
+        w->tf_version = ~0ull;
     }
-    if (w->t_version == w->version) return VS_OK;
-    // W [N,K] -> W^T [K,N] row-major, and its fragment-major copy for the latency kernels (as vs_weights_pack does for W)
+    // W [N,K] -> W^T [K,N] row-major, and its fragment-major copy for the latency kernels (as vsw_ensure does for W)
+    const bool do_t = w->t_version != w->version, do_f = frags && w->tf_version != w->version;
+    if (!do_t && !do_f) return VS_OK;
     auto both = [&](const float *W, size_t t_off, size_t tf_off, int N, int K) -> int {
-        if (int rc = vst_transpose(W, w->tblob + t_off, N, K, st)) return rc;
-        return vsk_pack_fragments(w->tblob + t_off, w->tblob + tf_off, K, N, st);
+        if (do_t) if (int rc = vst_transpose(W, w->tblob + t_off, N, K, st)) return rc;
+        if (do_f) return vsk_pack_fragments(w->tblob + t_off, w->tblob + tf_off, K, N, st);
+        return 0;
     };
     VST_LAUNCH(both(w->p(w->embed_w), w->t_embed_w, w->tf_embed_w, (int)d, (int)din));                       // [d,din] -> [din,d]
     for (int l = 0; l < w->desc.num_layers; ++l) {
@@ -142,13 +147,22 @@ int ensure_transposed(vs_weights *w, hipStream_t st) {
         VST_LAUNCH(both(w->p(P.w1), Q.t_w1, Q.tf_w1, (int)(4 * d), (int)d));                                 // [4d,d] -> [d,4d]
         VST_LAUNCH(both(w->p(P.w2), Q.t_w2, Q.tf_w2, (int)d, (int)(4 * d)));                                 // [d,4d] -> [4d,d]
     }
-    w->t_version = w->version;
+    if (do_t) w->t_version = w->version;
+    if (do_f) w->tf_version = w->version;
     return VS_OK;
 }
 
 }  // namespace
 
 extern "C" {
+
+int vs_train_prepare(vs_weights *w, void *stream) {
+    if (!w) return failf(VS_ERR_INVALID, "weights is NULL");
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev != w->device)
+        return failf(VS_ERR_INVALID, "called on device %d, the weights handle lives on device %d", dev, w->device);
+    return ensure_transposed(w, (hipStream_t)stream, false);
+}
 
 size_t vs_train_saved_bytes(const vs_weights *w, int32_t B, int32_t T) {
     if (!w || B <= 0 || T <= 0) return 0;
@@ -195,12 +209,15 @@ int vs_train_forward(const vs_weights *w, const float *x, const uint8_t *key_pad
         return failf(VS_ERR_INVALID, "saved/workspace must be 256-byte, hidden 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     const int d = D.d_model, H = D.num_heads, L = D.num_layers, M = B * T;
-    const float p = drop ? drop->p : 0.f, p_embed = drop ? drop->p_embed : 0.f;
+    const float p = drop ? drop->p : 0.f;
+    // the embedding dropout lives INSIDE PositionalEncoding (simnet.py:224,237): a use_pos=False model has none
+    const float p_embed = (drop && w->has_pe) ? drop->p_embed : 0.f;
     const unsigned long long seed = drop ? drop->seed : 0ull;
     const float scale = 1.0f / sqrtf((float)d);              // simnet.py:126: d_model ** -0.5
     float *sv = (float *)saved, *ws = (float *)workspace;
     float *a = ws + W.a;
 
+    if (M <= vsk_skinny_max_rows()) if (int rc = vsw_ensure(w, VSW_FRAGMENTS, stream)) return rc;
     // Embedding + positional table + dropout(sparsity)   simnet.py:211, 237-238
     float *h0 = sv + S.h0;
     VST_LAUNCH(vsk_linear(x, w->p(w->embed_w), w->p(w->f_embed_w), w->p(w->embed_b), h0, M, d, D.in_features, 0,
@@ -250,9 +267,11 @@ int vs_train_backward(vs_weights *w, const float *x, const uint8_t *key_pad_mask
         return failf(VS_ERR_WORKSPACE, "workspace %zu bytes < %zu needed", workspace_bytes, W.total * sizeof(float));
     if (((uintptr_t)saved & 255) || ((uintptr_t)workspace & 255)) return failf(VS_ERR_INVALID, "saved/workspace must be 256-byte aligned");
     hipStream_t st = (hipStream_t)stream;
-    if (int rc = ensure_transposed(w, st)) return rc;
+    if (int rc = ensure_transposed(w, st, B * T <= vsk_skinny_max_rows())) return rc;
     const int d = D.d_model, H = D.num_heads, L = D.num_layers, M = B * T, nc = D.num_classes;
-    const float p = drop ? drop->p : 0.f, p_embed = drop ? drop->p_embed : 0.f;
+    const float p = drop ? drop->p : 0.f;
+    // the embedding dropout lives INSIDE PositionalEncoding (simnet.py:224,237): a use_pos=False model has none
+    const float p_embed = (drop && w->has_pe) ? drop->p_embed : 0.f;
     const unsigned long long seed = drop ? drop->seed : 0ull;
     const float scale = 1.0f / sqrtf((float)d);
     const float *sv = (const float *)saved;

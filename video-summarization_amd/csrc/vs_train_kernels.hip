@@ -600,8 +600,9 @@ int vst_weighted_colsum(const float *w, int ws, const float *Y, float *part, int
 // splits for the wgrad of an [N, K] weight over M rows: enough blocks for ~2 per CU, at least 64 rows per split
 int vst_wgrad_splits(int M, int N, int K) {
     const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
-    int cus = vsk_device_cus();
-    if (cus <= 0) cus = 256;
+    // the split count sizes the caller's workspace (vs_train_workspace_bytes) AND the launch, possibly queried with
+    // different devices current: it must not depend on the device.  256 = the CUs of an MI355X (the only target).
+    constexpr int cus = 256;
     int S = (2 * cus + tiles - 1) / tiles;
     const int maxS = (M + 63) / 64;
     if (S > maxS) S = maxS;

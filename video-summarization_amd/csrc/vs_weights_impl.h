@@ -33,14 +33,26 @@ struct vs_weights {
     bool has_pe = false;
     std::vector<LayerOff> layers;
     const float *p(size_t off) const { return blob + off; }
+    // Kernel-layout IMAGES of the parameters, one version stamp per family: built by vsw_ensure() when a forward that
+    // reads the family runs, never at pack / update time (a training step never pays for the f16x3 / bf16 images, a
+    // large-batch scorer never for the fragment-major latency copies).
+    mutable unsigned long long f_version = ~0ull;   // f_*: fragment-major fp32 copies (latency kernels, rows <= VS_SKINNY_ROWS)
+    mutable unsigned long long h_version = ~0ull;   // h_*: their fp16x3 counterparts
+    mutable unsigned long long b_version = ~0ull;   // b_*: LDS images of the fused bf16 layer kernels
 
     // ---- training side ----
     unsigned long long version = 0;       // bumped by every pack / update
     float *tblob = nullptr;               // second device allocation: transposed weights + a zero vector
     unsigned long long t_version = ~0ull; // version the transposes were built from
+    unsigned long long tf_version = ~0ull;// ... and their fragment-major copies (latency kernels only)
     size_t t_embed_w = 0, tf_embed_w = 0, zeros = 0;
     std::vector<LayerOffT> tlayers;
     const float *tp(size_t off) const { return tblob + off; }
 };
 
 int vs_fail_msg(int code, const char *msg);     // vs_scorer.cpp: sets the thread-local error text
+
+// (re)builds the image families in `families` that are older than the handle's parameters, stream-ordered on `st`.
+// A handle's calls must be issued on ONE stream at a time (or be ordered by the caller): include/vs_scorer.h.
+enum { VSW_FRAGMENTS = 1, VSW_F16X3 = 2, VSW_BF16 = 4 };
+int vsw_ensure(const vs_weights *w, unsigned families, void *stream);

@@ -219,11 +219,18 @@ class _PinnedRing:
         for i in range(slots):
             self._free.put((i, None))
 
-    def acquire(self) -> int:
-        slot, ev = self._free.get()
-        if ev is not None:
-            ev.synchronize()
-        return slot
+    def acquire(self, stop: Optional[threading.Event] = None) -> Optional[int]:
+        """A free slot, or None once ``stop`` is set (checked every 50 ms while waiting)."""
+        while True:
+            try:
+                slot, ev = self._free.get(timeout=0.05)
+            except queue.Empty:
+                if stop is not None and stop.is_set():
+                    return None
+                continue
+            if ev is not None:
+                ev.synchronize()
+            return slot
 
     def release(self, slot: int, copied: Optional["torch.cuda.Event"]) -> None:
         self._free.put((slot, copied))
@@ -232,7 +239,10 @@ class _PinnedRing:
 class RaggedFeeder:
     """Iterates ``videos`` (a sequence of [T_i, D] arrays / tensors, e.g. ``TSDataset.data``) as PACKED host batches
     ``(slot, x [sum T, D] view of a ring buffer, lengths, indices)`` in length-bucketed order, filled by a producer
-    thread while the consumer computes.  ``done(slot, event)`` returns a buffer to the ring."""
+    thread while the consumer computes.  ``done(slot, event)`` returns a buffer to the ring.  ``close()`` (also on
+    ``with`` exit, and when iteration ends) stops the producer and joins it, whether or not every batch was consumed:
+    a consumer that raises or breaks out of its loop must not leave a thread blocked on the ring with the pinned
+    buffers alive."""
 
     def __init__(self, videos: Sequence, max_frames: int = 65536, max_waste: float = 0.25, slots: int = 3,
                  indices: Optional[Sequence[int]] = None):
@@ -245,33 +255,65 @@ class RaggedFeeder:
         self.ring = _PinnedRing(slots, cap, d)
         self._q: "queue.Queue" = queue.Queue(maxsize=slots)
         self._err: List[BaseException] = []
+        self._stop = threading.Event()
         self._thread = threading.Thread(target=self._produce, daemon=True)
         self._thread.start()
+
+    def _put(self, item) -> bool:
+        while not self._stop.is_set():
+            try:
+                self._q.put(item, timeout=0.05)
+                return True
+            except queue.Full:
+                continue
+        return False
 
     def _produce(self) -> None:
         try:
             for batch in self.batches:
-                slot = self.ring.acquire()
+                slot = self.ring.acquire(self._stop)
+                if slot is None:
+                    return
                 buf, row = self.ring.buffers[slot], 0
                 for i in batch:
                     v = self.videos[i]
                     t = v if isinstance(v, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32))
                     buf[row: row + self.lengths[i]].copy_(t)
                     row += self.lengths[i]
-                self._q.put((slot, buf[:row], [self.lengths[i] for i in batch], list(batch)))
+                if not self._put((slot, buf[:row], [self.lengths[i] for i in batch], list(batch))):
+                    return
         except BaseException as e:              # surfaced to the consumer: a feeder must not die silently
             self._err.append(e)
         finally:
-            self._q.put(None)
+            self._put(None)
 
     def __iter__(self) -> Iterator[Tuple[int, torch.Tensor, List[int], List[int]]]:
-        while True:
-            item = self._q.get()
-            if item is None:
-                if self._err:
-                    raise self._err[0]
-                return
-            yield item
+        try:
+            while True:
+                item = self._q.get()
+                if item is None:
+                    if self._err:
+                        raise self._err[0]
+                    return
+                yield item
+        finally:                                # exhausted, the consumer raised, or the generator was dropped
+            self.close()
+
+    def close(self, timeout: float = 5.0) -> None:
+        """Stops the producer thread and waits for it; idempotent."""
+        self._stop.set()
+        if self._thread.is_alive() and threading.current_thread() is not self._thread:
+            self._thread.join(timeout)
+
+    @property
+    def alive(self) -> bool:
+        return self._thread.is_alive()
+
+    def __enter__(self) -> "RaggedFeeder":
+        return self
+
+    def __exit__(self, *exc) -> None:
+        self.close()
 
     def done(self, slot: int, copied=None) -> None:
         self.ring.release(slot, copied)
@@ -301,21 +343,24 @@ def score_dataset(model, videos: Sequence, device, max_frames: int = 65536, indi
         feeder.done(slot, ev)
         return dx, lengths, idx, ev
 
-    it = iter(feeder)
-    first = next(it, None)
-    if first is not None:
-        staged = upload(first)
-    while staged is not None:
-        nxt = next(it, None)
-        upcoming = upload(nxt) if nxt is not None else None
-        dx, lengths, idx, ev = staged
-        compute.wait_event(ev)
-        dx.record_stream(compute)
-        sc = model.score_packed(dx, lengths)
-        host = torch.empty(sc.shape, dtype=sc.dtype, pin_memory=True)
-        host.copy_(sc, non_blocking=True)
-        pending.append((host, lengths, idx))
-        staged = upcoming
+    try:
+        it = iter(feeder)
+        first = next(it, None)
+        if first is not None:
+            staged = upload(first)
+        while staged is not None:
+            nxt = next(it, None)
+            upcoming = upload(nxt) if nxt is not None else None
+            dx, lengths, idx, ev = staged
+            compute.wait_event(ev)
+            dx.record_stream(compute)
+            sc = model.score_packed(dx, lengths)
+            host = torch.empty(sc.shape, dtype=sc.dtype, pin_memory=True)
+            host.copy_(sc, non_blocking=True)
+            pending.append((host, lengths, idx))
+            staged = upcoming
+    finally:
+        feeder.close()                           # also when score_packed / the upload raised: no producer left behind
     torch.cuda.synchronize(device)
     for host, lengths, idx in pending:
         row = 0

@@ -131,6 +131,9 @@ class _TrainForward(torch.autograd.Function):
         hidden = torch.empty((B, T, module.d_model), dtype=torch.float32, device=x.device)
         cfg = _lib.DropoutCfg(float(p_embed), float(p), int(seed))
         with torch.cuda.device(x.device):
+            if not getattr(packed, "train_prepared", False):     # one-time allocation of the dgrad transposes, outside the backward
+                _lib.check(lib.vs_train_prepare(packed.handle, torch.cuda.current_stream(x.device).cuda_stream))
+                packed.train_prepared = True
             saved = torch.empty((lib.vs_train_saved_bytes(packed.handle, B, T),), dtype=torch.uint8, device=x.device)
             ws = torch.empty((lib.vs_train_workspace_bytes(packed.handle, B, T),), dtype=torch.uint8, device=x.device)
             stream = torch.cuda.current_stream(x.device).cuda_stream
@@ -244,6 +247,7 @@ class SimNet(nn.Module):
         self._packed: Optional[_Packed] = None
         self._packed_key = None
         self._packed_shape = None
+        self._packed_pe_key = None
 
     # ---- reference helper kept for API parity (simnet.py:47-56) ----
     def process_mask(self, mask: Tensor) -> Tensor:
@@ -288,9 +292,16 @@ class SimNet(nn.Module):
                 raise RuntimeError("SimNet parameters are on %s but the input is on %s" % (t.device, device))
             ts.append(t.detach().to(torch.float32).contiguous())
         it = iter(ts)
+        reuse = self._packed is not None and self._packed_shape == shape_key
         P = _lib.ModelParams()
         P.embed_w, P.embed_b = next(it).data_ptr(), next(it).data_ptr()
         P.pos_embedding = next(it).data_ptr() if self.use_pos else None
+        if self.use_pos:
+            pe = self.embedding_layer.positional_encoding.pos_embedding
+            pe_key = (pe.data_ptr(), pe._version)
+            if reuse and pe_key == self._packed_pe_key:
+                P.pos_embedding = None          # the table (a buffer) is unchanged: vs_weights_update keeps the packed copy
+            self._packed_pe_key = pe_key
         layers = (_lib.LayerParams * max(self.num_layers, 1))()
         for l in range(self.num_layers):
             for name in ("wq", "bq", "wk", "bk", "wv", "bv", "wo", "bo", "ln1_g", "ln1_b",
@@ -302,7 +313,7 @@ class SimNet(nn.Module):
                               self.pe_len if self.use_pos else 0, self.num_classes)
         with torch.cuda.device(device):
             stream = torch.cuda.current_stream(device).cuda_stream
-            if self._packed is not None and self._packed_shape == shape_key:
+            if reuse:
                 # parameters were written (optimizer step, load_state_dict): refill the existing device storage
                 _lib.check(lib.vs_weights_update(self._packed.handle, C.byref(P), stream))
             else:
@@ -356,64 +367,33 @@ class SimNet(nn.Module):
     def _forward_cls(self, x: Tensor, mask: Optional[Tensor]):
         """``use_cls=True`` (simnet.py:47-51, 205-206, 214-216; no reference caller enables it): a learnable class token
         is prepended after the embedding, so the encoder sees T + 1 positions and both outputs have T + 1 rows.  Scoring
-        only (no-grad): the embedding runs through ``vs_linear_f32`` and the encoder blocks through the per-kernel C
-        entry points (``vs_qkv_proj_f32``, ``vs_attention_f32``, ``vs_linear_residual_layernorm_f32``) - the same HIP
-        kernels as the packed-weight path, driven layer by layer, because the token has to enter between them."""
+        only (no-grad).  One C call, ``vs_scorer_forward_cls``: the packed weights of the main path (cached, re-packed
+        only when a parameter changes), the token row inserted by a kernel of the library - no per-call weight casts,
+        no ``torch.cat``; every compute mode of the main path."""
         if self._needs_autograd(x):
             raise NotImplementedError("use_cls=True is supported for scoring (torch.no_grad / eval with frozen "
                                       "parameters) only; no reference caller trains with a class token")
         lib = _lib.load()
         B, T, _ = x.shape
-        d, H, dev = self.d_model, self.num_heads, x.device
-        T1, M1 = T + 1, B * (T + 1)
-        emb = self.embedding_layer
-
-        def f32(t):
-            return t.detach().to(torch.float32).contiguous()
-
+        dev = x.device
+        x32 = (x if x.dtype == torch.float32 else x.float()).contiguous()
+        packed = self._packed_weights(dev)
+        cls = self.embedding_layer.cls_token.detach()
+        if cls.dtype != torch.float32 or not cls.is_contiguous():
+            cls = cls.to(torch.float32).contiguous()
+        m = None
+        if mask is not None:
+            m = mask.contiguous()
+            m = m.view(torch.uint8) if m.dtype == torch.bool else m.to(torch.uint8)
+        flags = (_lib.VS_FLAG_SIGMOID if self.fused_sigmoid else 0) | self._attention_flag()
+        scores = torch.empty((B, T + 1, self.num_classes), dtype=torch.float32, device=dev)
+        hidden = torch.empty((B, T + 1, self.d_model), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
+            ws = torch.empty((max(lib.vs_scorer_workspace_bytes_cls(packed.handle, B, T), 256),), dtype=torch.uint8, device=dev)
             st = torch.cuda.current_stream(dev).cuda_stream
-            xe = f32(x).view(B * T, self.in_features)
-            e = torch.empty((B * T, d), dtype=torch.float32, device=dev)
-            w, b = f32(emb.feature_transform.weight), f32(emb.feature_transform.bias)
-            pe = f32(emb.positional_encoding.pos_embedding)[0, :T] if self.use_pos else None
-            _lib.check(lib.vs_linear_f32(xe.data_ptr(), w.data_ptr(), b.data_ptr(), e.data_ptr(), B * T, d, self.in_features,
-                                         0, _ptr(pe), T if self.use_pos else 0, st))
-            h = torch.cat([f32(emb.cls_token).expand(B, 1, d), e.view(B, T, d)], dim=1).contiguous()      # :214-216
-            m = None
-            if mask is not None:
-                mk = mask.view(torch.uint8) if mask.dtype == torch.bool else mask.to(torch.uint8)
-                m = torch.cat([torch.zeros((B, 1), dtype=torch.uint8, device=dev), mk], dim=1).contiguous()
-            scores = torch.empty((B, T1, self.num_classes), dtype=torch.float32, device=dev)
-            qkv = torch.empty((3, B, H, T1, d // H), dtype=torch.float32, device=dev)
-            att, h1, ffn = (torch.empty((M1, n), dtype=torch.float32, device=dev) for n in (d, d, 4 * d))
-            L = self.num_layers
-            for l, blk in enumerate(self.encoder.module_list):
-                wqkv = torch.cat([f32(blk.sa.q.weight), f32(blk.sa.k.weight), f32(blk.sa.v.weight)], dim=0)
-                bqkv = torch.cat([f32(blk.sa.q.bias), f32(blk.sa.k.bias), f32(blk.sa.v.bias)], dim=0)
-                _lib.check(lib.vs_qkv_proj_f32(h.data_ptr(), wqkv.data_ptr(), bqkv.data_ptr(), qkv.data_ptr(), B, T1, d, H, st))
-                _lib.check(lib.vs_attention_f32(qkv[0].data_ptr(), qkv[1].data_ptr(), qkv[2].data_ptr(), _ptr(m), att.data_ptr(),
-                                                B, H, T1, d // H, float(d) ** -0.5, st))
-                wo, bo = f32(blk.sa.feature_projection.weight), f32(blk.sa.feature_projection.bias)
-                g1, b1 = f32(blk.norm1.weight), f32(blk.norm1.bias)
-                _lib.check(lib.vs_linear_residual_layernorm_f32(att.data_ptr(), wo.data_ptr(), bo.data_ptr(), h.data_ptr(),
-                                                                g1.data_ptr(), b1.data_ptr(), h1.data_ptr(), M1, d, d,
-                                                                None, None, 0, 0, None, st))
-                w1, bb1 = f32(blk.mlp.fc1.weight), f32(blk.mlp.fc1.bias)
-                _lib.check(lib.vs_linear_f32(h1.data_ptr(), w1.data_ptr(), bb1.data_ptr(), ffn.data_ptr(), M1, 4 * d, d, 1,
-                                             None, 0, st))
-                w2, bb2 = f32(blk.mlp.fc2.weight), f32(blk.mlp.fc2.bias)
-                g2, b2 = f32(blk.norm2.weight), f32(blk.norm2.bias)
-                last = l == L - 1
-                fw, fb = f32(self.final_layer.weight), f32(self.final_layer.bias)
-                out = torch.empty((B, T1, d), dtype=torch.float32, device=dev)
-                _lib.check(lib.vs_linear_residual_layernorm_f32(ffn.data_ptr(), w2.data_ptr(), bb2.data_ptr(), h1.data_ptr(),
-                                                                g2.data_ptr(), b2.data_ptr(), out.data_ptr(), M1, d, 4 * d,
-                                                                fw.data_ptr() if last else None, fb.data_ptr() if last else None,
-                                                                self.num_classes, 1 if self.fused_sigmoid else 0,
-                                                                scores.data_ptr() if last else None, st))
-                h = out
-        return scores, h
+            _lib.check(lib.vs_scorer_forward_cls(packed.handle, x32.data_ptr(), _ptr(m), cls.data_ptr(), B, T, flags,
+                                                 scores.data_ptr(), hidden.data_ptr(), ws.data_ptr(), ws.numel(), st))
+        return scores, hidden
 
     @torch.no_grad()
     def score(self, x: Tensor, mask: Optional[Tensor] = None) -> Tensor:
