@@ -445,25 +445,64 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_lp(
 // buffer loads of K(t+3) / V(t+2) between them.  One barrier per tile; K and V double-buffered in LDS, the
 // key-mask bias triple-buffered (it is read two iterations after it is written).
 // ------------------------------------------------------------------------------------------
+// Round 3 (VALU diet; per 64-key tile and wave 105 -> ~70 vector instructions at bf16):
+//  * the row constant c (the "running max", log2 units) is FOLDED INTO THE PRODUCT: S' = [K,1][Q,-c]^T, one extra MFMA
+//    per 32-key block (k = 16 step whose only non-zero column is the ones / -c pair) replaces the accumulator
+//    zero-init and the 32 subtractions in front of exp2.  c is kept exactly representable in the operand type (rounded
+//    UP to a bf16 / f16 value), so the step adds exactly -c;
+//  * NO max chain in the steady state: P = exp2(S') is computed straight away, and an OR over the packed P registers
+//    tells whether any P >= 2 (bit 14 of a non-negative bf16 / f16 number): only then - a key beat the row constant by
+//    more than 1 - the rare path recomputes the tile's maximum, raises c, rescales O and l and redoes the tile's P.
+//    The constant is set CMARGIN = 6 above the maximum seen, so P <= 2^-6 after a raise and the next raise needs a
+//    key 2^7 above that maximum (round 2's deferred maximum, THR 8, with the test moved from S to the packed P);
+//  * a block of S' that was started with a row constant that has been raised since ("stale bias": the MFMAs of tile
+//    t + 1 run while tile t's softmax may raise c) is shifted by the difference first (rare path as well).
 // IO16 (PREC 1 only): q (already multiplied by scale * log2 e), k, v arrive as bf16 and the output is written as bf16
 // (the QKV epilogue / the out-projection do the rounding this kernel / that kernel would do anyway: same bits)
-template <int DH, int NW, int PREC, bool VARLEN = false, bool IO16 = false>       // VARLEN: packed ragged batches, see attn_fwd_pipe
+// DIAG (diagnostic library only): per-wave stamps, diag[(block * NW + wave) * 16 + ..]: 0 prologue, 1 phase A (S(t+1) ||
+// softmax(t)), 2 phase B (P.V + row sums || staging), 3 barrier, 7 epilogue, 8 total, 9 / 10 wall clock, 11 tiles
+// ABL (diagnostic library only, timing ablations with WRONG results): 1 no staging inside the loop (no global loads,
+// no LDS writes), 2 no block barriers inside the loop, 4 no fragment reads inside the loop (LDS offsets pinned to tile 0
+// and hoistable), 8 no softmax work (P fragments constant)
+template <int DH, int NW, int PREC, bool VARLEN = false, bool IO16 = false, int DIAG = 0, int ABL = 0>       // VARLEN: packed ragged batches, see attn_fwd_pipe
 __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_lp_pipe(
     const float *__restrict__ Q, const float *__restrict__ Kg, const float *__restrict__ Vg,
     const uint8_t *__restrict__ mask, float *__restrict__ out, int H, int T, float scale_log2e, int BH,
-    const int *__restrict__ cu = nullptr, const int2 *__restrict__ work = nullptr, int Mtot = 0) {
+    const int *__restrict__ cu = nullptr, const int2 *__restrict__ work = nullptr, int Mtot = 0,
+    unsigned long long *__restrict__ diag = nullptr) {
+    unsigned long long dg[12] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull}, tbeg = 0, tl = 0;
+    if constexpr (DIAG != 0) { dg[9] = __builtin_amdgcn_s_memrealtime(); tbeg = vs_stamp(); tl = tbeg; }
+    auto lap = [&](int slot) __attribute__((always_inline)) {
+        if constexpr (DIAG != 0) { const unsigned long long t = vs_stamp(); dg[slot] += t - tl; tl = t; }
+    };
     constexpr int KT = 64, NS = DH / 16, ND = DH / 32, NT = 64 * NW, QB = 32 * NW;
     constexpr int NP = PREC == 2 ? 2 : 1, NPROD = PREC == 2 ? 3 : 1;
-    constexpr int LDK = DH + 8, LDV = KT + 4, D4 = DH / 4;
+    // DMA (bf16 storage, head dim 64, 8-wave blocks): K and V tiles are dense [64 keys][128 B] images filled by LDS-DMA
+    // (global_load_lds_dwordx4: one 1-KiB piece = 8 key rows per wave instruction, wave w owns piece w of either tile -
+    // no staging registers, no ds_write, no v_perm), XOR-swizzled through the per-lane SOURCE address so that the reads
+    // are conflict-free: K fragments (ds_read_b128, lanes = 32 key rows) see 16-byte chunk c of row k at chunk
+    // c ^ ((k >> 1) & 7); V^T fragments come from the ROW-MAJOR V tile by ds_read_b64_tr_b16 (4 keys x 16 d per 16
+    // lanes, transposed by the LDS), with the two 64-byte halves of a row swapped where bit 1 of the key is set.
+    constexpr bool DMA = PREC == 1 && IO16 && DH == 64 && NW == 8;
+    constexpr int LDK = DMA ? DH : DH + 8, LDV = KT + 4, D4 = DH / 4;
     constexpr int KPT = KT * D4 / NT;
     static_assert(KPT == 2 || KPT == 4, "staging packs 2 or 4 keys per V^T store");
     constexpr float THR = 8.0f;
     typedef unsigned short h16;
     static_assert(!IO16 || PREC == 1, "bf16 storage belongs to the bf16 mode");
     constexpr int ES = IO16 ? 2 : 4;                  // bytes per stored q/k/v element
-    __shared__ __attribute__((aligned(16))) h16 Kb[2][NP][KT * LDK];
-    __shared__ __attribute__((aligned(16))) h16 Vt[2][NP][DH * LDV];
-    __shared__ __attribute__((aligned(16))) float mb[3][KT];
+    // STAG (8-wave blocks: waves w and w + 4 share a SIMD): waves 4..7 run HALF A TILE BEHIND waves 0..3, so that on
+    // every SIMD one wave is in phase A (10 MFMAs + the tile's softmax: VALU-bound) while its partner is in phase B
+    // (the P.V MFMAs + staging: MFMA-bound) - the two pipes of the SIMD are asked for complementary work instead of
+    // the same work twice (round 2: both waves in the same phase, 34 % of the wave cycles issue-stalled).  Two block
+    // barriers per tile keep the alternation; K is staged three tiles ahead and V two (a ring of three LDS tiles:
+    // the late half still reads a tile while the early half stages the next but one).
+    constexpr bool FOLD = PREC == 1 && DH <= 64;   // the row constant folded into the product + OR test; fp16x3 / head dim 128: round 2's max chain
+    constexpr bool STAG = NW == 8 && PREC == 1 && DH <= 64;   // (fp16x3 / head dim 128 fill the register file: they spill in this form)
+    constexpr int NBUF = STAG ? 3 : 2, KAHEAD = STAG ? 3 : 2, VAHEAD = KAHEAD - 1, NMB = KAHEAD + 1;
+    __shared__ __attribute__((aligned(16))) h16 Kb[NBUF][NP][KT * LDK];
+    __shared__ __attribute__((aligned(16))) h16 Vt[NBUF][NP][DMA ? KT * DH : DH * LDV];
+    __shared__ __attribute__((aligned(16))) float mb[NMB][KT];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -530,7 +569,11 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_lp_pipe(
     for (int d = 0; d <= ND; ++d)
 #pragma unroll
         for (int t = 0; t < 16; ++t) o[d][t] = 0.f;
+    // m_run: the row constant c subtracted from this query's scores (log2 units), exactly representable in the operand
+    // type; -inf until the first live key.  nbias: element 0 of the bias step's B operand = (-c, 0) packed (lanes with
+    // h == 1 hold k = 8..15 of the step: zero).
     float m_run = NEG_INF;
+    unsigned nbias = 0u;
     constexpr unsigned ONE2 = PREC == 2 ? 0x3C003C00u : 0x3F803F80u;
     const u32x4 ones_u = {ONE2, ONE2, ONE2, ONE2};
 
@@ -615,11 +658,38 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_lp_pipe(
         }
     };
     auto stage_m = [&](int mbuf) __attribute__((always_inline)) { if (tid < KT) mb[mbuf][tid] = pm; };
+    // DMA images: per-lane byte offsets of the swizzled reads (row part + chunk part; tile / block / step offsets are
+    // immediates) and of this lane's two LDS-DMA source pieces
+    int koff[NS], voff_tr[ND], dma_row = 0, dma_krel = 0, dma_vrel = 0;
+    if constexpr (DMA) {
+        const int swz = (r >> 1) & 7;
+#pragma unroll
+        for (int ks = 0; ks < NS; ++ks) koff[ks] = r * 128 + (((2 * ks + h) ^ swz) << 4);
+        const int i16 = lane & 15, y = (i16 >> 3) & 1, x = 2 * ((lane >> 4) & 1) + ((i16 >> 1) & 1);
+#pragma unroll
+        for (int d = 0; d < ND; ++d) voff_tr[d] = (4 * h + (i16 >> 2)) * 128 + ((4 * (d ^ y) + x) << 4) + 8 * (i16 & 1);
+        dma_row = 8 * wave + (lane >> 3);
+        dma_krel = ((lane & 7) ^ ((dma_row >> 1) & 7)) * 8;              // 16-bit elements inside the key's row
+        dma_vrel = ((lane & 7) ^ (4 * ((dma_row >> 1) & 1))) * 8;
+    }
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
     auto k_frag = [&](int buf, int ks, int n, u32x4 (&ka)[NP]) __attribute__((always_inline)) {
+        if constexpr (DMA) {
+            ka[0] = *(const u32x4 *)((const char *)&Kb[buf][0][0] + koff[ks] + n * 4096);
+            return;
+        }
 #pragma unroll
         for (int p = 0; p < NP; ++p) ka[p] = *(const u32x4 *)&Kb[buf][p][(32 * n + r) * LDK + 16 * ks + 8 * h];
     };
     auto v_frag = [&](int buf, int n, int ks, int d, u32x4 (&va)[NP]) __attribute__((always_inline)) {
+        if constexpr (DMA) {
+            const char *vb = (const char *)&Vt[buf][0][0] + voff_tr[d] + (32 * n + 16 * ks) * 128;
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)vb);
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(vb + 8 * 128));
+            const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+            va[0][0] = l2[0]; va[0][1] = l2[1]; va[0][2] = h2[0]; va[0][3] = h2[1];
+            return;
+        }
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             const h16 *vp = &Vt[buf][p][(32 * d + r) * LDV + 32 * n + 16 * ks + 4 * h];
@@ -628,18 +698,49 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_lp_pipe(
         }
     };
 
-    // ---- prologue: K(0), V(0), K(1) in LDS; K(2), V(1) in registers; S(0) computed ----
-    gload_k(0); gload_v(0); gload_m(0);
+    // LDS-DMA of this wave's pieces of K(tk) and V(tv) (tiles beyond the end re-read the last one; rows beyond T re-read
+    // row T - 1: finite values, masked by the key bias).  Asynchronous: counted by vmcnt, waited for at the end of phase A.
+    const h16 *Kg16 = (const h16 *)Kg + base, *Vg16 = (const h16 *)Vg + base;
+    auto dma_issue = [&](int tk, int tv, bool do_k, bool do_v) __attribute__((always_inline)) {
+        if constexpr (DMA) {
+            if (do_k) {
+                tk = tk < ntiles ? tk : ntiles - 1;
+                int key = tk * KT + dma_row; key = key < T ? key : T - 1;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(Kg16 + (size_t)key * DH + dma_krel),
+                                                 (__attribute__((address_space(3))) void *)&Kb[tk % NBUF][0][wave * 512], 16, 0, 0);
+            }
+            if (do_v) {
+                tv = tv < ntiles ? tv : ntiles - 1;
+                int key = tv * KT + dma_row; key = key < T ? key : T - 1;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(Vg16 + (size_t)key * DH + dma_vrel),
+                                                 (__attribute__((address_space(3))) void *)&Vt[tv % NBUF][0][wave * 512], 16, 0, 0);
+            }
+        }
+    };
+    if constexpr (DMA) {
+        // every tile of the prologue is requested at once (one HBM round trip instead of KAHEAD sequential ones)
 #pragma unroll
-    for (int i = 0; i < KPT; ++i) stage_k1(i, 0);
+        for (int u = 0; u < KAHEAD; ++u) dma_issue(u, u, true, u < VAHEAD);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) stage_v1(e, 0);
-    stage_m(0);
-    gload_k(1); gload_m(1);
+        for (int u = 0; u < KAHEAD; ++u) { gload_m(u); stage_m(u % NMB); }
+        gload_m(KAHEAD);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        // ---- prologue: K(0 .. KAHEAD-1), V(0 .. VAHEAD-1) in LDS; K(KAHEAD), V(VAHEAD) in registers; S(0) computed ----
 #pragma unroll
-    for (int i = 0; i < KPT; ++i) stage_k1(i, 1);
-    stage_m(1);
-    gload_k(2); gload_m(2); gload_v(1);
+        for (int u = 0; u < KAHEAD; ++u) {
+            gload_k(u); gload_m(u);
+            if (u < VAHEAD) gload_v(u);
+#pragma unroll
+            for (int i = 0; i < KPT; ++i) stage_k1(i, u % NBUF);
+            if (u < VAHEAD) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) stage_v1(e, u % NBUF);
+            }
+            stage_m(u % NMB);
+        }
+        gload_k(KAHEAD); gload_m(KAHEAD); gload_v(VAHEAD);
+    }
     __syncthreads();
     f32x16 sa[2], sb[2];
 #pragma unroll
@@ -655,14 +756,77 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_lp_pipe(
             static_for<NPROD>([&](auto prc) { mma_prod(prc, ka, qreg[ks], sa[n]); });
         }
 
-    // softmax state of the tile in flight
+    // bf16: c = maximum + 6 and the OR test (P >= 2).  f16 (fp16x3): its 5-bit exponent would push the small P of a
+    // "+6" constant into the subnormals (measured: 2.4e-4 on the output), so there c = maximum - 8 (P <= 2^8 after a
+    // raise: the whole normal range below is precision) and the test is a packed-f16 MAX tree against 2^15.
+    constexpr float CMARGIN = PREC == 2 ? -8.0f : 6.0f;
+    (void)CMARGIN;
+    // P fragments of the tile in flight
+    u32x4 pf[2][2][NP];
+    f16x2 pmaxh = {(_Float16)0.f, (_Float16)0.f};
+    float cb_a = 0.f, cb_b = 0.f;                    // the row constant S(a) / S(b) were started with
+    // Rare path: bring a tile's S' (started with the constant `cb`) onto the current row constant, raising it to the
+    // tile's maximum if that is larger (or if there is none yet): S' shifted, O and l rescaled, the bias operand rebuilt.
+    // `raise`: THIS row asked for a larger constant (one of its P reached 2).  Rows that only ride along (the branch is
+    // wave-uniform) must come out bit for bit unchanged - a row's result may not depend on the rows it shares a wave
+    // with (batch invariance) - so they are shifted by 0 and scaled by 1.
+    auto rebase = [&](f32x16 (&sv)[2], float &cb, bool raise) __attribute__((always_inline)) {
+        float mx = __builtin_fmaxf(__builtin_fmaxf(sv[0][0], sv[0][1]), sv[1][0]);
+        mx = __builtin_fmaxf(mx, sv[1][1]);
+#pragma unroll
+        for (int t = 2; t < 16; t += 2) {
+            mx = __builtin_fmaxf(__builtin_fmaxf(mx, sv[0][t]), sv[0][t + 1]);
+            mx = __builtin_fmaxf(__builtin_fmaxf(mx, sv[1][t]), sv[1][t + 1]);
+        }
+        const float raw = pair_max(mx) + cb;         // the tile's maximum, absolute; -inf if every key is masked
+        float c_new = m_run;
+        if ((raise || m_run == NEG_INF) && raw + CMARGIN > m_run) {   // round UP to a value the operand type holds exactly
+            // c = the tile's maximum + CMARGIN: P <= 2^-CMARGIN now, and the next raise only when a key beats this
+            // maximum by 2^(CMARGIN + 1) (the deferred maximum of round 2, THR 8, in the OR test's terms)
+            const float cl = __builtin_fminf(__builtin_fmaxf(raw + CMARGIN, -32768.f), 32768.f);
+            const unsigned b = __builtin_bit_cast(unsigned, cl);
+            constexpr unsigned LOW = PREC == 2 ? 0x1FFFu : 0xFFFFu;       // f16: 10 mantissa bits, bf16: 7
+            c_new = __builtin_bit_cast(float, (cl >= 0.f ? b + LOW : b) & ~LOW);
+            if (PREC == 2 && __builtin_fabsf(c_new) < 0.0001220703125f) c_new = cl > 0.f ? 0.0001220703125f : 0.f;   // below 2^-13: not a normal f16
+        }
+        const float u_new = (c_new == NEG_INF) ? 0.f : c_new;
+        const float shift = cb - u_new;              // finite
+        const float alpha = __builtin_amdgcn_exp2f(m_run - u_new);      // 1 for rows that keep their constant; 0 from -inf
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) sv[n][t] += shift;
+#pragma unroll
+        for (int d = 0; d <= ND; ++d)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) o[d][t] *= alpha;
+        m_run = c_new;
+        cb = u_new;
+        unsigned pl[NP];
+        pack(-u_new, 0.f, pl);
+        nbias = h == 0 ? pl[0] : 0u;
+    };
+    auto p_pair = [&](auto kc, f32x16 (&sv)[2]) __attribute__((always_inline)) {
+        constexpr int k = decltype(kc)::value, n = k / 8, ks = (k / 4) % 2, j = k % 4;
+        unsigned pl[NP];
+        pack(__builtin_amdgcn_exp2f(sv[n][8 * ks + 2 * j]), __builtin_amdgcn_exp2f(sv[n][8 * ks + 2 * j + 1]), pl);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) pf[n][ks][p][j] = pl[p];
+        // f16: running packed maximum of the hi plane, pair by pair (v_pk_max_f16).  (A 15-max tree over the finished
+        // fragments in unit 17 was folded by hipcc to 3 maxima over 4 of the 16 registers, with the other exponentials
+        // sunk behind the test: an overflowing P went undetected - found by the fp64 kernel test.)
+        if constexpr (PREC == 2) pmaxh = __builtin_elementwise_max(pmaxh, __builtin_bit_cast(f16x2, pl[0]));
+    };
+    // one unit of softmax(t) work on s_in (S' of tile t, started with the row constant cb): 0 stale-constant check,
+    // 1..16 one (n, ks, j) pair each: exp2, pack / split into the P fragments, 17 did any P reach 2?
+    // fp16x3 keeps round 2's form (the folded form needs ~25 registers more than the 256 this precision already fills:
+    // measured 6.5 -> 7.9 ms at configs[4] with the spills): row maximum by a max3 chain, deferred raise (THR 8),
+    // subtraction in front of exp2, accumulators started at zero.  Units 0..3 max chain, 4 check, 5..20 one pair each.
     float sm_mx = 0.f;
     f32x2 sm_mm = {0.f, 0.f};
-    u32x4 pf[2][2][NP];
-    // one unit of softmax(t) work on s_in: 0..3 max3 chain, 4 deferred-max check (+ rare rescale), 5..20 one
-    // (n, ks, j) pair each: subtract, exp2, pack / split into the P fragments
-    auto sm_unit = [&](auto uc, f32x16 (&sv)[2]) __attribute__((always_inline)) {
+    auto sm_unit_max = [&](auto uc, f32x16 (&sv)[2]) __attribute__((always_inline)) {
         constexpr int U = decltype(uc)::value;
+        constexpr float THR = 8.0f;
         if constexpr (U == 0) {
             sm_mx = __builtin_fmaxf(__builtin_fmaxf(sv[0][0], sv[0][1]), sv[1][0]);
             sm_mx = __builtin_fmaxf(sm_mx, sv[1][1]);
@@ -701,16 +865,54 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_lp_pipe(
             for (int p = 0; p < NP; ++p) pf[n][ks][p][j] = pl[p];
         }
     };
-    constexpr int NU = 21;
-    constexpr int NSLOT_A = NS * 2 * NPROD, RA = (NU + NSLOT_A - 1) / NSLOT_A;
+    auto sm_unit = [&](auto uc, f32x16 (&sv)[2], float &cb) __attribute__((always_inline)) {
+        constexpr int U = decltype(uc)::value;
+        if constexpr (!FOLD) { sm_unit_max(uc, sv); return; }
+        if constexpr (U == 0) {
+            const float u_run = (m_run == NEG_INF) ? 0.f : m_run;
+            if (__builtin_expect(__any(cb != u_run || m_run == NEG_INF), 0)) rebase(sv, cb, false);
+        }
+        if constexpr (U >= 1 && U < 17) p_pair(std::integral_constant<int, U - 1>{}, sv);
+        if constexpr (U == 17) {
+            unsigned acc = 0u;
+            bool hit;
+            if constexpr (PREC == 2) {
+                // the packed f16 maximum of the hi plane: either half >= 2^15 (0x7800; also inf / nan)?
+                acc = __builtin_bit_cast(unsigned, pmaxh);
+                hit = (acc & 0xFFFFu) >= 0x7800u || (acc >> 16) >= 0x7800u;
+                pmaxh = f16x2{(_Float16)0.f, (_Float16)0.f};
+            } else {
+                // non-negative bf16 numbers: bit 14 set <=> value >= 2 (also inf / nan)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) acc |= (pf[n][ks][0][0] | pf[n][ks][0][1]) | (pf[n][ks][0][2] | pf[n][ks][0][3]);
+                hit = (acc & 0x40004000u) != 0u;
+            }
+            if (__builtin_expect(__any(hit), 0)) {
+                const unsigned hbit = hit ? 1u : 0u;
+                auto pr = __builtin_amdgcn_permlane32_swap(hbit, hbit, false, false);     // a row lives in lanes l and l ^ 32
+                rebase(sv, cb, (((unsigned)pr[0] | (unsigned)pr[1]) & 1u) != 0u);
+                static_for<16>([&](auto kc) { p_pair(kc, sv); });
+                if constexpr (PREC == 2) pmaxh = f16x2{(_Float16)0.f, (_Float16)0.f};
+            }
+        }
+    };
+    constexpr int NU = FOLD ? 18 : 21;
+    constexpr bool FULLPF = PREC == 1 && DH <= 64;       // all K / V fragments of a tile in registers (see phase A)
+    constexpr int NKF = FULLPF ? NS * 2 : 2, NVF = FULLPF ? 4 * ND : 2;
+    constexpr int NBIAS = FOLD ? 2 : 0;                  // bias steps in front of the products
+    constexpr int NSLOT_A = 2 * NS * NPROD + NBIAS, RA = (NU + NSLOT_A - 1) / NSLOT_A;
     constexpr int NSLOT_B = 4 * (ND * NPROD + NP);
     constexpr int NITEM = KPT + 4 + 2, SB = NSLOT_B / NITEM > 0 ? NSLOT_B / NITEM : 1;    // staging items, slot stride
 
+    u32x4 abl_frag = {0u, 0u, 0u, 0u};
+    if constexpr ((ABL & 16) != 0) abl_frag = *(const u32x4 *)&Kb[0][0][r * LDK + 8 * h];
     // one iteration: s_in = S(t) (complete), s_out <- S(t+1)
-    auto iteration = [&](int t, f32x16 (&s_in)[2], f32x16 (&s_out)[2]) __attribute__((always_inline)) {
-        const int cur = t & 1, nxt = cur ^ 1;
+    auto iteration = [&](int t, f32x16 (&s_in)[2], float &cb_in, f32x16 (&s_out)[2], float &cb_out) __attribute__((always_inline)) {
+        const int cur = (ABL & 4) ? 0 : t % NBUF, nxt = (ABL & 4) ? 0 : (t + 1) % NBUF;                  // V(t) / K(t+1) live here
         if (mask != nullptr || (t + 1) * KT > T) {       // masked / ragged tile: key-mask bias first (rare)
-            const float *mp = mb[t % 3];
+            const float *mp = mb[t % NMB];
 #pragma unroll
             for (int n = 0; n < 2; ++n)
 #pragma unroll
@@ -720,27 +922,60 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_lp_pipe(
                     for (int e = 0; e < 4; ++e) s_in[n][4 * g + e] += bv[e];
                 }
         }
-        // ---- phase A: S(t+1) MFMAs, softmax(t) between them ----
+        // ---- phase A: S'(t+1) = [K,1][Q,-c]^T MFMAs, softmax(t) between them ----
+        // both 32-key blocks of the tile take the row constant as it is NOW (softmax(t) below may raise it meanwhile)
+        cb_out = (m_run == NEG_INF) ? 0.f : m_run;
+        const u32x4 nb = {nbias, 0u, 0u, 0u};
+        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        // FULLPF (bf16, head dim <= 64: the registers are there): every K fragment of tile t+1 is requested before
+        // the first MFMA and every V fragment of tile t during phase A, so no MFMA waits for an LDS read issued one
+        // gap earlier (round 2: `s_waitcnt lgkmcnt(0)` in front of every MFMA).  Otherwise: one fragment ahead.
+        u32x4 ka[NKF][NP], va[NVF][NP];
+        if constexpr ((ABL & 16) != 0) {
 #pragma unroll
-        for (int n = 0; n < 2; ++n)
+            for (int g = 0; g < NKF; ++g)
 #pragma unroll
-            for (int x = 0; x < 16; ++x) s_out[n][x] = 0.f;
-        u32x4 ka[2][NP];
-        k_frag(nxt, 0, 0, ka[0]);
+                for (int p = 0; p < NP; ++p) ka[g][p] = abl_frag;
+#pragma unroll
+            for (int g = 0; g < NVF; ++g)
+#pragma unroll
+                for (int p = 0; p < NP; ++p) va[g][p] = abl_frag;
+        } else
+        if constexpr (FULLPF) {
+#pragma unroll
+            for (int g = 0; g < NS * 2; ++g) k_frag(nxt, g % NS, g / NS, ka[g]);
+        } else {
+            k_frag(nxt, 0, 0, ka[0]);
+        }
         __builtin_amdgcn_sched_barrier(0);
         static_for<NSLOT_A>([&](auto ic) {
-            constexpr int i = decltype(ic)::value, g = i / NPROD, pr = i % NPROD, ks = g / 2, n = g % 2;
-            if constexpr (pr == 0 && g + 1 < NS * 2) k_frag(nxt, (g + 1) / 2, (g + 1) % 2, ka[(g + 1) & 1]);
-            mma_prod(std::integral_constant<int, pr>{}, ka[g & 1], qreg[ks], s_out[n]);
+            // slots 0, 1: the two bias steps (they need no LDS operand: the K fragment reads are in flight meanwhile);
+            // then the products, block-major
+            constexpr int i = decltype(ic)::value, PERN = NS * NPROD, n = i < NBIAS ? i : (i - NBIAS) / PERN,
+                          w = i < NBIAS ? 0 : 1 + (i - NBIAS) % PERN;
+            if constexpr (w == 0) {
+                s_out[n] = mma(ones_u, nb, zero16);                       // -c for every key row of the block
+            } else {
+                constexpr int ks = (w - 1) / NPROD, pr = (w - 1) % NPROD, g = n * NS + ks;       // fragment index: block-major
+                if constexpr (!FOLD && w == 1) s_out[n] = zero16;
+                if constexpr (!(ABL & 16) && !FULLPF && pr == 0 && g + 1 < NS * 2) k_frag(nxt, (g + 1) % NS, (g + 1) / NS, ka[(g + 1) & 1]);
+                mma_prod(std::integral_constant<int, pr>{}, ka[FULLPF ? g : (g & 1)], qreg[ks], s_out[n]);
+            }
+            if constexpr (!(ABL & 16) && FULLPF && i >= NBIAS && i - NBIAS < NVF) {
+                constexpr int f = i - NBIAS;
+                v_frag(cur, f / ND / 2, (f / ND) % 2, f % ND, va[f]);
+            }
             static_for<RA>([&](auto rc) {
                 constexpr int U = i * RA + decltype(rc)::value;
-                if constexpr (U < NU) sm_unit(std::integral_constant<int, U>{}, s_in);
+                if constexpr (U < NU && !(ABL & 8)) sm_unit(std::integral_constant<int, U>{}, s_in, cb_in);
             });
             __builtin_amdgcn_sched_barrier(0);
         });
-        // ---- phase B: O += V(t)^T P(t)^T and the row sums; staging of K(t+2), V(t+1), loads of K(t+3), V(t+2) ----
-        u32x4 va[2][NP];
-        v_frag(cur, 0, 0, 0, va[0]);
+        lap(1);
+        if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the pieces requested in phase B(t-1) have landed
+        if constexpr (STAG && !(ABL & 2)) { __syncthreads(); lap(3); }  // the partner wave of this SIMD changes phase too
+        // ---- phase B: O += V(t)^T P(t)^T and the row sums; staging of K(t+KAHEAD), V(t+VAHEAD), loads of the tiles after ----
+        if constexpr (!FULLPF && !(ABL & 16)) v_frag(cur, 0, 0, 0, va[0]);
         __builtin_amdgcn_sched_barrier(0);
         static_for<NSLOT_B>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
@@ -748,31 +983,44 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_lp_pipe(
             constexpr int g = i / PER, w = i % PER, n = g / 2, ks = g % 2;
             if constexpr (w < ND * NPROD) {
                 constexpr int d = w / NPROD, pr = w % NPROD, f = g * ND + d;       // fragment index
-                if constexpr (pr == 0 && f + 1 < 4 * ND)
+                if constexpr (!(ABL & 16) && !FULLPF && pr == 0 && f + 1 < 4 * ND)
                     v_frag(cur, (f + 1) / ND / 2, ((f + 1) / ND) % 2, (f + 1) % ND, va[(f + 1) & 1]);
-                mma_prod(std::integral_constant<int, pr>{}, va[f & 1], pf[n][ks], o[d]);
+                mma_prod(std::integral_constant<int, pr>{}, va[FULLPF ? f : (f & 1)], pf[n][ks], o[d]);
             } else {
                 constexpr int p = NP - 1 - (w - ND * NPROD);     // lo plane first
                 o[ND] = mma(ones_u, pf[n][ks][p], o[ND]);
             }
-            if constexpr (i % SB == SB - 1 && i / SB < NITEM) {
+            if constexpr (DMA) {
+                // K(t+KAHEAD) and V(t+VAHEAD) straight into their LDS tiles, as early in the phase as possible
+                if constexpr (!(ABL & 1) && i == 0) dma_issue(t + KAHEAD, t + VAHEAD, true, true);
+                if constexpr (!(ABL & 1) && i == 4) { stage_m((t + KAHEAD) % NMB); gload_m(t + KAHEAD + 1); }
+            } else
+            if constexpr (!(ABL & 1) && i % SB == SB - 1 && i / SB < NITEM) {
                 constexpr int item = i / SB;
-                if constexpr (item < KPT) stage_k1(item, cur);
-                else if constexpr (item < KPT + 4) stage_v1(item - KPT, nxt);
-                else if constexpr (item == KPT + 4) { stage_m((t + 2) % 3); }
-                else { gload_k(t + 3); gload_m(t + 3); gload_v(t + 2); }
+                if constexpr (item < KPT) stage_k1(item, (t + KAHEAD) % NBUF);
+                else if constexpr (item < KPT + 4) stage_v1(item - KPT, (t + VAHEAD) % NBUF);
+                else if constexpr (item == KPT + 4) { stage_m((t + KAHEAD) % NMB); }
+                else { gload_k(t + KAHEAD + 1); gload_m(t + KAHEAD + 1); gload_v(t + VAHEAD + 1); }
             }
             __builtin_amdgcn_sched_barrier(0);
         });
-        __syncthreads();
+        lap(2);
+        if constexpr (!(ABL & 2)) __syncthreads();
+        lap(3);
     };
 
+    lap(0);
+    // every wave passes the same number of barriers: the late half waits one out before its first tile, the early
+    // half after its last (wave-uniform branches: the wave index is made a scalar first)
+    const bool late = STAG && __builtin_amdgcn_readfirstlane(wave) >= NW / 2;
+    if (late) __syncthreads();
     int t = 0;
     for (; t + 1 < ntiles; t += 2) {
-        iteration(t, sa, sb);
-        iteration(t + 1, sb, sa);
+        iteration(t, sa, cb_a, sb, cb_b);
+        iteration(t + 1, sb, cb_b, sa, cb_a);
     }
-    if (t < ntiles) iteration(t, sa, sb);
+    if (t < ntiles) iteration(t, sa, cb_a, sb, cb_b);
+    if (STAG && !late) __syncthreads();
 
     const int q = q0 + r;
     if (q < T) {
@@ -792,6 +1040,16 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_lp_pipe(
                 } else
                 *(f32x4 *)(op + 32 * d + 8 * g + 4 * h) = v;
             }
+    }
+    if constexpr (DIAG != 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lap(7);
+        dg[8] = tl - tbeg; dg[10] = __builtin_amdgcn_s_memrealtime(); dg[11] = (unsigned long long)ntiles;
+        if (diag != nullptr && lane == 0) {
+            unsigned long long *o_ = diag + ((size_t)blockIdx.x * NW + wave) * 16;
+#pragma unroll
+            for (int i = 0; i < 12; ++i) o_[i] = dg[i];
+        }
     }
 }
 
@@ -1141,6 +1399,31 @@ int vsk_diag_attention(const float *q, const float *k, const float *v, float *ou
                        scale * 1.4426950408889634f, BH, nullptr, nullptr, 0, diag);
     VSK_CHECK_LAUNCH();
     return (int)g.x;     // > 0: blocks launched (the caller sizes / reads diag[blocks * 8 * 16])
+}
+// prec 1: bf16 in / out (q pre-scaled; the bf16 mode's form), prec 2: fp16x3 on fp32 q / k / v
+int vsk_diag_attention_lp(const float *q, const float *k, const float *v, float *out, int B, int H, int T, float scale,
+                          int prec, unsigned long long *diag, hipStream_t st) {
+    const int BH = B * H, nq = (T + 255) / 256;
+    dim3 g(8 * ((BH + 7) / 8) * nq);
+    const float sl2 = scale * 1.4426950408889634f;
+    if (prec >= 100) {      // timing ablations of the bf16 kernel (no stamps): prec = 100 + ABL
+#define VSK_ABL(A_) case A_: hipLaunchKernelGGL((attn_fwd_lp_pipe<64, 8, 1, false, true, 0, A_>), g, dim3(512), 0, st, q, k, v, nullptr, out, H, T, sl2, BH, nullptr, nullptr, 0, nullptr); break;
+        switch (prec - 100) {
+            VSK_ABL(0) VSK_ABL(1) VSK_ABL(2) VSK_ABL(3) VSK_ABL(4) VSK_ABL(5) VSK_ABL(7) VSK_ABL(16) VSK_ABL(17) VSK_ABL(19)
+            default: return -1;
+        }
+#undef VSK_ABL
+        VSK_CHECK_LAUNCH();
+        return (int)g.x;
+    }
+    if (prec == 1)
+        hipLaunchKernelGGL((attn_fwd_lp_pipe<64, 8, 1, false, true, 1>), g, dim3(512), 0, st, q, k, v, nullptr, out, H, T, sl2, BH,
+                           nullptr, nullptr, 0, diag);
+    else
+        hipLaunchKernelGGL((attn_fwd_lp_pipe<64, 8, 2, false, false, 1>), g, dim3(512), 0, st, q, k, v, nullptr, out, H, T, sl2, BH,
+                           nullptr, nullptr, 0, diag);
+    VSK_CHECK_LAUNCH();
+    return (int)g.x;
 }
 #endif
 

@@ -41,6 +41,8 @@ int vsk_rows_res_ln(const float *a, const float *res, const float *gamma, const 
                     hipStream_t st);
 int vsk_diag_attention(const float *q, const float *k, const float *v, float *out, int B, int H, int T, float scale,
                        unsigned long long *diag, hipStream_t st);      // diagnostic library only; returns the blocks launched
+int vsk_diag_attention_lp(const float *q, const float *k, const float *v, float *out, int B, int H, int T, float scale,
+                          int prec, unsigned long long *diag, hipStream_t st);
 int vsk_diag_gemm(const float *A, const float *W, const float *bias, float *C, int M, int N, int K,
                   int grid, unsigned long long *diag, hipStream_t st);
 // fc1 + ReLU + fc2 + residual + LayerNorm (+ score head) in one kernel; d_model == 256 only (-1 otherwise)

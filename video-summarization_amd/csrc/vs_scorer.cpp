@@ -674,6 +674,10 @@ int vs_diag_attention(const float *q, const float *k, const float *v, float *out
     const int blocks = vsk_diag_attention(q, k, v, out, B, H, T, scale, diag, (hipStream_t)stream);
     return blocks;
 }
+int vs_diag_attention_lp(const float *q, const float *k, const float *v, float *out, int32_t B, int32_t H, int32_t T,
+                         float scale, int32_t prec, unsigned long long *diag, void *stream) {
+    return vsk_diag_attention_lp(q, k, v, out, B, H, T, scale, prec, diag, (hipStream_t)stream);
+}
 #endif  // VS_WITH_DIAG
 
 static int linear_entry(const float *A, const float *W, const float *bias, float *C, int32_t M, int32_t N,
