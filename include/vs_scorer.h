@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define VS_ABI_VERSION 2
+#define VS_ABI_VERSION 3
 
 /* status codes */
 #define VS_OK 0

@@ -32,7 +32,19 @@ typedef struct vs_dropout_cfg {
     float p_embed;
     float p;
     uint64_t seed;
+    uint32_t flags;      /* VS_TRAIN_FLAG_*; 0 = exact fp32 everywhere */
+    uint32_t reserved;   /* 0 */
 } vs_dropout_cfg;
+
+/* Low-precision training, the counterpart of the reference's fp16 autocast (`with amp.autocast():` around the forward,
+ * train.py:120, pretrain.py:59): every Linear of the forward (embedding, q/k/v, feature_projection, fc1, fc2), every
+ * dgrad GEMM and every weight-gradient GEMM of the backward multiplies bf16-ROUNDED operands on the bf16 matrix pipe
+ * (v_mfma_f32_32x32x16_bf16) with fp32 accumulation; tensors stay fp32 in HBM, and bias, residual, LayerNorm, softmax,
+ * the attention products, dropout and the loss stay exact fp32 - what autocast keeps in fp32 (softmax, layer_norm, mse)
+ * plus the attention matmuls.  Applied from 8192 frames per batch up (below, the exact latency kernels are faster);
+ * pass the SAME flags to forward and backward.  Gradients then differ from the float64 truth by ~1e-2 relative
+ * (tests/tolerances.py: TRAIN_LP_GRAD_RTOL), where the exact path is at 1e-6. */
+#define VS_TRAIN_FLAG_BF16_LINEAR 1u
 
 /* Gradient destinations: the mirror of vs_layer_params / vs_model_params (nn.Linear layout [out, in]); every
  * pointer is a device buffer of the parameter's shape that the backward OVERWRITES (it does not accumulate). */
@@ -125,6 +137,9 @@ int vs_train_attention_backward(const float *q, const float *k, const float *v, 
 /* dW [N,K] = dY[M,N]^T X[M,K], db [N] = column sums of dY; scratch >= vs_train_wgrad_scratch_floats(M,N,K) floats. */
 size_t vs_train_wgrad_scratch_floats(int32_t M, int32_t N, int32_t K);
 int vs_train_wgrad(const float *dY, const float *X, int32_t M, int32_t N, int32_t K, float *dW, float *db,
+                   float *scratch, void *stream);
+/* The same on the bf16 matrix pipe (VS_TRAIN_FLAG_BF16_LINEAR): dY and X rounded to bf16, fp32 accumulation; db exact. */
+int vs_train_wgrad_bf16(const float *dY, const float *X, int32_t M, int32_t N, int32_t K, float *dW, float *db,
                    float *scratch, void *stream);
 /* keep masks (bytes, 1 = kept) exactly as the kernels draw them: attention weights [B,H,T,T]; elementwise [M,cols] */
 int vs_train_dropout_mask_attention(uint8_t *keep, int32_t B, int32_t H, int32_t T, uint64_t seed, uint32_t site,

@@ -276,6 +276,111 @@ def test_wgrad_kernel(vsa, M, N, K):
     _close(db, dY.sum(0), "db", atol=None, rtol=2e-5)
 
 
+@pytest.mark.parametrize("M,N,K", [(4096, 256, 1024), (1000, 768, 256), (333, 128, 132), (65, 4, 8), (8192, 1024, 256)])
+def test_wgrad_bf16_kernel(vsa, M, N, K):
+    """The weight-gradient GEMM on the bf16 matrix pipe (low-precision training): against float64 on the SAME bf16-rounded
+    operands (every index map of the transposed LDS reads is then pinned to fp32 rounding: 2e-5 relative), the bias
+    gradient against the unrounded column sums, and twice for bitwise reproducibility."""
+    lib = vsa._lib.load()
+    g = torch.Generator().manual_seed(M + N + 1)
+    dY = torch.randn(M, N, generator=g)
+    X = torch.randn(M, K, generator=g)
+    dYd, Xd = dY.to(_dev()), X.to(_dev())
+    dW = torch.full((N, K), float("nan"), device=_dev())
+    db = torch.full((N,), float("nan"), device=_dev())
+    scratch = torch.empty(lib.vs_train_wgrad_scratch_floats(M, N, K), device=_dev())
+    for it in range(2):
+        vsa._lib.check(lib.vs_train_wgrad_bf16(dYd.data_ptr(), Xd.data_ptr(), M, N, K, dW.data_ptr(), db.data_ptr(),
+                                               scratch.data_ptr(), _stream()))
+        torch.cuda.synchronize()
+        first = (dW.clone(), db.clone()) if it == 0 else first
+    assert torch.equal(first[0], dW) and torch.equal(first[1], db)
+    r = lambda t: t.to(torch.bfloat16).double()          # noqa: E731  (round to nearest even, like v_cvt_pk_bf16_f32)
+    _close(dW, r(dY).t() @ r(X), "dW", atol=None, rtol=2e-5)
+    _close(db, dY.double().sum(0), "db", atol=None, rtol=2e-5)
+    # and the distance to the unrounded product is the bf16 rounding itself (~2^-9 per operand, averaged over M terms)
+    _close(dW, dY.double().t() @ X.double(), "dW vs unrounded", atol=None, rtol=1e-2)
+
+
+@pytest.fixture
+def lp_train_everywhere(vsa):
+    """low-precision GEMMs from the first row on (default: from 8192 frames per batch)"""
+    vsa._lib.set_option("VS_LP_MIN_ROWS", 0)
+    yield
+    vsa._lib.set_option("VS_LP_MIN_ROWS", -1)
+
+
+@pytest.mark.parametrize("case", train_cases(), ids=lambda c: c["name"])
+def test_bf16_training_gradients_within_the_low_precision_tolerance(vsa, lp_train_everywhere, case):
+    """``set_train_dtype("bf16")`` - the counterpart of the reference's fp16 autocast (train.py:120): every Linear, dgrad
+    and wgrad GEMM on the bf16 matrix pipe.  Loss and every gradient against the float64 goldens of the IMPORTED reference
+    at tests/tolerances.py's TRAIN_LP_* (per tensor, relative to its largest entry)."""
+    c = case
+    z = np.load(os.path.join(GOLDEN, c["name"] + ".npz"))
+    sd = vsa.synth.make_state_dict(c["d"], c["L"], c["wseed"])
+    x, mask, target, R = _inputs(vsa.synth, c)
+    m = vsa.SimNet(num_heads=c["H"], d_model=c["d"], num_layers=c["L"], sparsity=0.0, dropout=0.0)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(_dev()).train().set_train_dtype("bf16")
+    xd = x.to(_dev()).requires_grad_(True)
+    md = None if mask is None else mask.to(_dev())
+    pred, hidden = m(xd, md)
+    mk = md if md is not None else torch.zeros(x.shape[:2], dtype=torch.bool, device=_dev())
+    loss = vsa.mse_with_mask_loss(pred, target.to(_dev()), mk)
+    if c["hidden_w"]:
+        loss = loss + c["hidden_w"] * (hidden * R.to(_dev())).sum()
+    loss.backward()
+    torch.cuda.synchronize()
+    want = float(z["loss"])
+    assert abs(loss.item() - want) <= tol.TRAIN_LP_LOSS_RTOL * max(1.0, abs(want)), (loss.item(), want)
+    grads = {"x": xd.grad}
+    grads.update({k: p.grad for k, p in m.named_parameters()})
+    worst, worst_k = 0.0, None
+    for k in json.loads(str(z["keys"])):
+        g = grads[k]
+        assert g is not None and torch.isfinite(g).all(), k
+        g2 = g.reshape(-1, g.shape[-1]) if g.dim() > 1 else g.reshape(1, -1)
+        rows = torch.from_numpy(z["r:" + k])
+        want_g = torch.from_numpy(z["g:" + k]).double()
+        tot, nrm, gmax, ref32 = z["s:" + k]
+        err = (g2[rows.to(g2.device)].double().cpu() - want_g).abs().max().item()
+        assert err <= tol.TRAIN_LP_GRAD_RTOL * gmax + 1e-6, "%s: err %.3e, max|g| %.3e" % (k, err, gmax)
+        assert abs(g.double().norm().item() - nrm) <= 2e-2 * nrm + 1e-7, k
+        if gmax > 1e-6 and err / gmax > worst:
+            worst, worst_k = err / gmax, k
+    assert worst > 1e-5, "the low-precision path did not run (gradients at exact-fp32 accuracy)"
+    print("%s: bf16 training, worst gradient error relative to the tensor's max: %.2e (%s)" % (c["name"], worst, worst_k))
+
+
+def test_bf16_training_loss_curve_tracks_the_exact_path(vsa, lp_train_everywhere):
+    """40 Adam steps from one initialisation and one dropout seed stream, exact fp32 vs bf16 GEMMs: the losses fall
+    together (every step within 3 % of the exact run's loss) and both end below 0.7 x their start."""
+    def run(dtype):
+        torch.manual_seed(7)
+        sd = vsa.synth.make_state_dict(256, 2, 31)
+        m = vsa.SimNet(num_heads=4, d_model=256, num_layers=2, sparsity=0.0, dropout=0.1)
+        m.load_state_dict(sd)
+        m = m.to(_dev()).train().set_train_dtype(dtype)
+        opt = torch.optim.Adam(m.parameters(), lr=2e-4)
+        x = vsa.synth.make_features(4, 200, 9, "pool5", [200, 150, 180, 120]).to(_dev())
+        mask = vsa.synth.padding_mask(x)
+        tgt = torch.rand(4, 200, generator=torch.Generator().manual_seed(3)).to(_dev())
+        out = []
+        for _ in range(40):
+            pred, _h = m(x, mask)
+            loss = vsa.mse_with_mask_loss(pred, tgt, mask)
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            opt.step()
+            out.append(loss.item())
+        return out
+    a, b = run("fp32"), run("bf16")
+    assert a[-1] < 0.7 * a[0] and b[-1] < 0.7 * b[0], (a[0], a[-1], b[0], b[-1])
+    rel = max(abs(u - v) / u for u, v in zip(a, b))
+    print("loss curves: exact %.4f -> %.4f, bf16 %.4f -> %.4f, worst step-wise relative difference %.2e" % (a[0], a[-1], b[0], b[-1], rel))
+    assert rel < 3e-2 and a != b
+
+
 def test_dropout_hash_statistics(vsa):
     """Keep rate, independence across modules (sites) and seeds, and determinism of the counter hash."""
     lib = vsa._lib.load()

@@ -14,9 +14,9 @@ int vsk_linear(const float *A, const float *W, const float *Wf, const float *bia
                int relu, const float *pe, int T, int bf16, hipStream_t st);
 // training-path epilogues on the same GEMM kernels (exact fp32): ReLU/dropout gate of a dgrad; fc1 + ReLU + dropout
 int vsk_linear_gate(const float *A, const float *W, const float *Wf, const float *bias, const float *gate, float scale,
-                    float *C, int M, int N, int K, hipStream_t st);
+                    float *C, int M, int N, int K, hipStream_t st, int bf16 = 0);
 int vsk_linear_relu_dropout(const float *A, const float *W, const float *Wf, const float *bias, float *C, int M, int N,
-                            int K, unsigned long long seed, unsigned site, float p, hipStream_t st);
+                            int K, unsigned long long seed, unsigned site, float p, hipStream_t st, int bf16 = 0);
 int vsk_pack_fragments(const float *W, float *Wf, int N, int K, hipStream_t st);
 // the fp16x3 counterpart (hi|lo f16 halves of 2^10 * W, same size): pass it as `Wf` together with bf16 == 2
 int vsk_pack_fragments_f16x3(const float *W, float *Wh, int N, int K, hipStream_t st);

@@ -1891,14 +1891,14 @@ int vsk_linear(const float *A, const float *W, const float *Wf, const float *bia
 // training path: C = (gate > 0 ? (A W^T + bias) * scale : 0), gate [M,N] - the ReLU / mlp.dropout backward in the
 // epilogue of the fc2 dgrad GEMM (exact fp32 kernels only)
 int vsk_linear_gate(const float *A, const float *W, const float *Wf, const float *bias, const float *gate, float scale,
-                    float *C, int M, int N, int K, hipStream_t st) {
-    return launch_gemm<EPI_GATE>(A, W, Wf, bias, C, M, N, K, gate, 1, 0, 0, 0, st, EpiArgs{0ull, 0u, 0.f, scale});
+                    float *C, int M, int N, int K, hipStream_t st, int bf16) {
+    return launch_gemm<EPI_GATE>(A, W, Wf, bias, C, M, N, K, gate, 1, 0, 0, bf16, st, EpiArgs{0ull, 0u, 0.f, scale});
 }
 
 // training path: C = dropout_{seed,site,p}(relu(A W^T + bias)) - mlp.fc1 + ReLU + mlp.dropout in one GEMM
 int vsk_linear_relu_dropout(const float *A, const float *W, const float *Wf, const float *bias, float *C, int M, int N,
-                            int K, unsigned long long seed, unsigned site, float p, hipStream_t st) {
-    return launch_gemm<EPI_RELU_DROP>(A, W, Wf, bias, C, M, N, K, nullptr, 1, 0, 0, 0, st, EpiArgs{seed, site, p, 0.f});
+                            int K, unsigned long long seed, unsigned site, float p, hipStream_t st, int bf16) {
+    return launch_gemm<EPI_RELU_DROP>(A, W, Wf, bias, C, M, N, K, nullptr, 1, 0, 0, bf16, st, EpiArgs{seed, site, p, 0.f});
 }
 
 #ifdef VS_WITH_DIAG

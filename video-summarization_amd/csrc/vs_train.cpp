@@ -212,6 +212,9 @@ int vs_train_forward(const vs_weights *w, const float *x, const uint8_t *key_pad
     const float p = drop ? drop->p : 0.f;
     // the embedding dropout lives INSIDE PositionalEncoding (simnet.py:224,237): a use_pos=False model has none
     const float p_embed = (drop && w->has_pe) ? drop->p_embed : 0.f;
+    // low-precision training (VS_TRAIN_FLAG_BF16_LINEAR): every Linear / dgrad / wgrad GEMM on the bf16 matrix pipe, from the
+    // batch size up where the LDS-tiled kernels beat the exact latency kernels (the threshold of the scoring path)
+    const int lp = (drop && (drop->flags & VS_TRAIN_FLAG_BF16_LINEAR) && (long long)B * T > vsk_options().lp_min_rows) ? 1 : 0;
     const unsigned long long seed = drop ? drop->seed : 0ull;
     const float scale = 1.0f / sqrtf((float)d);              // simnet.py:126: d_model ** -0.5
     float *sv = (float *)saved, *ws = (float *)workspace;
@@ -221,7 +224,7 @@ int vs_train_forward(const vs_weights *w, const float *x, const uint8_t *key_pad
     // Embedding + positional table + dropout(sparsity)   simnet.py:211, 237-238
     float *h0 = sv + S.h0;
     VST_LAUNCH(vsk_linear(x, w->p(w->embed_w), w->p(w->f_embed_w), w->p(w->embed_b), h0, M, d, D.in_features, 0,
-                          w->has_pe ? w->p(w->pe) : nullptr, T, 0, st));
+                          w->has_pe ? w->p(w->pe) : nullptr, T, lp, st));
     if (p_embed > 0.f) VST_LAUNCH(vst_dropout_rows(h0, M, d, seed, VS_SITE_EMBED, p_embed, st));
     const float *h_in = h0;
     for (int l = 0; l < L; ++l) {
@@ -229,18 +232,18 @@ int vs_train_forward(const vs_weights *w, const float *x, const uint8_t *key_pad
         const LayerSaved &A = S.layers[l];
         const bool last = l == L - 1;
         float *qkv = sv + A.qkv;
-        VST_LAUNCH(vsk_qkv(h_in, w->p(P.wqkv), w->p(P.f_wqkv), w->p(P.bqkv), qkv, B, T, d, H, 0, st));          // :148-153
+        VST_LAUNCH(vsk_qkv(h_in, w->p(P.wqkv), w->p(P.f_wqkv), w->p(P.bqkv), qkv, B, T, d, H, lp, st));         // :148-153
         VST_LAUNCH(vst_attention_fwd(qkv, qkv + (size_t)M * d, qkv + 2 * (size_t)M * d, key_pad_mask, sv + A.att,
                                      sv + A.lse, B, H, T, d / H, scale, seed, VS_SITE_LAYER(l, VS_SITE_ATTN), p, st));   // :155-161
-        VST_LAUNCH(vsk_linear(sv + A.att, w->p(P.wo), w->p(P.f_wo), w->p(P.bo), a, M, d, d, 0, nullptr, 1, 0, st));       // :163
+        VST_LAUNCH(vsk_linear(sv + A.att, w->p(P.wo), w->p(P.f_wo), w->p(P.bo), a, M, d, d, 0, nullptr, 1, lp, st));      // :163
         VST_LAUNCH(vst_rows_fwd(a, h_in, w->p(P.ln1g), w->p(P.ln1b), sv + A.z1, sv + A.y1, nullptr, sv + A.st1, M, d,
                                 seed, VS_SITE_LAYER(l, VS_SITE_DROP1), p, nullptr, nullptr, 0, nullptr, st));              // :107
         if (p > 0.f)        // fc1 + ReLU + mlp.dropout in one GEMM epilogue (:181)
             VST_LAUNCH(vsk_linear_relu_dropout(sv + A.y1, w->p(P.w1), w->p(P.f_w1), w->p(P.b1), sv + A.ffn, M, 4 * d, d, seed,
-                                               VS_SITE_LAYER(l, VS_SITE_MLP), p, st));
+                                               VS_SITE_LAYER(l, VS_SITE_MLP), p, st, lp));
         else
-            VST_LAUNCH(vsk_linear(sv + A.y1, w->p(P.w1), w->p(P.f_w1), w->p(P.b1), sv + A.ffn, M, 4 * d, d, 1, nullptr, 1, 0, st));
-        VST_LAUNCH(vsk_linear(sv + A.ffn, w->p(P.w2), w->p(P.f_w2), w->p(P.b2), a, M, d, 4 * d, 0, nullptr, 1, 0, st));   // :182
+            VST_LAUNCH(vsk_linear(sv + A.y1, w->p(P.w1), w->p(P.f_w1), w->p(P.b1), sv + A.ffn, M, 4 * d, d, 1, nullptr, 1, lp, st));
+        VST_LAUNCH(vsk_linear(sv + A.ffn, w->p(P.w2), w->p(P.f_w2), w->p(P.b2), a, M, d, 4 * d, 0, nullptr, 1, lp, st));  // :182
         VST_LAUNCH(vst_rows_fwd(a, sv + A.y1, w->p(P.ln2g), w->p(P.ln2b), sv + A.z2, sv + A.y2, last ? hidden : nullptr,
                                 sv + A.st2, M, d, seed, VS_SITE_LAYER(l, VS_SITE_DROP2), p,
                                 last ? w->p(w->final_w) : nullptr, last ? w->p(w->final_b) : nullptr, D.num_classes,
@@ -272,6 +275,9 @@ int vs_train_backward(vs_weights *w, const float *x, const uint8_t *key_pad_mask
     const float p = drop ? drop->p : 0.f;
     // the embedding dropout lives INSIDE PositionalEncoding (simnet.py:224,237): a use_pos=False model has none
     const float p_embed = (drop && w->has_pe) ? drop->p_embed : 0.f;
+    // low-precision training (VS_TRAIN_FLAG_BF16_LINEAR): every Linear / dgrad / wgrad GEMM on the bf16 matrix pipe, from the
+    // batch size up where the LDS-tiled kernels beat the exact latency kernels (the threshold of the scoring path)
+    const int lp = (drop && (drop->flags & VS_TRAIN_FLAG_BF16_LINEAR) && (long long)B * T > vsk_options().lp_min_rows) ? 1 : 0;
     const unsigned long long seed = drop ? drop->seed : 0ull;
     const float scale = 1.0f / sqrtf((float)d);
     const float *sv = (const float *)saved;
@@ -311,37 +317,37 @@ int vs_train_backward(vs_weights *w, const float *x, const uint8_t *key_pad_mask
         VST_LAUNCH(vst_reduce_rows(part, nblk, 2, d, G.ln2_g, G.ln2_b, nullptr, 1, st));
         const float *dm = p > 0.f ? dbr : dz;
         // mlp.fc2: weight/bias gradient, then the gradient of its input
-        VST_LAUNCH(vst_wgrad(dm, d, sv + A.ffn, 4 * d, M, d, 4 * d, G.w2, nullptr, nullptr, G.b2, nullptr, nullptr, d, wg, st));
+        VST_LAUNCH(vst_wgrad(dm, d, sv + A.ffn, 4 * d, M, d, 4 * d, G.w2, nullptr, nullptr, G.b2, nullptr, nullptr, d, wg, st, lp));
         // ... through mlp.dropout + ReLU in the GEMM's epilogue: the saved activation is > 0 exactly where both let
         // the value through
-        VST_LAUNCH(vsk_linear_gate(dm, w->tp(Q.t_w2), w->tp(Q.tf_w2), zeros, sv + A.ffn, p > 0.f ? 1.0f / (1.0f - p) : 1.0f, gf, M, 4 * d, d, st));
-        VST_LAUNCH(vst_wgrad(gf, 4 * d, sv + A.y1, d, M, 4 * d, d, G.w1, nullptr, nullptr, G.b1, nullptr, nullptr, 4 * d, wg, st));
+        VST_LAUNCH(vsk_linear_gate(dm, w->tp(Q.t_w2), w->tp(Q.tf_w2), zeros, sv + A.ffn, p > 0.f ? 1.0f / (1.0f - p) : 1.0f, gf, M, 4 * d, d, st, lp));
+        VST_LAUNCH(vst_wgrad(gf, 4 * d, sv + A.y1, d, M, 4 * d, d, G.w1, nullptr, nullptr, G.b1, nullptr, nullptr, 4 * d, wg, st, lp));
         // d y1 = dz2 (residual) + d(fc1 input): the residual rides in the GEMM epilogue
-        VST_LAUNCH(vsk_linear(gf, w->tp(Q.t_w1), w->tp(Q.tf_w1), zeros, dy1, M, d, 4 * d, 0, dz, M, 0, st));
+        VST_LAUNCH(vsk_linear(gf, w->tp(Q.t_w1), w->tp(Q.tf_w1), zeros, dy1, M, d, 4 * d, 0, dz, M, lp, st));
         // norm1; d(feature_projection output) = dropout1 mask on dz1
         VST_LAUNCH(vst_ln_bwd(dy1, nullptr, nullptr, 0, sv + A.z1, sv + A.st1, w->p(P.ln1g), dz, p > 0.f ? dbr : nullptr, part,
                               M, d, seed, VS_SITE_LAYER(l, VS_SITE_DROP1), p, st));
         VST_LAUNCH(vst_reduce_rows(part, nblk, 2, d, G.ln1_g, G.ln1_b, nullptr, 1, st));
         const float *da = p > 0.f ? dbr : dz;
-        VST_LAUNCH(vst_wgrad(da, d, sv + A.att, d, M, d, d, G.wo, nullptr, nullptr, G.bo, nullptr, nullptr, d, wg, st));
-        VST_LAUNCH(vsk_linear(da, w->tp(Q.t_wo), w->tp(Q.tf_wo), zeros, datt, M, d, d, 0, nullptr, 1, 0, st));
+        VST_LAUNCH(vst_wgrad(da, d, sv + A.att, d, M, d, d, G.wo, nullptr, nullptr, G.bo, nullptr, nullptr, d, wg, st, lp));
+        VST_LAUNCH(vsk_linear(da, w->tp(Q.t_wo), w->tp(Q.tf_wo), zeros, datt, M, d, d, 0, nullptr, 1, lp, st));
         // attention
         const float *qkv = sv + A.qkv;
         VST_LAUNCH(vst_head_rowdot(datt, sv + A.att, delta, M, T, H, d / H, st));
         VST_LAUNCH(vst_attention_bwd(qkv, qkv + (size_t)M * d, qkv + 2 * (size_t)M * d, key_pad_mask, datt, sv + A.lse, delta,
                                      dqkv, B, H, T, d / H, scale, seed, VS_SITE_LAYER(l, VS_SITE_ATTN), p, st));
         // q / k / v projections: one [3d, d] weight gradient dealt to the three parameters
-        VST_LAUNCH(vst_wgrad(dqkv, 3 * d, h_in, d, M, 3 * d, d, G.wq, G.wk, G.wv, G.bq, G.bk, G.bv, d, wg, st));
+        VST_LAUNCH(vst_wgrad(dqkv, 3 * d, h_in, d, M, 3 * d, d, G.wq, G.wk, G.wv, G.bq, G.bk, G.bv, d, wg, st, lp));
         // gradient of the layer input = dz1 (residual) + dqkv Wqkv
-        VST_LAUNCH(vsk_linear(dqkv, w->tp(Q.t_wqkv), w->tp(Q.tf_wqkv), zeros, g[cur ^ 1], M, d, 3 * d, 0, dz, M, 0, st));
+        VST_LAUNCH(vsk_linear(dqkv, w->tp(Q.t_wqkv), w->tp(Q.tf_wqkv), zeros, g[cur ^ 1], M, d, 3 * d, 0, dz, M, lp, st));
         cur ^= 1;
     }
     // Embedding (simnet.py:211, 237-238): dropout(sparsity) mask, then the Linear
     float *gh0 = g[cur];
     if (p_embed > 0.f) VST_LAUNCH(vst_dropout_rows(gh0, M, d, seed, VS_SITE_EMBED, p_embed, st));
     VST_LAUNCH(vst_wgrad(gh0, d, x, D.in_features, M, d, D.in_features, grads->embed_w, nullptr, nullptr, grads->embed_b,
-                         nullptr, nullptr, d, wg, st));
-    if (dx) VST_LAUNCH(vsk_linear(gh0, w->tp(w->t_embed_w), w->tp(w->tf_embed_w), zeros, dx, M, D.in_features, d, 0, nullptr, 1, 0, st));
+                         nullptr, nullptr, d, wg, st, lp));
+    if (dx) VST_LAUNCH(vsk_linear(gh0, w->tp(w->t_embed_w), w->tp(w->tf_embed_w), zeros, dx, M, D.in_features, d, 0, nullptr, 1, lp, st));
     return VS_OK;
 }
 
@@ -457,6 +463,14 @@ int vs_train_wgrad(const float *dY, const float *X, int32_t M, int32_t N, int32_
     if (!dY || !X || !dW || !scratch) return failf(VS_ERR_INVALID, "NULL pointer");
     if (M <= 0 || N <= 0 || K <= 0 || N % 4 || K % 4) return failf(VS_ERR_INVALID, "M=%d N=%d K=%d unsupported (N, K multiples of 4)", M, N, K);
     VST_LAUNCH(vst_wgrad(dY, N, X, K, M, N, K, dW, nullptr, nullptr, db, nullptr, nullptr, N, scratch, (hipStream_t)stream));
+    return VS_OK;
+}
+
+int vs_train_wgrad_bf16(const float *dY, const float *X, int32_t M, int32_t N, int32_t K, float *dW, float *db,
+                        float *scratch, void *stream) {
+    if (!dY || !X || !dW || !scratch) return failf(VS_ERR_INVALID, "NULL pointer");
+    if (M <= 0 || N <= 0 || K <= 0 || N % 4 || K % 4) return failf(VS_ERR_INVALID, "M=%d N=%d K=%d unsupported (N, K multiples of 4)", M, N, K);
+    VST_LAUNCH(vst_wgrad(dY, N, X, K, M, N, K, dW, nullptr, nullptr, db, nullptr, nullptr, N, scratch, (hipStream_t)stream, 1));
     return VS_OK;
 }
 

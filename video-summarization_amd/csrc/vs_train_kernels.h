@@ -29,7 +29,7 @@ int vst_weighted_colsum(const float *w, int ws, const float *Y, float *part, int
 int vst_wgrad_splits(int M, int N, int K);
 size_t vst_wgrad_workspace_floats(int M, int N, int K);
 int vst_wgrad(const float *dY, int ldy, const float *X, int ldx, int M, int N, int K, float *dW0, float *dW1, float *dW2,
-              float *db0, float *db1, float *db2, int rows_per_dest, float *work, hipStream_t st);
+              float *db0, float *db1, float *db2, int rows_per_dest, float *work, hipStream_t st, int prec = 0);   // prec 1: bf16 matrix pipe
 int vst_reduce_rows(const float *part, int S, int rows, int cols, float *d0, float *d1, float *d2, int rows_per_dest,
                     hipStream_t st);
 int vst_transpose(const float *in, float *out, int rows, int cols, hipStream_t st);

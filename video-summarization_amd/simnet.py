@@ -118,7 +118,7 @@ class _TrainForward(torch.autograd.Function):
 
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)     # train.py:120 calls under amp.autocast()
-    def forward(ctx, module, x, mask, p, p_embed, seed, *params):
+    def forward(ctx, module, x, mask, p, p_embed, seed, tflags, *params):
         lib = _lib.load()
         B, T, _ = x.shape
         x = x.contiguous()
@@ -129,7 +129,7 @@ class _TrainForward(torch.autograd.Function):
         packed = module._packed_weights(x.device)
         scores = torch.empty((B, T, module.num_classes), dtype=torch.float32, device=x.device)
         hidden = torch.empty((B, T, module.d_model), dtype=torch.float32, device=x.device)
-        cfg = _lib.DropoutCfg(float(p_embed), float(p), int(seed))
+        cfg = _lib.DropoutCfg(float(p_embed), float(p), int(seed), int(tflags), 0)
         with torch.cuda.device(x.device):
             if not getattr(packed, "train_prepared", False):     # one-time allocation of the dgrad transposes, outside the backward
                 _lib.check(lib.vs_train_prepare(packed.handle, torch.cuda.current_stream(x.device).cuda_stream))
@@ -141,7 +141,7 @@ class _TrainForward(torch.autograd.Function):
                                             hidden.data_ptr(), saved.data_ptr(), saved.numel(), ws.data_ptr(), ws.numel(),
                                             stream))
         ctx.save_for_backward(x, m, saved)
-        ctx.module, ctx.cfg, ctx.packed, ctx.packed_key = module, (float(p_embed), float(p), int(seed)), packed, module._packed_key
+        ctx.module, ctx.cfg, ctx.packed, ctx.packed_key = module, (float(p_embed), float(p), int(seed), int(tflags), 0), packed, module._packed_key
         ctx.set_materialize_grads(False)
         return scores, hidden
 
@@ -177,7 +177,7 @@ class _TrainForward(torch.autograd.Function):
                                              saved.data_ptr(), saved.numel(), C.byref(G), _ptr(dx), ws.data_ptr(),
                                              ws.numel(), stream))
         out = [g if t.requires_grad else None for g, t in zip(grads, params)]
-        return (None, dx, None, None, None, None, *out)
+        return (None, dx, None, None, None, None, None, *out)
 
 
 # --------------------------------------------------------------------------------------------
@@ -244,6 +244,7 @@ class SimNet(nn.Module):
         # default "fp32" is the only mode the 1e-4 parity bar applies to.
         self._attention_dtype = "fp32"
         self._linear_dtype = "fp32"       # "bf16": every Linear multiplies bf16-rounded operands (fp32 storage/accumulate)
+        self._train_dtype = "fp32"        # set_train_dtype("bf16"): the training path's counterpart of the reference's autocast
         self._packed: Optional[_Packed] = None
         self._packed_key = None
         self._packed_shape = None
@@ -338,7 +339,8 @@ class SimNet(nn.Module):
         seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item()) if (p > 0.0 or p_embed > 0.0) else 0
         params = [t for t in self._tensors() if isinstance(t, nn.Parameter)]
         x32 = x if x.dtype == torch.float32 else x.float()
-        return _TrainForward.apply(self, x32, mask, p, p_embed, seed, *params)
+        tflags = _lib.VS_TRAIN_FLAG_BF16_LINEAR if self._train_dtype == "bf16" else 0
+        return _TrainForward.apply(self, x32, mask, p, p_embed, seed, tflags, *params)
 
     def forward(self, x: Tensor, mask=None, vis_attention=None, model_score: bool = False):
         """Same contract as reference ``SimNet.forward`` (simnet.py:32-45): returns
@@ -452,6 +454,17 @@ class SimNet(nn.Module):
             raise ValueError("compute dtype must be 'fp32', 'fp16x3' or 'bf16', got %r" % (value,))
         self.attention_dtype = value if (head_ok or value == "fp32") else "fp32"
         self.linear_dtype = value
+        return self
+
+    def set_train_dtype(self, value: str) -> "SimNet":
+        """Arithmetic of the TRAINING path's matrix products (forward Linears, dgrad and wgrad GEMMs): 'fp32' (default:
+        exact fp32 MFMA, gradients at 1e-6 of the float64 truth) or 'bf16' - the counterpart of the reference's
+        ``with amp.autocast():`` (train.py:120, pretrain.py:59): operands rounded to bf16, fp32 accumulation, and - as
+        under autocast - LayerNorm, softmax and the loss in fp32; the attention products stay exact fp32 too.  Applies
+        from 8192 frames per batch up.  Gradients within ~1e-2 (relative to each tensor's maximum) of the truth."""
+        if value not in ("fp32", "bf16"):
+            raise ValueError("train dtype must be 'fp32' or 'bf16', got %r" % (value,))
+        self._train_dtype = value
         return self
 
     @torch.no_grad()
