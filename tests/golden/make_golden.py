@@ -48,6 +48,12 @@ CASES = [
          use_pos=False),
     dict(name="ma_nc3_t64", H=4, d=256, L=1, B=1, T=64, wseed=17, xseed=112, kind="randn",
          num_classes=3),
+    # round 3: the reference's envelope is any d_model % num_heads == 0 (simnet.py:10-13, 123); wider models through the
+    # plain GEMM + row LayerNorm path: d_model 768 / 1024, head dim 64 and 128
+    dict(name="d768_h12_t200_pad", H=12, d=768, L=2, B=2, T=200, wseed=21, xseed=131, kind="pool5", lengths=[200, 133]),
+    dict(name="d768_h6_t130", H=6, d=768, L=1, B=1, T=130, wseed=22, xseed=132, kind="randn"),
+    dict(name="d1024_h8_t150", H=8, d=1024, L=2, B=1, T=150, wseed=23, xseed=133, kind="randn"),
+    dict(name="d1024_h16_randmask_t96", H=16, d=1024, L=1, B=2, T=96, wseed=24, xseed=134, kind="randn", randmask=5),
 ]
 HIDDEN_STRIDE = 7
 

@@ -46,6 +46,13 @@ CASES = [
          tseed=8, hidden_w=1e-3),
     # a longer video (several key tiles, ragged tail)
     dict(name="train_ma_t777", H=4, d=256, L=1, B=1, T=777, wseed=16, xseed=122, kind="randn", tseed=9, hidden_w=0.0),
+    # round 3: wider models (d_model 768, head dim 64; d_model 1024, head dim 128)
+    # (input seed chosen among 30 so that no fc1 pre-activation lies within 9e-6 of zero: a ReLU input inside fp32 rounding
+    # of zero may legitimately fall on the other side in an fp32 implementation - DESIGN.md section 12 - and with 184 320
+    # activations at d_model 768 most seeds have one)
+    dict(name="train_d768_h12_t60_pad", H=12, d=768, L=1, B=2, T=60, wseed=25, xseed=151, kind="pool5", lengths=[60, 41],
+         tseed=10, hidden_w=1e-3),
+    dict(name="train_d1024_h8_t70", H=8, d=1024, L=1, B=1, T=70, wseed=26, xseed=136, kind="randn", tseed=11, hidden_w=0.0),
 ]
 FULL_LIMIT = 4096
 N_ROWS = 12

@@ -99,7 +99,10 @@ def test_gradients_match_reference_golden(vsa, case):
         err = (got - want.double()).abs().max().item()
         assert err <= ATOL and err <= RTOL * gmax + 1e-6, "%s: err %.3e, max|g| %.3e (reference fp32 own err %.3e)" % (k, err, gmax, ref32)
         # whole-tensor checks for the sampled ones: sum and L2 norm
-        assert abs(g.double().sum().item() - tot) <= 1e-3 * max(abs(tot), nrm) + 1e-7, k     # coherent over a row: looser
+        # whole-tensor sum: the per-element bound (RTOL * gmax) allows a random-walk sum error of sqrt(numel) times that; a
+        # quarter of it is granted on top of the relative term (the 768 x 768 key-projection gradient sums to ~0: every
+        # row of it is orthogonal to the softmax's shift invariance, so the sum is pure rounding)
+        assert abs(g.double().sum().item() - tot) <= 1e-3 * max(abs(tot), nrm) + 0.25 * RTOL * gmax * g.numel() ** 0.5 + 1e-7, k
         assert abs(g.double().norm().item() - nrm) <= 1e-4 * nrm + 1e-7, k
         worst = max(worst, err / (gmax + 1e-12) if gmax > 1e-6 else 0.0)
     print("%s: worst gradient error relative to the tensor's max: %.2e" % (c["name"], worst))
@@ -335,7 +338,7 @@ def test_bf16_training_gradients_within_the_low_precision_tolerance(vsa, lp_trai
     assert abs(loss.item() - want) <= tol.TRAIN_LP_LOSS_RTOL * max(1.0, abs(want)), (loss.item(), want)
     grads = {"x": xd.grad}
     grads.update({k: p.grad for k, p in m.named_parameters()})
-    worst, worst_k = 0.0, None
+    worst, worst_k, worst_l2 = 0.0, None, 0.0
     for k in json.loads(str(z["keys"])):
         g = grads[k]
         assert g is not None and torch.isfinite(g).all(), k
@@ -343,13 +346,21 @@ def test_bf16_training_gradients_within_the_low_precision_tolerance(vsa, lp_trai
         rows = torch.from_numpy(z["r:" + k])
         want_g = torch.from_numpy(z["g:" + k]).double()
         tot, nrm, gmax, ref32 = z["s:" + k]
-        err = (g2[rows.to(g2.device)].double().cpu() - want_g).abs().max().item()
+        diff = g2[rows.to(g2.device)].double().cpu() - want_g
+        err = diff.abs().max().item()
+        l2 = diff.norm().item() / (want_g.norm().item() + 1e-30)
+        # two bounds per tensor: the largest element error relative to the tensor's largest entry (a ReLU unit whose
+        # pre-activation is within bf16 rounding of zero flips and moves ONE row of d_fc1 / one entry of its bias: a few
+        # per cent of the maximum in these 60..800-frame batches), and the relative L2 error over the sampled rows
         assert err <= tol.TRAIN_LP_GRAD_RTOL * gmax + 1e-6, "%s: err %.3e, max|g| %.3e" % (k, err, gmax)
+        assert l2 <= tol.TRAIN_LP_GRAD_L2 or gmax < 1e-6, "%s: relative L2 error %.3e" % (k, l2)
         assert abs(g.double().norm().item() - nrm) <= 2e-2 * nrm + 1e-7, k
         if gmax > 1e-6 and err / gmax > worst:
             worst, worst_k = err / gmax, k
+        if gmax > 1e-6 and l2 > worst_l2:
+            worst_l2 = l2
     assert worst > 1e-5, "the low-precision path did not run (gradients at exact-fp32 accuracy)"
-    print("%s: bf16 training, worst gradient error relative to the tensor's max: %.2e (%s)" % (c["name"], worst, worst_k))
+    print("%s: bf16 training, worst gradient error relative to the tensor's max: %.2e (%s); worst relative L2 error %.2e" % (c["name"], worst, worst_k, worst_l2))
 
 
 def test_bf16_training_loss_curve_tracks_the_exact_path(vsa, lp_train_everywhere):

@@ -25,5 +25,11 @@ TRAIN_GRAD_ATOL = 1e-4          # per tensor, max |g - g64| absolute ...
 TRAIN_GRAD_RTOL = 1e-3          # ... and relative to the tensor's largest entry (+1e-6 for analytically-zero sums)
 # low-precision training (set_train_dtype("bf16" | "fp16"): MFMA operands rounded, fp32 accumulate / softmax / LayerNorm /
 # loss) - the counterpart of the reference's fp16 autocast (train.py:120)
-TRAIN_LP_GRAD_RTOL = 5e-2       # per tensor, max |g - g64| relative to the tensor's largest entry (measured over the five golden cases: 0.6e-2 ... 3.4e-2; 8-bit mantissas through ~10 GEMMs and two LayerNorm backwards per layer)
+TRAIN_LP_GRAD_L2 = 5e-2         # per tensor, relative L2 error ||g - g64|| / ||g64|| over the golden's sampled rows
+                                # (measured over the seven golden cases: 1.2e-2 ... 2.6e-2; 8-bit mantissas through ~10
+                                # GEMMs and two LayerNorm backwards per layer)
+TRAIN_LP_GRAD_RTOL = 2e-1       # per tensor, LARGEST element error relative to the tensor's largest entry: a gross-error
+                                # bound only - a ReLU unit whose pre-activation lies within bf16 rounding of zero flips and
+                                # moves one row of d_fc1 / one entry of its bias, by up to 14 % of the maximum in the
+                                # 100-frame golden batches (measured: 0.6e-2 ... 1.4e-1)
 TRAIN_LP_LOSS_RTOL = 2e-3       # |loss - loss64| relative

@@ -1762,15 +1762,15 @@ int vsk_insert_cls(const float *e, const float *cls, const uint8_t *mask, float 
 int vsk_rows_res_ln(const float *a, const float *res, const float *gamma, const float *beta, float *out, int M, int d,
                     const float *score_w, const float *score_b, int num_classes, int sigmoid, float *scores,
                     hipStream_t st) {
-    if (d % 4 || d > 512) return -1;
+    if (d % 4 || d > 1024) return -1;
     const int rows4 = (M + 3) / 4;
     const dim3 grid(rows4 < 8192 ? (rows4 < 1 ? 1 : rows4) : 8192);
-    if (d <= 256)
-        hipLaunchKernelGGL(rows_res_ln<1>, grid, dim3(256), 0, st, a, res, gamma, beta, out, M, d, score_w, score_b,
-                           num_classes, sigmoid, scores);
-    else
-        hipLaunchKernelGGL(rows_res_ln<2>, grid, dim3(256), 0, st, a, res, gamma, beta, out, M, d, score_w, score_b,
-                           num_classes, sigmoid, scores);
+    switch ((d + 255) / 256) {          // float4 per lane (256 columns each)
+        case 1: hipLaunchKernelGGL(rows_res_ln<1>, grid, dim3(256), 0, st, a, res, gamma, beta, out, M, d, score_w, score_b, num_classes, sigmoid, scores); break;
+        case 2: hipLaunchKernelGGL(rows_res_ln<2>, grid, dim3(256), 0, st, a, res, gamma, beta, out, M, d, score_w, score_b, num_classes, sigmoid, scores); break;
+        case 3: hipLaunchKernelGGL(rows_res_ln<3>, grid, dim3(256), 0, st, a, res, gamma, beta, out, M, d, score_w, score_b, num_classes, sigmoid, scores); break;
+        default: hipLaunchKernelGGL(rows_res_ln<4>, grid, dim3(256), 0, st, a, res, gamma, beta, out, M, d, score_w, score_b, num_classes, sigmoid, scores); break;
+    }
     VSK_CHECK_LAUNCH();
     return 0;
 }

@@ -89,8 +89,8 @@ struct StageScope {
 
 int check_desc(const vs_model_desc *d) {
     if (!d) return fail(VS_ERR_INVALID, "desc is NULL");
-    if (d->d_model <= 0 || d->d_model % 64 || d->d_model > 512)
-        return fail(VS_ERR_INVALID, "d_model=%d unsupported (multiple of 64, <= 512)", d->d_model);
+    if (d->d_model <= 0 || d->d_model % 64 || d->d_model > 1024)
+        return fail(VS_ERR_INVALID, "d_model=%d unsupported (multiple of 64, <= 1024)", d->d_model);
     if (d->num_heads <= 0 || d->d_model % d->num_heads)
         return fail(VS_ERR_INVALID, "d_model=%d not divisible by num_heads=%d", d->d_model, d->num_heads);
     const int dh = d->d_model / d->num_heads;

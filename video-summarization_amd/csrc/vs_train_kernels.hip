@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void ln_bwd_rows(
     const float *__restrict__ z, const float *__restrict__ stats, const float *__restrict__ gamma,
     float *__restrict__ dz, float *__restrict__ dbranch, float *__restrict__ part, int M, int d,
     unsigned long long seed, unsigned site, float p) {
-    __shared__ float red[4][2][512];
+    __shared__ float red[4][2][256 * NV];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const DropSite ds = drop_site(seed, site, p);
     f32x4 ag[NV], ab[NV], gm[NV];
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void head_rowdot(const float *__restrict__ dO,
 template <int NV>
 __global__ __launch_bounds__(256) void weighted_colsum(const float *__restrict__ w, int ws, const float *__restrict__ Y,
                                                        float *__restrict__ part, int M, int d) {
-    __shared__ float red[4][516];
+    __shared__ float red[4][256 * NV + 4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     f32x4 acc[NV];
     float sw = 0.f;
@@ -649,17 +649,24 @@ int row_grid(int M) { const int b = (M + 3) / 4; return b < 512 ? (b < 1 ? 1 : b
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
+// rows of up to 1024 columns: NV = float4 per lane (256 columns each)
+#define VST_NV_DISPATCH(d_, KERN_, ...)                                              \
+    do {                                                                             \
+        switch (((d_) + 255) / 256) {                                                \
+            case 1: hipLaunchKernelGGL(KERN_<1>, __VA_ARGS__); break;                \
+            case 2: hipLaunchKernelGGL(KERN_<2>, __VA_ARGS__); break;                \
+            case 3: hipLaunchKernelGGL(KERN_<3>, __VA_ARGS__); break;                \
+            default: hipLaunchKernelGGL(KERN_<4>, __VA_ARGS__); break;               \
+        }                                                                            \
+    } while (0)
+
 int vst_rows_fwd(const float *a, const float *res, const float *gamma, const float *beta, float *z, float *y,
                  float *y_copy, float *stats, int M, int d, unsigned long long seed, unsigned site, float p,
                  const float *score_w, const float *score_b, int num_classes, float *scores, hipStream_t st) {
-    if (d % 4 || d > 512) return -1;
+    if (d % 4 || d > 1024) return -1;
     const dim3 grid((M + 3) / 4 < 4096 ? (M + 3) / 4 : 4096);
-    if (d <= 256)
-        hipLaunchKernelGGL(train_rows_fwd<1>, grid, dim3(256), 0, st, a, res, gamma, beta, z, y, y_copy, stats, M, d, seed,
-                           site, p, score_w, score_b, num_classes, scores);
-    else
-        hipLaunchKernelGGL(train_rows_fwd<2>, grid, dim3(256), 0, st, a, res, gamma, beta, z, y, y_copy, stats, M, d, seed,
-                           site, p, score_w, score_b, num_classes, scores);
+    VST_NV_DISPATCH(d, train_rows_fwd, grid, dim3(256), 0, st, a, res, gamma, beta, z, y, y_copy, stats, M, d, seed, site, p,
+                    score_w, score_b, num_classes, scores);
     VSK_CHECK_LAUNCH();
     return 0;
 }
@@ -669,14 +676,10 @@ int vst_ln_bwd_blocks(int M) { return row_grid(M); }
 int vst_ln_bwd(const float *dy, const float *dsc, const float *score_w, int num_classes, const float *z,
                const float *stats, const float *gamma, float *dz, float *dbranch, float *part, int M, int d,
                unsigned long long seed, unsigned site, float p, hipStream_t st) {
-    if (d % 4 || d > 512) return -1;
+    if (d % 4 || d > 1024) return -1;
     const dim3 grid(row_grid(M));
-    if (d <= 256)
-        hipLaunchKernelGGL(ln_bwd_rows<1>, grid, dim3(256), 0, st, dy, dsc, score_w, num_classes, z, stats, gamma, dz,
-                           dbranch, part, M, d, seed, site, p);
-    else
-        hipLaunchKernelGGL(ln_bwd_rows<2>, grid, dim3(256), 0, st, dy, dsc, score_w, num_classes, z, stats, gamma, dz,
-                           dbranch, part, M, d, seed, site, p);
+    VST_NV_DISPATCH(d, ln_bwd_rows, grid, dim3(256), 0, st, dy, dsc, score_w, num_classes, z, stats, gamma, dz, dbranch, part,
+                    M, d, seed, site, p);
     VSK_CHECK_LAUNCH();
     return 0;
 }
@@ -701,19 +704,17 @@ int vst_gate_bwd(float *g, const float *act, size_t n, float scale, hipStream_t 
 
 int vst_head_rowdot(const float *dO, const float *O, float *delta, int M, int T, int H, int dh, hipStream_t st) {
     const int d = H * dh;
-    if (d > 512 || (dh != 32 && dh != 64 && dh != 128)) return -1;
+    if (d > 1024 || (dh != 32 && dh != 64 && dh != 128)) return -1;
     const dim3 grid((M + 3) / 4 < 4096 ? (M + 3) / 4 : 4096);
-    if (d <= 256) hipLaunchKernelGGL(head_rowdot<1>, grid, dim3(256), 0, st, dO, O, delta, M, T, H, dh);
-    else hipLaunchKernelGGL(head_rowdot<2>, grid, dim3(256), 0, st, dO, O, delta, M, T, H, dh);
+    VST_NV_DISPATCH(d, head_rowdot, grid, dim3(256), 0, st, dO, O, delta, M, T, H, dh);
     VSK_CHECK_LAUNCH();
     return 0;
 }
 
 int vst_weighted_colsum(const float *w, int ws, const float *Y, float *part, int M, int d, hipStream_t st) {
-    if (d % 4 || d > 512) return -1;
+    if (d % 4 || d > 1024) return -1;
     const dim3 grid(row_grid(M));
-    if (d <= 256) hipLaunchKernelGGL(weighted_colsum<1>, grid, dim3(256), 0, st, w, ws, Y, part, M, d);
-    else hipLaunchKernelGGL(weighted_colsum<2>, grid, dim3(256), 0, st, w, ws, Y, part, M, d);
+    VST_NV_DISPATCH(d, weighted_colsum, grid, dim3(256), 0, st, w, ws, Y, part, M, d);
     VSK_CHECK_LAUNCH();
     return 0;
 }
