@@ -40,7 +40,8 @@ extern "C" {
 #define VS_FLAG_BF16_LINEAR 4u /* opt-in: every Linear (embed, q/k/v, feature_projection, fc1, fc2) multiplies
                                 bf16-rounded operands on the bf16 matrix pipe; tensors stay fp32 in HBM, and
                                 bias, accumulation, residual, LayerNorm and the score head stay fp32.
-                                d_model <= 256.  Same tolerance caveat as VS_FLAG_BF16_ATTENTION.  Batches of up
+                                Any supported d_model (<= 256: the fused bf16-storage layer kernels; above: plain bf16
+                                GEMMs + the row LayerNorm pass, fp32 storage).  Same tolerance caveat as VS_FLAG_BF16_ATTENTION.  Batches of up
                                 to 8192 frames keep the (faster, exact) fp32 latency kernels (bf16 only:
                                 fp16x3 has latency kernels of its own). */
 #define VS_FLAG_BF16 (VS_FLAG_BF16_ATTENTION | VS_FLAG_BF16_LINEAR)

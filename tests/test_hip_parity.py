@@ -1255,3 +1255,25 @@ def test_class_token_scoring_launches_no_torch_kernels_after_the_first_call(vsa)
         m.set_compute_dtype("bf16")
         lb, _ = m(x, mask)
         assert (lb.cpu() - rl).abs().max().item() < tol.BF16_LOGIT_TOL
+
+
+@pytest.mark.parametrize("name", ["mb_t320", "mb_pad_t150", "d768_h12_t200_pad", "d1024_h8_t150", "d1024_h16_randmask_t96"])
+def test_bf16_mode_on_wide_models_matches_reference_golden(vsa, lp_linear_everywhere, name):
+    """Round 3: ``set_compute_dtype("bf16")`` for d_model > 256 (M-B = the reference's argparse default, train.py:169-173;
+    d_model 768 / 1024): plain bf16 GEMMs + the row LayerNorm pass, bf16 attention at head dim 64 / 128.  Against the
+    vectors of the imported reference at the bf16 mode's stated tolerance."""
+    case = [c for c in golden_cases() if c["name"] == name][0]
+    sd, x, mask = build_case(vsa.synth, case)
+    g = load_golden(name)
+    m = vsa.SimNet(num_heads=case["H"], d_model=case["d"], num_layers=case["L"], sparsity=0.0, dropout=0.3)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(_dev()).eval().set_compute_dtype("bf16")
+    assert m.attention_dtype == "bf16" and m.linear_dtype == "bf16"
+    with torch.no_grad():
+        logits, hidden = m(x.to(_dev()), None if mask is None else mask.to(_dev()))
+        exact = m.set_compute_dtype("fp32")(x.to(_dev()), None if mask is None else mask.to(_dev()))[0]
+    valid = torch.ones(x.shape[:2], dtype=torch.bool) if mask is None else ~mask
+    err = (logits.cpu() - g["logits"])[valid].abs().max().item()
+    print("bf16 mode %s: max |logit - reference| %.2e" % (name, err))
+    assert 1e-6 < err < tol.BF16_LOGIT_TOL
+    assert (exact.cpu() - g["logits"])[valid].abs().max().item() < TOL

@@ -15,7 +15,7 @@ m = m.to(dev).eval()
 x = torch.randn(64, 1024, 1024, device=dev)
 with torch.no_grad():
     ref = m.score(x).clone()
-    for lin, att in (("fp32", "fp32"), ("fp32", "bf16"), ("fp16x3", "fp32"), ("fp16x3", "bf16")):
+    for lin, att in (("fp32", "fp32"), ("fp32", "bf16"), ("fp16x3", "fp32"), ("fp16x3", "bf16"), ("bf16", "bf16")):
         m.linear_dtype, m.attention_dtype = lin, att
         for _ in range(3): m.score(x)
         torch.cuda.synchronize(); t0 = time.perf_counter()

@@ -346,8 +346,6 @@ int forward_core(const vs_weights *w, const float *x, const uint8_t *key_pad_mas
     const int Tf = T;                   // frames per video (rows of x, positional rows)
     if (cls) T += 1;                    // sequence length the encoder sees
     if ((long long)B * T > (1ll << 30)) return fail(VS_ERR_INVALID, "B*T too large");
-    if ((flags & VS_FLAG_BF16_LINEAR) && D.d_model > 256)
-        return fail(VS_ERR_INVALID, "VS_FLAG_BF16_LINEAR needs d_model <= 256 (got %d)", D.d_model);
     if ((flags & VS_FLAG_BF16_LINEAR) && (flags & VS_FLAG_F16X3_LINEAR))
         return fail(VS_ERR_INVALID, "VS_FLAG_BF16_LINEAR and VS_FLAG_F16X3_LINEAR are exclusive");
     if ((flags & (VS_FLAG_BF16_ATTENTION | VS_FLAG_F16X3_ATTENTION)) && D.d_model / D.num_heads != 32 && D.d_model / D.num_heads != 64 &&
@@ -391,8 +389,10 @@ int forward_core(const vs_weights *w, const float *x, const uint8_t *key_pad_mas
     // bf16 mode: the tensors that are only ever read as bf16 matrix operands are WRITTEN as bf16 by their producers
     // (q * scale * log2 e, k, v; the attention output; the MLP hidden tensor) - same bits, half the HBM bytes
     const int aprec = pk ? pk->prec : (flags & VS_FLAG_F16X3_ATTENTION) ? 2 : (flags & VS_FLAG_BF16_ATTENTION) ? 1 : 0;
-    const bool qkv16 = lbf == 1 && aprec == 1 && !vsk_options().lp_store32 && !vsk_options().attn_lp_simple;
-    const bool ffn16 = lbf == 1 && !vsk_options().lp_store32;
+    // (d_model > 256 - M-B and wider - has no bf16-storage consumers: its LayerNorm GEMMs are the plain bf16 GEMM + the
+    // row pass, which read fp32, and the head-dim-128 attention reads fp32 q / k / v: fp32 storage there)
+    const bool qkv16 = lbf == 1 && aprec == 1 && d <= 256 && !vsk_options().lp_store32 && !vsk_options().attn_lp_simple;
+    const bool ffn16 = lbf == 1 && d <= 256 && !vsk_options().lp_store32;
     const bool mlp16 = lbf == 1 && vsk_mlp_bf16_supported(d) && !vsk_options().lp_mlp_unfused && !vsk_options().lp_store32;
     const size_t kv_stride = qkv16 ? (size_t)M * d / 2 : (size_t)M * d;      // floats between the q, k and v planes
 
@@ -461,7 +461,7 @@ int forward_core(const vs_weights *w, const float *x, const uint8_t *key_pad_mas
         have_qkv = false;
         // d_model > 256: plain GEMM + the row LayerNorm pass (faster than the fused wide kernel at every M; the
         // GEMM's output goes to a region of the workspace that is free at that point: q after the attention, att after fc1)
-        const bool split_ln = d > 256 && lnbf != 1;
+        const bool split_ln = d > 256;
         {
             StageScope ps(VS_STAGE_OUTPROJ_LN, st);
             if (split_ln) {
