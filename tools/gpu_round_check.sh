@@ -1,13 +1,13 @@
 # Round checkpoint on the GPU box: the whole -m gpu suite, smoke(), the headline bench, the HBM-traffic PMC passes, the
 # rocprofv3 kernel-trace of the same bench command, PMC summaries, M-B and training profiles.  Outputs: gpurun_out/rNN/
 set -e
-TAG=${1:-r02b}
+TAG=${1:-r03z}
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/$TAG
 # HBM-traffic passes first: the bench contract test below wants a traffic file measured on the sources that are loaded
 bash tools/collect_traffic.sh > gpurun_out/$TAG/traffic.log 2>&1
 cp gpurun_out/traffic.json gpurun_out/$TAG/traffic.json
-cp gpurun_out/traffic.json profiles/r02_hbm_traffic.json      # (on the box; copy gpurun_out/$TAG/traffic.json home as well)
+cp gpurun_out/traffic.json profiles/r03_hbm_traffic.json      # (on the box; copy gpurun_out/$TAG/traffic.json home as well)
 python -m pytest tests -x -q -m gpu > gpurun_out/$TAG/gputest.log 2>&1 || { tail -40 gpurun_out/$TAG/gputest.log; exit 1; }
 tail -3 gpurun_out/$TAG/gputest.log
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
@@ -28,4 +28,12 @@ VS_BENCH_D=1024 python tools/bench_long.py 64 1024 fp32,bf16,fp16x3 > gpurun_out
 VS_MLP_ABLS=1,2,4,7,8 python tools/bench_mlp_fused.py > gpurun_out/$TAG/mlp_fused_ablations.txt 2>&1
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/$TAG/prof_long_bf16 -- python3 $GRAFT_REPO_ROOT/tools/bench_long.py 8 8192 bf16 > /dev/null 2>&1 )
 bash tools/pmc_cmd.sh gpurun_out/$TAG/pmc_summary_long_bf16.txt tools/bench_long.py 8 8192 bf16 > /dev/null 2>&1
+# round 3: the other bench workloads, wide models, attention timelines / ablations / issue probe, raw PMC of the bf16 attention
+python bench.py --workload corpus --steps 20 --warmup 3 > gpurun_out/$TAG/bench_corpus.json 2> gpurun_out/$TAG/bench_corpus.err
+python bench.py --workload long --steps 20 --warmup 3 > gpurun_out/$TAG/bench_long.json 2> gpurun_out/$TAG/bench_long.err
+python tools/bench_wide.py > gpurun_out/$TAG/bench_wide.txt 2>&1
+python tools/bench_mb_modes.py > gpurun_out/$TAG/mb_modes.txt 2>&1
+python tools/diag_attention.py > gpurun_out/$TAG/attention_timeline_exact.txt 2>&1
+python tools/diag_attention.py abl > gpurun_out/$TAG/attn_bf16_ablations.txt 2>&1
+./tools/valu_probe > gpurun_out/$TAG/valu_probe.txt 2>&1 || true
 echo done
