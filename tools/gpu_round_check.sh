@@ -11,6 +11,7 @@ cp gpurun_out/traffic.json profiles/r03_hbm_traffic.json      # (on the box; cop
 python -m pytest tests -x -q -m gpu > gpurun_out/$TAG/gputest.log 2>&1 || { tail -40 gpurun_out/$TAG/gputest.log; exit 1; }
 tail -3 gpurun_out/$TAG/gputest.log
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+set +e          # measurements below: one failing profile step must not skip the rest
 python bench.py > gpurun_out/$TAG/bench.json 2> gpurun_out/$TAG/bench.err
 cat gpurun_out/$TAG/bench.json
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/$TAG/prof -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras > $GRAFT_REPO_ROOT/gpurun_out/$TAG/prof_bench.json 2>$GRAFT_REPO_ROOT/gpurun_out/$TAG/prof.err )

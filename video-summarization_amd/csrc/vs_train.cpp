@@ -41,7 +41,7 @@ int failf(int code, const char *fmt, ...) {
 size_t align_floats(size_t n) { return (n + 63) / 64 * 64; }      // 256-byte granules
 
 // ---- activation record (floats) ----
-struct LayerSaved { size_t qkv, att, lse, z1, st1, y1, ffn, z2, st2, y2; };
+struct LayerSaved { size_t qkv, att, lse, z1, st1, y1, ffn, z2, st2, y2, dbits; };
 struct SavedLayout {
     size_t h0 = 0, total = 0;
     std::vector<LayerSaved> layers;
@@ -58,6 +58,7 @@ SavedLayout saved_layout(const vs_model_desc &D, int B, int T) {
         L.z1 = take(M * d); L.st1 = take(2 * M); L.y1 = take(M * d);
         L.ffn = take(4 * M * d);
         L.z2 = take(M * d); L.st2 = take(2 * M); L.y2 = take(M * d);
+        L.dbits = take(vst_attention_dropout_bits_words(B, D.num_heads, T));     // the layer's attention keep masks, bit-packed
     }
     S.total = off;
     return S;
@@ -233,8 +234,10 @@ int vs_train_forward(const vs_weights *w, const float *x, const uint8_t *key_pad
         const bool last = l == L - 1;
         float *qkv = sv + A.qkv;
         VST_LAUNCH(vsk_qkv(h_in, w->p(P.wqkv), w->p(P.f_wqkv), w->p(P.bqkv), qkv, B, T, d, H, lp, st));         // :148-153
+        unsigned *dbits = p > 0.f ? (unsigned *)(sv + A.dbits) : nullptr;
+        if (dbits) VST_LAUNCH(vst_attention_dropout_bits(dbits, B, H, T, seed, VS_SITE_LAYER(l, VS_SITE_ATTN), p, st));
         VST_LAUNCH(vst_attention_fwd(qkv, qkv + (size_t)M * d, qkv + 2 * (size_t)M * d, key_pad_mask, sv + A.att,
-                                     sv + A.lse, B, H, T, d / H, scale, seed, VS_SITE_LAYER(l, VS_SITE_ATTN), p, st));   // :155-161
+                                     sv + A.lse, B, H, T, d / H, scale, seed, VS_SITE_LAYER(l, VS_SITE_ATTN), p, st, dbits));   // :155-161
         VST_LAUNCH(vsk_linear(sv + A.att, w->p(P.wo), w->p(P.f_wo), w->p(P.bo), a, M, d, d, 0, nullptr, 1, lp, st));      // :163
         VST_LAUNCH(vst_rows_fwd(a, h_in, w->p(P.ln1g), w->p(P.ln1b), sv + A.z1, sv + A.y1, nullptr, sv + A.st1, M, d,
                                 seed, VS_SITE_LAYER(l, VS_SITE_DROP1), p, nullptr, nullptr, 0, nullptr, st));              // :107
@@ -335,7 +338,8 @@ int vs_train_backward(vs_weights *w, const float *x, const uint8_t *key_pad_mask
         const float *qkv = sv + A.qkv;
         VST_LAUNCH(vst_head_rowdot(datt, sv + A.att, delta, M, T, H, d / H, st));
         VST_LAUNCH(vst_attention_bwd(qkv, qkv + (size_t)M * d, qkv + 2 * (size_t)M * d, key_pad_mask, datt, sv + A.lse, delta,
-                                     dqkv, B, H, T, d / H, scale, seed, VS_SITE_LAYER(l, VS_SITE_ATTN), p, st));
+                                     dqkv, B, H, T, d / H, scale, seed, VS_SITE_LAYER(l, VS_SITE_ATTN), p, st,
+                                     p > 0.f ? (const unsigned *)(sv + A.dbits) : nullptr));
         // q / k / v projections: one [3d, d] weight gradient dealt to the three parameters
         VST_LAUNCH(vst_wgrad(dqkv, 3 * d, h_in, d, M, 3 * d, d, G.wq, G.wk, G.wv, G.bq, G.bk, G.bv, d, wg, st, lp));
         // gradient of the layer input = dz1 (residual) + dqkv Wqkv

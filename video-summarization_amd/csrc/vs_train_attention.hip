@@ -18,8 +18,13 @@
 //   attn_bwd_dkdv    owner = keys.     S = Q K^T and dP = dO V^T (lane = key), dV^T += dO^T P~, dK^T += Q^T dS.
 // Recomputing S and dP in both backward kernels costs 7 products instead of 5 but needs no atomics and no
 // cross-block hand-off: every output element is written once, by one wave, in a fixed order (bitwise reproducible).
-// The dropout keep decisions come from vs_train_device.h's counter hash of (seed, site, (b*H + h)*T + query, key) and
-// are rebuilt identically in all three kernels.
+// The dropout keep decisions come from vs_train_device.h's counter hash of (seed, site, (b*H + h)*T + query, key).
+// DROP 1: every kernel evaluates the hash per element (13 vector instructions beside a 64-cycle MFMA: 20 % of the
+// forward).  DROP 2 (round 3, the full training path): attn_dropout_bits evaluates it ONCE per layer into two bit-packed
+// copies - one word per (query, 32 keys) for the kernels whose lanes own queries, one per (key, 32 queries) for the
+// kernel whose lanes own keys - which the forward leaves in the activation record for the backward: a kernel reads one
+// word per tile and lane and extracts a bit per element (3 instructions).  Same hash, same masks (GPU test: the two
+// forms give bit-identical outputs).
 #include <atomic>
 
 #include "vs_train_device.h"
@@ -95,11 +100,11 @@ __device__ __forceinline__ f32x16 st_tile(const TileLds<DH> &t, const f32x4 (&qf
 // ------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------
-template <int DH, bool DROP>
+template <int DH, int DROP>        // DROP 0: none, 1: hash per element, 2: bit-packed keep masks (dbits)
 __global__ __launch_bounds__(256) void attn_fwd_train(
     const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
     const uint8_t *__restrict__ mask, float *__restrict__ out, float *__restrict__ lse2, int H, int T, float scale,
-    unsigned long long seed, unsigned site, float p) {
+    unsigned long long seed, unsigned site, float p, const unsigned *__restrict__ dbits) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];      // 2 x TileLds<DH>: 68 KB at head dim 128
     TileLds<DH> *lds = reinterpret_cast<TileLds<DH> *>(lds_raw);
     const int nq = (T + 127) / 128;
@@ -127,6 +132,8 @@ __global__ __launch_bounds__(256) void attn_fwd_train(
         }
     };
     const int nkt = (T + 31) / 32;
+    const unsigned *bq = DROP == 2 ? dbits + ((size_t)bh * T + qc) * nkt : nullptr;      // this query's keep words
+    unsigned kw = DROP == 2 ? bq[0] : 0u;
     sg.load(kb, DH, vb, DH, 0, T, 1.0f);
     sg.store(lds[0]);
     side(lds[0], 0);
@@ -134,6 +141,8 @@ __global__ __launch_bounds__(256) void attn_fwd_train(
     for (int kt = 0; kt < nkt; ++kt) {
         const TileLds<DH> &t = lds[kt & 1];
         if (kt + 1 < nkt) sg.load(kb, DH, vb, DH, 32 * (kt + 1), T, 1.0f);
+        const unsigned kw_cur = kw;
+        if (DROP == 2 && kt + 1 < nkt) kw = bq[kt + 1];
         f32x16 s = st_tile<DH>(t, qf, r, h);
         float mx = s[0];
 #pragma unroll
@@ -147,10 +156,15 @@ __global__ __launch_bounds__(256) void attn_fwd_train(
         for (int e = 0; e < 16; ++e) { s[e] = __builtin_amdgcn_exp2f(s[e] - m_use); ls += s[e]; }
         l_run = l_run * alpha + ls;
         m_run = m_new;
-        if (DROP) {
+        if (DROP == 1) {
 #pragma unroll
             for (int e = 0; e < 16; ++e)
                 s[e] = drop_keep(ds, rkq, (unsigned)(32 * kt + acc_row(e, h))) ? s[e] * ds.scale : 0.f;
+        }
+        if (DROP == 2) {
+            const unsigned kwh = kw_cur >> (4 * h);                  // bit acc_row(e, h) = (e & 3) + 8 (e >> 2) + 4 h
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s[e] = (kwh >> ((e & 3) + 8 * (e >> 2)) & 1u) ? s[e] * ds.scale : 0.f;
         }
 #pragma unroll
         for (int cb = 0; cb < DH / 32; ++cb)
@@ -187,12 +201,12 @@ __global__ __launch_bounds__(256) void attn_fwd_train(
 // ------------------------------------------------------------------------------------------
 // backward, queries own: dQ
 // ------------------------------------------------------------------------------------------
-template <int DH, bool DROP>
+template <int DH, int DROP>
 __global__ __launch_bounds__(256) void attn_bwd_dq(
     const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
     const uint8_t *__restrict__ mask, const float *__restrict__ dO, const float *__restrict__ lse2,
     const float *__restrict__ delta, float *__restrict__ dqkv, int H, int T, float scale, unsigned long long seed,
-    unsigned site, float p) {
+    unsigned site, float p, const unsigned *__restrict__ dbits) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];      // 2 x TileLds<DH>: 68 KB at head dim 128
     TileLds<DH> *lds = reinterpret_cast<TileLds<DH> *>(lds_raw);
     const int nq = (T + 127) / 128, d = H * DH;
@@ -223,6 +237,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq(
         }
     };
     const int nkt = (T + 31) / 32;
+    const unsigned *bq = DROP == 2 ? dbits + ((size_t)bh * T + qc) * nkt : nullptr;
+    unsigned kw = DROP == 2 ? bq[0] : 0u;
     sg.load(kb, DH, vb, DH, 0, T, 1.0f);
     sg.store(lds[0]);
     side(lds[0], 0);
@@ -230,6 +246,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq(
     for (int kt = 0; kt < nkt; ++kt) {
         const TileLds<DH> &t = lds[kt & 1];
         if (kt + 1 < nkt) sg.load(kb, DH, vb, DH, 32 * (kt + 1), T, 1.0f);
+        const unsigned kwh = kw >> (4 * h);
+        if (DROP == 2 && kt + 1 < nkt) kw = bq[kt + 1];
         f32x16 s = st_tile<DH>(t, qf, r, h);
         f32x16 dp = zero16();
 #pragma unroll
@@ -242,7 +260,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq(
         for (int e = 0; e < 16; ++e) {
             const float pe = __builtin_amdgcn_exp2f(s[e] - lq);
             float g = dp[e];
-            if (DROP) g = drop_keep(ds, rkq, (unsigned)(32 * kt + acc_row(e, h))) ? g * ds.scale : 0.f;
+            if (DROP == 1) g = drop_keep(ds, rkq, (unsigned)(32 * kt + acc_row(e, h))) ? g * ds.scale : 0.f;
+            if (DROP == 2) g = (kwh >> ((e & 3) + 8 * (e >> 2)) & 1u) ? g * ds.scale : 0.f;
             s[e] = pe * (g - dq_delta);
         }
 #pragma unroll
@@ -273,12 +292,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq(
 // ------------------------------------------------------------------------------------------
 // backward, keys own: dK and dV
 // ------------------------------------------------------------------------------------------
-template <int DH, bool DROP>
+template <int DH, int DROP>
 __global__ __launch_bounds__(256) void attn_bwd_dkdv(
     const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
     const uint8_t *__restrict__ mask, const float *__restrict__ dO, const float *__restrict__ lse2,
     const float *__restrict__ delta, float *__restrict__ dqkv, int H, int T, float scale, unsigned long long seed,
-    unsigned site, float p) {
+    unsigned site, float p, const unsigned *__restrict__ dbits) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];      // 2 x TileLds<DH>: 68 KB at head dim 128
     TileLds<DH> *lds = reinterpret_cast<TileLds<DH> *>(lds_raw);
     const int nk = (T + 127) / 128, d = H * DH;
@@ -308,10 +327,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv(
             const bool ok = qi < T;
             t.s0[tid] = ok ? lse2[(size_t)bh * T + qi] : __builtin_inff();      // p = exp2(s - inf) = 0 on rows >= T
             t.s1[tid] = ok ? delta[(size_t)bh * T + qi] : 0.f;
-            t.rk[tid] = drop_rowkey(ds, (unsigned)(bh * T + (ok ? qi : 0)));
+            if (DROP == 1) t.rk[tid] = drop_rowkey(ds, (unsigned)(bh * T + (ok ? qi : 0)));
         }
     };
     const int nqt = (T + 31) / 32;
+    // DROP 2: the key-major copy (second half of dbits): one word per (key, 32 queries)
+    const unsigned *bk = DROP == 2 ? dbits + (size_t)gridDim.x / nk * T * nqt + ((size_t)bh * T + kc) * nqt : nullptr;
+    unsigned kw = DROP == 2 ? bk[0] : 0u;
     sg.load(qb, DH, dob, d, 0, T, sl2);
     sg.store(lds[0]);
     side(lds[0], 0);
@@ -319,6 +341,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv(
     for (int it = 0; it < nqt; ++it) {
         const TileLds<DH> &t = lds[it & 1];
         if (it + 1 < nqt) sg.load(qb, DH, dob, d, 32 * (it + 1), T, sl2);
+        const unsigned kwh = kw >> (4 * h);
+        if (DROP == 2 && it + 1 < nqt) kw = bk[it + 1];
         // S[query][key] - lse2[query]: the row constant is the accumulator's initial value
         f32x16 s, dp = zero16();
 #pragma unroll
@@ -342,14 +366,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv(
         for (int tg = 0; tg < 4; ++tg) {
             const f32x4 dl = *(const f32x4 *)&t.s1[8 * tg + 4 * h];
             u32x4 rk4 = {0u, 0u, 0u, 0u};
-            if (DROP) rk4 = *(const u32x4 *)&t.rk[8 * tg + 4 * h];
+            if (DROP == 1) rk4 = *(const u32x4 *)&t.rk[8 * tg + 4 * h];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int i = 4 * tg + e;
                 const float pe = __builtin_amdgcn_exp2f(s[i] + kbias);
                 float g = dp[i], pk = pe;
-                if (DROP) {
-                    const bool keep = drop_keep(ds, rk4[e], (unsigned)ki);
+                if (DROP != 0) {
+                    const bool keep = DROP == 1 ? drop_keep(ds, rk4[e], (unsigned)ki) : (kwh >> (e + 8 * tg) & 1u) != 0u;
                     g = keep ? g * ds.scale : 0.f;
                     pk = keep ? pe * ds.scale : 0.f;
                 }
@@ -383,6 +407,41 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv(
                 *(f32x4 *)(op + d + 32 * cb + 8 * tg + 4 * h) = wk;
                 *(f32x4 *)(op + 2 * d + 32 * cb + 8 * tg + 4 * h) = wv;
             }
+    }
+}
+
+// The keep decisions of one layer's attention dropout, bit-packed twice: words [BH][T queries][W] with bit j of word w =
+// keep(query, key 32 w + j), then words [BH][T keys][W] with bit j of word w = keep(query 32 w + j, key); W = ceil(T / 32).
+// A wave owns 32 queries x 64 keys: lane l hashes query (l & 31) against the 32 keys of word (l >> 5); the transposed
+// words come from 32 ballots (bit j of every lane's word = the column of key j).  Bits beyond T are 0.
+__global__ __launch_bounds__(256) void attn_dropout_bits(unsigned *__restrict__ bits, int BH, int T, unsigned long long seed,
+                                                         unsigned site, float p) {
+    const int W = (T + 31) / 32, W2 = (W + 1) / 2;
+    const DropSite ds = drop_site(seed, site, p);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, g = lane >> 5;
+    const size_t ntile = (size_t)BH * W * W2;
+    unsigned *bitsK = bits + (size_t)BH * T * W;
+    for (size_t tile = (size_t)blockIdx.x * 4 + wave; tile < ntile; tile += (size_t)gridDim.x * 4) {
+        const int t2 = (int)(tile % W2), qt = (int)((tile / W2) % W), bh = (int)(tile / ((size_t)W2 * W));
+        const int q = 32 * qt + r, kw = 2 * t2 + g;
+        unsigned word = 0u;
+        if (q < T && kw < W) {
+            const unsigned rk = drop_rowkey(ds, (unsigned)(bh * T + q));
+#pragma unroll 8
+            for (int j = 0; j < 32; ++j) {
+                const int key = 32 * kw + j;
+                word |= (key < T && drop_keep(ds, rk, (unsigned)key)) ? (1u << j) : 0u;
+            }
+            bits[((size_t)bh * T + q) * W + kw] = word;
+        }
+        unsigned mine = 0u;
+#pragma unroll 8
+        for (int j = 0; j < 32; ++j) {
+            const unsigned long long bal = __ballot((word >> j) & 1u);
+            if (r == j) mine = g == 0 ? (unsigned)bal : (unsigned)(bal >> 32);
+        }
+        const int key = 64 * t2 + 32 * g + r;       // lane (r, g) holds the queries-of-this-tile word of key 64 t2 + 32 g + r
+        if (key < T) bitsK[((size_t)bh * T + key) * W + qt] = mine;
     }
 }
 
@@ -427,33 +486,52 @@ static int allow_lds(const void *kernel, size_t bytes, std::atomic<unsigned char
         if (const int rc_ = allow_lds((const void *)KERNEL_<DH_, DROP_>, lds_bytes_, done_)) return rc_;        \
         hipLaunchKernelGGL((KERNEL_<DH_, DROP_>), grid, dim3(256), lds_bytes_, st, __VA_ARGS__);                \
     } while (0)
+#define VST_ATTN_DH(KERNEL_, DH_, ...)                                                                          \
+    do {                                                                                                        \
+        if (!(p > 0.f)) VST_ATTN_LAUNCH(KERNEL_, DH_, 0, __VA_ARGS__);                                          \
+        else if (dbits != nullptr) VST_ATTN_LAUNCH(KERNEL_, DH_, 2, __VA_ARGS__);                               \
+        else VST_ATTN_LAUNCH(KERNEL_, DH_, 1, __VA_ARGS__);                                                     \
+    } while (0)
 #define VST_ATTN_DISPATCH(KERNEL_, ...)                                                                         \
     do {                                                                                                        \
-        const bool drop = p > 0.f;                                                                              \
-        if (dh == 32) { if (drop) VST_ATTN_LAUNCH(KERNEL_, 32, true, __VA_ARGS__); else VST_ATTN_LAUNCH(KERNEL_, 32, false, __VA_ARGS__); } \
-        else if (dh == 64) { if (drop) VST_ATTN_LAUNCH(KERNEL_, 64, true, __VA_ARGS__); else VST_ATTN_LAUNCH(KERNEL_, 64, false, __VA_ARGS__); } \
-        else if (dh == 128) { if (drop) VST_ATTN_LAUNCH(KERNEL_, 128, true, __VA_ARGS__); else VST_ATTN_LAUNCH(KERNEL_, 128, false, __VA_ARGS__); } \
+        if (dh == 32) VST_ATTN_DH(KERNEL_, 32, __VA_ARGS__);                                                    \
+        else if (dh == 64) VST_ATTN_DH(KERNEL_, 64, __VA_ARGS__);                                               \
+        else if (dh == 128) VST_ATTN_DH(KERNEL_, 128, __VA_ARGS__);                                             \
         else return -1;                                                                                         \
     } while (0)
 
+size_t vst_attention_dropout_bits_words(int B, int H, int T) { return 2 * (size_t)B * H * T * ((T + 31) / 32); }
+
+// dbits (vst_attention_dropout_bits_words(B, H, T) words) <- both bit-packed copies of this layer's keep decisions
+int vst_attention_dropout_bits(unsigned *dbits, int B, int H, int T, unsigned long long seed, unsigned site, float p,
+                               hipStream_t st) {
+    const int W = (T + 31) / 32;
+    const size_t ntile = (size_t)B * H * W * ((W + 1) / 2);
+    const int blocks = (int)((ntile + 3) / 4 < 16384 ? (ntile + 3) / 4 : 16384);
+    hipLaunchKernelGGL(attn_dropout_bits, dim3(blocks < 1 ? 1 : blocks), dim3(256), 0, st, dbits, B * H, T, seed, site, p);
+    VSK_CHECK_LAUNCH();
+    return 0;
+}
+
+// dbits: the bit-packed keep masks (vst_attention_dropout_bits) or nullptr (the kernels then hash per element: same masks)
 int vst_attention_fwd(const float *q, const float *k, const float *v, const uint8_t *mask, float *out, float *lse2,
                       int B, int H, int T, int dh, float scale, unsigned long long seed, unsigned site, float p,
-                      hipStream_t st) {
+                      hipStream_t st, const unsigned *dbits) {
     if (p < 0.f || p >= 1.f) return -1;
     const dim3 grid(B * H * ((T + 127) / 128));
-    VST_ATTN_DISPATCH(attn_fwd_train, q, k, v, mask, out, lse2, H, T, scale, seed, site, p);
+    VST_ATTN_DISPATCH(attn_fwd_train, q, k, v, mask, out, lse2, H, T, scale, seed, site, p, dbits);
     VSK_CHECK_LAUNCH();
     return 0;
 }
 
 int vst_attention_bwd(const float *q, const float *k, const float *v, const uint8_t *mask, const float *dO,
                       const float *lse2, const float *delta, float *dqkv, int B, int H, int T, int dh, float scale,
-                      unsigned long long seed, unsigned site, float p, hipStream_t st) {
+                      unsigned long long seed, unsigned site, float p, hipStream_t st, const unsigned *dbits) {
     if (p < 0.f || p >= 1.f) return -1;
     const dim3 grid(B * H * ((T + 127) / 128));
-    VST_ATTN_DISPATCH(attn_bwd_dkdv, q, k, v, mask, dO, lse2, delta, dqkv, H, T, scale, seed, site, p);
+    VST_ATTN_DISPATCH(attn_bwd_dkdv, q, k, v, mask, dO, lse2, delta, dqkv, H, T, scale, seed, site, p, dbits);
     VSK_CHECK_LAUNCH();
-    VST_ATTN_DISPATCH(attn_bwd_dq, q, k, v, mask, dO, lse2, delta, dqkv, H, T, scale, seed, site, p);
+    VST_ATTN_DISPATCH(attn_bwd_dq, q, k, v, mask, dO, lse2, delta, dqkv, H, T, scale, seed, site, p, dbits);
     VSK_CHECK_LAUNCH();
     return 0;
 }

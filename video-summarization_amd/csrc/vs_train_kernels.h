@@ -42,13 +42,17 @@ int vst_mse_mask_bwd(const float *out, const float *tgt, const unsigned char *ma
 // ---- attention (vs_train_attention.hip); q, k, v head-major [B,H,T,dh]; out / dO token-major [B*T, H*dh] ----
 // forward with dropout on the attention weights; lse2[b,h,t] = log2 sum_j exp(s_ij) (base-2 log-sum-exp of the
 // scaled, masked scores) is saved for the backward
+// dbits: both bit-packed copies of the layer's keep decisions (vst_attention_dropout_bits) or nullptr (hash per element)
+size_t vst_attention_dropout_bits_words(int B, int H, int T);
+int vst_attention_dropout_bits(unsigned *dbits, int B, int H, int T, unsigned long long seed, unsigned site, float p,
+                               hipStream_t st);
 int vst_attention_fwd(const float *q, const float *k, const float *v, const uint8_t *mask, float *out, float *lse2,
                       int B, int H, int T, int dh, float scale, unsigned long long seed, unsigned site, float p,
-                      hipStream_t st);
+                      hipStream_t st, const unsigned *dbits = nullptr);
 // dqkv token-major [B*T, 3*H*dh] (columns: dq | dk | dv, head h at h*dh); delta from vst_head_rowdot
 int vst_attention_bwd(const float *q, const float *k, const float *v, const uint8_t *mask, const float *dO,
                       const float *lse2, const float *delta, float *dqkv, int B, int H, int T, int dh, float scale,
-                      unsigned long long seed, unsigned site, float p, hipStream_t st);
+                      unsigned long long seed, unsigned site, float p, hipStream_t st, const unsigned *dbits = nullptr);
 // test hook: keep[b,h,i,j] (bytes) of the attention-weight dropout, exactly as the two kernels above draw it
 int vst_attention_dropout_mask(uint8_t *keep, int B, int H, int T, unsigned long long seed, unsigned site, float p,
                                hipStream_t st);
