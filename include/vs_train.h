@@ -45,6 +45,10 @@ typedef struct vs_dropout_cfg {
  * pass the SAME flags to forward and backward.  Gradients then differ from the float64 truth by 1-3e-2 in relative L2
  * norm per tensor (tests/tolerances.py: TRAIN_LP_GRAD_L2), where the exact path is at 1e-6. */
 #define VS_TRAIN_FLAG_BF16_LINEAR 1u
+/* ... and the attention products too (S = q k^T, P v, and the five products of the backward), head dim 32 / 64: q * scale,
+ * k, v, dO, the probabilities and dS rounded to bf16, fp32 scores / softmax / lse / accumulation (head dim 128: exact). */
+#define VS_TRAIN_FLAG_BF16_ATTENTION 2u
+#define VS_TRAIN_FLAG_BF16 (VS_TRAIN_FLAG_BF16_LINEAR | VS_TRAIN_FLAG_BF16_ATTENTION)
 
 /* Gradient destinations: the mirror of vs_layer_params / vs_model_params (nn.Linear layout [out, in]); every
  * pointer is a device buffer of the parameter's shape that the backward OVERWRITES (it does not accumulate). */
@@ -134,6 +138,21 @@ int vs_train_attention_backward(const float *q, const float *k, const float *v, 
                                 const float *out, const float *d_out, const float *lse2, float *dqkv, float *scratch,
                                 int32_t B, int32_t H, int32_t T, int32_t dh, float scale, uint64_t seed, uint32_t site,
                                 float p, void *stream);
+/* The attention-weight dropout of one layer, bit-packed (what the full training path keeps in its activation record):
+ * dbits >= vs_train_attention_dropout_bits_bytes(B, H, T) bytes; same keep decisions as vs_train_dropout_mask_attention. */
+size_t vs_train_attention_dropout_bits_bytes(int32_t B, int32_t H, int32_t T);
+int vs_train_attention_dropout_bits(void *dbits, int32_t B, int32_t H, int32_t T, uint64_t seed, uint32_t site, float p,
+                                    void *stream);
+/* vs_train_attention_forward / _backward on the bf16 matrix pipe (VS_TRAIN_FLAG_BF16_ATTENTION); dh in {32, 64}; p > 0 needs
+ * dbits (from vs_train_attention_dropout_bits with the same seed / site / p). */
+int vs_train_attention_forward_bf16(const float *q, const float *k, const float *v, const uint8_t *key_pad_mask, float *out,
+                                    float *lse2, int32_t B, int32_t H, int32_t T, int32_t dh, float scale, float p,
+                                    const void *dbits, void *stream);
+int vs_train_attention_backward_bf16(const float *q, const float *k, const float *v, const uint8_t *key_pad_mask,
+                                     const float *out, const float *d_out, const float *lse2, float *dqkv, float *scratch,
+                                     int32_t B, int32_t H, int32_t T, int32_t dh, float scale, float p, const void *dbits,
+                                     void *stream);
+
 /* dW [N,K] = dY[M,N]^T X[M,K], db [N] = column sums of dY; scratch >= vs_train_wgrad_scratch_floats(M,N,K) floats. */
 size_t vs_train_wgrad_scratch_floats(int32_t M, int32_t N, int32_t K);
 int vs_train_wgrad(const float *dY, const float *X, int32_t M, int32_t N, int32_t K, float *dW, float *db,

@@ -257,6 +257,73 @@ def test_attention_forward_and_backward_kernels(vsa, B, H, T, dh, masked, p):
     _close(dqkv[:, :, 2 * d:], tok(v.grad), "dv")
 
 
+@pytest.mark.parametrize("B,H,T,dh,masked,p", [(2, 4, 320, 64, False, 0.0), (1, 2, 777, 64, False, 0.0), (2, 4, 200, 64, True, 0.0),
+                                                (2, 8, 65, 32, True, 0.0), (1, 4, 1, 64, False, 0.0), (2, 4, 130, 64, True, 0.3),
+                                                (1, 8, 97, 32, False, 0.5), (1, 4, 513, 64, True, 0.2)])
+def test_attention_forward_and_backward_kernels_bf16(vsa, B, H, T, dh, masked, p):
+    """The training attention on the bf16 matrix pipe (VS_TRAIN_FLAG_BF16_ATTENTION): forward (values + log-sum-exp) and
+    backward (dq | dk | dv) against float64 torch autograd on UNROUNDED operands, the library's own dropout mask applied
+    explicitly in the checker.  Bounds relative to each tensor's largest entry: the bf16 rounding of q, k, v, dO, P and dS
+    (2^-9 each) - a wrong index map of the row / transposed LDS fragments would be an O(1) error.  Run twice: bitwise
+    reproducible."""
+    lib = vsa._lib.load()
+    q, k, v = _qkv(B, H, T, dh, 100 + T)
+    q.requires_grad_(True), k.requires_grad_(True), v.requires_grad_(True)
+    mask = vsa.synth.random_mask(B, T, 5) if masked else None
+    scale = (H * dh) ** -0.5
+    seed, site = 0x1234567887654321, 7
+    keep, dbits = None, None
+    if p > 0:
+        kd = torch.empty(B, H, T, T, dtype=torch.uint8, device=_dev())
+        vsa._lib.check(lib.vs_train_dropout_mask_attention(kd.data_ptr(), B, H, T, seed, site, p, _stream()))
+        keep = kd.cpu()
+        dbits = torch.empty(lib.vs_train_attention_dropout_bits_bytes(B, H, T), dtype=torch.uint8, device=_dev())
+        vsa._lib.check(lib.vs_train_attention_dropout_bits(dbits.data_ptr(), B, H, T, seed, site, p, _stream()))
+        # the bit-packed copies hold exactly the decisions of the byte dump, in both orientations
+        W = (T + 31) // 32
+        words = dbits.view(torch.int32).cpu().view(2, B * H, T, W)
+        bit = lambda wds, j: (wds[..., j // 32] >> (j % 32)) & 1      # noqa: E731
+        kq = torch.stack([bit(words[0], j) for j in range(T)], dim=-1).view(B, H, T, T)        # [.., query, key]
+        kk = torch.stack([bit(words[1], j) for j in range(T)], dim=-1).view(B, H, T, T)        # [.., key, query]
+        assert torch.equal(kq.to(torch.uint8), keep) and torch.equal(kk.transpose(2, 3).to(torch.uint8), keep)
+    want, lse2 = torch_ref.attention_with_mask(q, k, v, mask, scale, keep, p)
+    dO = torch.randn(B, T, H * dh, generator=torch.Generator().manual_seed(9), dtype=torch.float64)
+    want.backward(dO)
+    qd, kd_, vd = (t.detach().float().to(_dev()).contiguous() for t in (q, k, v))
+    md = None if mask is None else mask.to(_dev()).view(torch.uint8)
+    dOd = dO.float().to(_dev())
+    d = H * dh
+    runs = []
+    for _ in range(2):
+        out = torch.full((B, T, d), float("nan"), device=_dev())
+        lse = torch.full((B, H, T), float("nan"), device=_dev())
+        vsa._lib.check(lib.vs_train_attention_forward_bf16(qd.data_ptr(), kd_.data_ptr(), vd.data_ptr(), None if md is None else md.data_ptr(),
+                                                           out.data_ptr(), lse.data_ptr(), B, H, T, dh, scale, p,
+                                                           None if dbits is None else dbits.data_ptr(), _stream()))
+        dqkv = torch.full((B, T, 3 * d), float("nan"), device=_dev())
+        scratch = torch.empty(B * H * T, device=_dev())
+        vsa._lib.check(lib.vs_train_attention_backward_bf16(qd.data_ptr(), kd_.data_ptr(), vd.data_ptr(), None if md is None else md.data_ptr(),
+                                                            out.data_ptr(), dOd.data_ptr(), lse.data_ptr(), dqkv.data_ptr(), scratch.data_ptr(),
+                                                            B, H, T, dh, scale, p, None if dbits is None else dbits.data_ptr(), _stream()))
+        torch.cuda.synchronize()
+        runs.append((out.clone(), lse.clone(), dqkv.clone()))
+    assert all(torch.equal(a, b) for a, b in zip(*runs))
+    out, lse, dqkv = runs[0]
+    assert torch.isfinite(out).all() and torch.isfinite(dqkv).all()
+    _close(out, want, "attention out (bf16)", atol=None, rtol=1.5e-2)
+    assert (lse.cpu().double() - lse2.detach()).abs().max().item() < 2e-2
+    tok = lambda g: g.permute(0, 2, 1, 3).reshape(B, T, d)       # noqa: E731  head-major grad -> token-major
+    # a one-key row has dS = P (dP - delta) = 0 analytically; in bf16 dP (rounded operands) and delta (fp32 row dot) no
+    # longer cancel to the last bit, so dq / dk get an absolute floor of bf16 rounding of an O(1) dP times the scale
+    floor = 3e-3 if T == 1 else 0.0
+    for name, got, ref in (("dq", dqkv[:, :, :d], tok(q.grad)), ("dk", dqkv[:, :, d:2 * d], tok(k.grad))):
+        if floor and ref.abs().max().item() < floor:
+            assert got.abs().max().item() < floor, name
+        else:
+            _close(got, ref, name + " (bf16)", atol=None, rtol=3e-2)
+    _close(dqkv[:, :, 2 * d:], tok(v.grad), "dv (bf16)", atol=None, rtol=3e-2)
+
+
 @pytest.mark.parametrize("M,N,K", [(300, 256, 1024), (4096, 1024, 256), (77, 768, 256), (1000, 64, 192), (5000, 512, 2048),
                                    (16, 256, 256), (1, 128, 64)])
 def test_wgrad_kernel(vsa, M, N, K):
@@ -352,8 +419,20 @@ def test_bf16_training_gradients_within_the_low_precision_tolerance(vsa, lp_trai
         # two bounds per tensor: the largest element error relative to the tensor's largest entry (a ReLU unit whose
         # pre-activation is within bf16 rounding of zero flips and moves ONE row of d_fc1 / one entry of its bias: a few
         # per cent of the maximum in these 60..800-frame batches), and the relative L2 error over the sampled rows
+        if gmax < 1e-6:
+            # analytically zero (k.bias: softmax is shift invariant, so the dk rows sum to zero) - with the attention
+            # backward itself on bf16 operands the rows no longer cancel to fp32 rounding
+            assert g.double().norm().item() <= tol.TRAIN_LP_ZERO_ATOL, "%s: |g| %.3e" % (k, g.double().norm().item())
+            continue
         assert err <= tol.TRAIN_LP_GRAD_RTOL * gmax + 1e-6, "%s: err %.3e, max|g| %.3e" % (k, err, gmax)
-        assert l2 <= tol.TRAIN_LP_GRAD_L2 or gmax < 1e-6, "%s: relative L2 error %.3e" % (k, l2)
+        if diff.dim() > 1 and diff.shape[0] >= 4 and l2 > tol.TRAIN_LP_GRAD_L2:
+            # ReLU-flip allowance (tests/tolerances.py): ONE sampled row - the fc1 unit that flipped - is set aside from the
+            # L2 figure (it stays under the largest-element bound above); everything else must meet the L2 bound
+            sq = diff.pow(2).sum(-1)
+            keep_rows = torch.ones_like(sq, dtype=torch.bool)
+            keep_rows[sq.argmax()] = False
+            l2 = sq[keep_rows].sum().sqrt().item() / (want_g[keep_rows].norm().item() + 1e-30)
+        assert l2 <= tol.TRAIN_LP_GRAD_L2, "%s: relative L2 error %.3e" % (k, l2)
         assert abs(g.double().norm().item() - nrm) <= 2e-2 * nrm + 1e-7, k
         if gmax > 1e-6 and err / gmax > worst:
             worst, worst_k = err / gmax, k

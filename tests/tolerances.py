@@ -28,8 +28,12 @@ TRAIN_GRAD_RTOL = 1e-3          # ... and relative to the tensor's largest entry
 TRAIN_LP_GRAD_L2 = 5e-2         # per tensor, relative L2 error ||g - g64|| / ||g64|| over the golden's sampled rows
                                 # (measured over the seven golden cases: 1.2e-2 ... 2.6e-2; 8-bit mantissas through ~10
                                 # GEMMs and two LayerNorm backwards per layer)
+                                # - with ONE sampled row per tensor set aside when it alone breaks the bound: a flipped ReLU
+                                # unit's whole fc1.weight row moves (measured: 78 % of the squared error in one of 8 rows)
 TRAIN_LP_GRAD_RTOL = 2e-1       # per tensor, LARGEST element error relative to the tensor's largest entry: a gross-error
                                 # bound only - a ReLU unit whose pre-activation lies within bf16 rounding of zero flips and
                                 # moves one row of d_fc1 / one entry of its bias, by up to 14 % of the maximum in the
                                 # 100-frame golden batches (measured: 0.6e-2 ... 1.4e-1)
+TRAIN_LP_ZERO_ATOL = 5e-5       # norm of a gradient that is analytically zero (k.bias: softmax shift invariance) once the
+                                # attention backward itself runs on bf16 operands (measured 4.0e-6)
 TRAIN_LP_LOSS_RTOL = 2e-3       # |loss - loss64| relative

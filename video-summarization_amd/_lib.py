@@ -18,7 +18,8 @@ INCLUDE = os.path.join(ROOT, "include")
 LIB_PATH = os.path.join(HERE, "libvsscore.so")
 DIAG_LIB_PATH = os.path.join(HERE, "libvsscore_diag.so")
 SOURCES = ("vs_kernels.hip", "vs_attention.hip", "vs_mlp_fused.hip", "vs_scorer.cpp", "vs_eval.cpp",
-           "vs_train_kernels.hip", "vs_train_attention.hip", "vs_pretrain_kernels.hip", "vs_train.cpp")
+           "vs_train_kernels.hip", "vs_train_attention.hip", "vs_train_attention_bf16.hip", "vs_pretrain_kernels.hip",
+           "vs_train.cpp")
 ABI_VERSION = 3
 
 VS_OK, VS_ERR_INVALID, VS_ERR_WORKSPACE, VS_ERR_HIP = 0, 1, 2, 3
@@ -28,6 +29,7 @@ VS_FLAG_BF16_LINEAR = 4
 VS_FLAG_F16X3_LINEAR = 8
 VS_FLAG_F16X3_ATTENTION = 16
 VS_TRAIN_FLAG_BF16_LINEAR = 1
+VS_TRAIN_FLAG_BF16_ATTENTION = 2
 
 # every symbol include/vs_scorer.h declares
 EXPORTS = ("vs_abi_version", "vs_last_error", "vs_weights_pack", "vs_weights_free", "vs_weights_update", "vs_set_option",
@@ -43,7 +45,8 @@ EVAL_EXPORTS = ("vs_eval_upsample", "vs_eval_knapsack", "vs_eval_generate_summar
 # include/vs_train.h
 TRAIN_EXPORTS = ("vs_train_prepare", "vs_train_saved_bytes", "vs_train_workspace_bytes", "vs_train_forward", "vs_train_backward",
                  "vs_mse_mask_loss_forward", "vs_mse_mask_loss_backward", "vs_train_attention_forward",
-                 "vs_train_attention_backward", "vs_train_wgrad_scratch_floats", "vs_train_wgrad", "vs_train_wgrad_bf16",
+                 "vs_train_attention_backward", "vs_train_attention_dropout_bits_bytes", "vs_train_attention_dropout_bits",
+                 "vs_train_attention_forward_bf16", "vs_train_attention_backward_bf16", "vs_train_wgrad_scratch_floats", "vs_train_wgrad", "vs_train_wgrad_bf16",
                  "vs_train_dropout_mask_attention", "vs_train_dropout_mask_rows", "vs_train_dropout_site", "vs_train_saved_field",
                  "vs_pretrain_head_state_bytes", "vs_pretrain_head_workspace_bytes", "vs_pretrain_head_forward",
                  "vs_pretrain_head_backward")
@@ -254,6 +257,17 @@ def load() -> C.CDLL:
         lib.vs_train_attention_backward.restype = C.c_int
         lib.vs_train_attention_backward.argtypes = ([C.c_void_p] * 9 + [C.c_int32] * 4 + [C.c_float, C.c_uint64, C.c_uint32,
                                                                                         C.c_float, C.c_void_p])
+        lib.vs_train_attention_dropout_bits_bytes.restype = C.c_size_t
+        lib.vs_train_attention_dropout_bits_bytes.argtypes = [C.c_int32] * 3
+        lib.vs_train_attention_dropout_bits.restype = C.c_int
+        lib.vs_train_attention_dropout_bits.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, C.c_uint32,
+                                                        C.c_float, C.c_void_p]
+        lib.vs_train_attention_forward_bf16.restype = C.c_int
+        lib.vs_train_attention_forward_bf16.argtypes = ([C.c_void_p] * 6 + [C.c_int32] * 4 + [C.c_float, C.c_float, C.c_void_p,
+                                                                                            C.c_void_p])
+        lib.vs_train_attention_backward_bf16.restype = C.c_int
+        lib.vs_train_attention_backward_bf16.argtypes = ([C.c_void_p] * 9 + [C.c_int32] * 4 + [C.c_float, C.c_float, C.c_void_p,
+                                                                                             C.c_void_p])
         lib.vs_train_wgrad_scratch_floats.restype = C.c_size_t
         lib.vs_train_wgrad_scratch_floats.argtypes = [C.c_int32] * 3
         lib.vs_train_wgrad.restype = C.c_int

@@ -216,6 +216,9 @@ int vs_train_forward(const vs_weights *w, const float *x, const uint8_t *key_pad
     // low-precision training (VS_TRAIN_FLAG_BF16_LINEAR): every Linear / dgrad / wgrad GEMM on the bf16 matrix pipe, from the
     // batch size up where the LDS-tiled kernels beat the exact latency kernels (the threshold of the scoring path)
     const int lp = (drop && (drop->flags & VS_TRAIN_FLAG_BF16_LINEAR) && (long long)B * T > vsk_options().lp_min_rows) ? 1 : 0;
+    // ... and (VS_TRAIN_FLAG_BF16_ATTENTION) the attention products of the forward and the backward, head dim 32 / 64
+    const bool lpa = drop && (drop->flags & VS_TRAIN_FLAG_BF16_ATTENTION) && (long long)B * T > vsk_options().lp_min_rows &&
+                     vst_attention_bf16_supported(w->desc.d_model / w->desc.num_heads);
     const unsigned long long seed = drop ? drop->seed : 0ull;
     const float scale = 1.0f / sqrtf((float)d);              // simnet.py:126: d_model ** -0.5
     float *sv = (float *)saved, *ws = (float *)workspace;
@@ -236,6 +239,10 @@ int vs_train_forward(const vs_weights *w, const float *x, const uint8_t *key_pad
         VST_LAUNCH(vsk_qkv(h_in, w->p(P.wqkv), w->p(P.f_wqkv), w->p(P.bqkv), qkv, B, T, d, H, lp, st));         // :148-153
         unsigned *dbits = p > 0.f ? (unsigned *)(sv + A.dbits) : nullptr;
         if (dbits) VST_LAUNCH(vst_attention_dropout_bits(dbits, B, H, T, seed, VS_SITE_LAYER(l, VS_SITE_ATTN), p, st));
+        if (lpa)
+            VST_LAUNCH(vst_attention_fwd_bf16(qkv, qkv + (size_t)M * d, qkv + 2 * (size_t)M * d, key_pad_mask, sv + A.att,
+                                              sv + A.lse, B, H, T, d / H, scale, p, dbits, st));
+        else
         VST_LAUNCH(vst_attention_fwd(qkv, qkv + (size_t)M * d, qkv + 2 * (size_t)M * d, key_pad_mask, sv + A.att,
                                      sv + A.lse, B, H, T, d / H, scale, seed, VS_SITE_LAYER(l, VS_SITE_ATTN), p, st, dbits));   // :155-161
         VST_LAUNCH(vsk_linear(sv + A.att, w->p(P.wo), w->p(P.f_wo), w->p(P.bo), a, M, d, d, 0, nullptr, 1, lp, st));      // :163
@@ -281,6 +288,9 @@ int vs_train_backward(vs_weights *w, const float *x, const uint8_t *key_pad_mask
     // low-precision training (VS_TRAIN_FLAG_BF16_LINEAR): every Linear / dgrad / wgrad GEMM on the bf16 matrix pipe, from the
     // batch size up where the LDS-tiled kernels beat the exact latency kernels (the threshold of the scoring path)
     const int lp = (drop && (drop->flags & VS_TRAIN_FLAG_BF16_LINEAR) && (long long)B * T > vsk_options().lp_min_rows) ? 1 : 0;
+    // ... and (VS_TRAIN_FLAG_BF16_ATTENTION) the attention products of the forward and the backward, head dim 32 / 64
+    const bool lpa = drop && (drop->flags & VS_TRAIN_FLAG_BF16_ATTENTION) && (long long)B * T > vsk_options().lp_min_rows &&
+                     vst_attention_bf16_supported(w->desc.d_model / w->desc.num_heads);
     const unsigned long long seed = drop ? drop->seed : 0ull;
     const float scale = 1.0f / sqrtf((float)d);
     const float *sv = (const float *)saved;
@@ -337,6 +347,11 @@ int vs_train_backward(vs_weights *w, const float *x, const uint8_t *key_pad_mask
         // attention
         const float *qkv = sv + A.qkv;
         VST_LAUNCH(vst_head_rowdot(datt, sv + A.att, delta, M, T, H, d / H, st));
+        if (lpa)
+            VST_LAUNCH(vst_attention_bwd_bf16(qkv, qkv + (size_t)M * d, qkv + 2 * (size_t)M * d, key_pad_mask, datt, sv + A.lse,
+                                              delta, dqkv, B, H, T, d / H, scale, p,
+                                              p > 0.f ? (const unsigned *)(sv + A.dbits) : nullptr, st));
+        else
         VST_LAUNCH(vst_attention_bwd(qkv, qkv + (size_t)M * d, qkv + 2 * (size_t)M * d, key_pad_mask, datt, sv + A.lse, delta,
                                      dqkv, B, H, T, d / H, scale, seed, VS_SITE_LAYER(l, VS_SITE_ATTN), p, st,
                                      p > 0.f ? (const unsigned *)(sv + A.dbits) : nullptr));
@@ -454,6 +469,41 @@ int vs_train_attention_backward(const float *q, const float *k, const float *v, 
     hipStream_t st = (hipStream_t)stream;
     VST_LAUNCH(vst_head_rowdot(d_out, out, scratch, B * T, T, H, dh, st));
     VST_LAUNCH(vst_attention_bwd(q, k, v, key_pad_mask, d_out, lse2, scratch, dqkv, B, H, T, dh, scale, seed, site, p, st));
+    return VS_OK;
+}
+
+size_t vs_train_attention_dropout_bits_bytes(int32_t B, int32_t H, int32_t T) {
+    if (B <= 0 || H <= 0 || T <= 0) return 0;
+    return vst_attention_dropout_bits_words(B, H, T) * sizeof(unsigned);
+}
+
+int vs_train_attention_dropout_bits(void *dbits, int32_t B, int32_t H, int32_t T, uint64_t seed, uint32_t site, float p,
+                                    void *stream) {
+    if (!dbits || B <= 0 || H <= 0 || T <= 0) return failf(VS_ERR_INVALID, "dropout_bits: bad arguments");
+    VST_LAUNCH(vst_attention_dropout_bits((unsigned *)dbits, B, H, T, seed, site, p, (hipStream_t)stream));
+    return VS_OK;
+}
+
+int vs_train_attention_forward_bf16(const float *q, const float *k, const float *v, const uint8_t *key_pad_mask, float *out,
+                                    float *lse2, int32_t B, int32_t H, int32_t T, int32_t dh, float scale, float p,
+                                    const void *dbits, void *stream) {
+    if (!q || !k || !v || !out || !lse2) return failf(VS_ERR_INVALID, "NULL pointer");
+    if (B <= 0 || H <= 0 || T <= 0) return failf(VS_ERR_INVALID, "B=%d H=%d T=%d", B, H, T);
+    VST_LAUNCH(vst_attention_fwd_bf16(q, k, v, key_pad_mask, out, lse2, B, H, T, dh, scale, p, (const unsigned *)dbits,
+                                      (hipStream_t)stream));
+    return VS_OK;
+}
+
+int vs_train_attention_backward_bf16(const float *q, const float *k, const float *v, const uint8_t *key_pad_mask,
+                                     const float *out, const float *d_out, const float *lse2, float *dqkv, float *scratch,
+                                     int32_t B, int32_t H, int32_t T, int32_t dh, float scale, float p, const void *dbits,
+                                     void *stream) {
+    if (!q || !k || !v || !out || !d_out || !lse2 || !dqkv || !scratch) return failf(VS_ERR_INVALID, "NULL pointer");
+    if (B <= 0 || H <= 0 || T <= 0) return failf(VS_ERR_INVALID, "B=%d H=%d T=%d", B, H, T);
+    hipStream_t st = (hipStream_t)stream;
+    VST_LAUNCH(vst_head_rowdot(d_out, out, scratch, B * T, T, H, dh, st));
+    VST_LAUNCH(vst_attention_bwd_bf16(q, k, v, key_pad_mask, d_out, lse2, scratch, dqkv, B, H, T, dh, scale, p,
+                                      (const unsigned *)dbits, st));
     return VS_OK;
 }
 

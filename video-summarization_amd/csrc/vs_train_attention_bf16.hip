@@ -1,0 +1,470 @@
+// vs_train_attention_bf16.hip — the training path's attention on the bf16 matrix pipe (low-precision training,
+// VS_TRAIN_FLAG_BF16_ATTENTION; reference simnet.py:155-161 under `amp.autocast()`, train.py:120): forward with dropout
+// and a saved log-sum-exp, and the flash-style backward, head dim 32 / 64.
+//
+// Same decomposition as the exact kernels of vs_train_attention.hip - three kernels, 4 waves x 32 "owner" rows per block,
+// the other sequence streamed through LDS, S and dP recomputed in both backward kernels so that every output element is
+// written once by one wave (no atomics, bitwise reproducible) - on v_mfma_f32_32x32x16_bf16:
+//   * q * scale * log2(e), k, v, dO and the probabilities / dS are rounded to bf16 (round to nearest even) on their way
+//     into LDS / the MFMA; scores, softmax statistics, lse, delta and every accumulator stay fp32; tensors stay fp32 in HBM;
+//   * a 64-row tile of the streamed sequence is ONE row-major bf16 image [64][DH] per matrix that serves both kinds of
+//     read: ROW fragments (ds_read_b128: lane = row, 8 consecutive columns) for the products that contract over the head
+//     dimension (S, dP), and TRANSPOSED fragments (ds_read_b64_tr_b16: 4 rows x 16 columns per 16 lanes, delivered
+//     column-major) for the products that contract over the streamed rows (P.V, dS.K, P~^T.dO, dS^T.Q).  16-byte chunk c of
+//     row m is stored at chunk c ^ swz(m), chosen per head dim so that both reads are bank-conflict-free;
+//   * "accumulator as operand": registers 8s .. 8s+7 of a 32x32 fp32 result, packed pairwise, are the B operand of the
+//     next product's 16-row step s (row order 16s + 8(j>>2) + 4h + (j&3) - the transposed fragments follow it);
+//   * row constants enter as the accumulator's initial value where the row index is the accumulator's row (-lse2, -delta in
+//     the key-owner kernel);
+//   * dropout keep decisions come bit-packed from attn_dropout_bits (vs_train_attention.hip): one word per tile and lane.
+#include <atomic>
+
+#include "vs_train_device.h"
+#include "vs_train_kernels.h"
+
+namespace {
+
+constexpr float NEG_INF_B = -__builtin_inff();
+typedef unsigned short h16;
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+// swizzle of a [rows][DH] bf16 image (rows of 2 DH bytes): XOR of the 16-byte chunk index
+template <int DH>
+__device__ __forceinline__ int img_swz(int row) {
+    if constexpr (DH == 32) return (row >> 2) & 3;
+    else if constexpr (DH == 64) return (((row >> 1) & 1) << 2) | ((row >> 2) & 3);
+    else return ((row & 3) << 2) | ((row >> 2) & 3);
+}
+template <int DH>
+__device__ __forceinline__ int img_off(int row, int chunk) { return row * (2 * DH) + ((chunk ^ img_swz<DH>(row)) << 4); }
+
+// row fragment: lane (r, h) <- columns 16 ks + 8 h .. + 7 of row rbase + r
+template <int DH>
+__device__ __forceinline__ bf16x8 row_frag(const unsigned char *img, int rbase, int ks, int r, int h) {
+    return __builtin_bit_cast(bf16x8, *(const u32x4 *)(img + img_off<DH>(rbase + r, 2 * ks + h)));
+}
+// transposed fragment: lane (r, h) <- rows r0 + {4h .. 4h+3, 8 + 4h .. 8 + 4h+3} of column 32 db + r
+template <int DH>
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned char *img, int r0, int db, int lane) {
+    const int i16 = lane & 15, qq = i16 >> 2, p = i16 & 3, g2 = (lane >> 4) & 1, h = lane >> 5;
+    const int row = r0 + 4 * h + qq, chunk = 4 * db + 2 * g2 + (p >> 1), sub = 8 * (p & 1);
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(img + img_off<DH>(row, chunk) + sub));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(img + img_off<DH>(row + 8, chunk) + sub));
+    const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+    const u32x4 v = {l2[0], l2[1], h2[0], h2[1]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int DH>
+struct TileB {                                  // one staged 64-row tile pair + its per-row side data
+    unsigned char a[64 * 2 * DH];               // K (fwd, dq) | Q * scale * log2e (dkdv)
+    unsigned char b[64 * 2 * DH];               // V (fwd, dq) | dO               (dkdv)
+    float s0[64];                               // key bias (0 / -inf)  |  -lse2 (-inf on rows >= T)
+    float s1[64];                               //                      |  -delta
+};
+
+// global fp32 -> registers -> bf16 LDS image of a 64 x DH tile pair by 256 threads (DH / 16 float4 per thread and matrix)
+template <int DH>
+struct StagerB {
+    static constexpr int NV = DH / 16;
+    f32x4 va[NV], vb[NV];
+    __device__ __forceinline__ void load(const float *pa, size_t lda, const float *pb, size_t ldb, int row0, int nrows, float mul_a) {
+        const int tid = threadIdx.x;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = tid + 256 * i, row = idx / (DH / 4), c4 = (idx % (DH / 4)) * 4;
+            const bool ok = row0 + row < nrows;
+            va[i] = ok ? *(const f32x4 *)(pa + (size_t)(row0 + row) * lda + c4) * mul_a : f32x4{0.f, 0.f, 0.f, 0.f};
+            vb[i] = ok ? *(const f32x4 *)(pb + (size_t)(row0 + row) * ldb + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    __device__ __forceinline__ void store(TileB<DH> &t) const {
+        const int tid = threadIdx.x;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = tid + 256 * i, row = idx / (DH / 4), c4 = (idx % (DH / 4)) * 4;
+            const int off = img_off<DH>(row, c4 >> 3) + ((c4 & 4) << 1);
+            u32x2 ua, ub;
+            ua[0] = pack_bf16(va[i][0], va[i][1]); ua[1] = pack_bf16(va[i][2], va[i][3]);
+            ub[0] = pack_bf16(vb[i][0], vb[i][1]); ub[1] = pack_bf16(vb[i][2], vb[i][3]);
+            *(u32x2 *)(t.a + off) = ua;
+            *(u32x2 *)(t.b + off) = ub;
+        }
+    }
+};
+
+__device__ __forceinline__ f32x16 zero16b() {
+    f32x16 z;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) z[t] = 0.f;
+    return z;
+}
+
+// the owner's own rows as B-operand fragments: lane (r, h) <- src[16 ks + 8 h .. + 7] * mul, rounded to bf16
+template <int DH>
+__device__ __forceinline__ void owner_frags(const float *src, float mul, int h, bf16x8 (&f)[DH / 16]) {
+#pragma unroll
+    for (int ks = 0; ks < DH / 16; ++ks) {
+        const f32x4 v0 = *(const f32x4 *)(src + 16 * ks + 8 * h) * mul, v1 = *(const f32x4 *)(src + 16 * ks + 8 * h + 4) * mul;
+        const u32x4 u = {pack_bf16(v0[0], v0[1]), pack_bf16(v0[2], v0[3]), pack_bf16(v1[0], v1[1]), pack_bf16(v1[2], v1[3])};
+        f[ks] = __builtin_bit_cast(bf16x8, u);
+    }
+}
+// registers 8 s .. 8 s + 7 of a 32x32 result -> the B operand of the next product's 16-row step s
+__device__ __forceinline__ bf16x8 pack_step(const f32x16 &x, int s) {
+    const u32x4 u = {pack_bf16(x[8 * s], x[8 * s + 1]), pack_bf16(x[8 * s + 2], x[8 * s + 3]),
+                     pack_bf16(x[8 * s + 4], x[8 * s + 5]), pack_bf16(x[8 * s + 6], x[8 * s + 7])};
+    return __builtin_bit_cast(bf16x8, u);
+}
+
+// ------------------------------------------------------------------------------------------
+// forward: owner = queries
+// ------------------------------------------------------------------------------------------
+template <int DH, bool DROP>
+__global__ __launch_bounds__(256) void attn_fwd_train_bf16(
+    const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
+    const uint8_t *__restrict__ mask, float *__restrict__ out, float *__restrict__ lse2, int H, int T, float scale,
+    float drop_scale, const unsigned *__restrict__ dbits) {
+    constexpr int NS = DH / 16, ND = DH / 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    TileB<DH> *lds = reinterpret_cast<TileB<DH> *>(lds_raw);
+    const int nq = (T + 127) / 128;
+    const int bh = blockIdx.x / nq, qt = blockIdx.x - bh * nq, b = bh / H, hd = bh - b * H;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int qi = qt * 128 + wave * 32 + r, qc = qi < T ? qi : T - 1;
+    const float sl2 = scale * 1.4426950408889634f;
+    const float *qb = q + (size_t)bh * T * DH, *kb = k + (size_t)bh * T * DH, *vb = v + (size_t)bh * T * DH;
+
+    bf16x8 qf[NS];
+    owner_frags<DH>(qb + (size_t)qc * DH, sl2, h, qf);
+    f32x16 o[ND];
+#pragma unroll
+    for (int db = 0; db < ND; ++db) o[db] = zero16b();
+    float m_run = NEG_INF_B, l_run = 0.f;
+
+    StagerB<DH> sg;
+    auto side = [&](TileB<DH> &t, int key0) __attribute__((always_inline)) {
+        if (tid < 64) {
+            const int key = key0 + tid;
+            t.s0[tid] = (key >= T || (mask != nullptr && mask[(size_t)b * T + key])) ? NEG_INF_B : 0.f;
+        }
+    };
+    const int nkt = (T + 63) / 64, W = (T + 31) / 32;
+    const unsigned *bq = DROP ? dbits + ((size_t)bh * T + qc) * W : nullptr;
+    sg.load(kb, DH, vb, DH, 0, T, 1.0f);
+    sg.store(lds[0]);
+    side(lds[0], 0);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const TileB<DH> &t = lds[kt & 1];
+        if (kt + 1 < nkt) sg.load(kb, DH, vb, DH, 64 * (kt + 1), T, 1.0f);
+        unsigned kw[2] = {0u, 0u};
+        if (DROP) { kw[0] = bq[2 * kt]; kw[1] = 2 * kt + 1 < W ? bq[2 * kt + 1] : 0u; }
+        f32x16 s[2];
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            s[n] = zero16b();
+#pragma unroll
+            for (int ks = 0; ks < NS; ++ks) s[n] = MFMA_BF16(row_frag<DH>(t.a, 32 * n, ks, r, h), qf[ks], s[n]);
+#pragma unroll
+            for (int tg = 0; tg < 4; ++tg) {
+                const f32x4 bv = *(const f32x4 *)&t.s0[32 * n + 8 * tg + 4 * h];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s[n][4 * tg + e] += bv[e];
+            }
+        }
+        float mx = s[0][0];
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[n][e]);
+        mx = pair_max(mx);
+        const float m_new = fmaxf(m_run, mx);
+        const float m_use = m_new == NEG_INF_B ? 0.f : m_new;
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
+        float ls = 0.f;
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const unsigned kwh = kw[n] >> (4 * h);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float pe = __builtin_amdgcn_exp2f(s[n][e] - m_use);
+                ls += pe;
+                s[n][e] = !DROP ? pe : (kwh >> ((e & 3) + 8 * (e >> 2)) & 1u) ? pe * drop_scale : 0.f;
+            }
+        }
+        l_run = l_run * alpha + ls;
+        m_run = m_new;
+#pragma unroll
+        for (int db = 0; db < ND; ++db)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o[db][e] *= alpha;
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 pf = pack_step(s[n], s2);
+#pragma unroll
+                for (int db = 0; db < ND; ++db) o[db] = MFMA_BF16(tr_frag<DH>(t.b, 32 * n + 16 * s2, db, lane), pf, o[db]);
+            }
+        if (kt + 1 < nkt) { sg.store(lds[(kt + 1) & 1]); side(lds[(kt + 1) & 1], 64 * (kt + 1)); }
+        __syncthreads();
+    }
+    const float l_tot = pair_sum(l_run);
+    const float inv = 1.0f / l_tot;
+    if (qi < T) {
+        float *op = out + ((size_t)b * T + qi) * (H * DH) + hd * DH;
+#pragma unroll
+        for (int db = 0; db < ND; ++db)
+#pragma unroll
+            for (int tg = 0; tg < 4; ++tg) {
+                f32x4 w;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) w[e] = o[db][4 * tg + e] * inv;
+                *(f32x4 *)(op + 32 * db + 8 * tg + 4 * h) = w;
+            }
+        if (h == 0) lse2[(size_t)bh * T + qi] = m_run + log2f(l_tot);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// backward, queries own: dQ
+// ------------------------------------------------------------------------------------------
+template <int DH, bool DROP>
+__global__ __launch_bounds__(256) void attn_bwd_dq_bf16(
+    const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
+    const uint8_t *__restrict__ mask, const float *__restrict__ dO, const float *__restrict__ lse2,
+    const float *__restrict__ delta, float *__restrict__ dqkv, int H, int T, float scale, float drop_scale,
+    const unsigned *__restrict__ dbits) {
+    constexpr int NS = DH / 16, ND = DH / 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    TileB<DH> *lds = reinterpret_cast<TileB<DH> *>(lds_raw);
+    const int nq = (T + 127) / 128, d = H * DH;
+    const int bh = blockIdx.x / nq, qt = blockIdx.x - bh * nq, b = bh / H, hd = bh - b * H;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int qi = qt * 128 + wave * 32 + r, qc = qi < T ? qi : T - 1;
+    const float sl2 = scale * 1.4426950408889634f;
+    const float *qb = q + (size_t)bh * T * DH, *kb = k + (size_t)bh * T * DH, *vb = v + (size_t)bh * T * DH;
+
+    bf16x8 qf[NS], dof[NS];
+    owner_frags<DH>(qb + (size_t)qc * DH, sl2, h, qf);
+    owner_frags<DH>(dO + ((size_t)b * T + qc) * d + hd * DH, 1.0f, h, dof);
+    const float lq = lse2[(size_t)bh * T + qc], dq_delta = delta[(size_t)bh * T + qc];
+    f32x16 acc[ND];
+#pragma unroll
+    for (int db = 0; db < ND; ++db) acc[db] = zero16b();
+
+    StagerB<DH> sg;
+    auto side = [&](TileB<DH> &t, int key0) __attribute__((always_inline)) {
+        if (tid < 64) {
+            const int key = key0 + tid;
+            t.s0[tid] = (key >= T || (mask != nullptr && mask[(size_t)b * T + key])) ? NEG_INF_B : 0.f;
+        }
+    };
+    const int nkt = (T + 63) / 64, W = (T + 31) / 32;
+    const unsigned *bq = DROP ? dbits + ((size_t)bh * T + qc) * W : nullptr;
+    sg.load(kb, DH, vb, DH, 0, T, 1.0f);
+    sg.store(lds[0]);
+    side(lds[0], 0);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const TileB<DH> &t = lds[kt & 1];
+        if (kt + 1 < nkt) sg.load(kb, DH, vb, DH, 64 * (kt + 1), T, 1.0f);
+        unsigned kw[2] = {0u, 0u};
+        if (DROP) { kw[0] = bq[2 * kt]; kw[1] = 2 * kt + 1 < W ? bq[2 * kt + 1] : 0u; }
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            f32x16 s = zero16b(), dp = zero16b();
+#pragma unroll
+            for (int ks = 0; ks < NS; ++ks) {
+                s = MFMA_BF16(row_frag<DH>(t.a, 32 * n, ks, r, h), qf[ks], s);
+                dp = MFMA_BF16(row_frag<DH>(t.b, 32 * n, ks, r, h), dof[ks], dp);
+            }
+            const unsigned kwh = kw[n] >> (4 * h);
+#pragma unroll
+            for (int tg = 0; tg < 4; ++tg) {
+                const f32x4 bv = *(const f32x4 *)&t.s0[32 * n + 8 * tg + 4 * h];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int i = 4 * tg + e;
+                    const float pe = __builtin_amdgcn_exp2f(s[i] + bv[e] - lq);
+                    float g = dp[i];
+                    if (DROP) g = (kwh >> (e + 8 * tg) & 1u) ? g * drop_scale : 0.f;
+                    s[i] = pe * (g - dq_delta);
+                }
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 dsf = pack_step(s, s2);
+#pragma unroll
+                for (int db = 0; db < ND; ++db) acc[db] = MFMA_BF16(tr_frag<DH>(t.a, 32 * n + 16 * s2, db, lane), dsf, acc[db]);
+            }
+        }
+        if (kt + 1 < nkt) { sg.store(lds[(kt + 1) & 1]); side(lds[(kt + 1) & 1], 64 * (kt + 1)); }
+        __syncthreads();
+    }
+    if (qi < T) {
+        float *op = dqkv + ((size_t)b * T + qi) * (3 * d) + hd * DH;
+#pragma unroll
+        for (int db = 0; db < ND; ++db)
+#pragma unroll
+            for (int tg = 0; tg < 4; ++tg) {
+                f32x4 w;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) w[e] = acc[db][4 * tg + e] * scale;
+                *(f32x4 *)(op + 32 * db + 8 * tg + 4 * h) = w;
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// backward, keys own: dK and dV
+// ------------------------------------------------------------------------------------------
+template <int DH, bool DROP>
+__global__ __launch_bounds__(256) void attn_bwd_dkdv_bf16(
+    const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
+    const uint8_t *__restrict__ mask, const float *__restrict__ dO, const float *__restrict__ lse2,
+    const float *__restrict__ delta, float *__restrict__ dqkv, int H, int T, float scale, float drop_scale,
+    const unsigned *__restrict__ dbits, int BH) {
+    constexpr int NS = DH / 16, ND = DH / 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    TileB<DH> *lds = reinterpret_cast<TileB<DH> *>(lds_raw);
+    const int nk = (T + 127) / 128, d = H * DH;
+    const int bh = blockIdx.x / nk, ktile = blockIdx.x - bh * nk, b = bh / H, hd = bh - b * H;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int ki = ktile * 128 + wave * 32 + r, kc = ki < T ? ki : T - 1;
+    const float sl2 = scale * 1.4426950408889634f;
+    const float *qb = q + (size_t)bh * T * DH, *kb = k + (size_t)bh * T * DH, *vb = v + (size_t)bh * T * DH;
+    const float *dob = dO + (size_t)b * T * d + hd * DH;          // row stride d
+
+    bf16x8 kf[NS], vf[NS];
+    owner_frags<DH>(kb + (size_t)kc * DH, 1.0f, h, kf);
+    owner_frags<DH>(vb + (size_t)kc * DH, 1.0f, h, vf);
+    const float kbias = (ki >= T || (mask != nullptr && mask[(size_t)b * T + kc])) ? NEG_INF_B : 0.f;
+    f32x16 dk[ND], dv[ND];
+#pragma unroll
+    for (int db = 0; db < ND; ++db) { dk[db] = zero16b(); dv[db] = zero16b(); }
+
+    StagerB<DH> sg;
+    auto side = [&](TileB<DH> &t, int q0) __attribute__((always_inline)) {
+        if (tid < 64) {
+            const int qi = q0 + tid;
+            const bool ok = qi < T;
+            t.s0[tid] = ok ? -lse2[(size_t)bh * T + qi] : NEG_INF_B;      // p = exp2(s - inf) = 0 on rows >= T
+            t.s1[tid] = ok ? -delta[(size_t)bh * T + qi] : 0.f;
+        }
+    };
+    const int nqt = (T + 63) / 64, W = (T + 31) / 32;
+    const unsigned *bk = DROP ? dbits + (size_t)BH * T * W + ((size_t)bh * T + kc) * W : nullptr;     // the key-major copy
+    sg.load(qb, DH, dob, d, 0, T, sl2);
+    sg.store(lds[0]);
+    side(lds[0], 0);
+    __syncthreads();
+    for (int it = 0; it < nqt; ++it) {
+        const TileB<DH> &t = lds[it & 1];
+        if (it + 1 < nqt) sg.load(qb, DH, dob, d, 64 * (it + 1), T, sl2);
+        unsigned kw[2] = {0u, 0u};
+        if (DROP) { kw[0] = bk[2 * it]; kw[1] = 2 * it + 1 < W ? bk[2 * it + 1] : 0u; }
+#pragma unroll
+        for (int qblk = 0; qblk < 2; ++qblk) {
+            // S[query][key] - lse2[query] and dP[query][key] - delta[query]: the row constants are the initial accumulators
+            f32x16 s, dp;
+#pragma unroll
+            for (int tg = 0; tg < 4; ++tg) {
+                const f32x4 lv = *(const f32x4 *)&t.s0[32 * qblk + 8 * tg + 4 * h];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { s[4 * tg + e] = lv[e]; dp[4 * tg + e] = 0.f; }
+            }
+#pragma unroll
+            for (int ks = 0; ks < NS; ++ks) {
+                s = MFMA_BF16(row_frag<DH>(t.a, 32 * qblk, ks, r, h), kf[ks], s);
+                dp = MFMA_BF16(row_frag<DH>(t.b, 32 * qblk, ks, r, h), vf[ks], dp);
+            }
+            const unsigned kwh = kw[qblk] >> (4 * h);
+            f32x16 pd;          // dropped-out probabilities (the B operand of dV)
+#pragma unroll
+            for (int tg = 0; tg < 4; ++tg) {
+                const f32x4 dl = *(const f32x4 *)&t.s1[32 * qblk + 8 * tg + 4 * h];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int i = 4 * tg + e;
+                    const float pe = __builtin_amdgcn_exp2f(s[i] + kbias);
+                    float g = dp[i], pk = pe;
+                    if (DROP) {
+                        const bool keep = (kwh >> (e + 8 * tg) & 1u) != 0u;
+                        g = keep ? g * drop_scale : 0.f;
+                        pk = keep ? pe * drop_scale : 0.f;
+                    }
+                    pd[i] = pk;
+                    s[i] = pe * (g + dl[e]);          // dS  (s1 holds -delta)
+                }
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 pdf = pack_step(pd, s2), dsf = pack_step(s, s2);
+#pragma unroll
+                for (int db = 0; db < ND; ++db) {
+                    dv[db] = MFMA_BF16(tr_frag<DH>(t.b, 32 * qblk + 16 * s2, db, lane), pdf, dv[db]);
+                    dk[db] = MFMA_BF16(tr_frag<DH>(t.a, 32 * qblk + 16 * s2, db, lane), dsf, dk[db]);
+                }
+            }
+        }
+        if (it + 1 < nqt) { sg.store(lds[(it + 1) & 1]); side(lds[(it + 1) & 1], 64 * (it + 1)); }
+        __syncthreads();
+    }
+    if (ki < T) {
+        float *op = dqkv + ((size_t)b * T + ki) * (3 * d) + hd * DH;
+        const float ln2 = 0.6931471805599453f;       // dK = scale * dS^T Q = (dS^T Qs) / log2(e)
+#pragma unroll
+        for (int db = 0; db < ND; ++db)
+#pragma unroll
+            for (int tg = 0; tg < 4; ++tg) {
+                f32x4 wk, wv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { wk[e] = dk[db][4 * tg + e] * ln2; wv[e] = dv[db][4 * tg + e]; }
+                *(f32x4 *)(op + d + 32 * db + 8 * tg + 4 * h) = wk;
+                *(f32x4 *)(op + 2 * d + 32 * db + 8 * tg + 4 * h) = wv;
+            }
+    }
+}
+
+}  // namespace
+
+#define VSTB_LAUNCH(KERNEL_, DH_, DROP_, ...)                                                                   \
+    do {                                                                                                        \
+        constexpr size_t lds_bytes_ = 2 * sizeof(TileB<DH_>);                                                   \
+        static_assert(lds_bytes_ <= 64 * 1024, "static-size dynamic LDS below the 64 KB default limit");        \
+        hipLaunchKernelGGL((KERNEL_<DH_, DROP_>), grid, dim3(256), lds_bytes_, st, __VA_ARGS__);                \
+    } while (0)
+#define VSTB_DISPATCH(KERNEL_, ...)                                                                             \
+    do {                                                                                                        \
+        const bool drop = p > 0.f;                                                                              \
+        if (dh == 32) { if (drop) VSTB_LAUNCH(KERNEL_, 32, true, __VA_ARGS__); else VSTB_LAUNCH(KERNEL_, 32, false, __VA_ARGS__); } \
+        else if (dh == 64) { if (drop) VSTB_LAUNCH(KERNEL_, 64, true, __VA_ARGS__); else VSTB_LAUNCH(KERNEL_, 64, false, __VA_ARGS__); } \
+        else return -1;                                                                                         \
+    } while (0)
+
+bool vst_attention_bf16_supported(int dh) { return dh == 32 || dh == 64; }
+
+int vst_attention_fwd_bf16(const float *q, const float *k, const float *v, const uint8_t *mask, float *out, float *lse2,
+                           int B, int H, int T, int dh, float scale, float p, const unsigned *dbits, hipStream_t st) {
+    if (p < 0.f || p >= 1.f || (p > 0.f && dbits == nullptr)) return -1;
+    const float ds = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
+    const dim3 grid(B * H * ((T + 127) / 128));
+    VSTB_DISPATCH(attn_fwd_train_bf16, q, k, v, mask, out, lse2, H, T, scale, ds, dbits);
+    VSK_CHECK_LAUNCH();
+    return 0;
+}
+
+int vst_attention_bwd_bf16(const float *q, const float *k, const float *v, const uint8_t *mask, const float *dO,
+                           const float *lse2, const float *delta, float *dqkv, int B, int H, int T, int dh, float scale,
+                           float p, const unsigned *dbits, hipStream_t st) {
+    if (p < 0.f || p >= 1.f || (p > 0.f && dbits == nullptr)) return -1;
+    const float ds = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
+    const dim3 grid(B * H * ((T + 127) / 128));
+    VSTB_DISPATCH(attn_bwd_dkdv_bf16, q, k, v, mask, dO, lse2, delta, dqkv, H, T, scale, ds, dbits, B * H);
+    VSK_CHECK_LAUNCH();
+    VSTB_DISPATCH(attn_bwd_dq_bf16, q, k, v, mask, dO, lse2, delta, dqkv, H, T, scale, ds, dbits);
+    VSK_CHECK_LAUNCH();
+    return 0;
+}

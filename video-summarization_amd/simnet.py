@@ -339,7 +339,7 @@ class SimNet(nn.Module):
         seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item()) if (p > 0.0 or p_embed > 0.0) else 0
         params = [t for t in self._tensors() if isinstance(t, nn.Parameter)]
         x32 = x if x.dtype == torch.float32 else x.float()
-        tflags = _lib.VS_TRAIN_FLAG_BF16_LINEAR if self._train_dtype == "bf16" else 0
+        tflags = (_lib.VS_TRAIN_FLAG_BF16_LINEAR | _lib.VS_TRAIN_FLAG_BF16_ATTENTION) if self._train_dtype == "bf16" else 0
         return _TrainForward.apply(self, x32, mask, p, p_embed, seed, tflags, *params)
 
     def forward(self, x: Tensor, mask=None, vis_attention=None, model_score: bool = False):
