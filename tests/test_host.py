@@ -131,8 +131,8 @@ def test_compute_dtype_switches_are_validated(vsa):
     wide = vsa.SimNet(num_heads=4, d_model=512, num_layers=1)          # M-B: head dim 128
     wide.set_compute_dtype("fp16x3")                                   # plain projections emulated, the rest exact
     assert wide.attention_dtype == "fp32" and wide.linear_dtype == "fp16x3"
-    with pytest.raises(ValueError):
-        wide.set_compute_dtype("bf16")
+    wide.set_compute_dtype("bf16")                                     # head dim 128 has a bf16 attention; plain bf16 GEMMs
+    assert wide.attention_dtype == "bf16" and wide.linear_dtype == "bf16"
     with pytest.raises(ValueError):
         wide.attention_dtype = "fp16x3"
     flags = vsa._lib
