@@ -24,6 +24,7 @@ ap.add_argument("--torch", action="store_true", help="also time the composed-tor
 ap.add_argument("--shapes", default="4x320,4x640,16x1024,64x1024")
 ap.add_argument("--model", default="A")
 ap.add_argument("--iters", type=int, default=10)
+ap.add_argument("--only-bf16", action="store_true", help="time only the set_train_dtype('bf16') step (for a kernel profile)")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 H, d, L = (4, 256, 4) if args.model == "A" else (4, 512, 3)
@@ -77,6 +78,11 @@ for shape in args.shapes.split(","):
         pred, _ = m(x, mask)
         return pred
 
+    if args.only_bf16:
+        m.set_train_dtype("bf16")
+        print("B=%3d T=%4d  bf16 fwd+loss+bwd %.3f ms" % (B, T, timed(step, args.iters)), flush=True)
+        m.set_train_dtype("fp32")
+        continue
     with torch.no_grad():
         ev = timed(lambda: m.eval()(x, mask), args.iters)
     m.train()

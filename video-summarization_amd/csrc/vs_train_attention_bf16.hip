@@ -117,11 +117,33 @@ __device__ __forceinline__ bf16x8 pack_step(const f32x16 &x, int s) {
     return __builtin_bit_cast(bf16x8, u);
 }
 
+// keep decision `bit` of a lane's dropout word as a multiplier: 1 / (1 - p) or 0  (v_bfe_i32 + v_and)
+__device__ __forceinline__ float keep_mul(unsigned word, int bit, unsigned ds_bits) {
+    return __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_sbfe((int)word, (unsigned)bit, 1u) & ds_bits);
+}
+// the two dropout words of a 64-row tile, one tile ahead of their use (a load consumed at once would expose the latency of
+// every stage load issued before it: vmcnt retires in order)
+__device__ __forceinline__ void load_kw(const unsigned *row, int tile, int W, unsigned (&kw)[2]) {
+    kw[0] = 2 * tile < W ? row[2 * tile] : 0u;
+    kw[1] = 2 * tile + 1 < W ? row[2 * tile + 1] : 0u;
+}
+// accumulator whose initial value is a per-row constant from LDS (rows 8 tg + 4 h + e of the 32-row block at c)
+__device__ __forceinline__ f32x16 rows_init(const float *c, int h) {
+    f32x16 a;
+#pragma unroll
+    for (int tg = 0; tg < 4; ++tg) {
+        const f32x4 v = *(const f32x4 *)&c[8 * tg + 4 * h];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[4 * tg + e] = v[e];
+    }
+    return a;
+}
+
 // ------------------------------------------------------------------------------------------
 // forward: owner = queries
 // ------------------------------------------------------------------------------------------
 template <int DH, bool DROP>
-__global__ __launch_bounds__(256) void attn_fwd_train_bf16(
+__global__ __launch_bounds__(256, 2) void attn_fwd_train_bf16(
     const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
     const uint8_t *__restrict__ mask, float *__restrict__ out, float *__restrict__ lse2, int H, int T, float scale,
     float drop_scale, const unsigned *__restrict__ dbits) {
@@ -151,27 +173,24 @@ __global__ __launch_bounds__(256) void attn_fwd_train_bf16(
     };
     const int nkt = (T + 63) / 64, W = (T + 31) / 32;
     const unsigned *bq = DROP ? dbits + ((size_t)bh * T + qc) * W : nullptr;
+    const unsigned dsb = __builtin_bit_cast(unsigned, drop_scale);
+    unsigned kwn[2] = {0u, 0u};
+    if (DROP) load_kw(bq, 0, W, kwn);
     sg.load(kb, DH, vb, DH, 0, T, 1.0f);
     sg.store(lds[0]);
     side(lds[0], 0);
     __syncthreads();
     for (int kt = 0; kt < nkt; ++kt) {
         const TileB<DH> &t = lds[kt & 1];
+        const unsigned kw[2] = {kwn[0], kwn[1]};
+        if (DROP && kt + 1 < nkt) load_kw(bq, kt + 1, W, kwn);
         if (kt + 1 < nkt) sg.load(kb, DH, vb, DH, 64 * (kt + 1), T, 1.0f);
-        unsigned kw[2] = {0u, 0u};
-        if (DROP) { kw[0] = bq[2 * kt]; kw[1] = 2 * kt + 1 < W ? bq[2 * kt + 1] : 0u; }
         f32x16 s[2];
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
-            s[n] = zero16b();
+            s[n] = rows_init(&t.s0[32 * n], h);              // the key bias (0 / -inf) is the accumulator's initial value
 #pragma unroll
             for (int ks = 0; ks < NS; ++ks) s[n] = MFMA_BF16(row_frag<DH>(t.a, 32 * n, ks, r, h), qf[ks], s[n]);
-#pragma unroll
-            for (int tg = 0; tg < 4; ++tg) {
-                const f32x4 bv = *(const f32x4 *)&t.s0[32 * n + 8 * tg + 4 * h];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) s[n][4 * tg + e] += bv[e];
-            }
         }
         float mx = s[0][0];
 #pragma unroll
@@ -190,7 +209,7 @@ __global__ __launch_bounds__(256) void attn_fwd_train_bf16(
             for (int e = 0; e < 16; ++e) {
                 const float pe = __builtin_amdgcn_exp2f(s[n][e] - m_use);
                 ls += pe;
-                s[n][e] = !DROP ? pe : (kwh >> ((e & 3) + 8 * (e >> 2)) & 1u) ? pe * drop_scale : 0.f;
+                s[n][e] = !DROP ? pe : pe * keep_mul(kwh, (e & 3) + 8 * (e >> 2), dsb);
             }
         }
         l_run = l_run * alpha + ls;
@@ -231,7 +250,7 @@ __global__ __launch_bounds__(256) void attn_fwd_train_bf16(
 // backward, queries own: dQ
 // ------------------------------------------------------------------------------------------
 template <int DH, bool DROP>
-__global__ __launch_bounds__(256) void attn_bwd_dq_bf16(
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16(
     const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
     const uint8_t *__restrict__ mask, const float *__restrict__ dO, const float *__restrict__ lse2,
     const float *__restrict__ delta, float *__restrict__ dqkv, int H, int T, float scale, float drop_scale,
@@ -263,18 +282,21 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16(
     };
     const int nkt = (T + 63) / 64, W = (T + 31) / 32;
     const unsigned *bq = DROP ? dbits + ((size_t)bh * T + qc) * W : nullptr;
+    const unsigned dsb = __builtin_bit_cast(unsigned, drop_scale);
+    unsigned kwn[2] = {0u, 0u};
+    if (DROP) load_kw(bq, 0, W, kwn);
     sg.load(kb, DH, vb, DH, 0, T, 1.0f);
     sg.store(lds[0]);
     side(lds[0], 0);
     __syncthreads();
     for (int kt = 0; kt < nkt; ++kt) {
         const TileB<DH> &t = lds[kt & 1];
+        const unsigned kw[2] = {kwn[0], kwn[1]};
+        if (DROP && kt + 1 < nkt) load_kw(bq, kt + 1, W, kwn);
         if (kt + 1 < nkt) sg.load(kb, DH, vb, DH, 64 * (kt + 1), T, 1.0f);
-        unsigned kw[2] = {0u, 0u};
-        if (DROP) { kw[0] = bq[2 * kt]; kw[1] = 2 * kt + 1 < W ? bq[2 * kt + 1] : 0u; }
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
-            f32x16 s = zero16b(), dp = zero16b();
+            f32x16 s = rows_init(&t.s0[32 * n], h), dp = zero16b();        // key bias = initial accumulator
 #pragma unroll
             for (int ks = 0; ks < NS; ++ks) {
                 s = MFMA_BF16(row_frag<DH>(t.a, 32 * n, ks, r, h), qf[ks], s);
@@ -282,16 +304,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16(
             }
             const unsigned kwh = kw[n] >> (4 * h);
 #pragma unroll
-            for (int tg = 0; tg < 4; ++tg) {
-                const f32x4 bv = *(const f32x4 *)&t.s0[32 * n + 8 * tg + 4 * h];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int i = 4 * tg + e;
-                    const float pe = __builtin_amdgcn_exp2f(s[i] + bv[e] - lq);
-                    float g = dp[i];
-                    if (DROP) g = (kwh >> (e + 8 * tg) & 1u) ? g * drop_scale : 0.f;
-                    s[i] = pe * (g - dq_delta);
-                }
+            for (int i = 0; i < 16; ++i) {
+                const float pe = __builtin_amdgcn_exp2f(s[i] - lq);
+                const float g = DROP ? fmaf(dp[i], keep_mul(kwh, (i & 3) + 8 * (i >> 2), dsb), -dq_delta) : dp[i] - dq_delta;
+                s[i] = pe * g;
             }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
@@ -321,7 +337,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16(
 // backward, keys own: dK and dV
 // ------------------------------------------------------------------------------------------
 template <int DH, bool DROP>
-__global__ __launch_bounds__(256) void attn_bwd_dkdv_bf16(
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_bf16(
     const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
     const uint8_t *__restrict__ mask, const float *__restrict__ dO, const float *__restrict__ lse2,
     const float *__restrict__ delta, float *__restrict__ dqkv, int H, int T, float scale, float drop_scale,
@@ -340,7 +356,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_bf16(
     bf16x8 kf[NS], vf[NS];
     owner_frags<DH>(kb + (size_t)kc * DH, 1.0f, h, kf);
     owner_frags<DH>(vb + (size_t)kc * DH, 1.0f, h, vf);
-    const float kbias = (ki >= T || (mask != nullptr && mask[(size_t)b * T + kc])) ? NEG_INF_B : 0.f;
+    const bool kmasked = mask != nullptr && mask[(size_t)b * T + kc];
     f32x16 dk[ND], dv[ND];
 #pragma unroll
     for (int db = 0; db < ND; ++db) { dk[db] = zero16b(); dv[db] = zero16b(); }
@@ -356,47 +372,48 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_bf16(
     };
     const int nqt = (T + 63) / 64, W = (T + 31) / 32;
     const unsigned *bk = DROP ? dbits + (size_t)BH * T * W + ((size_t)bh * T + kc) * W : nullptr;     // the key-major copy
+    const unsigned dsb = __builtin_bit_cast(unsigned, drop_scale);
+    unsigned kwn[2] = {0u, 0u};
+    if (DROP) load_kw(bk, 0, W, kwn);
     sg.load(qb, DH, dob, d, 0, T, sl2);
     sg.store(lds[0]);
     side(lds[0], 0);
     __syncthreads();
     for (int it = 0; it < nqt; ++it) {
         const TileB<DH> &t = lds[it & 1];
+        const unsigned kw[2] = {kwn[0], kwn[1]};
+        if (DROP && it + 1 < nqt) load_kw(bk, it + 1, W, kwn);
         if (it + 1 < nqt) sg.load(qb, DH, dob, d, 64 * (it + 1), T, sl2);
-        unsigned kw[2] = {0u, 0u};
-        if (DROP) { kw[0] = bk[2 * it]; kw[1] = 2 * it + 1 < W ? bk[2 * it + 1] : 0u; }
 #pragma unroll
         for (int qblk = 0; qblk < 2; ++qblk) {
-            // S[query][key] - lse2[query] and dP[query][key] - delta[query]: the row constants are the initial accumulators
-            f32x16 s, dp;
-#pragma unroll
-            for (int tg = 0; tg < 4; ++tg) {
-                const f32x4 lv = *(const f32x4 *)&t.s0[32 * qblk + 8 * tg + 4 * h];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { s[4 * tg + e] = lv[e]; dp[4 * tg + e] = 0.f; }
-            }
+            // S[query][key] - lse2[query] and (no dropout) dP[query][key] - delta[query]: the row constants are the initial
+            // accumulators.  With dropout the decision multiplies dP BEFORE delta leaves, so -delta joins in the fma below.
+            f32x16 s = rows_init(&t.s0[32 * qblk], h), dp = DROP ? zero16b() : rows_init(&t.s1[32 * qblk], h);
 #pragma unroll
             for (int ks = 0; ks < NS; ++ks) {
                 s = MFMA_BF16(row_frag<DH>(t.a, 32 * qblk, ks, r, h), kf[ks], s);
                 dp = MFMA_BF16(row_frag<DH>(t.b, 32 * qblk, ks, r, h), vf[ks], dp);
             }
+            // (a masked owner key needs no bias here: its lane is one COLUMN of every product below, so whatever it
+            // computes stays in its own dK / dV row, which is written as zero at the end)
             const unsigned kwh = kw[qblk] >> (4 * h);
             f32x16 pd;          // dropped-out probabilities (the B operand of dV)
 #pragma unroll
             for (int tg = 0; tg < 4; ++tg) {
-                const f32x4 dl = *(const f32x4 *)&t.s1[32 * qblk + 8 * tg + 4 * h];
+                f32x4 dl = {0.f, 0.f, 0.f, 0.f};
+                if (DROP) dl = *(const f32x4 *)&t.s1[32 * qblk + 8 * tg + 4 * h];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int i = 4 * tg + e;
-                    const float pe = __builtin_amdgcn_exp2f(s[i] + kbias);
-                    float g = dp[i], pk = pe;
+                    const float pe = __builtin_amdgcn_exp2f(s[i]);
                     if (DROP) {
-                        const bool keep = (kwh >> (e + 8 * tg) & 1u) != 0u;
-                        g = keep ? g * drop_scale : 0.f;
-                        pk = keep ? pe * drop_scale : 0.f;
+                        const float km = keep_mul(kwh, e + 8 * tg, dsb);
+                        pd[i] = pe * km;
+                        s[i] = pe * fmaf(dp[i], km, dl[e]);      // dS  (s1 holds -delta)
+                    } else {
+                        pd[i] = pe;
+                        s[i] = pe * dp[i];
                     }
-                    pd[i] = pk;
-                    s[i] = pe * (g + dl[e]);          // dS  (s1 holds -delta)
                 }
             }
 #pragma unroll
@@ -421,7 +438,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_bf16(
             for (int tg = 0; tg < 4; ++tg) {
                 f32x4 wk, wv;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { wk[e] = dk[db][4 * tg + e] * ln2; wv[e] = dv[db][4 * tg + e]; }
+                for (int e = 0; e < 4; ++e) { wk[e] = kmasked ? 0.f : dk[db][4 * tg + e] * ln2; wv[e] = kmasked ? 0.f : dv[db][4 * tg + e]; }
                 *(f32x4 *)(op + d + 32 * db + 8 * tg + 4 * h) = wk;
                 *(f32x4 *)(op + 2 * d + 32 * db + 8 * tg + 4 * h) = wv;
             }
