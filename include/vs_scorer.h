@@ -193,6 +193,16 @@ int vs_linear_f16x3(const float *A, const float *W, const float *bias, float *C,
                     int32_t M, int32_t N, int32_t K, int32_t relu,
                     const float *pe, int32_t T, void *stream);
 
+/* The wide models' bf16 Linear (d_model > 256 under VS_FLAG_BF16_LINEAR): BOTH operands already bf16 in device memory
+ * (A16 [M,K], W16 [N,K] row-major, 16-byte aligned; K, N multiples of 32), fp32 accumulation, C fp32 [M,N] (c16 == 0) or
+ * bf16 (c16 != 0).  vs_to_bf16 is the rounding (nearest even) the producers apply: dst16[i] = bf16(src[i]), n % 8 == 0. */
+int vs_linear_bf16_operands(const void *A16, const void *W16, const float *bias, void *C,
+                            int32_t M, int32_t N, int32_t K, int32_t relu, int32_t c16, void *stream);
+/* the same product with the q/k/v epilogue: out[3][B][H][T][dh] (fp32, or bf16 with q times scale * log2 e when c16 != 0) */
+int vs_qkv_proj_bf16_operands(const void *h16, const void *Wqkv16, const float *bqkv, void *qkv,
+                              int32_t B, int32_t T, int32_t d, int32_t H, int32_t c16, void *stream);
+int vs_to_bf16(const float *src, void *dst16, size_t n, void *stream);
+
 /* qkv = h * Wqkv^T + b, scattered head-major: out[3][B][H][T][dh]  (simnet.py:148-153). */
 int vs_qkv_proj_f32(const float *h, const float *Wqkv, const float *bqkv, float *qkv,
                     int32_t B, int32_t T, int32_t d, int32_t H, void *stream);

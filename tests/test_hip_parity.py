@@ -634,6 +634,66 @@ def test_linear_bf16_kernel(vsa, M, N, K, relu, T):
     assert (out.cpu().double() - ref).abs().max().item() < 1e-4
 
 
+@pytest.mark.parametrize("M,N,K,relu,c16", [(300, 256, 1024, 0, 0), (129, 1024, 256, 1, 1), (64, 768, 256, 0, 0), (1000, 512, 2048, 0, 0),
+                                            (2048, 2048, 512, 1, 1), (1, 32, 32, 0, 0), (257, 96, 64, 1, 0), (4096, 1536, 512, 0, 1),
+                                            (130, 288, 96, 0, 1)])
+def test_linear_bf16_operands_kernel(vsa, M, N, K, relu, c16):
+    """The wide models' bf16 Linear (vs_gemm_ring.hip): bf16 operands from device memory by LDS-DMA, fp32 accumulation.
+    vs_to_bf16 must round exactly like torch (nearest even); the product against float64 on the SAME rounded operands
+    leaves fp32 accumulation order only (1e-4 on O(1) outputs); a bf16 output is the nearest bf16 of the fp32 result up
+    to that accumulation noise (one bf16 ulp)."""
+    lib = vsa._lib.load()
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g)
+    ref = _rb(A) @ _rb(W).t() + b.double()
+    if relu:
+        ref = F.relu(ref)
+    dA, dW, db = A.to(_dev()), W.to(_dev()), b.to(_dev())
+    pad = (-(M * K)) % 8                                  # vs_to_bf16 converts 8 elements per thread
+    A16 = torch.empty(M * K + pad, dtype=torch.bfloat16, device=_dev())
+    W16 = torch.empty(N * K, dtype=torch.bfloat16, device=_dev())
+    srcA = torch.cat([dA.reshape(-1), torch.zeros(pad, device=_dev())]) if pad else dA.reshape(-1)
+    vsa._lib.check(lib.vs_to_bf16(srcA.data_ptr(), A16.data_ptr(), M * K + pad, _stream()))
+    vsa._lib.check(lib.vs_to_bf16(dW.data_ptr(), W16.data_ptr(), N * K, _stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(A16[:M * K].cpu(), A.reshape(-1).to(torch.bfloat16)) and torch.equal(W16.cpu(), W.reshape(-1).to(torch.bfloat16))
+    out = torch.full((M, N), float("nan"), device=_dev(), dtype=torch.bfloat16 if c16 else torch.float32)
+    vsa._lib.check(lib.vs_linear_bf16_operands(A16.data_ptr(), W16.data_ptr(), db.data_ptr(), out.data_ptr(), M, N, K, relu, c16, _stream()))
+    torch.cuda.synchronize()
+    got = out.cpu().double()
+    assert torch.isfinite(got).all()
+    if c16:
+        assert ((got - ref).abs() <= 2.0 ** -8 * ref.abs() + 1e-4).all()
+    else:
+        assert (got - ref).abs().max().item() < 1e-4
+
+
+@pytest.mark.parametrize("B,T,d,H,c16", [(2, 200, 512, 4, 0), (3, 130, 768, 12, 1), (1, 77, 1024, 8, 0), (2, 64, 1024, 16, 1)])
+def test_qkv_projection_bf16_operands_kernel(vsa, B, T, d, H, c16):
+    """The same kernel's q/k/v epilogue: [3][B][H][T][dh], q pre-multiplied by scale * log2(e) in the bf16-output form."""
+    lib = vsa._lib.load()
+    g = torch.Generator().manual_seed(B * T + d)
+    h = torch.randn(B * T, d, generator=g)
+    W = torch.randn(3 * d, d, generator=g) / math.sqrt(d)
+    b = torch.randn(3 * d, generator=g)
+    ref = (_rb(h) @ _rb(W).t() + b.double()).view(B, T, 3, H, d // H).permute(2, 0, 3, 1, 4).contiguous()
+    if c16:
+        ref[0] *= d ** -0.5 * 1.4426950408889634
+    h16 = h.to(torch.bfloat16).to(_dev())
+    W16 = W.to(torch.bfloat16).to(_dev())
+    out = torch.full((3, B, H, T, d // H), float("nan"), device=_dev(), dtype=torch.bfloat16 if c16 else torch.float32)
+    vsa._lib.check(lib.vs_qkv_proj_bf16_operands(h16.data_ptr(), W16.data_ptr(), b.to(_dev()).data_ptr(), out.data_ptr(), B, T, d, H, c16, _stream()))
+    torch.cuda.synchronize()
+    got = out.cpu().double()
+    assert torch.isfinite(got).all()
+    if c16:
+        assert ((got - ref).abs() <= 2.0 ** -8 * ref.abs() + 1e-4).all()
+    else:
+        assert (got - ref).abs().max().item() < 1e-4
+
+
 @pytest.mark.parametrize("M,N,K,nc,sig", [(300, 256, 256, 0, 0), (100, 256, 1024, 1, 0), (64, 128, 512, 3, 0),
                                           (1000, 192, 320, 2, 1), (33, 64, 256, 1, 0)])
 def test_linear_residual_layernorm_bf16_kernel(vsa, M, N, K, nc, sig):

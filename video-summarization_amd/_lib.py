@@ -17,7 +17,7 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(ROOT, "include")
 LIB_PATH = os.path.join(HERE, "libvsscore.so")
 DIAG_LIB_PATH = os.path.join(HERE, "libvsscore_diag.so")
-SOURCES = ("vs_kernels.hip", "vs_attention.hip", "vs_mlp_fused.hip", "vs_scorer.cpp", "vs_eval.cpp",
+SOURCES = ("vs_kernels.hip", "vs_attention.hip", "vs_mlp_fused.hip", "vs_gemm_ring.hip", "vs_scorer.cpp", "vs_eval.cpp",
            "vs_train_kernels.hip", "vs_train_attention.hip", "vs_train_attention_bf16.hip", "vs_pretrain_kernels.hip",
            "vs_train.cpp")
 ABI_VERSION = 3
@@ -38,6 +38,7 @@ EXPORTS = ("vs_abi_version", "vs_last_error", "vs_weights_pack", "vs_weights_fre
            "vs_attention_f32", "vs_attention_bf16", "vs_attention_f16x3", "vs_linear_residual_layernorm_f32",
            "vs_linear_bf16", "vs_linear_residual_layernorm_bf16", "vs_linear_f16x3",
            "vs_linear_residual_layernorm_f16x3", "vs_mlp_block_bf16",
+           "vs_linear_bf16_operands", "vs_qkv_proj_bf16_operands", "vs_to_bf16",
            "vs_profile_enable", "vs_profile_collect", "vs_stage_name")
 # include/vs_eval.h
 EVAL_EXPORTS = ("vs_eval_upsample", "vs_eval_knapsack", "vs_eval_generate_summary", "vs_eval_fscore",
@@ -212,6 +213,12 @@ def load() -> C.CDLL:
                                                          + [C.c_int32] * 2 + [C.c_void_p] * 2)
         lib.vs_linear_bf16.restype = C.c_int
         lib.vs_linear_bf16.argtypes = lib.vs_linear_f32.argtypes
+        lib.vs_linear_bf16_operands.restype = C.c_int
+        lib.vs_linear_bf16_operands.argtypes = [C.c_void_p] * 4 + [C.c_int32] * 5 + [C.c_void_p]
+        lib.vs_qkv_proj_bf16_operands.restype = C.c_int
+        lib.vs_qkv_proj_bf16_operands.argtypes = [C.c_void_p] * 4 + [C.c_int32] * 5 + [C.c_void_p]
+        lib.vs_to_bf16.restype = C.c_int
+        lib.vs_to_bf16.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         lib.vs_linear_residual_layernorm_bf16.restype = C.c_int
         lib.vs_linear_residual_layernorm_bf16.argtypes = lib.vs_linear_residual_layernorm_f32.argtypes
         lib.vs_linear_f16x3.restype = C.c_int

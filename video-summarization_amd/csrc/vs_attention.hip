@@ -1521,8 +1521,11 @@ int vsk_attention_bf16(const float *q, const float *k, const float *v, const uin
     dim3 grid(8 * ((BH + 7) / 8) * (wide ? r8 / 256 : r4 / 128));
     const bool simple = vsk_options().attn_lp_simple != 0;      // A/B switch for tools/, not a fallback
     if (dh == 128) {     // head dim 128 (M-B): bf16 only, 8-wave blocks only (fp16x3 does not fit the register file: 48 spills)
-        if (prec != 1) return -1;
+        if (prec != 1 && prec != (1 | VSK_STORE16)) return -1;
         dim3 g128(8 * ((BH + 7) / 8) * (r8 / 256));
+        if (prec == (1 | VSK_STORE16))      // bf16 q (pre-scaled) / k / v in, bf16 out (the wide models' bf16-operand path)
+            hipLaunchKernelGGL((attn_fwd_lp_pipe<128, 8, 1, false, true>), g128, dim3(512), 0, st, q, k, v, mask, out, H, T, sl2, BH);
+        else
         hipLaunchKernelGGL((attn_fwd_lp_pipe<128, 8, 1>), g128, dim3(512), 0, st, q, k, v, mask, out, H, T, sl2, BH);
         VSK_CHECK_LAUNCH();
         return 0;

@@ -38,7 +38,7 @@ int vsk_linear_res_ln(const float *A, const float *W, const float *Wf, const flo
 // out = LayerNorm(a + res) * gamma + beta (+ score head): the row pass behind a plain GEMM for d_model > 256
 int vsk_rows_res_ln(const float *a, const float *res, const float *gamma, const float *beta, float *out, int M, int d,
                     const float *score_w, const float *score_b, int num_classes, int sigmoid, float *scores,
-                    hipStream_t st);
+                    hipStream_t st, void *out16 = nullptr);      // out16: optional bf16 copy of the output rows
 int vsk_diag_attention(const float *q, const float *k, const float *v, float *out, int B, int H, int T, float scale,
                        unsigned long long *diag, hipStream_t st);      // diagnostic library only; returns the blocks launched
 int vsk_diag_attention_lp(const float *q, const float *k, const float *v, float *out, int B, int H, int T, float scale,
@@ -120,3 +120,10 @@ struct VskOptions {
 VskOptions &vsk_options();
 // per-device cache of the CU count (one process may drive several GPUs)
 int vsk_device_cus();
+
+// ---- vs_gemm_ring.hip: bf16 x bf16 operands from HBM (wide models' bf16 mode) ----
+// epi: 0 bias, 1 bias + ReLU, 3 bias + q/k/v head-major scatter (q additionally times qscale when c16)
+bool vsk_gemm16_supported(int M, int N, int K);
+int vsk_gemm16(const void *A16, const void *W16, const float *bias, void *C, int M, int N, int K, int epi, int c16,
+               int T, int H, int dh, float qscale, hipStream_t st);
+int vsk_to_bf16(const float *src, void *dst, size_t n, hipStream_t st);

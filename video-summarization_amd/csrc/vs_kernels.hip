@@ -63,15 +63,21 @@ __device__ __forceinline__ unsigned long long stamp() { return vs_stamp(); }
 // C16 (PREC 1 only; fc1 and QKV): C is stored as bf16 - its only consumers (attention, fc2) round it to bf16 on entry
 // anyway, so the results are bit-identical and the tensor costs half the HBM bytes.  EPI_QKV then also pre-multiplies
 // q by ea.scale (the attention's scale * log2 e), which the bf16-input attention kernel no longer does.
-template <int EPI, int NWM = 2, int DIAG = 0, int NJ = 2, int PREC = 0, int C16 = 0>     // DIAG (tools/diag_gemm.py only) 2: epilogue skipped (wrong output) + per-wave cycles/wall clock; 1, 3: the same with the epilogue
+// KW (PREC 1 only): k-tile width.  A bf16 k-tile of 32 is 16 MFMAs of 32 cycles per wave - 1 024 cycles for the SIMD's two
+// waves, half the latency of the global loads that were issued at its start (measured: 3 255 cycles per k-tile).  KW = 64
+// (K % 64 == 0) doubles the distance between a load and its use and halves the barriers; the LDS rows (64 bf16 + 16 B pad)
+// then have the fp32 layout's 144-byte stride.
+template <int EPI, int NWM = 2, int DIAG = 0, int NJ = 2, int PREC = 0, int C16 = 0, int KW = 32>     // DIAG (tools/diag_gemm.py only) 2: epilogue skipped (wrong output) + per-wave cycles/wall clock; 1, 3: the same with the epilogue
 __global__ __launch_bounds__(128 * NWM, 2) void gemm_nt_128(
     const float *__restrict__ A, const float *__restrict__ W, const float *__restrict__ bias,
     float *__restrict__ C, int M, int N, int K, const float *__restrict__ pe, int T, int H, int dh,
     unsigned long long *__restrict__ diag = nullptr, EpiArgs ea = EpiArgs{0ull, 0u, 0.f, 0.f}) {
-    constexpr int BM = 64 * NWM, BN = 64 * NJ, BK = 32, LD = BK + 4;
+    static_assert(KW == 32 || (KW == 64 && PREC == 1), "64-wide k-tiles exist for the bf16 operands only");
+    constexpr int BM = 64 * NWM, BN = 64 * NJ, BK = KW, LD = 36;
     constexpr int NT = 128 * NWM;                       // threads
-    constexpr int LA = BM * 8 / NT, LW = BN * 8 / NT;   // float4 of A / of W per thread per k-tile (4, 4 | 4, 2)
-    constexpr int RS = NT / 8;                          // row stride of the staging map
+    constexpr int F4R = BK / 4;                         // float4 per k-tile row
+    constexpr int LA = BM * F4R / NT, LW = BN * F4R / NT;   // float4 of A / of W per thread per k-tile (4, 4 | 4, 2; KW 64: 8, 8)
+    constexpr int RS = NT / F4R;                        // row stride of the staging map
     __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LD];
 
     const int tiles_n = (N + BN - 1) / BN;
@@ -86,7 +92,7 @@ __global__ __launch_bounds__(128 * NWM, 2) void gemm_nt_128(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int wr = wave >> 1, wc = wave & 1;
-    const int lrow = tid >> 3, lc4 = (tid & 7) * 4;      // staging map: rows lrow + RS*i
+    const int lrow = tid / F4R, lc4 = (tid % F4R) * 4;   // staging map: rows lrow + RS*i
     const int nk = K / BK;
 
     // Per-output-tile state, set up ONCE per tile (integer division, 64-bit row pointers, this lane's
@@ -118,7 +124,7 @@ __global__ __launch_bounds__(128 * NWM, 2) void gemm_nt_128(
         }
     };
     f32x4 pa[LA], pw[LW];
-    constexpr int LDB = 20;                             // BF: LDS row stride in floats (80 B = 32 bf16 + pad)
+    constexpr int LDB = BK == 64 ? 36 : 20;             // BF: LDS row stride in floats (32 bf16 + pad = 80 B | 64 bf16 + pad = 144 B)
     auto stage = [&](int buf) __attribute__((always_inline)) {
         float *As = smem + buf * (BM + BN) * LD, *Ws = As + BM * LD;
         if constexpr (PREC == 2) {
@@ -200,7 +206,7 @@ __global__ __launch_bounds__(128 * NWM, 2) void gemm_nt_128(
             return;
         }
         if constexpr (PREC == 1) {
-            // 2 k-steps of 16: lane (r,h) supplies k = 16ks + 8h .. +7 (one b128 of the bf16 row)
+            // BK / 16 k-steps of 16: lane (r,h) supplies k = 16ks + 8h .. +7 (one b128 of the bf16 row)
             const float *ap = As + (64 * wr + r) * LDB + 4 * h;
             const float *wp = Ws + (32 * NJ * wc + r) * LDB + 4 * h;
 #pragma unroll
@@ -208,7 +214,7 @@ __global__ __launch_bounds__(128 * NWM, 2) void gemm_nt_128(
 #pragma unroll
             for (int i = 0; i < LW; ++i) pw[i] = *(const f32x4 *)(wptr[i] + koff);
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
+            for (int ks = 0; ks < BK / 16; ++ks) {
                 bf16x8 fa[2], fw[NJ];
 #pragma unroll
                 for (int i = 0; i < 2; ++i) fa[i] = __builtin_bit_cast(bf16x8, *(const u32x4 *)(ap + 32 * i * LDB + 8 * ks));
@@ -1585,7 +1591,8 @@ __global__ __launch_bounds__(256) void rows_res_ln(const float *__restrict__ a, 
                                                    const float *__restrict__ gamma, const float *__restrict__ beta,
                                                    float *__restrict__ out, int M, int d,
                                                    const float *__restrict__ score_w, const float *__restrict__ score_b,
-                                                   int num_classes, int sigmoid, float *__restrict__ scores) {
+                                                   int num_classes, int sigmoid, float *__restrict__ scores,
+                                                   unsigned short *__restrict__ out16) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     auto wsum = [](float v) __attribute__((always_inline)) { v += __shfl_xor(v, 32); return half_sum(v); };
     for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
@@ -1618,6 +1625,10 @@ __global__ __launch_bounds__(256) void rows_res_ln(const float *__restrict__ a, 
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[u][e] = (v[u][e] - mean) * rstd * g[e] + b[e];
                 *(f32x4 *)(out + (size_t)row * d + c) = v[u];
+                if (out16 != nullptr) {       // the bf16 copy the next bf16-operand GEMM reads (vs_gemm_ring.hip)
+                    u32x2 u2; u2[0] = pack_bf16(v[u][0], v[u][1]); u2[1] = pack_bf16(v[u][2], v[u][3]);
+                    *(u32x2 *)(out16 + (size_t)row * d + c) = u2;
+                }
             }
         }
         if (score_w != nullptr) {
@@ -1761,15 +1772,15 @@ int vsk_insert_cls(const float *e, const float *cls, const uint8_t *mask, float 
 
 int vsk_rows_res_ln(const float *a, const float *res, const float *gamma, const float *beta, float *out, int M, int d,
                     const float *score_w, const float *score_b, int num_classes, int sigmoid, float *scores,
-                    hipStream_t st) {
+                    hipStream_t st, void *out16) {
     if (d % 4 || d > 1024) return -1;
     const int rows4 = (M + 3) / 4;
     const dim3 grid(rows4 < 8192 ? (rows4 < 1 ? 1 : rows4) : 8192);
     switch ((d + 255) / 256) {          // float4 per lane (256 columns each)
-        case 1: hipLaunchKernelGGL(rows_res_ln<1>, grid, dim3(256), 0, st, a, res, gamma, beta, out, M, d, score_w, score_b, num_classes, sigmoid, scores); break;
-        case 2: hipLaunchKernelGGL(rows_res_ln<2>, grid, dim3(256), 0, st, a, res, gamma, beta, out, M, d, score_w, score_b, num_classes, sigmoid, scores); break;
-        case 3: hipLaunchKernelGGL(rows_res_ln<3>, grid, dim3(256), 0, st, a, res, gamma, beta, out, M, d, score_w, score_b, num_classes, sigmoid, scores); break;
-        default: hipLaunchKernelGGL(rows_res_ln<4>, grid, dim3(256), 0, st, a, res, gamma, beta, out, M, d, score_w, score_b, num_classes, sigmoid, scores); break;
+        case 1: hipLaunchKernelGGL(rows_res_ln<1>, grid, dim3(256), 0, st, a, res, gamma, beta, out, M, d, score_w, score_b, num_classes, sigmoid, scores, (unsigned short *)out16); break;
+        case 2: hipLaunchKernelGGL(rows_res_ln<2>, grid, dim3(256), 0, st, a, res, gamma, beta, out, M, d, score_w, score_b, num_classes, sigmoid, scores, (unsigned short *)out16); break;
+        case 3: hipLaunchKernelGGL(rows_res_ln<3>, grid, dim3(256), 0, st, a, res, gamma, beta, out, M, d, score_w, score_b, num_classes, sigmoid, scores, (unsigned short *)out16); break;
+        default: hipLaunchKernelGGL(rows_res_ln<4>, grid, dim3(256), 0, st, a, res, gamma, beta, out, M, d, score_w, score_b, num_classes, sigmoid, scores, (unsigned short *)out16); break;
     }
     VSK_CHECK_LAUNCH();
     return 0;
@@ -1827,11 +1838,13 @@ static int launch_gemm(const float *A, const float *W, const float *Wf, const fl
             if (N % 256 == 0 && M > 128) {
                 const int blocks = persistent_blocks(((M + 255) / 256) * (N / 256), 1);
                 if (blocks < 0) return (int)hipErrorInvalidDevice;
-                hipLaunchKernelGGL((gemm_nt_128<EPI, 4, 0, 4, 1, 1>), dim3(blocks), dim3(512), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr, ea);
+                if (K % 64 == 0) hipLaunchKernelGGL((gemm_nt_128<EPI, 4, 0, 4, 1, 1, 64>), dim3(blocks), dim3(512), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr, ea);
+                else hipLaunchKernelGGL((gemm_nt_128<EPI, 4, 0, 4, 1, 1>), dim3(blocks), dim3(512), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr, ea);
             } else {
                 const int blocks = persistent_blocks(((M + 127) / 128) * ((N + 127) / 128), 2);
                 if (blocks < 0) return (int)hipErrorInvalidDevice;
-                hipLaunchKernelGGL((gemm_nt_128<EPI, 2, 0, 2, 1, 1>), dim3(blocks), dim3(256), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr, ea);
+                if (K % 64 == 0) hipLaunchKernelGGL((gemm_nt_128<EPI, 2, 0, 2, 1, 1, 64>), dim3(blocks), dim3(256), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr, ea);
+                else hipLaunchKernelGGL((gemm_nt_128<EPI, 2, 0, 2, 1, 1>), dim3(blocks), dim3(256), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr, ea);
             }
             VSK_CHECK_LAUNCH();
             return 0;
@@ -1842,11 +1855,13 @@ static int launch_gemm(const float *A, const float *W, const float *Wf, const fl
         if (N % 256 == 0 && M > 128) {
             const int blocks = persistent_blocks(((M + 255) / 256) * (N / 256), 1);
             if (blocks < 0) return (int)hipErrorInvalidDevice;
-            hipLaunchKernelGGL((gemm_nt_128<EPI, 4, 0, 4, 1>), dim3(blocks), dim3(512), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr, ea);
+            if (K % 64 == 0) hipLaunchKernelGGL((gemm_nt_128<EPI, 4, 0, 4, 1, 0, 64>), dim3(blocks), dim3(512), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr, ea);
+            else hipLaunchKernelGGL((gemm_nt_128<EPI, 4, 0, 4, 1>), dim3(blocks), dim3(512), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr, ea);
         } else {
             const int blocks = persistent_blocks(((M + 127) / 128) * ((N + 127) / 128), 2);
             if (blocks < 0) return (int)hipErrorInvalidDevice;
-            hipLaunchKernelGGL((gemm_nt_128<EPI, 2, 0, 2, 1>), dim3(blocks), dim3(256), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr, ea);
+            if (K % 64 == 0) hipLaunchKernelGGL((gemm_nt_128<EPI, 2, 0, 2, 1, 0, 64>), dim3(blocks), dim3(256), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr, ea);
+            else hipLaunchKernelGGL((gemm_nt_128<EPI, 2, 0, 2, 1>), dim3(blocks), dim3(256), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr, ea);
         }
         VSK_CHECK_LAUNCH();
         return 0;
@@ -1948,9 +1963,9 @@ int vsk_diag_gemm(const float *A, const float *W, const float *bias, float *C, i
     if (dprec && atoi(dprec) == 1) {      // the bf16 instantiation (256x256 tiles): mode 2 = without, else with the epilogue
         blocks = grid > 0 ? grid : persistent_blocks(((M + 255) / 256) * (N / 256), 1);
         if (m == 2)
-            hipLaunchKernelGGL((gemm_nt_128<EPI_RELU, 4, 2, 4, 1>), dim3(blocks), dim3(512), 0, st, A, W, bias, C, M, N, K, nullptr, 1, 0, 0, diag);
+            hipLaunchKernelGGL((gemm_nt_128<EPI_RELU, 4, 2, 4, 1, 0, 64>), dim3(blocks), dim3(512), 0, st, A, W, bias, C, M, N, K, nullptr, 1, 0, 0, diag);
         else
-            hipLaunchKernelGGL((gemm_nt_128<EPI_RELU, 4, 3, 4, 1>), dim3(blocks), dim3(512), 0, st, A, W, bias, C, M, N, K, nullptr, 1, 0, 0, diag);
+            hipLaunchKernelGGL((gemm_nt_128<EPI_RELU, 4, 3, 4, 1, 0, 64>), dim3(blocks), dim3(512), 0, st, A, W, bias, C, M, N, K, nullptr, 1, 0, 0, diag);
         VSK_CHECK_LAUNCH();
         return 0;
     }

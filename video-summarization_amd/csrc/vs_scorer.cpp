@@ -234,6 +234,13 @@ int vsw_ensure(const vs_weights *w, unsigned families, void *stream) {
                 pk &= vsk_pack_mlp_bf16(blob + L.wo, blob + L.w1, blob + L.w2, blob + L.b_mlp, (int)d, st) == 0;
                 pk &= vsk_pack_qkv_bf16(blob + L.wqkv, blob + L.b_qkv, (int)d, st) == 0;
             }
+        if (d > 256)
+            for (const auto &L : w->layers) {
+                pk &= vsk_to_bf16(blob + L.wqkv, blob + L.r_wqkv, 3 * d * d, st) == 0;
+                pk &= vsk_to_bf16(blob + L.wo, blob + L.r_wo, d * d, st) == 0;
+                pk &= vsk_to_bf16(blob + L.w1, blob + L.r_w1, 4 * d * d, st) == 0;
+                pk &= vsk_to_bf16(blob + L.w2, blob + L.r_w2, 4 * d * d, st) == 0;
+            }
         if (pk) w->b_version = w->version;
     }
     if (!pk) return fail(VS_ERR_HIP, "weight image packing failed: %s", hipGetErrorString(hipGetLastError()));
@@ -279,6 +286,10 @@ int vs_weights_pack(const vs_model_desc *desc, const vs_model_params *params, vo
         for (auto &L : w->layers) {
             L.b_mlp = take(vsk_mlp_bf16_image_bytes((int)d) / sizeof(float));
             L.b_qkv = take(vsk_qkv_bf16_image_bytes((int)d) / sizeof(float));
+        }
+    if (d > 256)
+        for (auto &L : w->layers) {
+            L.r_wqkv = take(3 * d * d / 2); L.r_wo = take(d * d / 2); L.r_w1 = take(4 * d * d / 2); L.r_w2 = take(4 * d * d / 2);
         }
     w->has_b_embed = vsk_embed_bf16_image_bytes((int)d, (int)din) != 0;
     if (w->has_b_embed) w->b_embed = take(vsk_embed_bf16_image_bytes((int)d, (int)din) / sizeof(float));
@@ -394,7 +405,13 @@ int forward_core(const vs_weights *w, const float *x, const uint8_t *key_pad_mas
     const bool qkv16 = lbf == 1 && aprec == 1 && d <= 256 && !vsk_options().lp_store32 && !vsk_options().attn_lp_simple;
     const bool ffn16 = lbf == 1 && d <= 256 && !vsk_options().lp_store32;
     const bool mlp16 = lbf == 1 && vsk_mlp_bf16_supported(d) && !vsk_options().lp_mlp_unfused && !vsk_options().lp_store32;
-    const size_t kv_stride = qkv16 ? (size_t)M * d / 2 : (size_t)M * d;      // floats between the q, k and v planes
+    // d_model > 256 in bf16 mode with a bf16 attention: the bf16-OPERAND GEMM (vs_gemm_ring.hip).  Every Linear after the
+    // embedding reads bf16 from HBM: q/k/v, the attention output and the MLP hidden tensor are written as bf16 by their
+    // producers, and the two LayerNorm passes write a bf16 copy of their rows beside the fp32 residual stream.
+    const bool ring = lbf == 1 && aprec == 1 && !pk && d > 256 && !opt.lp_store32 && vsk_gemm16_supported(M, d, d);
+    const size_t kv_stride = (qkv16 || ring) ? (size_t)M * d / 2 : (size_t)M * d;      // floats between the q, k and v planes
+    void *h16 = ffn + 2 * md;               // [M, d] bf16 copy of the current LayerNorm output (the upper half of ffn: the
+                                            // bf16 hidden tensor needs the lower half only)
 
     // bf16 mode with bf16 q/k/v: every layer's tail kernel also projects its output rows to the NEXT layer's q/k/v, and
     // the embedding kernel to the first layer's
@@ -421,9 +438,40 @@ int forward_core(const vs_weights *w, const float *x, const uint8_t *key_pad_mas
         VS_LAUNCH(vsk_linear(x, w->p(w->embed_w), w->p(lbf == 2 ? w->h_embed_w : w->f_embed_w), w->p(w->embed_b), h0, M, d, D.in_features, 0,
                              pe_rows, T, lbf, st));
     }
+    if (ring && L > 0) VS_LAUNCH(vsk_to_bf16(h0, h16, (size_t)M * d, st));
     for (int l = 0; l < L; ++l) {
         const LayerOff &P = w->layers[l];
         const bool last = l == L - 1;
+        if (ring) {
+            const float qs = vsk_attention_qscale(scale);
+            {
+                StageScope ps(VS_STAGE_QKV, st);
+                VS_LAUNCH(vsk_gemm16(h16, w->p(P.r_wqkv), w->p(P.bqkv), qkv, M, 3 * d, d, 3, 1, T, H, d / H, qs, st));
+            }
+            {
+                StageScope ps(VS_STAGE_ATTENTION, st);
+                VS_LAUNCH(vsk_attention_bf16(qkv, qkv + kv_stride, qkv + 2 * kv_stride, key_pad_mask, att, B, H, T, d / H, scale,
+                                             1 | VSK_STORE16, st));
+            }
+            float *dst = (last && hidden) ? hidden : h0;
+            {   // out-projection (bf16 attention output in, fp32 out into the q region, free by now) + norm1 -> h1 (+ bf16 copy)
+                StageScope ps(VS_STAGE_OUTPROJ_LN, st);
+                VS_LAUNCH(vsk_gemm16(att, w->p(P.r_wo), w->p(P.bo), qkv, M, d, d, 0, 0, 1, 0, 0, 1.0f, st));
+                VS_LAUNCH(vsk_rows_res_ln(qkv, h0, w->p(P.ln1g), w->p(P.ln1b), h1, M, d, nullptr, nullptr, 0, 0, nullptr, st, h16));
+            }
+            {
+                StageScope ps(VS_STAGE_FC1, st);
+                VS_LAUNCH(vsk_gemm16(h16, w->p(P.r_w1), w->p(P.b1), ffn, M, 4 * d, d, 1, 1, 1, 0, 0, 1.0f, st));
+            }
+            {   // fc2 (fp32 out into the att region) + norm2 (+ score head) -> h0 / hidden (+ bf16 copy for the next layer)
+                StageScope ps(VS_STAGE_FC2_LN, st);
+                VS_LAUNCH(vsk_gemm16(ffn, w->p(P.r_w2), w->p(P.b2), att, M, d, 4 * d, 0, 0, 1, 0, 0, 1.0f, st));
+                VS_LAUNCH(vsk_rows_res_ln(att, h1, w->p(P.ln2g), w->p(P.ln2b), dst, M, d, last ? w->p(w->final_w) : nullptr,
+                                          last ? w->p(w->final_b) : nullptr, D.num_classes, sig, last ? scores : nullptr, st,
+                                          last ? nullptr : h16));
+            }
+            continue;
+        }
         VskNextQkv nq{}, *next = nullptr;
         if (qkv_fused && !last) {
             const LayerOff &N = w->layers[l + 1];
@@ -687,6 +735,31 @@ static int linear_entry(const float *A, const float *W, const float *bias, float
         return fail(VS_ERR_INVALID, "M=%d N=%d K=%d unsupported (N, K multiples of 32)", M, N, K);
     if (pe && (T <= 0 || relu)) return fail(VS_ERR_INVALID, "pe needs T > 0 and relu == 0");
     VS_LAUNCH(vsk_linear(A, W, nullptr, bias, C, M, N, K, relu, pe, T > 0 ? T : 1, bf16, (hipStream_t)stream));
+    return VS_OK;
+}
+
+int vs_linear_bf16_operands(const void *A16, const void *W16, const float *bias, void *C, int32_t M, int32_t N, int32_t K,
+                            int32_t relu, int32_t c16, void *stream) {
+    if (!A16 || !W16 || !bias || !C) return fail(VS_ERR_INVALID, "NULL pointer");
+    if (!vsk_gemm16_supported(M, N, K)) return fail(VS_ERR_INVALID, "M=%d N=%d K=%d unsupported (N, K multiples of 32)", M, N, K);
+    if (((uintptr_t)A16 | (uintptr_t)W16 | (uintptr_t)C | (uintptr_t)bias) & 15) return fail(VS_ERR_INVALID, "operands must be 16-byte aligned");
+    VS_LAUNCH(vsk_gemm16(A16, W16, bias, C, M, N, K, relu ? 1 : 0, c16 ? 1 : 0, 1, 0, 0, 1.0f, (hipStream_t)stream));
+    return VS_OK;
+}
+
+int vs_qkv_proj_bf16_operands(const void *h16, const void *Wqkv16, const float *bqkv, void *qkv, int32_t B, int32_t T,
+                              int32_t d, int32_t H, int32_t c16, void *stream) {
+    if (!h16 || !Wqkv16 || !bqkv || !qkv) return fail(VS_ERR_INVALID, "NULL pointer");
+    if (B <= 0 || T <= 0 || d <= 0 || d % 32 || H <= 0 || d % H || (d / H) % 32)
+        return fail(VS_ERR_INVALID, "B=%d T=%d d=%d H=%d unsupported", B, T, d, H);
+    VS_LAUNCH(vsk_gemm16(h16, Wqkv16, bqkv, qkv, B * T, 3 * d, d, 3, c16 ? 1 : 0, T, H, d / H,
+                         vsk_attention_qscale(1.0f / sqrtf((float)d)), (hipStream_t)stream));
+    return VS_OK;
+}
+
+int vs_to_bf16(const float *src, void *dst16, size_t n, void *stream) {
+    if (!src || !dst16 || n % 8 || (((uintptr_t)src | (uintptr_t)dst16) & 15)) return fail(VS_ERR_INVALID, "vs_to_bf16: n %% 8 == 0, 16-byte aligned pointers");
+    VS_LAUNCH(vsk_to_bf16(src, dst16, n, (hipStream_t)stream));
     return VS_OK;
 }
 

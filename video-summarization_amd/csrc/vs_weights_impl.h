@@ -13,6 +13,7 @@ struct LayerOff {
     size_t h_wqkv, h_wo, h_w1, h_w2;        // their fp16x3 counterparts (hi|lo f16 halves, same size)
     size_t b_mlp;                           // Wo, W1, W2 as the LDS images of the fused bf16 layer-tail kernel (vsk_pack_mlp_bf16)
     size_t b_qkv;                           // Wqkv as the LDS images of that kernel's QKV epilogue (vsk_pack_qkv_bf16)
+    size_t r_wqkv, r_wo, r_w1, r_w2;        // d_model > 256: plain row-major bf16 copies for the bf16-operand GEMM (vs_gemm_ring.hip)
 };
 
 // transposed weights for the dgrad GEMMs of the training backward (dX = dY W is an NT GEMM against W^T); built
