@@ -11,18 +11,22 @@
 // COPY of each LayerNorm output beside the fp32 residual stream), which doubles the flops per byte, and nothing is left
 // to convert, so the tiles go from L2 into LDS by LDS-DMA (global_load_lds_dwordx4) with no register staging at all.
 //
-// Shape.  128 x 256 output tile per 4-wave block (2 x 2 waves of 64 x 128: 2 x 4 MFMA tiles of 32x32, 128 accumulator
-// registers), TWO blocks per CU: they drift out of phase, so one block's epilogue (store-bound) runs beside the other's
-// k-loop.  k-tiles of 32 (one 64-byte row per operand row) in a ring of 3 LDS stages of 24 KB; per k-tile a wave issues
-// 6 DMA instructions (1 KB each: 16 rows), waits for the pieces it issued two k-tiles ago (`s_waitcnt vmcnt(6)`), meets
-// the block at ONE barrier, and runs 16 MFMAs from 12 conflict-free ds_read_b128.
-// LDS image: row R of a stage is 64 B = 4 chunks of 16 B (8 k); chunk c is stored at position c ^ ((R >> 2) & 3) - the DMA
-// writes lane-linear, so the swizzle is applied to the SOURCE address; a fragment read (lane = row, one chunk) is then
-// conflict-free in each 16-lane group of ds_read_b128 (MI355X_MICROARCH.md, LDS table).
+// Shape (K % 64 == 0).  256 x 256 output tile per 8-wave block (4 x 2 waves of 64 x 128: 2 x 4 MFMA tiles of 32x32, 128
+// accumulator registers), one block per CU, k-tiles of 64 (one 128-byte row = one cache line per operand row) in a ring
+// of 2 LDS stages of 64 KB; per k-tile a wave issues 8 DMA instructions (1 KB each: 8 rows), waits for the pieces it
+// issued one k-tile ago, meets the block at ONE barrier, and runs 32 MFMAs from 24 conflict-free ds_read_b128.
+// Otherwise (K % 32 == 0): 128 x 256 tiles on 4-wave blocks, two per CU, k-tiles of 32 (64-byte rows), 3 stages of 24 KB.
+// Measured at 65 536 rows (tools/bench_gemm16.py, profiles/r03c_gemm16.txt): 680-1 060 TF against 390-670 TF for
+// gemm_nt_128's bf16 form; k-loop alone ~1 100-1 200 TF on every shape (0.45 of the dense peak); the epilogue - stores at
+// ~23 GB/s per CU whatever their width - is 15-35 % of a tile at K = 512 and is not overlapped (one block per CU).
+// Configurations measured slower: 128 x 256 x 32 in 3 stages, two blocks per CU (570-910 TF: 64-byte rows, 85 flop/B);
+// 256 x 256 x 32 in 4 stages (590-945); 256 x 128 x 64 in 3 stages (510-860); 128 x 256 x 64 in 2 stages, two blocks
+// per CU (455-870).
+// LDS image: chunk c (16 B = 8 k) of row R is stored at position c ^ swz(R), swz = (R >> 1) & 7 for 128-byte rows,
+// (R >> 2) & 3 for 64-byte rows - the DMA writes lane-linear, so the swizzle is applied to the SOURCE address; a fragment
+// read (lane = row, one chunk) is then conflict-free in each 16-lane group of ds_read_b128 (MI355X_MICROARCH.md, LDS table).
 // Output tiles are numbered so that the blocks of one XCD (blockIdx % 8) own a contiguous chunk of the tile list, N
 // fastest: the N-tiles of one A row-panel run together and read it through one L2.
-#include <cstdlib>
-
 #include "vs_kernels.h"
 #include "vs_device.h"
 
@@ -31,22 +35,28 @@ namespace {
 typedef unsigned short h16;
 enum { RG_BIAS = 0, RG_RELU = 1, RG_QKV = 3 };
 
-constexpr int RBN = 256;
-constexpr int RTLD = 36;                            // epilogue transposition scratch: floats per row
+constexpr int RTLD = 36;                           // epilogue transposition scratch: floats per row
 
 template <int N_> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory"); }
 
 // NWM: waves along M (block = NWM x 2 waves, tile = 64 NWM x 256);  BK: k-tile (32: 64-byte rows, 64: 128-byte rows);
 // NST: ring stages
-template <int EPI, int C16, int NWM, int BK, int NST>
+// PERSISTENT: the grid is one block per CU (two for the 4-wave forms) and every block walks its list of output tiles
+// (gemm_nt_128's: the blocks of one XCD own one contiguous chunk of the tile list, N fastest) with ONE continuous ring:
+// the first k-tile(s) of the next output tile are requested before the epilogue of the current one, into the stage(s)
+// the epilogue's transposition scratch does not use.
+// (Tried and measured without effect, so not kept: waiting at the next tile's first k-tile with `s_waitcnt vmcnt(#stores)`
+// so that the stores drain under the new MFMAs; starting every other block half a tile late; spreading a k-tile's DMA
+// requests over its k-steps; rotating the k-loop's start by column tile; a 3-stage ring of 256 x 128 tiles.)
+template <int EPI, int C16, int NWM, int BK, int NST, int NJ = 4>
 __global__ __launch_bounds__(128 * NWM, 2) void gemm16_ring(
     const h16 *__restrict__ A, const h16 *__restrict__ W, const float *__restrict__ bias, float *__restrict__ C,
     int M, int N, int K, int T, int H, int dh, float qscale) {
-    constexpr int BM = 64 * NWM, NW = 2 * NWM;
+    constexpr int BM = 64 * NWM, NW = 2 * NWM, RBN = 64 * NJ;
     constexpr int ROWB = 2 * BK, CPR = ROWB / 16, RPP = 1024 / ROWB;       // row bytes, 16-byte chunks per row, rows per 1-KB piece
     constexpr int APW = BM / RPP / NW, WPW = RBN / RPP / NW, PPS = APW + WPW;   // DMA pieces per wave and stage
     constexpr int STAGE_BYTES = (BM + RBN) * ROWB;
-    static_assert(NST * STAGE_BYTES >= NW * 32 * RTLD * 4, "the ring doubles as the epilogue's transposition scratch");
+    static_assert(STAGE_BYTES >= NW * 32 * RTLD * 4, "one stage doubles as the epilogue's transposition scratch");
     static_assert((NST - 1) * PPS <= 63, "vmcnt immediate");
     __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * STAGE_BYTES];
     // chunk c of row R lives at chunk position c ^ swz(R): conflict-free ds_read_b128 with lane = row
@@ -55,10 +65,12 @@ __global__ __launch_bounds__(128 * NWM, 2) void gemm16_ring(
 
     const int tiles_n = (N + RBN - 1) / RBN;
     const int ntiles = ((M + BM - 1) / BM) * tiles_n;
-    const int xl = blockIdx.x & 7, j = blockIdx.x >> 3;
+    // this block's tile list: start + j, start + j + G, ...   (chunk [start, start + len) per XCD label)
+    const int xl = blockIdx.x & 7, j = blockIdx.x >> 3, G = gridDim.x >> 3;
     const int cq = ntiles >> 3, cr = ntiles & 7;
-    const int tile = xl * cq + (xl < cr ? xl : cr) + j;          // grid = ntiles: every (xl, j) is a tile of chunk xl
-    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * RBN;
+    const int start = xl * cq + (xl < cr ? xl : cr), len = cq + (xl < cr ? 1 : 0);
+    const int my_tiles = len > j ? (len - j + G - 1) / G : 0;
+    if (my_tiles == 0) return;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
@@ -68,20 +80,27 @@ __global__ __launch_bounds__(128 * NWM, 2) void gemm16_ring(
     // ---- this lane's DMA sources: pieces wave + NW p of A (APW) and of W (WPW); a piece = RPP rows
     const int prow = lane / CPR, pcp = lane % CPR;
     const h16 *asrc[APW], *wsrc[WPW];
+    int nx_m0 = 0, nx_n0 = 0;
+    auto set_tile = [&](int it) __attribute__((always_inline)) {
+        const int tile = start + j + it * G;
+        nx_m0 = (tile / tiles_n) * BM;
+        nx_n0 = (tile % tiles_n) * RBN;
 #pragma unroll
-    for (int p = 0; p < APW; ++p) {
-        const int R = RPP * (wave + NW * p) + prow;
-        int gr = m0 + R; gr = gr < M ? gr : M - 1;
-        asrc[p] = A + (size_t)gr * K + 8 * (pcp ^ swz(R));
-    }
+        for (int p = 0; p < APW; ++p) {
+            const int R = RPP * (wave + NW * p) + prow;
+            int gr = nx_m0 + R; gr = gr < M ? gr : M - 1;
+            asrc[p] = A + (size_t)gr * K + 8 * (pcp ^ swz(R));
+        }
 #pragma unroll
-    for (int p = 0; p < WPW; ++p) {
-        const int R = RPP * (wave + NW * p) + prow;
-        int gr = n0 + R; gr = gr < N ? gr : N - 1;
-        wsrc[p] = W + (size_t)gr * K + 8 * (pcp ^ swz(R));
-    }
-    auto issue = [&](int kt) __attribute__((always_inline)) {
-        unsigned char *sb = smem + (kt % NST) * STAGE_BYTES;
+        for (int p = 0; p < WPW; ++p) {
+            const int R = RPP * (wave + NW * p) + prow;
+            int gr = nx_n0 + R; gr = gr < N ? gr : N - 1;
+            wsrc[p] = W + (size_t)gr * K + 8 * (pcp ^ swz(R));
+        }
+    };
+    // k-tile kt of the tile set_tile() named last -> ring stage `slot`
+    auto issue = [&](int kt, int slot) __attribute__((always_inline)) {
+        unsigned char *sb = smem + slot * STAGE_BYTES;
         const int koff = kt * BK;
 #pragma unroll
         for (int p = 0; p < APW; ++p)
@@ -93,90 +112,155 @@ __global__ __launch_bounds__(128 * NWM, 2) void gemm16_ring(
                                              (__attribute__((address_space(3))) void *)(sb + BM * ROWB + 1024 * (wave + NW * p)), 16, 0, 0);
     };
 
-    // acc[i][jj][t] = C[m = 64 wr + 32 i + r][n = 128 wc + 32 jj + 8 (t >> 2) + 4 h + (t & 3)]   (lane = output ROW: the W
-    // fragment is the MFMA's A operand, the activation fragment its B operand - as in gemm_nt_128)
-    f32x16 acc[2][4];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-            for (int t = 0; t < 16; ++t) acc[i][jj][t] = 0.f;
-
+    int g = 0;                              // k-tiles consumed so far: k-tile kt of the current tile lives in stage (g + kt) % NST
+    set_tile(0);
 #pragma unroll
     for (int u = 0; u < NST - 1; ++u)
-        if (u < nk) issue(u);
-    for (int kt = 0; kt < nk; ++kt) {
-        // the pieces this wave requested for k-tile kt have landed (those of the k-tiles after it may still fly) ...
-        const int ahead = nk - 1 - kt;            // k-tiles requested after kt, capped at NST - 2
-        if (NST >= 4 && ahead >= 2) wait_vm<2 * PPS>();
-        else if (NST >= 3 && ahead >= 1) wait_vm<PPS>();
-        else wait_vm<0>();
-        __syncthreads();          // ... and so have everybody's; every wave has finished k-tile kt - 1: its stage is free
-        if (kt + NST - 1 < nk) issue(kt + NST - 1);
-        const unsigned char *sa = smem + (kt % NST) * STAGE_BYTES, *sw = sa + BM * ROWB;
+        if (u < nk) issue(u, u % NST);
+    for (int it = 0; it < my_tiles; ++it) {
+        const int m0 = nx_m0, n0 = nx_n0;
+        // acc[i][jj][t] = C[m = 64 wr + 32 i + r][n = 32 NJ wc + 32 jj + 8 (t >> 2) + 4 h + (t & 3)]   (lane = output ROW: the
+        // W fragment is the MFMA's A operand, the activation fragment its B operand - as in gemm_nt_128)
+        f32x16 acc[2][NJ];
 #pragma unroll
-        for (int ks = 0; ks < BK / 16; ++ks) {
-            bf16x8 fa[2], fw[4];
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int i = 0; i < 2; ++i) fa[i] = __builtin_bit_cast(bf16x8, *(const u32x4 *)(sa + ring_off(64 * wr + 32 * i + r, 2 * ks + h)));
+            for (int jj = 0; jj < NJ; ++jj)
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) fw[jj] = __builtin_bit_cast(bf16x8, *(const u32x4 *)(sw + ring_off(128 * wc + 32 * jj + r, 2 * ks + h)));
+                for (int t = 0; t < 16; ++t) acc[i][jj][t] = 0.f;
+
+        for (int kt = 0; kt < nk; ++kt) {
+            // the pieces this wave requested for k-tile kt have landed (those of the k-tiles after it may still fly) ...
+            const int ahead = nk - 1 - kt;            // k-tiles requested after kt, capped at NST - 2
+            if (NST >= 4 && ahead >= 2 && (kt >= NST - 1 || it == 0)) wait_vm<2 * PPS>();
+            else if (NST >= 3 && ahead >= 1 && (kt >= NST - 1 || it == 0)) wait_vm<PPS>();
+            else wait_vm<0>();
+            __syncthreads();      // ... and so have everybody's; every wave has finished the k-tile before: its stage is free
+            if (kt + NST - 1 < nk) issue(kt + NST - 1, (g + kt + NST - 1) % NST);
+            const unsigned char *sa = smem + ((g + kt) % NST) * STAGE_BYTES, *sw = sa + BM * ROWB;
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                acc[0][jj] = MFMA_BF16(fw[jj], fa[0], acc[0][jj]);
-                acc[1][jj] = MFMA_BF16(fw[jj], fa[1], acc[1][jj]);
+            for (int ks = 0; ks < BK / 16; ++ks) {
+                bf16x8 fa[2], fw[NJ];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) fa[i] = __builtin_bit_cast(bf16x8, *(const u32x4 *)(sa + ring_off(64 * wr + 32 * i + r, 2 * ks + h)));
+#pragma unroll
+                for (int jj = 0; jj < NJ; ++jj) fw[jj] = __builtin_bit_cast(bf16x8, *(const u32x4 *)(sw + ring_off(32 * NJ * wc + 32 * jj + r, 2 * ks + h)));
+#pragma unroll
+                for (int jj = 0; jj < NJ; ++jj) {
+                    acc[0][jj] = MFMA_BF16(fw[jj], fa[0], acc[0][jj]);
+                    acc[1][jj] = MFMA_BF16(fw[jj], fa[1], acc[1][jj]);
+                }
             }
         }
-    }
-    __syncthreads();              // every wave has read its last fragments: the ring becomes the transposition scratch
+        g += nk;
+        __syncthreads();          // every wave has read its last fragments: that stage becomes the transposition scratch,
+                                  // the others take the next tile's first k-tiles
+        if (it + 1 < my_tiles) {
+            set_tile(it + 1);
+#pragma unroll
+            for (int u = 0; u < NST - 1; ++u)
+                if (u < nk) issue(u, (g + u) % NST);
+        }
 
-    // ---- epilogue (gemm_nt_128's): a lane owns output ROWS; each 32x32 sub-tile is transposed through a wave-private
-    // corner of LDS so that every store instruction writes whole 128-byte lines
-    float *tp = reinterpret_cast<float *>(smem) + wave * (32 * RTLD);
-    const int trow = lane >> 3, tc4 = (lane & 7) * 4;
-    int b0 = 0, t0 = 0;
-    if (EPI == RG_QKV) { b0 = m0 / T; t0 = m0 - b0 * T; }
+        // ---- epilogue (gemm_nt_128's): a lane owns output ROWS; each 32x32 sub-tile is transposed through a wave-private
+        // corner of LDS so that every store instruction writes whole 128-byte lines
+        float *tp = reinterpret_cast<float *>(smem + ((g + NST - 1) % NST) * STAGE_BYTES) + wave * (32 * RTLD);
+        const int trow = lane >> 3, tc4 = (lane & 7) * 4;
+        int b0 = 0, t0 = 0;
+        if (EPI == RG_QKV) { b0 = m0 / T; t0 = m0 - b0 * T; }
+        // bf16 output: TWO sub-tiles (64 columns) per round, transposed as packed bf16 (bias / ReLU / q scale applied in the
+        // owner's registers first): half the LDS traffic of the fp32 transposition and 16-byte stores.  (The store phase
+        // itself is bound by bytes, not instructions - ~23 GB/s per CU with 8-byte and with 16-byte stores alike.)
+        if (C16 != 0 && NJ % 2 == 0 && (EPI != RG_QKV || dh % 64 == 0)) {
+            unsigned char *tb = reinterpret_cast<unsigned char *>(tp);          // 32 rows x (128 B + 16 B pad)
+            const int tc8 = (lane & 7) * 8;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < 2; ++i) {
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
+                for (int jp = 0; jp < NJ / 2; ++jp) {
+                    const int c64 = n0 + 32 * NJ * wc + 64 * jp;
+                    int which = 0, head = 0, e0 = 0;
+                    if (EPI == RG_QKV) { const int d = H * dh; which = c64 / d; const int c = c64 - which * d; head = c / dh; e0 = c - head * dh; }
+                    const float mul = (EPI == RG_QKV && which == 0) ? qscale : 1.0f;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                f32x4 v;
+                    for (int u = 0; u < 2; ++u) {
+                        const int jj = 2 * jp + u;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[i][jj][4 * q + e];
-                *(f32x4 *)&tp[r * RTLD + 8 * q + 4 * h] = v;
-            }
-            const int c32 = n0 + 128 * wc + 32 * jj;              // a 32-column block never straddles a head
-            int which = 0, head = 0, e0 = 0;
-            if (EPI == RG_QKV) { const int d = H * dh; which = c32 / d; const int c = c32 - which * d; head = c / dh; e0 = c - head * dh; }
-            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-            if (c32 < N) bv = *(const f32x4 *)(bias + c32 + tc4);
+                        for (int q = 0; q < 4; ++q) {
+                            const int cb = c64 + 32 * u + 8 * q + 4 * h;
+                            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+                            if (cb < N) bv = *(const f32x4 *)(bias + cb);
+                            f32x4 v;
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const int ro = 64 * wr + 32 * i + trow + 8 * p;
-                f32x4 v = *(const f32x4 *)&tp[(trow + 8 * p) * RTLD + tc4] + bv;
-                if (EPI == RG_RELU) {
+                            for (int e = 0; e < 4; ++e) {
+                                v[e] = acc[i][jj][4 * q + e] + bv[e];
+                                if (EPI == RG_RELU) v[e] = relu1(v[e]);
+                                if (EPI == RG_QKV) v[e] *= mul;
+                            }
+                            u32x2 pk; pk[0] = pack_bf16(v[0], v[1]); pk[1] = pack_bf16(v[2], v[3]);
+                            *(u32x2 *)(tb + r * 144 + 64 * u + 16 * q + 8 * h) = pk;
+                        }
+                    }
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = relu1(v[e]);
+                    for (int p = 0; p < 4; ++p) {
+                        const int ro = 64 * wr + 32 * i + trow + 8 * p;
+                        const u32x4 pk = *(const u32x4 *)(tb + (trow + 8 * p) * 144 + 2 * tc8);
+                        const int row = m0 + ro;
+                        int bb = b0, tt = t0 + ro;
+                        if (EPI == RG_QKV) { while (tt >= T) { tt -= T; ++bb; } }
+                        if (row < M && c64 + tc8 < N) {
+                            h16 *C2 = (h16 *)C;
+                            if (EPI == RG_QKV)
+                                *(u32x4 *)(C2 + (size_t)which * M * (H * dh) + (((size_t)bb * H + head) * T + tt) * dh + e0 + tc8) = pk;
+                            else
+                                *(u32x4 *)(C2 + (size_t)row * N + c64 + tc8) = pk;
+                        }
+                    }
                 }
-                const int row = m0 + ro;
-                int bb = b0, tt = t0 + ro;
-                if (EPI == RG_QKV) { while (tt >= T) { tt -= T; ++bb; } }
-                if (row < M && c32 < N) {
-                    if constexpr (C16 != 0) {
-                        if (EPI == RG_QKV && which == 0) v *= qscale;
-                        u32x2 u; u[0] = pack_bf16(v[0], v[1]); u[1] = pack_bf16(v[2], v[3]);
-                        h16 *C2 = (h16 *)C;
-                        if (EPI == RG_QKV)
-                            *(u32x2 *)(C2 + (size_t)which * M * (H * dh) + (((size_t)bb * H + head) * T + tt) * dh + e0 + tc4) = u;
+            }
+            continue;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int jj = 0; jj < NJ; ++jj) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[i][jj][4 * q + e];
+                    *(f32x4 *)&tp[r * RTLD + 8 * q + 4 * h] = v;
+                }
+                const int c32 = n0 + 32 * NJ * wc + 32 * jj;              // a 32-column block never straddles a head
+                int which = 0, head = 0, e0 = 0;
+                if (EPI == RG_QKV) { const int d = H * dh; which = c32 / d; const int c = c32 - which * d; head = c / dh; e0 = c - head * dh; }
+                f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+                if (c32 < N) bv = *(const f32x4 *)(bias + c32 + tc4);
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const int ro = 64 * wr + 32 * i + trow + 8 * p;
+                    f32x4 v = *(const f32x4 *)&tp[(trow + 8 * p) * RTLD + tc4] + bv;
+                    if (EPI == RG_RELU) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = relu1(v[e]);
+                    }
+                    const int row = m0 + ro;
+                    int bb = b0, tt = t0 + ro;
+                    if (EPI == RG_QKV) { while (tt >= T) { tt -= T; ++bb; } }
+                    if (row < M && c32 < N) {
+                        if constexpr (C16 != 0) {
+                            if (EPI == RG_QKV && which == 0) v *= qscale;
+                            u32x2 u; u[0] = pack_bf16(v[0], v[1]); u[1] = pack_bf16(v[2], v[3]);
+                            h16 *C2 = (h16 *)C;
+                            if (EPI == RG_QKV)
+                                *(u32x2 *)(C2 + (size_t)which * M * (H * dh) + (((size_t)bb * H + head) * T + tt) * dh + e0 + tc4) = u;
+                            else
+                                *(u32x2 *)(C2 + (size_t)row * N + c32 + tc4) = u;
+                        } else if (EPI == RG_QKV)
+                            *(f32x4 *)(C + (size_t)which * M * (H * dh) + (((size_t)bb * H + head) * T + tt) * dh + e0 + tc4) = v;
                         else
-                            *(u32x2 *)(C2 + (size_t)row * N + c32 + tc4) = u;
-                    } else if (EPI == RG_QKV)
-                        *(f32x4 *)(C + (size_t)which * M * (H * dh) + (((size_t)bb * H + head) * T + tt) * dh + e0 + tc4) = v;
-                    else
-                        *(f32x4 *)(C + (size_t)row * N + c32 + tc4) = v;
+                            *(f32x4 *)(C + (size_t)row * N + c32 + tc4) = v;
+                    }
                 }
             }
         }
@@ -202,20 +286,24 @@ int vsk_gemm16(const void *A16, const void *W16, const float *bias, void *C, int
                int T, int H, int dh, float qscale, hipStream_t st) {
     if (!vsk_gemm16_supported(M, N, K)) return -1;
     if (epi == RG_QKV && (T <= 0 || H <= 0 || dh <= 0 || dh % 32 || N != 3 * H * dh || M % T)) return -1;
-    static const int cfg_env = []() { const char *e = getenv("VS_RING_CFG"); return e ? atoi(e) : -1; }();     // experiment switch (tools/bench_gemm16.py)
     // 256 x 256 tiles with 128-byte rows (whole cache lines per row and DMA) measured fastest wherever K allows them
-    const int cfg = cfg_env >= 0 ? cfg_env : (K % 64 == 0 ? 2 : 0);
-    if (cfg >= 2 && K % 64) return -1;
+    const int cfg = K % 64 == 0 ? 2 : 0;
     const h16 *a = (const h16 *)A16, *w = (const h16 *)W16;
     float *c = (float *)C;
-#define VSK_RING2(EPI_, C16_, NWM_, BK_, NST_) \
-    hipLaunchKernelGGL((gemm16_ring<EPI_, C16_, NWM_, BK_, NST_>), dim3(((M + 64 * NWM_ - 1) / (64 * NWM_)) * ((N + RBN - 1) / RBN)), dim3(128 * NWM_), 0, st, a, w, bias, c, M, N, K, T, H, dh, qscale)
+    const int cus = vsk_device_cus();
+    if (cus <= 0) return (int)hipErrorInvalidDevice;
+#define VSK_RING2(EPI_, C16_, NWM_, BK_, NST_, NJ_)                                                                               \
+    do {                                                                                                                         \
+        const int nt_ = ((M + 64 * NWM_ - 1) / (64 * NWM_)) * ((N + 64 * NJ_ - 1) / (64 * NJ_));                                \
+        int g_ = (NWM_ == 2 ? 2 : 1) * cus; g_ -= g_ % 8; if (g_ < 8) g_ = 8;                                                    \
+        const int need_ = (nt_ + 7) / 8 * 8;                                                                                     \
+        hipLaunchKernelGGL((gemm16_ring<EPI_, C16_, NWM_, BK_, NST_, NJ_>), dim3(need_ < g_ ? need_ : g_), dim3(128 * NWM_), 0, st, \
+                           a, w, bias, c, M, N, K, T, H, dh, qscale);                                                            \
+    } while (0)
 #define VSK_RING(EPI_, C16_)                                    \
     do {                                                        \
-        if (cfg == 1) VSK_RING2(EPI_, C16_, 4, 32, 4);          \
-        else if (cfg == 2) VSK_RING2(EPI_, C16_, 4, 64, 2);     \
-        else if (cfg == 3) VSK_RING2(EPI_, C16_, 2, 64, 2);     \
-        else VSK_RING2(EPI_, C16_, 2, 32, 3);                   \
+        if (cfg == 2) VSK_RING2(EPI_, C16_, 4, 64, 2, 4);       \
+        else VSK_RING2(EPI_, C16_, 2, 32, 3, 4);                \
     } while (0)
     if (epi == RG_BIAS) { if (c16) VSK_RING(RG_BIAS, 1); else VSK_RING(RG_BIAS, 0); }
     else if (epi == RG_RELU) { if (c16) VSK_RING(RG_RELU, 1); else VSK_RING(RG_RELU, 0); }
