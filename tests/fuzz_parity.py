@@ -18,7 +18,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import tolerances as tol  # noqa: E402
 
 TOL = {"fp32": tol.FP32_TOL, "fp16x3": tol.FP32_TOL, "bf16": tol.BF16_LOGIT_TOL}
-ARCH = [(4, 256, 4), (4, 256, 1), (8, 256, 2), (4, 128, 2), (2, 128, 3), (4, 512, 1), (8, 512, 2)]   # (H, d, L)
+ARCH = [(4, 256, 4), (4, 256, 1), (8, 256, 2), (4, 128, 2), (2, 128, 3), (4, 512, 1), (8, 512, 2), (4, 512, 3), (12, 768, 2),
+        (8, 1024, 1), (16, 512, 2)]   # (H, d, L): head dims 32 / 64 / 128, d_model up to 1024
 LENGTHS = [1, 2, 17, 31, 32, 33, 63, 64, 65, 100, 127, 128, 129, 200, 255, 256, 257, 320, 511, 640, 777, 1024]
 
 
@@ -49,7 +50,7 @@ def run(budget: float, seed: int, max_cases: int = 1 << 30, progress: bool = Fal
             m = pkg.SimNet(num_heads=H, d_model=d, num_layers=L, sparsity=0.0, dropout=0.3)
             m.load_state_dict(sd, strict=True)
             m = m.to(dev).eval()
-            modes = ["fp32", "fp16x3"] + (["bf16"] if d <= 256 and d // H in (32, 64) else [])
+            modes = ["fp32", "fp16x3", "bf16"]       # bf16: any d_model since round 3 (d > 256: the bf16-operand GEMM path)
             with torch.no_grad():
                 rl, rh = oracle_forward(sd, x, mask, H)
                 valid = torch.ones(B, T, dtype=torch.bool) if mask is None else ~mask
