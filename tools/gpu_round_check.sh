@@ -37,4 +37,10 @@ python tools/bench_mb_modes.py > gpurun_out/$TAG/mb_modes.txt 2>&1
 python tools/diag_attention.py > gpurun_out/$TAG/attention_timeline_exact.txt 2>&1
 python tools/diag_attention.py abl > gpurun_out/$TAG/attn_bf16_ablations.txt 2>&1
 ./tools/valu_probe > gpurun_out/$TAG/valu_probe.txt 2>&1 || true
+# round 3, second half: the bf16-operand GEMM, M-B / wide models in bf16 mode (kernel trace + PMC), the bf16 training step
+python tools/bench_gemm16.py > gpurun_out/$TAG/gemm16.txt 2>&1
+( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/$TAG/prof_mb_bf16 -- python3 $GRAFT_REPO_ROOT/tools/prof_mb_bf16.py > $GRAFT_REPO_ROOT/gpurun_out/$TAG/prof_mb_bf16.txt 2>&1 )
+bash tools/pmc_cmd.sh gpurun_out/$TAG/pmc_summary_mb_bf16.txt tools/prof_mb_bf16.py > /dev/null 2>&1
+( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/$TAG/prof_train_bf16 -- python3 $GRAFT_REPO_ROOT/tools/bench_train.py --shapes 64x1024 --only-bf16 --iters 10 > $GRAFT_REPO_ROOT/gpurun_out/$TAG/prof_train_bf16.txt 2>&1 )
+bash tools/pmc_cmd.sh gpurun_out/$TAG/pmc_summary_train_bf16.txt tools/bench_train.py --shapes 64x1024 --only-bf16 --iters 4 > /dev/null 2>&1
 echo done
