@@ -1337,3 +1337,13 @@ def test_bf16_mode_on_wide_models_matches_reference_golden(vsa, lp_linear_everyw
     print("bf16 mode %s: max |logit - reference| %.2e" % (name, err))
     assert 1e-6 < err < tol.BF16_LOGIT_TOL
     assert (exact.cpu() - g["logits"])[valid].abs().max().item() < TOL
+    # the two halves separately: bf16 Linears with the exact attention run gemm_nt_128's bf16 form (fp32 operands rounded on
+    # their way into LDS) - a different kernel family from the bf16-operand GEMM of the full bf16 mode - and the bf16
+    # attention with exact Linears reads fp32 q / k / v
+    with torch.no_grad():
+        for lin, att in (("bf16", "fp32"), ("fp32", "bf16")):
+            m.linear_dtype, m.attention_dtype = lin, att
+            mixed = m(x.to(_dev()), None if mask is None else mask.to(_dev()))[0]
+            e2 = (mixed.cpu() - g["logits"])[valid].abs().max().item()
+            assert 1e-7 < e2 < tol.BF16_LOGIT_TOL, (lin, att, e2)
+            assert not torch.equal(mixed, logits)
