@@ -1812,6 +1812,9 @@ template <int EPI>
 static int launch_gemm(const float *A, const float *W, const float *Wf, const float *bias, float *C, int M, int N, int K,
                        const float *pe, int T, int H, int dh, int bf16, hipStream_t st,
                        EpiArgs ea = EpiArgs{0ull, 0u, 0.f, 0.f}) {
+    // bf16 form: 64-wide k-tiles from K = 512 up (measured: +6 % on M-B's K = 512 / 2048 products; at K = 256 - four
+    // k-tiles per output tile - the 35 registers it spills cost more than the halved barriers give: -4 %)
+    const bool kw64 = K % 64 == 0 && K >= 512;
     if (bf16 == 2 && Wf != nullptr && M <= skinny_max_rows() && N % 32 == 0 && K % 128 == 0) {
         // fp16x3 latency kernels (Wf is then the pack_fragments_f16x3 copy)
         if (const int attr_rc = VSK_ALLOW_BIG_LDS((skinny2_gemm<EPI, 2>))) return attr_rc;
@@ -1838,12 +1841,12 @@ static int launch_gemm(const float *A, const float *W, const float *Wf, const fl
             if (N % 256 == 0 && M > 128) {
                 const int blocks = persistent_blocks(((M + 255) / 256) * (N / 256), 1);
                 if (blocks < 0) return (int)hipErrorInvalidDevice;
-                if (K % 64 == 0) hipLaunchKernelGGL((gemm_nt_128<EPI, 4, 0, 4, 1, 1, 64>), dim3(blocks), dim3(512), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr, ea);
+                if (kw64) hipLaunchKernelGGL((gemm_nt_128<EPI, 4, 0, 4, 1, 1, 64>), dim3(blocks), dim3(512), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr, ea);
                 else hipLaunchKernelGGL((gemm_nt_128<EPI, 4, 0, 4, 1, 1>), dim3(blocks), dim3(512), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr, ea);
             } else {
                 const int blocks = persistent_blocks(((M + 127) / 128) * ((N + 127) / 128), 2);
                 if (blocks < 0) return (int)hipErrorInvalidDevice;
-                if (K % 64 == 0) hipLaunchKernelGGL((gemm_nt_128<EPI, 2, 0, 2, 1, 1, 64>), dim3(blocks), dim3(256), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr, ea);
+                if (kw64) hipLaunchKernelGGL((gemm_nt_128<EPI, 2, 0, 2, 1, 1, 64>), dim3(blocks), dim3(256), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr, ea);
                 else hipLaunchKernelGGL((gemm_nt_128<EPI, 2, 0, 2, 1, 1>), dim3(blocks), dim3(256), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr, ea);
             }
             VSK_CHECK_LAUNCH();
@@ -1855,12 +1858,12 @@ static int launch_gemm(const float *A, const float *W, const float *Wf, const fl
         if (N % 256 == 0 && M > 128) {
             const int blocks = persistent_blocks(((M + 255) / 256) * (N / 256), 1);
             if (blocks < 0) return (int)hipErrorInvalidDevice;
-            if (K % 64 == 0) hipLaunchKernelGGL((gemm_nt_128<EPI, 4, 0, 4, 1, 0, 64>), dim3(blocks), dim3(512), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr, ea);
+            if (kw64) hipLaunchKernelGGL((gemm_nt_128<EPI, 4, 0, 4, 1, 0, 64>), dim3(blocks), dim3(512), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr, ea);
             else hipLaunchKernelGGL((gemm_nt_128<EPI, 4, 0, 4, 1>), dim3(blocks), dim3(512), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr, ea);
         } else {
             const int blocks = persistent_blocks(((M + 127) / 128) * ((N + 127) / 128), 2);
             if (blocks < 0) return (int)hipErrorInvalidDevice;
-            if (K % 64 == 0) hipLaunchKernelGGL((gemm_nt_128<EPI, 2, 0, 2, 1, 0, 64>), dim3(blocks), dim3(256), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr, ea);
+            if (kw64) hipLaunchKernelGGL((gemm_nt_128<EPI, 2, 0, 2, 1, 0, 64>), dim3(blocks), dim3(256), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr, ea);
             else hipLaunchKernelGGL((gemm_nt_128<EPI, 2, 0, 2, 1>), dim3(blocks), dim3(256), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr, ea);
         }
         VSK_CHECK_LAUNCH();

@@ -369,46 +369,49 @@ __global__ __launch_bounds__(256) void wgrad_tn(const float *__restrict__ dY, in
 // The same weight gradient on the bf16 matrix pipe (low-precision training, VS_TRAIN_FLAG_BF16_LINEAR): dY and X are
 // rounded to bf16 on their way into LDS (v_cvt_pk_bf16_f32), products accumulate in fp32, the column sums of dY (bias
 // gradient) stay fp32 sums of the unrounded values.  v_mfma_f32_32x32x16_bf16 wants 8 consecutive m per lane for
-// ONE n (A) / ONE k (B): a column of the row-major [m][128] tile - read by ds_read_b64_tr_b16 (4 rows x 16 columns per
-// 16 lanes, transposed by the LDS).  Rows are 256 B; 16-byte chunk c of row m sits at chunk c ^ ((m & 3) << 2), which
+// ONE n (A) / ONE k (B): a column of the row-major [m][256] tile - read by ds_read_b64_tr_b16 (4 rows x 16 columns per
+// 16 lanes, transposed by the LDS).  Rows are 512 B; 16-byte chunk c of row m sits at chunk c ^ ((m & 3) << 2), which
 // spreads the 4 rows of a transposed read over the 4 quarters of the banks (conflict-free) and keeps a staging store's
-// 16 lanes on one row's 128 contiguous bytes.  32 rows per stage (two 16-m steps), double-buffered; same tile / wave
-// map, partial layout, split-K reduction and determinism as wgrad_tn.  HBM-bound at these shapes (it reads fp32).
+// 16 lanes on one row's contiguous bytes.  32 rows per stage (two 16-m steps), double-buffered; same partial layout,
+// split-K reduction and determinism as wgrad_tn.
+// Tile: 256 (n) x 256 (k) per 8-wave block (4 x 2 waves of 64 x 128), one block per CU.  The first version used wgrad_tn's
+// 128 x 128 tiles: every (n-tile, k-tile) block streams its column slab of dY and of X over all M rows, so the operands
+// were read tiles_k + tiles_n times from L2 - 32 flop per byte, ~100 us per call at 65 536 rows whatever the shape, the
+// L2 -> CU rate (~10 TB/s) and not HBM being the bound.  256 x 256 tiles halve those bytes (64 flop/B).
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void wgrad_tn_bf16(const float *__restrict__ dY, int ldy, const float *__restrict__ X, int ldx,
-                                                     float *__restrict__ partW, float *__restrict__ partB, int M, int N, int K,
-                                                     int rows_per_split) {
-    constexpr int BR = 32;
+__global__ __launch_bounds__(512, 2) void wgrad_tn_bf16(const float *__restrict__ dY, int ldy, const float *__restrict__ X, int ldx,
+                                                        float *__restrict__ partW, float *__restrict__ partB, int M, int N, int K,
+                                                        int rows_per_split) {
+    constexpr int BR = 32, TW = 256, ROWB = 2 * TW;          // rows per stage, tile width (columns of dY / of X), LDS row bytes
     typedef unsigned short h16;
     typedef short s16x4 __attribute__((ext_vector_type(4)));
-    __shared__ __attribute__((aligned(16))) h16 Ys[2][BR * 128];
-    __shared__ __attribute__((aligned(16))) h16 Xs[2][BR * 128];
-    __shared__ float red[8][132];
-    const int tiles_k = (K + 127) / 128;
+    __shared__ __attribute__((aligned(16))) h16 Ys[2][BR * TW];
+    __shared__ __attribute__((aligned(16))) h16 Xs[2][BR * TW];
+    __shared__ float red[8][TW + 4];
+    const int tiles_k = (K + TW - 1) / TW;
     const int tile_n = blockIdx.x / tiles_k, tile_k = blockIdx.x - tile_n * tiles_k;
-    const int n0 = tile_n * 128, k0 = tile_k * 128;
+    const int n0 = tile_n * TW, k0 = tile_k * TW;
     const int split = blockIdx.y;
     const int m_begin = split * rows_per_split, m_end = min(M, m_begin + rows_per_split);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
-    const int wn = wave >> 1, wk = wave & 1;
-    const int srow = tid >> 5, sc4 = (tid & 31) * 4;
+    const int wn = wave >> 1, wk = wave & 1;                 // 4 waves along n (64 each), 2 along k (128 each)
+    const int srow = tid >> 6, sc4 = (tid & 63) * 4;         // staging: 8 rows x 64 float4 per pass, 4 passes
     const bool n_ok = n0 + sc4 < N, k_ok = k0 + sc4 < K;
-    // staging store: 4 columns (8 B) of row m = srow + 8 i; physical chunk = ((tid & 31) >> 1) ^ ((m & 3) << 2)
-    const int st_off = srow * 256 + ((((tid & 31) >> 1) ^ ((srow & 3) << 2)) << 4) + 8 * (tid & 1);
+    // staging store: 4 columns (8 B) of row m = srow + 8 i; physical chunk = ((tid & 63) >> 1) ^ ((m & 3) << 2)
+    const int st_off = srow * ROWB + ((((tid & 63) >> 1) ^ ((srow & 3) << 2)) << 4) + 8 * (tid & 1);
     // transposed read: lane l of a 16-lane group gives row q = (l & 15) >> 2, columns 4 p .. 4 p + 3 (p = l & 3)
     const int q = (lane & 15) >> 2, pcol = lane & 3, cl = 2 * ((lane >> 4) & 1) + (pcol >> 1);
-    int a_off[2], b_off[2];
+    int a_off[2], b_off[4];
 #pragma unroll
-    for (int ib = 0; ib < 2; ++ib) {
-        a_off[ib] = (8 * h + q) * 256 + ((cl + 4 * ((2 * wn + ib) ^ q)) << 4) + 8 * (pcol & 1);
-        b_off[ib] = (8 * h + q) * 256 + ((cl + 4 * ((2 * wk + ib) ^ q)) << 4) + 8 * (pcol & 1);
-    }
+    for (int ib = 0; ib < 2; ++ib) a_off[ib] = (8 * h + q) * ROWB + ((cl + 4 * ((2 * wn + ib) ^ q)) << 4) + 8 * (pcol & 1);
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb) b_off[jb] = (8 * h + q) * ROWB + ((cl + 4 * ((4 * wk + jb) ^ q)) << 4) + 8 * (pcol & 1);
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][4];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int t = 0; t < 16; ++t) acc[i][j][t] = 0.f;
     f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
@@ -428,15 +431,15 @@ __global__ __launch_bounds__(256) void wgrad_tn_bf16(const float *__restrict__ d
             u32x2 uy, ux;
             uy[0] = pack_bf16(py[i][0], py[i][1]); uy[1] = pack_bf16(py[i][2], py[i][3]);
             ux[0] = pack_bf16(px[i][0], px[i][1]); ux[1] = pack_bf16(px[i][2], px[i][3]);
-            *(u32x2 *)((char *)&Ys[buf][0] + st_off + 8 * i * 256) = uy;
-            *(u32x2 *)((char *)&Xs[buf][0] + st_off + 8 * i * 256) = ux;
+            *(u32x2 *)((char *)&Ys[buf][0] + st_off + 8 * i * ROWB) = uy;
+            *(u32x2 *)((char *)&Xs[buf][0] + st_off + 8 * i * ROWB) = ux;
             bsum += py[i];
         }
     };
     auto frag = [&](const h16 *tile, int off) __attribute__((always_inline)) -> bf16x8 {
         const char *pb = (const char *)tile + off;
         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)pb);
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(pb + 4 * 256));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(pb + 4 * ROWB));
         const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
         const u32x4 v = {l2[0], l2[1], h2[0], h2[1]};
         return __builtin_bit_cast(bf16x8, v);
@@ -451,33 +454,37 @@ __global__ __launch_bounds__(256) void wgrad_tn_bf16(const float *__restrict__ d
             if (more) gload(m0 + BR);
 #pragma unroll
             for (int s = 0; s < BR / 16; ++s) {
-                const bf16x8 a0 = frag(Ys[buf], a_off[0] + s * 4096), a1 = frag(Ys[buf], a_off[1] + s * 4096);
-                const bf16x8 b0 = frag(Xs[buf], b_off[0] + s * 4096), b1 = frag(Xs[buf], b_off[1] + s * 4096);
-                acc[0][0] = MFMA_BF16(a0, b0, acc[0][0]);
-                acc[0][1] = MFMA_BF16(a0, b1, acc[0][1]);
-                acc[1][0] = MFMA_BF16(a1, b0, acc[1][0]);
-                acc[1][1] = MFMA_BF16(a1, b1, acc[1][1]);
+                bf16x8 a[2], b[4];
+#pragma unroll
+                for (int ib = 0; ib < 2; ++ib) a[ib] = frag(Ys[buf], a_off[ib] + s * 16 * ROWB);
+#pragma unroll
+                for (int jb = 0; jb < 4; ++jb) b[jb] = frag(Xs[buf], b_off[jb] + s * 16 * ROWB);
+#pragma unroll
+                for (int jb = 0; jb < 4; ++jb) {
+                    acc[0][jb] = MFMA_BF16(a[0], b[jb], acc[0][jb]);
+                    acc[1][jb] = MFMA_BF16(a[1], b[jb], acc[1][jb]);
+                }
             }
             if (more) stage(buf ^ 1);
             __syncthreads();
             buf ^= 1;
         }
     }
-    // partial tile: n = n0 + 64 wn + 32 ib + acc_row(t, h),  k = k0 + 64 wk + 32 jb + r
+    // partial tile: n = n0 + 64 wn + 32 ib + acc_row(t, h),  k = k0 + 128 wk + 32 jb + r
     float *pw = partW + (size_t)split * N * K;
 #pragma unroll
     for (int ib = 0; ib < 2; ++ib)
 #pragma unroll
-        for (int jb = 0; jb < 2; ++jb)
+        for (int jb = 0; jb < 4; ++jb)
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
-                const int n = n0 + 64 * wn + 32 * ib + acc_row(t, h), k = k0 + 64 * wk + 32 * jb + r;
+                const int n = n0 + 64 * wn + 32 * ib + acc_row(t, h), k = k0 + 128 * wk + 32 * jb + r;
                 if (n < N && k < K) pw[(size_t)n * K + k] = acc[ib][jb][t];
             }
     if (partB != nullptr && tile_k == 0) {
         *(f32x4 *)&red[srow][sc4] = bsum;
         __syncthreads();
-        if (tid < 128 && n0 + tid < N) {
+        if (tid < TW && n0 + tid < N) {
             float sum = 0.f;
 #pragma unroll
             for (int g = 0; g < 8; ++g) sum += red[g][tid];
@@ -731,21 +738,32 @@ int vst_wgrad_splits(int M, int N, int K) {
     return S < 1 ? 1 : S;
 }
 
-size_t vst_wgrad_workspace_floats(int M, int N, int K) {
-    const size_t S = (size_t)vst_wgrad_splits(M, N, K);
-    return S * ((size_t)N * K + N);
+// the bf16 kernel's: 256 x 256 tiles on 8-wave blocks, one per CU
+static int wgrad_splits_bf16(int M, int N, int K) {
+    const int tiles = ((N + 255) / 256) * ((K + 255) / 256);
+    constexpr int cus = 256;
+    int S = (cus + tiles - 1) / tiles;
+    const int maxS = (M + 63) / 64;
+    if (S > maxS) S = maxS;
+    return S < 1 ? 1 : S;
+}
+
+size_t vst_wgrad_workspace_floats(int M, int N, int K) {       // room for either kernel's partial tiles
+    const size_t S0 = (size_t)vst_wgrad_splits(M, N, K), S1 = (size_t)wgrad_splits_bf16(M, N, K);
+    return (S0 > S1 ? S0 : S1) * ((size_t)N * K + N);
 }
 
 int vst_wgrad(const float *dY, int ldy, const float *X, int ldx, int M, int N, int K, float *dW0, float *dW1, float *dW2,
               float *db0, float *db1, float *db2, int rows_per_dest, float *work, hipStream_t st, int prec) {
     if (N % 4 || K % 4 || ldy % 4 || ldx % 4) return -1;
-    const int S = vst_wgrad_splits(M, N, K);
+    const int S = prec == 1 ? wgrad_splits_bf16(M, N, K) : vst_wgrad_splits(M, N, K);
     int rps = (M + S - 1) / S;
     rps = (rps + 31) / 32 * 32;
     float *partW = work, *partB = work + (size_t)S * N * K;
     const dim3 grid(((N + 127) / 128) * ((K + 127) / 128), S);
     if (prec == 1)
-        hipLaunchKernelGGL(wgrad_tn_bf16, grid, dim3(256), 0, st, dY, ldy, X, ldx, partW, db0 ? partB : nullptr, M, N, K, rps);
+        hipLaunchKernelGGL(wgrad_tn_bf16, dim3(((N + 255) / 256) * ((K + 255) / 256), S), dim3(512), 0, st, dY, ldy, X, ldx, partW,
+                           db0 ? partB : nullptr, M, N, K, rps);
     else
         hipLaunchKernelGGL(wgrad_tn, grid, dim3(256), 0, st, dY, ldy, X, ldx, partW, db0 ? partB : nullptr, M, N, K, rps);
     VSK_CHECK_LAUNCH();
