@@ -1,9 +1,13 @@
 # Round checkpoint on the GPU box: the whole -m gpu suite, smoke(), the headline bench, the HBM-traffic PMC passes, the
 # rocprofv3 kernel-trace of the same bench command, PMC summaries, M-B and training profiles.  Outputs: gpurun_out/rNN/
+# usage: gpu_round_check.sh [tag] [part]   part 1 = parity + headline measurements, part 2 = the other modes' profiles,
+# no part = both (longer than one 20-minute gpurun call since round 3)
 set -e
 TAG=${1:-r03z}
+PART=${2:-0}
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/$TAG
+if [ "$PART" != "2" ]; then
 # HBM-traffic passes first: the bench contract test below wants a traffic file measured on the sources that are loaded
 bash tools/collect_traffic.sh > gpurun_out/$TAG/traffic.log 2>&1
 cp gpurun_out/traffic.json gpurun_out/$TAG/traffic.json
@@ -22,6 +26,9 @@ python tools/bench_train.py --model B --shapes 4x320,64x1024 >> gpurun_out/$TAG/
 bash tools/pmc_cmd.sh gpurun_out/$TAG/pmc_summary.txt bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-extras > /dev/null 2>&1
 bash tools/pmc_cmd.sh gpurun_out/$TAG/pmc_summary_mb.txt bench.py --model B --steps 6 --warmup 2 --no-cpu-baseline --no-extras --no-emulated > /dev/null 2>&1
 python tools/bench_configs.py > gpurun_out/$TAG/bench_configs.txt 2>&1
+fi
+if [ "$PART" = "1" ]; then echo "part 1 done"; exit 0; fi
+set +e
 # the opt-in modes: configs[4] (8 x 8192 x 2048) and the headline shape in fp32 / bf16 / fp16x3, the layer-tail kernel's
 # ablations, kernel trace + PMC summary of the bf16 mode at configs[4]
 python tools/bench_long.py 8 8192 fp32,bf16,fp16x3 > gpurun_out/$TAG/bench_long.txt 2>&1
