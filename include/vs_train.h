@@ -144,14 +144,16 @@ size_t vs_train_attention_dropout_bits_bytes(int32_t B, int32_t H, int32_t T);
 int vs_train_attention_dropout_bits(void *dbits, int32_t B, int32_t H, int32_t T, uint64_t seed, uint32_t site, float p,
                                     void *stream);
 /* vs_train_attention_forward / _backward on the bf16 matrix pipe (VS_TRAIN_FLAG_BF16_ATTENTION); dh in {32, 64}; p > 0 needs
- * dbits (from vs_train_attention_dropout_bits with the same seed / site / p). */
+ * dbits (from vs_train_attention_dropout_bits with the same seed / site / p).  in16 != 0: q, k, v point to bf16 [B,H,T,dh]
+ * planes, q already multiplied by scale * log2(e) - what the training forward stores when both low-precision flags are set
+ * (results are bit-identical to the fp32-stored form, whose values the kernels round to the same bf16). */
 int vs_train_attention_forward_bf16(const float *q, const float *k, const float *v, const uint8_t *key_pad_mask, float *out,
                                     float *lse2, int32_t B, int32_t H, int32_t T, int32_t dh, float scale, float p,
-                                    const void *dbits, void *stream);
+                                    const void *dbits, int32_t in16, void *stream);
 int vs_train_attention_backward_bf16(const float *q, const float *k, const float *v, const uint8_t *key_pad_mask,
                                      const float *out, const float *d_out, const float *lse2, float *dqkv, float *scratch,
                                      int32_t B, int32_t H, int32_t T, int32_t dh, float scale, float p, const void *dbits,
-                                     void *stream);
+                                     int32_t in16, void *stream);
 
 /* dW [N,K] = dY[M,N]^T X[M,K], db [N] = column sums of dY; scratch >= vs_train_wgrad_scratch_floats(M,N,K) floats. */
 size_t vs_train_wgrad_scratch_floats(int32_t M, int32_t N, int32_t K);

@@ -299,15 +299,30 @@ def test_attention_forward_and_backward_kernels_bf16(vsa, B, H, T, dh, masked, p
         lse = torch.full((B, H, T), float("nan"), device=_dev())
         vsa._lib.check(lib.vs_train_attention_forward_bf16(qd.data_ptr(), kd_.data_ptr(), vd.data_ptr(), None if md is None else md.data_ptr(),
                                                            out.data_ptr(), lse.data_ptr(), B, H, T, dh, scale, p,
-                                                           None if dbits is None else dbits.data_ptr(), _stream()))
+                                                           None if dbits is None else dbits.data_ptr(), 0, _stream()))
         dqkv = torch.full((B, T, 3 * d), float("nan"), device=_dev())
         scratch = torch.empty(B * H * T, device=_dev())
         vsa._lib.check(lib.vs_train_attention_backward_bf16(qd.data_ptr(), kd_.data_ptr(), vd.data_ptr(), None if md is None else md.data_ptr(),
                                                             out.data_ptr(), dOd.data_ptr(), lse.data_ptr(), dqkv.data_ptr(), scratch.data_ptr(),
-                                                            B, H, T, dh, scale, p, None if dbits is None else dbits.data_ptr(), _stream()))
+                                                            B, H, T, dh, scale, p, None if dbits is None else dbits.data_ptr(), 0, _stream()))
         torch.cuda.synchronize()
         runs.append((out.clone(), lse.clone(), dqkv.clone()))
     assert all(torch.equal(a, b) for a, b in zip(*runs))
+    # the bf16-STORED form (what the training forward saves when both low-precision flags are set: q times scale * log2 e,
+    # k, v as bf16 planes) gives the same bits: the kernels round the fp32-stored values to exactly these
+    q16 = (qd * (scale * 1.4426950408889634)).to(torch.bfloat16).contiguous()
+    k16, v16 = kd_.to(torch.bfloat16).contiguous(), vd.to(torch.bfloat16).contiguous()
+    out16 = torch.full((B, T, d), float("nan"), device=_dev())
+    lse16 = torch.full((B, H, T), float("nan"), device=_dev())
+    vsa._lib.check(lib.vs_train_attention_forward_bf16(q16.data_ptr(), k16.data_ptr(), v16.data_ptr(), None if md is None else md.data_ptr(),
+                                                       out16.data_ptr(), lse16.data_ptr(), B, H, T, dh, scale, p,
+                                                       None if dbits is None else dbits.data_ptr(), 1, _stream()))
+    dqkv16 = torch.full((B, T, 3 * d), float("nan"), device=_dev())
+    vsa._lib.check(lib.vs_train_attention_backward_bf16(q16.data_ptr(), k16.data_ptr(), v16.data_ptr(), None if md is None else md.data_ptr(),
+                                                        out16.data_ptr(), dOd.data_ptr(), lse16.data_ptr(), dqkv16.data_ptr(), scratch.data_ptr(),
+                                                        B, H, T, dh, scale, p, None if dbits is None else dbits.data_ptr(), 1, _stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(out16, runs[0][0]) and torch.equal(lse16, runs[0][1]) and torch.equal(dqkv16, runs[0][2])
     out, lse, dqkv = runs[0]
     assert torch.isfinite(out).all() and torch.isfinite(dqkv).all()
     _close(out, want, "attention out (bf16)", atol=None, rtol=1.5e-2)

@@ -271,10 +271,10 @@ def load() -> C.CDLL:
                                                         C.c_float, C.c_void_p]
         lib.vs_train_attention_forward_bf16.restype = C.c_int
         lib.vs_train_attention_forward_bf16.argtypes = ([C.c_void_p] * 6 + [C.c_int32] * 4 + [C.c_float, C.c_float, C.c_void_p,
-                                                                                            C.c_void_p])
+                                                                                            C.c_int32, C.c_void_p])
         lib.vs_train_attention_backward_bf16.restype = C.c_int
         lib.vs_train_attention_backward_bf16.argtypes = ([C.c_void_p] * 9 + [C.c_int32] * 4 + [C.c_float, C.c_float, C.c_void_p,
-                                                                                             C.c_void_p])
+                                                                                             C.c_int32, C.c_void_p])
         lib.vs_train_wgrad_scratch_floats.restype = C.c_size_t
         lib.vs_train_wgrad_scratch_floats.argtypes = [C.c_int32] * 3
         lib.vs_train_wgrad.restype = C.c_int

@@ -219,6 +219,8 @@ int vs_train_forward(const vs_weights *w, const float *x, const uint8_t *key_pad
     // ... and (VS_TRAIN_FLAG_BF16_ATTENTION) the attention products of the forward and the backward, head dim 32 / 64
     const bool lpa = drop && (drop->flags & VS_TRAIN_FLAG_BF16_ATTENTION) && (long long)B * T > vsk_options().lp_min_rows &&
                      vst_attention_bf16_supported(w->desc.d_model / w->desc.num_heads);
+    const bool qkv16 = lp && lpa;                                  // q / k / v of the record are bf16 planes
+    const size_t kvs = qkv16 ? (size_t)B * T * w->desc.d_model / 2 : (size_t)B * T * w->desc.d_model;     // floats between the planes
     const unsigned long long seed = drop ? drop->seed : 0ull;
     const float scale = 1.0f / sqrtf((float)d);              // simnet.py:126: d_model ** -0.5
     float *sv = (float *)saved, *ws = (float *)workspace;
@@ -236,12 +238,16 @@ int vs_train_forward(const vs_weights *w, const float *x, const uint8_t *key_pad
         const LayerSaved &A = S.layers[l];
         const bool last = l == L - 1;
         float *qkv = sv + A.qkv;
-        VST_LAUNCH(vsk_qkv(h_in, w->p(P.wqkv), w->p(P.f_wqkv), w->p(P.bqkv), qkv, B, T, d, H, lp, st));         // :148-153
+        // bf16 GEMMs + bf16 attention: q (times scale * log2 e), k, v are WRITTEN as bf16 by the QKV GEMM's epilogue (the
+        // scoring path's form) - the attention kernels' only readers round them to bf16 anyway: same bits, half the
+        // saved bytes, nothing to convert per streamed tile
+        VST_LAUNCH(vsk_qkv(h_in, w->p(P.wqkv), w->p(P.f_wqkv), w->p(P.bqkv), qkv, B, T, d, H, qkv16 ? (1 | VSK_STORE16) : lp, st,
+                           qkv16 ? vsk_attention_qscale(scale) : 1.0f));         // :148-153
         unsigned *dbits = p > 0.f ? (unsigned *)(sv + A.dbits) : nullptr;
         if (dbits) VST_LAUNCH(vst_attention_dropout_bits(dbits, B, H, T, seed, VS_SITE_LAYER(l, VS_SITE_ATTN), p, st));
         if (lpa)
-            VST_LAUNCH(vst_attention_fwd_bf16(qkv, qkv + (size_t)M * d, qkv + 2 * (size_t)M * d, key_pad_mask, sv + A.att,
-                                              sv + A.lse, B, H, T, d / H, scale, p, dbits, st));
+            VST_LAUNCH(vst_attention_fwd_bf16(qkv, qkv + kvs, qkv + 2 * kvs, key_pad_mask, sv + A.att,
+                                              sv + A.lse, B, H, T, d / H, scale, p, dbits, st, qkv16));
         else
         VST_LAUNCH(vst_attention_fwd(qkv, qkv + (size_t)M * d, qkv + 2 * (size_t)M * d, key_pad_mask, sv + A.att,
                                      sv + A.lse, B, H, T, d / H, scale, seed, VS_SITE_LAYER(l, VS_SITE_ATTN), p, st, dbits));   // :155-161
@@ -291,6 +297,8 @@ int vs_train_backward(vs_weights *w, const float *x, const uint8_t *key_pad_mask
     // ... and (VS_TRAIN_FLAG_BF16_ATTENTION) the attention products of the forward and the backward, head dim 32 / 64
     const bool lpa = drop && (drop->flags & VS_TRAIN_FLAG_BF16_ATTENTION) && (long long)B * T > vsk_options().lp_min_rows &&
                      vst_attention_bf16_supported(w->desc.d_model / w->desc.num_heads);
+    const bool qkv16 = lp && lpa;                                  // q / k / v of the record are bf16 planes
+    const size_t kvs = qkv16 ? (size_t)B * T * w->desc.d_model / 2 : (size_t)B * T * w->desc.d_model;     // floats between the planes
     const unsigned long long seed = drop ? drop->seed : 0ull;
     const float scale = 1.0f / sqrtf((float)d);
     const float *sv = (const float *)saved;
@@ -348,9 +356,9 @@ int vs_train_backward(vs_weights *w, const float *x, const uint8_t *key_pad_mask
         const float *qkv = sv + A.qkv;
         VST_LAUNCH(vst_head_rowdot(datt, sv + A.att, delta, M, T, H, d / H, st));
         if (lpa)
-            VST_LAUNCH(vst_attention_bwd_bf16(qkv, qkv + (size_t)M * d, qkv + 2 * (size_t)M * d, key_pad_mask, datt, sv + A.lse,
+            VST_LAUNCH(vst_attention_bwd_bf16(qkv, qkv + kvs, qkv + 2 * kvs, key_pad_mask, datt, sv + A.lse,
                                               delta, dqkv, B, H, T, d / H, scale, p,
-                                              p > 0.f ? (const unsigned *)(sv + A.dbits) : nullptr, st));
+                                              p > 0.f ? (const unsigned *)(sv + A.dbits) : nullptr, st, qkv16));
         else
         VST_LAUNCH(vst_attention_bwd(qkv, qkv + (size_t)M * d, qkv + 2 * (size_t)M * d, key_pad_mask, datt, sv + A.lse, delta,
                                      dqkv, B, H, T, d / H, scale, seed, VS_SITE_LAYER(l, VS_SITE_ATTN), p, st,
@@ -486,24 +494,24 @@ int vs_train_attention_dropout_bits(void *dbits, int32_t B, int32_t H, int32_t T
 
 int vs_train_attention_forward_bf16(const float *q, const float *k, const float *v, const uint8_t *key_pad_mask, float *out,
                                     float *lse2, int32_t B, int32_t H, int32_t T, int32_t dh, float scale, float p,
-                                    const void *dbits, void *stream) {
+                                    const void *dbits, int32_t in16, void *stream) {
     if (!q || !k || !v || !out || !lse2) return failf(VS_ERR_INVALID, "NULL pointer");
     if (B <= 0 || H <= 0 || T <= 0) return failf(VS_ERR_INVALID, "B=%d H=%d T=%d", B, H, T);
     VST_LAUNCH(vst_attention_fwd_bf16(q, k, v, key_pad_mask, out, lse2, B, H, T, dh, scale, p, (const unsigned *)dbits,
-                                      (hipStream_t)stream));
+                                      (hipStream_t)stream, in16 ? 1 : 0));
     return VS_OK;
 }
 
 int vs_train_attention_backward_bf16(const float *q, const float *k, const float *v, const uint8_t *key_pad_mask,
                                      const float *out, const float *d_out, const float *lse2, float *dqkv, float *scratch,
                                      int32_t B, int32_t H, int32_t T, int32_t dh, float scale, float p, const void *dbits,
-                                     void *stream) {
+                                     int32_t in16, void *stream) {
     if (!q || !k || !v || !out || !d_out || !lse2 || !dqkv || !scratch) return failf(VS_ERR_INVALID, "NULL pointer");
     if (B <= 0 || H <= 0 || T <= 0) return failf(VS_ERR_INVALID, "B=%d H=%d T=%d", B, H, T);
     hipStream_t st = (hipStream_t)stream;
     VST_LAUNCH(vst_head_rowdot(d_out, out, scratch, B * T, T, H, dh, st));
     VST_LAUNCH(vst_attention_bwd_bf16(q, k, v, key_pad_mask, d_out, lse2, scratch, dqkv, B, H, T, dh, scale, p,
-                                      (const unsigned *)dbits, st));
+                                      (const unsigned *)dbits, st, in16 ? 1 : 0));
     return VS_OK;
 }
 

@@ -63,32 +63,54 @@ struct TileB {                                  // one staged 64-row tile pair +
     float s1[64];                               //                      |  -delta
 };
 
-// global fp32 -> registers -> bf16 LDS image of a 64 x DH tile pair by 256 threads (DH / 16 float4 per thread and matrix)
-template <int DH>
+// global -> registers -> bf16 LDS image of a 64 x DH tile pair by 256 threads.  A16 / B16: that matrix already IS bf16 in
+// memory (q * scale * log2 e, k, v as the QKV GEMM's bf16 epilogue writes them: nothing to convert, 16-byte chunks go
+// straight into the image); otherwise fp32, rounded here (DH / 16 float4 per thread).
+template <int DH, bool A16 = false, bool B16 = false>
 struct StagerB {
-    static constexpr int NV = DH / 16;
-    f32x4 va[NV], vb[NV];
-    __device__ __forceinline__ void load(const float *pa, size_t lda, const float *pb, size_t ldb, int row0, int nrows, float mul_a) {
+    static constexpr int NV = DH / 16, NC = DH / 32;       // float4 per thread (fp32 source) | 16-byte chunks per thread (bf16 source)
+    f32x4 va[A16 ? 1 : NV], vb[B16 ? 1 : NV];
+    u32x4 ca[A16 ? NC : 1], cb[B16 ? NC : 1];
+    __device__ __forceinline__ void load(const void *pa_, size_t lda, const void *pb_, size_t ldb, int row0, int nrows, float mul_a) {
         const int tid = threadIdx.x;
+        const u32x4 zc = {0u, 0u, 0u, 0u};
+        if constexpr (A16 || B16) {
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int idx = tid + 256 * i, row = idx / (DH / 4), c4 = (idx % (DH / 4)) * 4;
-            const bool ok = row0 + row < nrows;
-            va[i] = ok ? *(const f32x4 *)(pa + (size_t)(row0 + row) * lda + c4) * mul_a : f32x4{0.f, 0.f, 0.f, 0.f};
-            vb[i] = ok ? *(const f32x4 *)(pb + (size_t)(row0 + row) * ldb + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < NC; ++i) {
+                const int idx = tid + 256 * i, row = idx / (DH / 8), c8 = (idx % (DH / 8)) * 8;
+                const bool ok = row0 + row < nrows;
+                if constexpr (A16) ca[i] = ok ? *(const u32x4 *)((const h16 *)pa_ + (size_t)(row0 + row) * lda + c8) : zc;
+                if constexpr (B16) cb[i] = ok ? *(const u32x4 *)((const h16 *)pb_ + (size_t)(row0 + row) * ldb + c8) : zc;
+            }
+        }
+        if constexpr (!A16 || !B16) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int idx = tid + 256 * i, row = idx / (DH / 4), c4 = (idx % (DH / 4)) * 4;
+                const bool ok = row0 + row < nrows;
+                if constexpr (!A16) va[i] = ok ? *(const f32x4 *)((const float *)pa_ + (size_t)(row0 + row) * lda + c4) * mul_a : f32x4{0.f, 0.f, 0.f, 0.f};
+                if constexpr (!B16) vb[i] = ok ? *(const f32x4 *)((const float *)pb_ + (size_t)(row0 + row) * ldb + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
         }
     }
     __device__ __forceinline__ void store(TileB<DH> &t) const {
         const int tid = threadIdx.x;
+        if constexpr (A16 || B16) {
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int idx = tid + 256 * i, row = idx / (DH / 4), c4 = (idx % (DH / 4)) * 4;
-            const int off = img_off<DH>(row, c4 >> 3) + ((c4 & 4) << 1);
-            u32x2 ua, ub;
-            ua[0] = pack_bf16(va[i][0], va[i][1]); ua[1] = pack_bf16(va[i][2], va[i][3]);
-            ub[0] = pack_bf16(vb[i][0], vb[i][1]); ub[1] = pack_bf16(vb[i][2], vb[i][3]);
-            *(u32x2 *)(t.a + off) = ua;
-            *(u32x2 *)(t.b + off) = ub;
+            for (int i = 0; i < NC; ++i) {
+                const int idx = tid + 256 * i, row = idx / (DH / 8), chunk = idx % (DH / 8);
+                if constexpr (A16) *(u32x4 *)(t.a + img_off<DH>(row, chunk)) = ca[i];
+                if constexpr (B16) *(u32x4 *)(t.b + img_off<DH>(row, chunk)) = cb[i];
+            }
+        }
+        if constexpr (!A16 || !B16) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int idx = tid + 256 * i, row = idx / (DH / 4), c4 = (idx % (DH / 4)) * 4;
+                const int off = img_off<DH>(row, c4 >> 3) + ((c4 & 4) << 1);
+                if constexpr (!A16) { u32x2 ua; ua[0] = pack_bf16(va[i][0], va[i][1]); ua[1] = pack_bf16(va[i][2], va[i][3]); *(u32x2 *)(t.a + off) = ua; }
+                if constexpr (!B16) { u32x2 ub; ub[0] = pack_bf16(vb[i][0], vb[i][1]); ub[1] = pack_bf16(vb[i][2], vb[i][3]); *(u32x2 *)(t.b + off) = ub; }
+            }
         }
     }
 };
@@ -109,6 +131,12 @@ __device__ __forceinline__ void owner_frags(const float *src, float mul, int h, 
         const u32x4 u = {pack_bf16(v0[0], v0[1]), pack_bf16(v0[2], v0[3]), pack_bf16(v1[0], v1[1]), pack_bf16(v1[2], v1[3])};
         f[ks] = __builtin_bit_cast(bf16x8, u);
     }
+}
+// ... from a row that already is bf16 in memory: lane (r, h) <- the 16-byte chunk 2 ks + h of the row
+template <int DH>
+__device__ __forceinline__ void owner_frags16(const h16 *src, int h, bf16x8 (&f)[DH / 16]) {
+#pragma unroll
+    for (int ks = 0; ks < DH / 16; ++ks) f[ks] = __builtin_bit_cast(bf16x8, *(const u32x4 *)(src + 16 * ks + 8 * h));
 }
 // registers 8 s .. 8 s + 7 of a 32x32 result -> the B operand of the next product's 16-row step s
 __device__ __forceinline__ bf16x8 pack_step(const f32x16 &x, int s) {
@@ -142,7 +170,7 @@ __device__ __forceinline__ f32x16 rows_init(const float *c, int h) {
 // ------------------------------------------------------------------------------------------
 // forward: owner = queries
 // ------------------------------------------------------------------------------------------
-template <int DH, bool DROP>
+template <int DH, bool DROP, bool IN16>          // IN16: q (pre-multiplied by scale * log2 e), k, v are bf16 in memory
 __global__ __launch_bounds__(256, 2) void attn_fwd_train_bf16(
     const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
     const uint8_t *__restrict__ mask, float *__restrict__ out, float *__restrict__ lse2, int H, int T, float scale,
@@ -155,16 +183,19 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_train_bf16(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
     const int qi = qt * 128 + wave * 32 + r, qc = qi < T ? qi : T - 1;
     const float sl2 = scale * 1.4426950408889634f;
-    const float *qb = q + (size_t)bh * T * DH, *kb = k + (size_t)bh * T * DH, *vb = v + (size_t)bh * T * DH;
+    constexpr int ES = IN16 ? 2 : 4;            // bytes per stored q / k / v element
+    const char *qb = (const char *)q + (size_t)bh * T * DH * ES, *kb = (const char *)k + (size_t)bh * T * DH * ES,
+               *vb = (const char *)v + (size_t)bh * T * DH * ES;
 
     bf16x8 qf[NS];
-    owner_frags<DH>(qb + (size_t)qc * DH, sl2, h, qf);
+    if constexpr (IN16) owner_frags16<DH>((const h16 *)qb + (size_t)qc * DH, h, qf);
+    else owner_frags<DH>((const float *)qb + (size_t)qc * DH, sl2, h, qf);
     f32x16 o[ND];
 #pragma unroll
     for (int db = 0; db < ND; ++db) o[db] = zero16b();
     float m_run = NEG_INF_B, l_run = 0.f;
 
-    StagerB<DH> sg;
+    StagerB<DH, IN16, IN16> sg;
     auto side = [&](TileB<DH> &t, int key0) __attribute__((always_inline)) {
         if (tid < 64) {
             const int key = key0 + tid;
@@ -249,7 +280,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_train_bf16(
 // ------------------------------------------------------------------------------------------
 // backward, queries own: dQ
 // ------------------------------------------------------------------------------------------
-template <int DH, bool DROP>
+template <int DH, bool DROP, bool IN16>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16(
     const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
     const uint8_t *__restrict__ mask, const float *__restrict__ dO, const float *__restrict__ lse2,
@@ -263,17 +294,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
     const int qi = qt * 128 + wave * 32 + r, qc = qi < T ? qi : T - 1;
     const float sl2 = scale * 1.4426950408889634f;
-    const float *qb = q + (size_t)bh * T * DH, *kb = k + (size_t)bh * T * DH, *vb = v + (size_t)bh * T * DH;
+    constexpr int ES = IN16 ? 2 : 4;
+    const char *qb = (const char *)q + (size_t)bh * T * DH * ES, *kb = (const char *)k + (size_t)bh * T * DH * ES,
+               *vb = (const char *)v + (size_t)bh * T * DH * ES;
 
     bf16x8 qf[NS], dof[NS];
-    owner_frags<DH>(qb + (size_t)qc * DH, sl2, h, qf);
+    if constexpr (IN16) owner_frags16<DH>((const h16 *)qb + (size_t)qc * DH, h, qf);
+    else owner_frags<DH>((const float *)qb + (size_t)qc * DH, sl2, h, qf);
     owner_frags<DH>(dO + ((size_t)b * T + qc) * d + hd * DH, 1.0f, h, dof);
     const float lq = lse2[(size_t)bh * T + qc], dq_delta = delta[(size_t)bh * T + qc];
     f32x16 acc[ND];
 #pragma unroll
     for (int db = 0; db < ND; ++db) acc[db] = zero16b();
 
-    StagerB<DH> sg;
+    StagerB<DH, IN16, IN16> sg;
     auto side = [&](TileB<DH> &t, int key0) __attribute__((always_inline)) {
         if (tid < 64) {
             const int key = key0 + tid;
@@ -336,7 +370,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16(
 // ------------------------------------------------------------------------------------------
 // backward, keys own: dK and dV
 // ------------------------------------------------------------------------------------------
-template <int DH, bool DROP>
+template <int DH, bool DROP, bool IN16>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_bf16(
     const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
     const uint8_t *__restrict__ mask, const float *__restrict__ dO, const float *__restrict__ lse2,
@@ -350,18 +384,25 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_bf16(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
     const int ki = ktile * 128 + wave * 32 + r, kc = ki < T ? ki : T - 1;
     const float sl2 = scale * 1.4426950408889634f;
-    const float *qb = q + (size_t)bh * T * DH, *kb = k + (size_t)bh * T * DH, *vb = v + (size_t)bh * T * DH;
+    constexpr int ES = IN16 ? 2 : 4;
+    const char *qb = (const char *)q + (size_t)bh * T * DH * ES, *kb = (const char *)k + (size_t)bh * T * DH * ES,
+               *vb = (const char *)v + (size_t)bh * T * DH * ES;
     const float *dob = dO + (size_t)b * T * d + hd * DH;          // row stride d
 
     bf16x8 kf[NS], vf[NS];
-    owner_frags<DH>(kb + (size_t)kc * DH, 1.0f, h, kf);
-    owner_frags<DH>(vb + (size_t)kc * DH, 1.0f, h, vf);
+    if constexpr (IN16) {
+        owner_frags16<DH>((const h16 *)kb + (size_t)kc * DH, h, kf);
+        owner_frags16<DH>((const h16 *)vb + (size_t)kc * DH, h, vf);
+    } else {
+        owner_frags<DH>((const float *)kb + (size_t)kc * DH, 1.0f, h, kf);
+        owner_frags<DH>((const float *)vb + (size_t)kc * DH, 1.0f, h, vf);
+    }
     const bool kmasked = mask != nullptr && mask[(size_t)b * T + kc];
     f32x16 dk[ND], dv[ND];
 #pragma unroll
     for (int db = 0; db < ND; ++db) { dk[db] = zero16b(); dv[db] = zero16b(); }
 
-    StagerB<DH> sg;
+    StagerB<DH, IN16, false> sg;                                  // Q bf16 when IN16; dO always fp32
     auto side = [&](TileB<DH> &t, int q0) __attribute__((always_inline)) {
         if (tid < 64) {
             const int qi = q0 + tid;
@@ -447,24 +488,32 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_bf16(
 
 }  // namespace
 
-#define VSTB_LAUNCH(KERNEL_, DH_, DROP_, ...)                                                                   \
+#define VSTB_LAUNCH(KERNEL_, DH_, DROP_, IN16_, ...)                                                            \
     do {                                                                                                        \
         constexpr size_t lds_bytes_ = 2 * sizeof(TileB<DH_>);                                                   \
         static_assert(lds_bytes_ <= 64 * 1024, "static-size dynamic LDS below the 64 KB default limit");        \
-        hipLaunchKernelGGL((KERNEL_<DH_, DROP_>), grid, dim3(256), lds_bytes_, st, __VA_ARGS__);                \
+        hipLaunchKernelGGL((KERNEL_<DH_, DROP_, IN16_>), grid, dim3(256), lds_bytes_, st, __VA_ARGS__);         \
+    } while (0)
+#define VSTB_DISPATCH2(KERNEL_, DH_, ...)                                                                       \
+    do {                                                                                                        \
+        if (drop && in16) VSTB_LAUNCH(KERNEL_, DH_, true, true, __VA_ARGS__);                                   \
+        else if (drop) VSTB_LAUNCH(KERNEL_, DH_, true, false, __VA_ARGS__);                                     \
+        else if (in16) VSTB_LAUNCH(KERNEL_, DH_, false, true, __VA_ARGS__);                                     \
+        else VSTB_LAUNCH(KERNEL_, DH_, false, false, __VA_ARGS__);                                              \
     } while (0)
 #define VSTB_DISPATCH(KERNEL_, ...)                                                                             \
     do {                                                                                                        \
         const bool drop = p > 0.f;                                                                              \
-        if (dh == 32) { if (drop) VSTB_LAUNCH(KERNEL_, 32, true, __VA_ARGS__); else VSTB_LAUNCH(KERNEL_, 32, false, __VA_ARGS__); } \
-        else if (dh == 64) { if (drop) VSTB_LAUNCH(KERNEL_, 64, true, __VA_ARGS__); else VSTB_LAUNCH(KERNEL_, 64, false, __VA_ARGS__); } \
+        if (dh == 32) VSTB_DISPATCH2(KERNEL_, 32, __VA_ARGS__);                                                 \
+        else if (dh == 64) VSTB_DISPATCH2(KERNEL_, 64, __VA_ARGS__);                                            \
         else return -1;                                                                                         \
     } while (0)
 
 bool vst_attention_bf16_supported(int dh) { return dh == 32 || dh == 64; }
 
+// in16: q (already times scale * log2 e), k, v are bf16 [B, H, T, dh] planes (the QKV GEMM's bf16 epilogue) instead of fp32
 int vst_attention_fwd_bf16(const float *q, const float *k, const float *v, const uint8_t *mask, float *out, float *lse2,
-                           int B, int H, int T, int dh, float scale, float p, const unsigned *dbits, hipStream_t st) {
+                           int B, int H, int T, int dh, float scale, float p, const unsigned *dbits, hipStream_t st, int in16) {
     if (p < 0.f || p >= 1.f || (p > 0.f && dbits == nullptr)) return -1;
     const float ds = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
     const dim3 grid(B * H * ((T + 127) / 128));
@@ -475,7 +524,7 @@ int vst_attention_fwd_bf16(const float *q, const float *k, const float *v, const
 
 int vst_attention_bwd_bf16(const float *q, const float *k, const float *v, const uint8_t *mask, const float *dO,
                            const float *lse2, const float *delta, float *dqkv, int B, int H, int T, int dh, float scale,
-                           float p, const unsigned *dbits, hipStream_t st) {
+                           float p, const unsigned *dbits, hipStream_t st, int in16) {
     if (p < 0.f || p >= 1.f || (p > 0.f && dbits == nullptr)) return -1;
     const float ds = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
     const dim3 grid(B * H * ((T + 127) / 128));
