@@ -188,6 +188,11 @@ int vs_linear_bf16(const float *A, const float *W, const float *bias, float *C,
                    int32_t M, int32_t N, int32_t K, int32_t relu,
                    const float *pe, int32_t T, void *stream);
 
+/* vs_linear_bf16 with A already stored as bf16 (A16 [M,K] row-major; W stays fp32 and is rounded on its way into LDS):
+ * the form the bf16 training mode runs fc2 and the fc1 input gradient in (pe: optional [M,N] fp32 term added to C). */
+int vs_linear_bf16_a16(const void *A16, const float *W, const float *bias, float *C,
+                       int32_t M, int32_t N, int32_t K, const float *pe, void *stream);
+
 /* vs_linear_f32 emulated on the f16 matrix pipe (see VS_FLAG_F16X3_LINEAR). */
 int vs_linear_f16x3(const float *A, const float *W, const float *bias, float *C,
                     int32_t M, int32_t N, int32_t K, int32_t relu,

@@ -670,6 +670,30 @@ def test_linear_bf16_operands_kernel(vsa, M, N, K, relu, c16):
         assert (got - ref).abs().max().item() < 1e-4
 
 
+@pytest.mark.parametrize("M,N,K,res", [(400, 256, 1024, 0), (129, 256, 1024, 1), (300, 1024, 256, 0), (2048, 512, 2048, 1), (64, 768, 256, 0),
+                                       (1, 32, 32, 0), (1000, 256, 96, 1)])
+def test_linear_bf16_stored_a_kernel(vsa, M, N, K, res):
+    """gemm_nt_128's bf16 form with A read as bf16 from memory (the bf16 training mode's fc2 and fc1 input gradient, the latter
+    with the residual gradient [M,N] added in the epilogue): same result as vs_linear_bf16 on the fp32 tensor that rounds to
+    this bf16 - BIT for bit (the fp32-operand form rounds to the same values on its way into LDS)."""
+    lib = vsa._lib.load()
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).to(torch.bfloat16)
+    W = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g)
+    R = torch.randn(M, N, generator=g) if res else None
+    ref = A.double() @ _rb(W).t() + b.double() + (R.double() if res else 0.0)
+    dA16, dA32, dW, db = A.to(_dev()), A.float().to(_dev()), W.to(_dev()), b.to(_dev())
+    dR = R.to(_dev()) if res else None
+    out = torch.full((M, N), float("nan"), device=_dev())
+    vsa._lib.check(lib.vs_linear_bf16_a16(dA16.data_ptr(), dW.data_ptr(), db.data_ptr(), out.data_ptr(), M, N, K, dR.data_ptr() if res else None, _stream()))
+    want = torch.full((M, N), float("nan"), device=_dev())
+    vsa._lib.check(lib.vs_linear_bf16(dA32.data_ptr(), dW.data_ptr(), db.data_ptr(), want.data_ptr(), M, N, K, 0, dR.data_ptr() if res else None, M if res else 0, _stream()))
+    torch.cuda.synchronize()
+    assert (out.cpu().double() - ref).abs().max().item() < 1e-4
+    assert torch.equal(out, want)
+
+
 @pytest.mark.parametrize("B,T,d,H,c16", [(2, 200, 512, 4, 0), (3, 130, 768, 12, 1), (1, 77, 1024, 8, 0), (2, 64, 1024, 16, 1)])
 def test_qkv_projection_bf16_operands_kernel(vsa, B, T, d, H, c16):
     """The same kernel's q/k/v epilogue: [3][B][H][T][dh], q pre-multiplied by scale * log2(e) in the bf16-output form."""

@@ -339,6 +339,35 @@ def test_attention_forward_and_backward_kernels_bf16(vsa, B, H, T, dh, masked, p
     _close(dqkv[:, :, 2 * d:], tok(v.grad), "dv (bf16)", atol=None, rtol=3e-2)
 
 
+@pytest.mark.parametrize("p", [0.0, 0.3])
+def test_bf16_training_storage_forms_agree_bit_for_bit(vsa, lp_train_everywhere, p):
+    """The bf16 training mode STORES the tensors that are only ever bf16 matrix operands as bf16 (q times scale * log2 e, k, v;
+    the MLP hidden tensor; the gated gradient of that tensor) - their producers' epilogues round them, their consumers read
+    them as they are.  VS_LP_STORE32 = 1 keeps them fp32, rounded by every consumer on its way into LDS: the same bf16 values,
+    so logits, hidden states and every gradient agree BIT for bit - except fc1.bias, a column sum of the gated gradient,
+    which sums the stored (rounded) values in one form and the fp32 values in the other."""
+    res = {}
+    try:
+        for store32 in (1, 0):
+            vsa._lib.set_option("VS_LP_STORE32", store32)
+            m = vsa.SimNet(num_heads=4, d_model=256, num_layers=2, sparsity=0.0, dropout=p)
+            m.load_state_dict(vsa.synth.make_state_dict(256, 2, 3))
+            m = m.to(_dev()).train().set_train_dtype("bf16")
+            x = torch.randn(2, 200, 1024, generator=torch.Generator().manual_seed(1)).to(_dev()).requires_grad_(True)
+            torch.manual_seed(5)
+            pred, hid = m(x, None)
+            ((pred ** 2).mean() + 1e-3 * hid.sum()).backward()
+            res[store32] = [("pred", pred.detach().clone()), ("hidden", hid.detach().clone()), ("dx", x.grad.clone())] + \
+                           [(n, q.grad.clone()) for n, q in m.named_parameters()]
+    finally:
+        vsa._lib.set_option("VS_LP_STORE32", -1)
+    for (n, a), (_n, b) in zip(res[1], res[0]):
+        if n.endswith("mlp.fc1.bias"):
+            assert (a - b).abs().max().item() <= 1e-3 * a.abs().max().item(), n
+        else:
+            assert torch.equal(a, b), n
+
+
 @pytest.mark.parametrize("M,N,K", [(300, 256, 1024), (4096, 1024, 256), (77, 768, 256), (1000, 64, 192), (5000, 512, 2048),
                                    (16, 256, 256), (1, 128, 64)])
 def test_wgrad_kernel(vsa, M, N, K):
@@ -515,9 +544,10 @@ def test_dropout_hash_statistics(vsa):
 # ---------------------------------------------------------------------------------------------
 # whole model WITH dropout: explicit-mask float64 model fed with the library's masks
 # ---------------------------------------------------------------------------------------------
-def _hip_gates(vsa, module, out_tensor, B, T, d, L):
+def _hip_gates(vsa, module, out_tensor, B, T, d, L, bf16=False):
     """The ReLU-and-dropout gate the HIP backward applies, per layer: sign pattern of the MLP activation in the
-    activation record the forward left for its backward (vs_train_saved_field)."""
+    activation record the forward left for its backward (vs_train_saved_field).  bf16: the record was written by a
+    forward whose GEMMs ran in the bf16 training mode - the activation is stored as bf16 (first half of its field)."""
     lib = vsa._lib.load()
     saved = out_tensor.grad_fn.saved_tensors[2]
     handle = module._packed.handle
@@ -525,7 +555,10 @@ def _hip_gates(vsa, module, out_tensor, B, T, d, L):
     for l in range(L):
         off, cnt = C.c_size_t(), C.c_size_t()
         vsa._lib.check(lib.vs_train_saved_field(handle, B, T, l, 0, C.byref(off), C.byref(cnt)))
-        act = saved[off.value: off.value + 4 * cnt.value].view(torch.float32).view(B, T, 4 * d)
+        if bf16:
+            act = saved[off.value: off.value + 2 * cnt.value].view(torch.bfloat16).view(B, T, 4 * d).float()
+        else:
+            act = saved[off.value: off.value + 4 * cnt.value].view(torch.float32).view(B, T, 4 * d)
         gates["gate%d" % l] = (act > 0).cpu()
     return gates
 

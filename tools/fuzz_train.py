@@ -72,7 +72,7 @@ def run(budget, seed, progress=True, lp=False):
         pred, hidden = m(xd, md)
         mk = md if md is not None else torch.zeros(B, T, dtype=torch.bool, device=dev)
         loss = pkg.mse_with_mask_loss(pred, target.to(dev), mk) + hidden_w * (hidden * R.to(dev)).sum()
-        gates = tht._hip_gates(pkg, m, pred, B, T, d, L)      # before backward frees the activation record
+        gates = tht._hip_gates(pkg, m, pred, B, T, d, L, bf16=lp)      # before backward frees the activation record
         loss.backward()
         masks = tht._library_masks(pkg, B, T, d, H, L, seed64, p, p_embed) if (p > 0 or p_embed > 0) else None
         params = {k: v.double().clone().requires_grad_("pos_embedding" not in k) for k, v in sd.items()}

@@ -38,7 +38,7 @@ EXPORTS = ("vs_abi_version", "vs_last_error", "vs_weights_pack", "vs_weights_fre
            "vs_attention_f32", "vs_attention_bf16", "vs_attention_f16x3", "vs_linear_residual_layernorm_f32",
            "vs_linear_bf16", "vs_linear_residual_layernorm_bf16", "vs_linear_f16x3",
            "vs_linear_residual_layernorm_f16x3", "vs_mlp_block_bf16",
-           "vs_linear_bf16_operands", "vs_qkv_proj_bf16_operands", "vs_to_bf16",
+           "vs_linear_bf16_operands", "vs_qkv_proj_bf16_operands", "vs_to_bf16", "vs_linear_bf16_a16",
            "vs_profile_enable", "vs_profile_collect", "vs_stage_name")
 # include/vs_eval.h
 EVAL_EXPORTS = ("vs_eval_upsample", "vs_eval_knapsack", "vs_eval_generate_summary", "vs_eval_fscore",
@@ -217,6 +217,8 @@ def load() -> C.CDLL:
         lib.vs_linear_bf16_operands.argtypes = [C.c_void_p] * 4 + [C.c_int32] * 5 + [C.c_void_p]
         lib.vs_qkv_proj_bf16_operands.restype = C.c_int
         lib.vs_qkv_proj_bf16_operands.argtypes = [C.c_void_p] * 4 + [C.c_int32] * 5 + [C.c_void_p]
+        lib.vs_linear_bf16_a16.restype = C.c_int
+        lib.vs_linear_bf16_a16.argtypes = [C.c_void_p] * 4 + [C.c_int32] * 3 + [C.c_void_p, C.c_void_p]
         lib.vs_to_bf16.restype = C.c_int
         lib.vs_to_bf16.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         lib.vs_linear_residual_layernorm_bf16.restype = C.c_int

@@ -65,6 +65,11 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 // the hazard recogniser must see this instruction - it needs a wait state after a v_exp_f32 (trans unit)
 // producing its input, and an asm statement does not get one (measured: wrong products).
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+// Bit pattern of a float / float of a bit pattern, through a by-value parameter ON PURPOSE: this hipcc (ROCm 7.2) compiles
+// `__builtin_bit_cast(unsigned, vec[k])` on an ext-vector ELEMENT as if k were 0 (seen as `load <1 x i32>` + splat in the
+// IR: the second dword of an 8-byte load was never fetched).  A scalar copy first is compiled correctly.
+__device__ __forceinline__ unsigned f32_bits(float x) { return __builtin_bit_cast(unsigned, x); }
+__device__ __forceinline__ float bits_f32(unsigned x) { return __builtin_bit_cast(float, x); }
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
     const f32x2 f = {lo, hi};

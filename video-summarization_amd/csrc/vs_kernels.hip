@@ -67,12 +67,16 @@ __device__ __forceinline__ unsigned long long stamp() { return vs_stamp(); }
 // waves, half the latency of the global loads that were issued at its start (measured: 3 255 cycles per k-tile).  KW = 64
 // (K % 64 == 0) doubles the distance between a load and its use and halves the barriers; the LDS rows (64 bf16 + 16 B pad)
 // then have the fp32 layout's 144-byte stride.
-template <int EPI, int NWM = 2, int DIAG = 0, int NJ = 2, int PREC = 0, int C16 = 0, int KW = 32>     // DIAG (tools/diag_gemm.py only) 2: epilogue skipped (wrong output) + per-wave cycles/wall clock; 1, 3: the same with the epilogue
+// A16 (PREC 1 only; training path's bf16 storage of the MLP hidden tensor and of its gradient): A is bf16 in memory - its
+// 8-byte pieces go into the LDS image as they are.  With C16, EPI_GATE's gate tensor (`pe`) is bf16 as well.
+template <int EPI, int NWM = 2, int DIAG = 0, int NJ = 2, int PREC = 0, int C16 = 0, int KW = 32, int A16 = 0>     // DIAG (tools/diag_gemm.py only) 2: epilogue skipped (wrong output) + per-wave cycles/wall clock; 1, 3: the same with the epilogue
 __global__ __launch_bounds__(128 * NWM, 2) void gemm_nt_128(
     const float *__restrict__ A, const float *__restrict__ W, const float *__restrict__ bias,
     float *__restrict__ C, int M, int N, int K, const float *__restrict__ pe, int T, int H, int dh,
     unsigned long long *__restrict__ diag = nullptr, EpiArgs ea = EpiArgs{0ull, 0u, 0.f, 0.f}) {
     static_assert(KW == 32 || (KW == 64 && PREC == 1), "64-wide k-tiles exist for the bf16 operands only");
+    static_assert(A16 == 0 || PREC == 1, "bf16-stored A belongs to the bf16 mode");
+    typedef unsigned short a16_t;
     constexpr int BM = 64 * NWM, BN = 64 * NJ, BK = KW, LD = 36;
     constexpr int NT = 128 * NWM;                       // threads
     constexpr int F4R = BK / 4;                         // float4 per k-tile row
@@ -109,7 +113,7 @@ __global__ __launch_bounds__(128 * NWM, 2) void gemm_nt_128(
 #pragma unroll
         for (int i = 0; i < LA; ++i) {
             int ar = nx_m0 + lrow + RS * i; ar = ar < M ? ar : M - 1;
-            aptr[i] = A + (size_t)ar * K + lc4;
+            aptr[i] = A16 ? (const float *)((const a16_t *)A + (size_t)ar * K + lc4) : A + (size_t)ar * K + lc4;
         }
 #pragma unroll
         for (int i = 0; i < LW; ++i) {
@@ -124,6 +128,14 @@ __global__ __launch_bounds__(128 * NWM, 2) void gemm_nt_128(
         }
     };
     f32x4 pa[LA], pw[LW];
+    // (A16: a piece is 4 bf16 = the first two dwords of pa[i])
+    auto load_a = [&](int i, int koff) __attribute__((always_inline)) {
+        if constexpr (A16 != 0) {
+            const f32x2 v = *(const f32x2 *)((const a16_t *)aptr[i] + koff);      // 8 bytes, moved as they are
+            pa[i][0] = v[0]; pa[i][1] = v[1];
+        } else
+            pa[i] = *(const f32x4 *)(aptr[i] + koff);
+    };
     constexpr int LDB = BK == 64 ? 36 : 20;             // BF: LDS row stride in floats (32 bf16 + pad = 80 B | 64 bf16 + pad = 144 B)
     auto stage = [&](int buf) __attribute__((always_inline)) {
         float *As = smem + buf * (BM + BN) * LD, *Ws = As + BM * LD;
@@ -146,7 +158,9 @@ __global__ __launch_bounds__(128 * NWM, 2) void gemm_nt_128(
         } else if constexpr (PREC == 1) {
 #pragma unroll
             for (int i = 0; i < LA; ++i) {
-                u32x2 u; u[0] = pack_bf16(pa[i][0], pa[i][1]); u[1] = pack_bf16(pa[i][2], pa[i][3]);
+                u32x2 u;
+                if constexpr (A16 != 0) { u[0] = f32_bits(pa[i][0]); u[1] = f32_bits(pa[i][1]); }
+                else { u[0] = pack_bf16(pa[i][0], pa[i][1]); u[1] = pack_bf16(pa[i][2], pa[i][3]); }
                 *(u32x2 *)&As[(lrow + RS * i) * LDB + lc4 / 2] = u;
             }
 #pragma unroll
@@ -210,7 +224,7 @@ __global__ __launch_bounds__(128 * NWM, 2) void gemm_nt_128(
             const float *ap = As + (64 * wr + r) * LDB + 4 * h;
             const float *wp = Ws + (32 * NJ * wc + r) * LDB + 4 * h;
 #pragma unroll
-            for (int i = 0; i < LA; ++i) pa[i] = *(const f32x4 *)(aptr[i] + koff);
+            for (int i = 0; i < LA; ++i) load_a(i, koff);
 #pragma unroll
             for (int i = 0; i < LW; ++i) pw[i] = *(const f32x4 *)(wptr[i] + koff);
 #pragma unroll
@@ -281,7 +295,7 @@ __global__ __launch_bounds__(128 * NWM, 2) void gemm_nt_128(
 
     set_tile(0);
 #pragma unroll
-    for (int i = 0; i < LA; ++i) pa[i] = *(const f32x4 *)aptr[i];
+    for (int i = 0; i < LA; ++i) load_a(i, 0);
 #pragma unroll
     for (int i = 0; i < LW; ++i) pw[i] = *(const f32x4 *)wptr[i];
     stage(0);
@@ -367,9 +381,15 @@ __global__ __launch_bounds__(128 * NWM, 2) void gemm_nt_128(
                             for (int e = 0; e < 4; ++e) v[e] += pv[e];
                         }
                         if (EPI == EPI_GATE) {
+                            if constexpr (C16 != 0) {       // bf16-stored activation: > 0 <=> its 16 bits are a positive integer
+                                const u32x2 g2 = *(const u32x2 *)((const a16_t *)pe + (size_t)row * N + c32 + tc4);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[e] = (short)(g2[e >> 1] >> (16 * (e & 1))) > 0 ? v[e] * ea.scale : 0.f;
+                            } else {
                             const f32x4 gv = *(const f32x4 *)(pe + (size_t)row * N + c32 + tc4);
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] = gv[e] > 0.f ? v[e] * ea.scale : 0.f;
+                            }
                         }
                         if (EPI == EPI_RELU_DROP) {
                             const DropSite dsite = drop_site(ea.seed, ea.site, ea.p);
@@ -1836,6 +1856,31 @@ static int launch_gemm(const float *A, const float *W, const float *Wf, const fl
         VSK_CHECK_LAUNCH();
         return 0;
     }
+    if constexpr (EPI == EPI_RELU_DROP || EPI == EPI_GATE) {
+        if (bf16 == (1 | VSK_STORE16)) {      // training path, bf16 storage of the MLP hidden tensor / of its gradient
+            const bool big = N % 256 == 0 && M > 128;
+            const int blocks = big ? persistent_blocks(((M + 255) / 256) * (N / 256), 1) : persistent_blocks(((M + 127) / 128) * ((N + 127) / 128), 2);
+            if (blocks < 0) return (int)hipErrorInvalidDevice;
+            if (big && kw64) hipLaunchKernelGGL((gemm_nt_128<EPI, 4, 0, 4, 1, 1, 64>), dim3(blocks), dim3(512), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr, ea);
+            else if (big) hipLaunchKernelGGL((gemm_nt_128<EPI, 4, 0, 4, 1, 1>), dim3(blocks), dim3(512), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr, ea);
+            else hipLaunchKernelGGL((gemm_nt_128<EPI, 2, 0, 2, 1, 1>), dim3(blocks), dim3(256), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr, ea);
+            VSK_CHECK_LAUNCH();
+            return 0;
+        }
+    }
+    if constexpr (EPI == EPI_BIAS || EPI == EPI_PE) {
+        if (bf16 == (1 | VSK_A16)) {          // training path: A (the bf16-stored hidden tensor / its gradient) read as bf16
+            const bool big = N % 256 == 0 && M > 128;
+            const int blocks = big ? persistent_blocks(((M + 255) / 256) * (N / 256), 1) : persistent_blocks(((M + 127) / 128) * ((N + 127) / 128), 2);
+            if (blocks < 0) return (int)hipErrorInvalidDevice;
+            if (big && kw64) hipLaunchKernelGGL((gemm_nt_128<EPI, 4, 0, 4, 1, 0, 64, 1>), dim3(blocks), dim3(512), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr, ea);
+            else if (big) hipLaunchKernelGGL((gemm_nt_128<EPI, 4, 0, 4, 1, 0, 32, 1>), dim3(blocks), dim3(512), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr, ea);
+            else hipLaunchKernelGGL((gemm_nt_128<EPI, 2, 0, 2, 1, 0, 32, 1>), dim3(blocks), dim3(256), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr, ea);
+            VSK_CHECK_LAUNCH();
+            return 0;
+        }
+    }
+    if (bf16 & VSK_A16) return -1;           // only the two consumers above read a bf16-stored A
     if constexpr (EPI == EPI_RELU || EPI == EPI_QKV) {
         if (bf16 == (1 | VSK_STORE16)) {      // bf16 matrix pipe, C stored as bf16 (fc1, QKV)
             if (N % 256 == 0 && M > 128) {

@@ -763,6 +763,15 @@ int vs_to_bf16(const float *src, void *dst16, size_t n, void *stream) {
     return VS_OK;
 }
 
+int vs_linear_bf16_a16(const void *A16, const float *W, const float *bias, float *C, int32_t M, int32_t N, int32_t K,
+                       const float *pe, void *stream) {
+    if (!A16 || !W || !bias || !C) return fail(VS_ERR_INVALID, "NULL pointer");
+    if (M <= 0 || N <= 0 || N % 32 || K <= 0 || K % 32)
+        return fail(VS_ERR_INVALID, "M=%d N=%d K=%d unsupported (N, K multiples of 32)", M, N, K);
+    VS_LAUNCH(vsk_linear((const float *)A16, W, nullptr, bias, C, M, N, K, 0, pe, M, 1 | VSK_A16, (hipStream_t)stream));
+    return VS_OK;
+}
+
 int vs_linear_f32(const float *A, const float *W, const float *bias, float *C, int32_t M, int32_t N,
                   int32_t K, int32_t relu, const float *pe, int32_t T, void *stream) {
     return linear_entry(A, W, bias, C, M, N, K, relu, pe, T, 0, stream);

@@ -219,7 +219,10 @@ int vs_train_forward(const vs_weights *w, const float *x, const uint8_t *key_pad
     // ... and (VS_TRAIN_FLAG_BF16_ATTENTION) the attention products of the forward and the backward, head dim 32 / 64
     const bool lpa = drop && (drop->flags & VS_TRAIN_FLAG_BF16_ATTENTION) && (long long)B * T > vsk_options().lp_min_rows &&
                      vst_attention_bf16_supported(w->desc.d_model / w->desc.num_heads);
-    const bool qkv16 = lp && lpa;                                  // q / k / v of the record are bf16 planes
+    // bf16 STORAGE of the tensors that are only ever bf16 matrix operands (VS_LP_STORE32 = 1 keeps them fp32: an A/B switch -
+    // the kernels round the fp32-stored values to the same bf16, so every result is bit-identical either way)
+    const bool qkv16 = lp && lpa && !vsk_options().lp_store32;     // q / k / v of the record are bf16 planes
+    const bool h16 = lp && !vsk_options().lp_store32;              // ... and so is the MLP hidden tensor (and, in the backward, its gradient)
     const size_t kvs = qkv16 ? (size_t)B * T * w->desc.d_model / 2 : (size_t)B * T * w->desc.d_model;     // floats between the planes
     const unsigned long long seed = drop ? drop->seed : 0ull;
     const float scale = 1.0f / sqrtf((float)d);              // simnet.py:126: d_model ** -0.5
@@ -254,12 +257,15 @@ int vs_train_forward(const vs_weights *w, const float *x, const uint8_t *key_pad
         VST_LAUNCH(vsk_linear(sv + A.att, w->p(P.wo), w->p(P.f_wo), w->p(P.bo), a, M, d, d, 0, nullptr, 1, lp, st));      // :163
         VST_LAUNCH(vst_rows_fwd(a, h_in, w->p(P.ln1g), w->p(P.ln1b), sv + A.z1, sv + A.y1, nullptr, sv + A.st1, M, d,
                                 seed, VS_SITE_LAYER(l, VS_SITE_DROP1), p, nullptr, nullptr, 0, nullptr, st));              // :107
+        // bf16 GEMMs: the MLP hidden tensor (post ReLU, post dropout) is only ever a matrix operand or a sign - it is written
+        // and saved as bf16 (h16), and fc2, its weight gradient and the backward's gate read it as such
         if (p > 0.f)        // fc1 + ReLU + mlp.dropout in one GEMM epilogue (:181)
             VST_LAUNCH(vsk_linear_relu_dropout(sv + A.y1, w->p(P.w1), w->p(P.f_w1), w->p(P.b1), sv + A.ffn, M, 4 * d, d, seed,
-                                               VS_SITE_LAYER(l, VS_SITE_MLP), p, st, lp));
+                                               VS_SITE_LAYER(l, VS_SITE_MLP), p, st, h16 ? (1 | VSK_STORE16) : lp));
         else
-            VST_LAUNCH(vsk_linear(sv + A.y1, w->p(P.w1), w->p(P.f_w1), w->p(P.b1), sv + A.ffn, M, 4 * d, d, 1, nullptr, 1, lp, st));
-        VST_LAUNCH(vsk_linear(sv + A.ffn, w->p(P.w2), w->p(P.f_w2), w->p(P.b2), a, M, d, 4 * d, 0, nullptr, 1, lp, st));  // :182
+            VST_LAUNCH(vsk_linear(sv + A.y1, w->p(P.w1), w->p(P.f_w1), w->p(P.b1), sv + A.ffn, M, 4 * d, d, 1, nullptr, 1,
+                                  h16 ? (1 | VSK_STORE16) : lp, st));
+        VST_LAUNCH(vsk_linear(sv + A.ffn, w->p(P.w2), w->p(P.f_w2), w->p(P.b2), a, M, d, 4 * d, 0, nullptr, 1, h16 ? (1 | VSK_A16) : lp, st));  // :182
         VST_LAUNCH(vst_rows_fwd(a, sv + A.y1, w->p(P.ln2g), w->p(P.ln2b), sv + A.z2, sv + A.y2, last ? hidden : nullptr,
                                 sv + A.st2, M, d, seed, VS_SITE_LAYER(l, VS_SITE_DROP2), p,
                                 last ? w->p(w->final_w) : nullptr, last ? w->p(w->final_b) : nullptr, D.num_classes,
@@ -297,7 +303,10 @@ int vs_train_backward(vs_weights *w, const float *x, const uint8_t *key_pad_mask
     // ... and (VS_TRAIN_FLAG_BF16_ATTENTION) the attention products of the forward and the backward, head dim 32 / 64
     const bool lpa = drop && (drop->flags & VS_TRAIN_FLAG_BF16_ATTENTION) && (long long)B * T > vsk_options().lp_min_rows &&
                      vst_attention_bf16_supported(w->desc.d_model / w->desc.num_heads);
-    const bool qkv16 = lp && lpa;                                  // q / k / v of the record are bf16 planes
+    // bf16 STORAGE of the tensors that are only ever bf16 matrix operands (VS_LP_STORE32 = 1 keeps them fp32: an A/B switch -
+    // the kernels round the fp32-stored values to the same bf16, so every result is bit-identical either way)
+    const bool qkv16 = lp && lpa && !vsk_options().lp_store32;     // q / k / v of the record are bf16 planes
+    const bool h16 = lp && !vsk_options().lp_store32;              // ... and so is the MLP hidden tensor (and, in the backward, its gradient)
     const size_t kvs = qkv16 ? (size_t)B * T * w->desc.d_model / 2 : (size_t)B * T * w->desc.d_model;     // floats between the planes
     const unsigned long long seed = drop ? drop->seed : 0ull;
     const float scale = 1.0f / sqrtf((float)d);
@@ -338,13 +347,18 @@ int vs_train_backward(vs_weights *w, const float *x, const uint8_t *key_pad_mask
         VST_LAUNCH(vst_reduce_rows(part, nblk, 2, d, G.ln2_g, G.ln2_b, nullptr, 1, st));
         const float *dm = p > 0.f ? dbr : dz;
         // mlp.fc2: weight/bias gradient, then the gradient of its input
-        VST_LAUNCH(vst_wgrad(dm, d, sv + A.ffn, 4 * d, M, d, 4 * d, G.w2, nullptr, nullptr, G.b2, nullptr, nullptr, d, wg, st, lp));
+        VST_LAUNCH(vst_wgrad(dm, d, sv + A.ffn, 4 * d, M, d, 4 * d, G.w2, nullptr, nullptr, G.b2, nullptr, nullptr, d, wg, st,
+                             h16 ? (1 | VST_WGRAD_X16) : lp));
         // ... through mlp.dropout + ReLU in the GEMM's epilogue: the saved activation is > 0 exactly where both let
         // the value through
-        VST_LAUNCH(vsk_linear_gate(dm, w->tp(Q.t_w2), w->tp(Q.tf_w2), zeros, sv + A.ffn, p > 0.f ? 1.0f / (1.0f - p) : 1.0f, gf, M, 4 * d, d, st, lp));
-        VST_LAUNCH(vst_wgrad(gf, 4 * d, sv + A.y1, d, M, 4 * d, d, G.w1, nullptr, nullptr, G.b1, nullptr, nullptr, 4 * d, wg, st, lp));
+        // (h16: the gate tensor is the bf16-stored activation, and the gated gradient gf - again only ever a matrix operand -
+        // is written as bf16 too)
+        VST_LAUNCH(vsk_linear_gate(dm, w->tp(Q.t_w2), w->tp(Q.tf_w2), zeros, sv + A.ffn, p > 0.f ? 1.0f / (1.0f - p) : 1.0f, gf, M, 4 * d, d, st,
+                                   h16 ? (1 | VSK_STORE16) : lp));
+        VST_LAUNCH(vst_wgrad(gf, 4 * d, sv + A.y1, d, M, 4 * d, d, G.w1, nullptr, nullptr, G.b1, nullptr, nullptr, 4 * d, wg, st,
+                             h16 ? (1 | VST_WGRAD_Y16) : lp));
         // d y1 = dz2 (residual) + d(fc1 input): the residual rides in the GEMM epilogue
-        VST_LAUNCH(vsk_linear(gf, w->tp(Q.t_w1), w->tp(Q.tf_w1), zeros, dy1, M, d, 4 * d, 0, dz, M, lp, st));
+        VST_LAUNCH(vsk_linear(gf, w->tp(Q.t_w1), w->tp(Q.tf_w1), zeros, dy1, M, d, 4 * d, 0, dz, M, h16 ? (1 | VSK_A16) : lp, st));
         // norm1; d(feature_projection output) = dropout1 mask on dz1
         VST_LAUNCH(vst_ln_bwd(dy1, nullptr, nullptr, 0, sv + A.z1, sv + A.st1, w->p(P.ln1g), dz, p > 0.f ? dbr : nullptr, part,
                               M, d, seed, VS_SITE_LAYER(l, VS_SITE_DROP1), p, st));

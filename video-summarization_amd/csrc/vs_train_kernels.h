@@ -26,6 +26,7 @@ int vst_head_rowdot(const float *dO, const float *O, float *delta, int M, int T,
 int vst_weighted_colsum(const float *w, int ws, const float *Y, float *part, int M, int d, hipStream_t st);
 // dW[N,K] = dY[M,N]^T X[M,K] (+ db = column sums of dY when db0 != NULL); rows of the result are dealt to up to three
 // destination tensors of rows_per_dest rows; work >= vst_wgrad_workspace_floats(M, N, K) floats
+enum { VST_WGRAD_Y16 = 2, VST_WGRAD_X16 = 4 };     // vst_wgrad prec = 1 | flag: dY / X is stored as bf16
 int vst_wgrad_splits(int M, int N, int K);
 size_t vst_wgrad_workspace_floats(int M, int N, int K);
 int vst_wgrad(const float *dY, int ldy, const float *X, int ldx, int M, int N, int K, float *dW0, float *dW1, float *dW2,

@@ -379,6 +379,8 @@ __global__ __launch_bounds__(256) void wgrad_tn(const float *__restrict__ dY, in
 // were read tiles_k + tiles_n times from L2 - 32 flop per byte, ~100 us per call at 65 536 rows whatever the shape, the
 // L2 -> CU rate (~10 TB/s) and not HBM being the bound.  256 x 256 tiles halve those bytes (64 flop/B).
 // ------------------------------------------------------------------------------------------
+// Y16 / X16: that operand is already bf16 in memory (the MLP hidden tensor and its gradient in the bf16 training mode).
+template <bool Y16, bool X16>
 __global__ __launch_bounds__(512, 2) void wgrad_tn_bf16(const float *__restrict__ dY, int ldy, const float *__restrict__ X, int ldx,
                                                         float *__restrict__ partW, float *__restrict__ partB, int M, int N, int K,
                                                         int rows_per_split) {
@@ -417,23 +419,38 @@ __global__ __launch_bounds__(512, 2) void wgrad_tn_bf16(const float *__restrict_
     f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
     f32x4 py[4], px[4];
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    // a bf16-stored operand: 4 elements = 8 bytes, parked in the first two dwords of its float4 slot
+    auto ld16 = [](const float *base, size_t off) __attribute__((always_inline)) {
+        const f32x2 v = *(const f32x2 *)((const h16 *)base + off);
+        return f32x4{v[0], v[1], 0.f, 0.f};
+    };
     auto gload = [&](int m0) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int m = m0 + srow + 8 * i;
-            py[i] = (m < m_end && n_ok) ? *(const f32x4 *)(dY + (size_t)m * ldy + n0 + sc4) : zero4;
-            px[i] = (m < m_end && k_ok) ? *(const f32x4 *)(X + (size_t)m * ldx + k0 + sc4) : zero4;
+            if constexpr (Y16) py[i] = (m < m_end && n_ok) ? ld16(dY, (size_t)m * ldy + n0 + sc4) : zero4;
+            else py[i] = (m < m_end && n_ok) ? *(const f32x4 *)(dY + (size_t)m * ldy + n0 + sc4) : zero4;
+            if constexpr (X16) px[i] = (m < m_end && k_ok) ? ld16(X, (size_t)m * ldx + k0 + sc4) : zero4;
+            else px[i] = (m < m_end && k_ok) ? *(const f32x4 *)(X + (size_t)m * ldx + k0 + sc4) : zero4;
         }
     };
     auto stage = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             u32x2 uy, ux;
-            uy[0] = pack_bf16(py[i][0], py[i][1]); uy[1] = pack_bf16(py[i][2], py[i][3]);
-            ux[0] = pack_bf16(px[i][0], px[i][1]); ux[1] = pack_bf16(px[i][2], px[i][3]);
+            if constexpr (Y16) {
+                const unsigned y0 = f32_bits(py[i][0]), y1 = f32_bits(py[i][1]);
+                uy[0] = y0; uy[1] = y1;
+                // the bias gradient sums the stored (bf16) values
+                bsum += f32x4{bits_f32(y0 << 16), bits_f32(y0 & 0xffff0000u), bits_f32(y1 << 16), bits_f32(y1 & 0xffff0000u)};
+            } else {
+                uy[0] = pack_bf16(py[i][0], py[i][1]); uy[1] = pack_bf16(py[i][2], py[i][3]);
+                bsum += py[i];
+            }
+            if constexpr (X16) { ux[0] = f32_bits(px[i][0]); ux[1] = f32_bits(px[i][1]); }
+            else { ux[0] = pack_bf16(px[i][0], px[i][1]); ux[1] = pack_bf16(px[i][2], px[i][3]); }
             *(u32x2 *)((char *)&Ys[buf][0] + st_off + 8 * i * ROWB) = uy;
             *(u32x2 *)((char *)&Xs[buf][0] + st_off + 8 * i * ROWB) = ux;
-            bsum += py[i];
         }
     };
     auto frag = [&](const h16 *tile, int off) __attribute__((always_inline)) -> bf16x8 {
@@ -756,15 +773,19 @@ size_t vst_wgrad_workspace_floats(int M, int N, int K) {       // room for eithe
 int vst_wgrad(const float *dY, int ldy, const float *X, int ldx, int M, int N, int K, float *dW0, float *dW1, float *dW2,
               float *db0, float *db1, float *db2, int rows_per_dest, float *work, hipStream_t st, int prec) {
     if (N % 4 || K % 4 || ldy % 4 || ldx % 4) return -1;
-    const int S = prec == 1 ? wgrad_splits_bf16(M, N, K) : vst_wgrad_splits(M, N, K);
+    const int S = (prec & 1) ? wgrad_splits_bf16(M, N, K) : vst_wgrad_splits(M, N, K);
     int rps = (M + S - 1) / S;
     rps = (rps + 31) / 32 * 32;
     float *partW = work, *partB = work + (size_t)S * N * K;
     const dim3 grid(((N + 127) / 128) * ((K + 127) / 128), S);
-    if (prec == 1)
-        hipLaunchKernelGGL(wgrad_tn_bf16, dim3(((N + 255) / 256) * ((K + 255) / 256), S), dim3(512), 0, st, dY, ldy, X, ldx, partW,
-                           db0 ? partB : nullptr, M, N, K, rps);
-    else
+    if (prec & 1) {       // + VST_WGRAD_Y16 / VST_WGRAD_X16: that operand is stored as bf16 (ld counted in elements)
+        const dim3 g16(((N + 255) / 256) * ((K + 255) / 256), S);
+        float *pb = db0 ? partB : nullptr;
+        if ((prec & VST_WGRAD_Y16) && (prec & VST_WGRAD_X16)) return -1;
+        if (prec & VST_WGRAD_Y16) hipLaunchKernelGGL((wgrad_tn_bf16<true, false>), g16, dim3(512), 0, st, dY, ldy, X, ldx, partW, pb, M, N, K, rps);
+        else if (prec & VST_WGRAD_X16) hipLaunchKernelGGL((wgrad_tn_bf16<false, true>), g16, dim3(512), 0, st, dY, ldy, X, ldx, partW, pb, M, N, K, rps);
+        else hipLaunchKernelGGL((wgrad_tn_bf16<false, false>), g16, dim3(512), 0, st, dY, ldy, X, ldx, partW, pb, M, N, K, rps);
+    } else
         hipLaunchKernelGGL(wgrad_tn, grid, dim3(256), 0, st, dY, ldy, X, ldx, partW, db0 ? partB : nullptr, M, N, K, rps);
     VSK_CHECK_LAUNCH();
     {
