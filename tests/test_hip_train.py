@@ -344,8 +344,9 @@ def test_bf16_training_storage_forms_agree_bit_for_bit(vsa, lp_train_everywhere,
     """The bf16 training mode STORES the tensors that are only ever bf16 matrix operands as bf16 (q times scale * log2 e, k, v;
     the MLP hidden tensor; the gated gradient of that tensor) - their producers' epilogues round them, their consumers read
     them as they are.  VS_LP_STORE32 = 1 keeps them fp32, rounded by every consumer on its way into LDS: the same bf16 values,
-    so logits, hidden states and every gradient agree BIT for bit - except fc1.bias, a column sum of the gated gradient,
-    which sums the stored (rounded) values in one form and the fp32 values in the other."""
+    so logits, hidden states and every gradient agree BIT for bit - except the bias gradients that are column sums of a
+    bf16-stored gradient (fc1.bias: the gated hidden gradient; q / k / v bias: dq | dk | dv of the attention backward),
+    which sum the stored (rounded) values in one form and the fp32 values in the other."""
     res = {}
     try:
         for store32 in (1, 0):
@@ -362,8 +363,10 @@ def test_bf16_training_storage_forms_agree_bit_for_bit(vsa, lp_train_everywhere,
     finally:
         vsa._lib.set_option("VS_LP_STORE32", -1)
     for (n, a), (_n, b) in zip(res[1], res[0]):
-        if n.endswith("mlp.fc1.bias"):
-            assert (a - b).abs().max().item() <= 1e-3 * a.abs().max().item(), n
+        if n.endswith("mlp.fc1.bias") or n.endswith(".sa.q.bias") or n.endswith(".sa.v.bias"):
+            assert (a - b).abs().max().item() <= 2e-3 * a.abs().max().item(), n
+        elif n.endswith(".sa.k.bias"):          # analytically zero
+            assert max(a.abs().max().item(), b.abs().max().item()) <= tol.TRAIN_LP_ZERO_ATOL, n
         else:
             assert torch.equal(a, b), n
 

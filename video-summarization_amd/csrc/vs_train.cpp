@@ -372,15 +372,17 @@ int vs_train_backward(vs_weights *w, const float *x, const uint8_t *key_pad_mask
         if (lpa)
             VST_LAUNCH(vst_attention_bwd_bf16(qkv, qkv + kvs, qkv + 2 * kvs, key_pad_mask, datt, sv + A.lse,
                                               delta, dqkv, B, H, T, d / H, scale, p,
-                                              p > 0.f ? (const unsigned *)(sv + A.dbits) : nullptr, st, qkv16));
+                                              p > 0.f ? (const unsigned *)(sv + A.dbits) : nullptr, st, qkv16, qkv16));
         else
         VST_LAUNCH(vst_attention_bwd(qkv, qkv + (size_t)M * d, qkv + 2 * (size_t)M * d, key_pad_mask, datt, sv + A.lse, delta,
                                      dqkv, B, H, T, d / H, scale, seed, VS_SITE_LAYER(l, VS_SITE_ATTN), p, st,
                                      p > 0.f ? (const unsigned *)(sv + A.dbits) : nullptr));
         // q / k / v projections: one [3d, d] weight gradient dealt to the three parameters
-        VST_LAUNCH(vst_wgrad(dqkv, 3 * d, h_in, d, M, 3 * d, d, G.wq, G.wk, G.wv, G.bq, G.bk, G.bv, d, wg, st, lp));
+        // (qkv16: dq | dk | dv arrive as bf16 - only ever matrix operands of the two GEMMs below)
+        VST_LAUNCH(vst_wgrad(dqkv, 3 * d, h_in, d, M, 3 * d, d, G.wq, G.wk, G.wv, G.bq, G.bk, G.bv, d, wg, st,
+                             qkv16 ? (1 | VST_WGRAD_Y16) : lp));
         // gradient of the layer input = dz1 (residual) + dqkv Wqkv
-        VST_LAUNCH(vsk_linear(dqkv, w->tp(Q.t_wqkv), w->tp(Q.tf_wqkv), zeros, g[cur ^ 1], M, d, 3 * d, 0, dz, M, lp, st));
+        VST_LAUNCH(vsk_linear(dqkv, w->tp(Q.t_wqkv), w->tp(Q.tf_wqkv), zeros, g[cur ^ 1], M, d, 3 * d, 0, dz, M, qkv16 ? (1 | VSK_A16) : lp, st));
         cur ^= 1;
     }
     // Embedding (simnet.py:211, 237-238): dropout(sparsity) mask, then the Linear

@@ -280,8 +280,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_train_bf16(
 // ------------------------------------------------------------------------------------------
 // backward, queries own: dQ
 // ------------------------------------------------------------------------------------------
-template <int DH, bool DROP, bool IN16>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16(
+template <int DH, bool DROP, bool IN16, bool OUT16>       // OUT16: dq | dk | dv written as bf16 [M][3 d] (their only readers -
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16(     // the QKV weight gradient and input gradient - are bf16 GEMMs)
     const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
     const uint8_t *__restrict__ mask, const float *__restrict__ dO, const float *__restrict__ lse2,
     const float *__restrict__ delta, float *__restrict__ dqkv, int H, int T, float scale, float drop_scale,
@@ -355,6 +355,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16(
     }
     if (qi < T) {
         float *op = dqkv + ((size_t)b * T + qi) * (3 * d) + hd * DH;
+        h16 *op16 = (h16 *)dqkv + ((size_t)b * T + qi) * (3 * d) + hd * DH;
 #pragma unroll
         for (int db = 0; db < ND; ++db)
 #pragma unroll
@@ -362,7 +363,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16(
                 f32x4 w;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) w[e] = acc[db][4 * tg + e] * scale;
-                *(f32x4 *)(op + 32 * db + 8 * tg + 4 * h) = w;
+                if constexpr (OUT16) *(u32x2 *)(op16 + 32 * db + 8 * tg + 4 * h) = u32x2{pack_bf16(w[0], w[1]), pack_bf16(w[2], w[3])};
+                else *(f32x4 *)(op + 32 * db + 8 * tg + 4 * h) = w;
             }
     }
 }
@@ -370,7 +372,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16(
 // ------------------------------------------------------------------------------------------
 // backward, keys own: dK and dV
 // ------------------------------------------------------------------------------------------
-template <int DH, bool DROP, bool IN16>
+template <int DH, bool DROP, bool IN16, bool OUT16>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_bf16(
     const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
     const uint8_t *__restrict__ mask, const float *__restrict__ dO, const float *__restrict__ lse2,
@@ -472,6 +474,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_bf16(
     }
     if (ki < T) {
         float *op = dqkv + ((size_t)b * T + ki) * (3 * d) + hd * DH;
+        h16 *op16 = (h16 *)dqkv + ((size_t)b * T + ki) * (3 * d) + hd * DH;
         const float ln2 = 0.6931471805599453f;       // dK = scale * dS^T Q = (dS^T Qs) / log2(e)
 #pragma unroll
         for (int db = 0; db < ND; ++db)
@@ -480,8 +483,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_bf16(
                 f32x4 wk, wv;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { wk[e] = kmasked ? 0.f : dk[db][4 * tg + e] * ln2; wv[e] = kmasked ? 0.f : dv[db][4 * tg + e]; }
+                if constexpr (OUT16) {
+                    *(u32x2 *)(op16 + d + 32 * db + 8 * tg + 4 * h) = u32x2{pack_bf16(wk[0], wk[1]), pack_bf16(wk[2], wk[3])};
+                    *(u32x2 *)(op16 + 2 * d + 32 * db + 8 * tg + 4 * h) = u32x2{pack_bf16(wv[0], wv[1]), pack_bf16(wv[2], wv[3])};
+                } else {
                 *(f32x4 *)(op + d + 32 * db + 8 * tg + 4 * h) = wk;
                 *(f32x4 *)(op + 2 * d + 32 * db + 8 * tg + 4 * h) = wv;
+                }
             }
     }
 }
@@ -522,15 +530,36 @@ int vst_attention_fwd_bf16(const float *q, const float *k, const float *v, const
     return 0;
 }
 
+#define VSTB_LAUNCH_B(KERNEL_, DH_, DROP_, IN16_, OUT16_, ...)                                                  \
+    do {                                                                                                        \
+        constexpr size_t lds_bytes_ = 2 * sizeof(TileB<DH_>);                                                   \
+        hipLaunchKernelGGL((KERNEL_<DH_, DROP_, IN16_, OUT16_>), grid, dim3(256), lds_bytes_, st, __VA_ARGS__); \
+    } while (0)
+#define VSTB_DISPATCH_B3(KERNEL_, DH_, DROP_, ...)                                                              \
+    do {                                                                                                        \
+        if (in16 && out16) VSTB_LAUNCH_B(KERNEL_, DH_, DROP_, true, true, __VA_ARGS__);                         \
+        else if (in16) VSTB_LAUNCH_B(KERNEL_, DH_, DROP_, true, false, __VA_ARGS__);                            \
+        else if (out16) VSTB_LAUNCH_B(KERNEL_, DH_, DROP_, false, true, __VA_ARGS__);                           \
+        else VSTB_LAUNCH_B(KERNEL_, DH_, DROP_, false, false, __VA_ARGS__);                                     \
+    } while (0)
+#define VSTB_DISPATCH_B(KERNEL_, ...)                                                                           \
+    do {                                                                                                        \
+        const bool drop = p > 0.f;                                                                              \
+        if (dh == 32) { if (drop) VSTB_DISPATCH_B3(KERNEL_, 32, true, __VA_ARGS__); else VSTB_DISPATCH_B3(KERNEL_, 32, false, __VA_ARGS__); } \
+        else if (dh == 64) { if (drop) VSTB_DISPATCH_B3(KERNEL_, 64, true, __VA_ARGS__); else VSTB_DISPATCH_B3(KERNEL_, 64, false, __VA_ARGS__); } \
+        else return -1;                                                                                         \
+    } while (0)
+
+// out16: dqkv is written as bf16 [M][3 d] (2-byte elements) instead of fp32
 int vst_attention_bwd_bf16(const float *q, const float *k, const float *v, const uint8_t *mask, const float *dO,
                            const float *lse2, const float *delta, float *dqkv, int B, int H, int T, int dh, float scale,
-                           float p, const unsigned *dbits, hipStream_t st, int in16) {
+                           float p, const unsigned *dbits, hipStream_t st, int in16, int out16) {
     if (p < 0.f || p >= 1.f || (p > 0.f && dbits == nullptr)) return -1;
     const float ds = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
     const dim3 grid(B * H * ((T + 127) / 128));
-    VSTB_DISPATCH(attn_bwd_dkdv_bf16, q, k, v, mask, dO, lse2, delta, dqkv, H, T, scale, ds, dbits, B * H);
+    VSTB_DISPATCH_B(attn_bwd_dkdv_bf16, q, k, v, mask, dO, lse2, delta, dqkv, H, T, scale, ds, dbits, B * H);
     VSK_CHECK_LAUNCH();
-    VSTB_DISPATCH(attn_bwd_dq_bf16, q, k, v, mask, dO, lse2, delta, dqkv, H, T, scale, ds, dbits);
+    VSTB_DISPATCH_B(attn_bwd_dq_bf16, q, k, v, mask, dO, lse2, delta, dqkv, H, T, scale, ds, dbits);
     VSK_CHECK_LAUNCH();
     return 0;
 }

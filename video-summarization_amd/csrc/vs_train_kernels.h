@@ -61,7 +61,7 @@ int vst_attention_fwd_bf16(const float *q, const float *k, const float *v, const
                            int B, int H, int T, int dh, float scale, float p, const unsigned *dbits, hipStream_t st, int in16 = 0);
 int vst_attention_bwd_bf16(const float *q, const float *k, const float *v, const uint8_t *mask, const float *dO,
                            const float *lse2, const float *delta, float *dqkv, int B, int H, int T, int dh, float scale,
-                           float p, const unsigned *dbits, hipStream_t st, int in16 = 0);      // in16: q (pre-scaled), k, v stored as bf16
+                           float p, const unsigned *dbits, hipStream_t st, int in16 = 0, int out16 = 0);      // in16: q (pre-scaled), k, v stored as bf16; out16: dqkv written as bf16
 // test hook: keep[b,h,i,j] (bytes) of the attention-weight dropout, exactly as the two kernels above draw it
 int vst_attention_dropout_mask(uint8_t *keep, int B, int H, int T, unsigned long long seed, unsigned site, float p,
                                hipStream_t st);
