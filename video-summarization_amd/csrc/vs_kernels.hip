@@ -1856,8 +1856,8 @@ static int launch_gemm(const float *A, const float *W, const float *Wf, const fl
         VSK_CHECK_LAUNCH();
         return 0;
     }
-    if constexpr (EPI == EPI_RELU_DROP || EPI == EPI_GATE) {
-        if (bf16 == (1 | VSK_STORE16)) {      // training path, bf16 storage of the MLP hidden tensor / of its gradient
+    if constexpr (EPI == EPI_RELU_DROP || EPI == EPI_GATE || EPI == EPI_BIAS) {
+        if (bf16 == (1 | VSK_STORE16)) {      // training path, bf16 storage of the MLP hidden tensor / of its gradient / of dO
             const bool big = N % 256 == 0 && M > 128;
             const int blocks = big ? persistent_blocks(((M + 255) / 256) * (N / 256), 1) : persistent_blocks(((M + 127) / 128) * ((N + 127) / 128), 2);
             if (blocks < 0) return (int)hipErrorInvalidDevice;

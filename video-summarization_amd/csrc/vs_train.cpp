@@ -365,10 +365,12 @@ int vs_train_backward(vs_weights *w, const float *x, const uint8_t *key_pad_mask
         VST_LAUNCH(vst_reduce_rows(part, nblk, 2, d, G.ln1_g, G.ln1_b, nullptr, 1, st));
         const float *da = p > 0.f ? dbr : dz;
         VST_LAUNCH(vst_wgrad(da, d, sv + A.att, d, M, d, d, G.wo, nullptr, nullptr, G.bo, nullptr, nullptr, d, wg, st, lp));
-        VST_LAUNCH(vsk_linear(da, w->tp(Q.t_wo), w->tp(Q.tf_wo), zeros, datt, M, d, d, 0, nullptr, 1, lp, st));
+        // (qkv16: d(attention output) is written as bf16 - the attention backward multiplies bf16 operands, and delta is then the
+        // row dot of the SAME rounded dO with the saved fp32 output)
+        VST_LAUNCH(vsk_linear(da, w->tp(Q.t_wo), w->tp(Q.tf_wo), zeros, datt, M, d, d, 0, nullptr, 1, qkv16 ? (1 | VSK_STORE16) : lp, st));
         // attention
         const float *qkv = sv + A.qkv;
-        VST_LAUNCH(vst_head_rowdot(datt, sv + A.att, delta, M, T, H, d / H, st));
+        VST_LAUNCH(vst_head_rowdot(datt, sv + A.att, delta, M, T, H, d / H, st, qkv16 ? 1 : lpa ? 2 : 0));
         if (lpa)
             VST_LAUNCH(vst_attention_bwd_bf16(qkv, qkv + kvs, qkv + 2 * kvs, key_pad_mask, datt, sv + A.lse,
                                               delta, dqkv, B, H, T, d / H, scale, p,
@@ -525,7 +527,7 @@ int vs_train_attention_backward_bf16(const float *q, const float *k, const float
     if (!q || !k || !v || !out || !d_out || !lse2 || !dqkv || !scratch) return failf(VS_ERR_INVALID, "NULL pointer");
     if (B <= 0 || H <= 0 || T <= 0) return failf(VS_ERR_INVALID, "B=%d H=%d T=%d", B, H, T);
     hipStream_t st = (hipStream_t)stream;
-    VST_LAUNCH(vst_head_rowdot(d_out, out, scratch, B * T, T, H, dh, st));
+    VST_LAUNCH(vst_head_rowdot(d_out, out, scratch, B * T, T, H, dh, st, 2));       // dO enters delta as the kernels see it: bf16
     VST_LAUNCH(vst_attention_bwd_bf16(q, k, v, key_pad_mask, d_out, lse2, scratch, dqkv, B, H, T, dh, scale, p,
                                       (const unsigned *)dbits, st, in16 ? 1 : 0));
     return VS_OK;

@@ -280,8 +280,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_train_bf16(
 // ------------------------------------------------------------------------------------------
 // backward, queries own: dQ
 // ------------------------------------------------------------------------------------------
-template <int DH, bool DROP, bool IN16, bool OUT16>       // OUT16: dq | dk | dv written as bf16 [M][3 d] (their only readers -
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16(     // the QKV weight gradient and input gradient - are bf16 GEMMs)
+// OUT16 ("gradient tensors are bf16"): dO [M][d] arrives as bf16 (written so by the out-projection's input-gradient GEMM) and
+// dq | dk | dv are written as bf16 [M][3 d] (their only readers - the QKV weight gradient and input gradient - are bf16 GEMMs)
+template <int DH, bool DROP, bool IN16, bool OUT16>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16(
     const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
     const uint8_t *__restrict__ mask, const float *__restrict__ dO, const float *__restrict__ lse2,
     const float *__restrict__ delta, float *__restrict__ dqkv, int H, int T, float scale, float drop_scale,
@@ -301,7 +303,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16(     // the QKV weigh
     bf16x8 qf[NS], dof[NS];
     if constexpr (IN16) owner_frags16<DH>((const h16 *)qb + (size_t)qc * DH, h, qf);
     else owner_frags<DH>((const float *)qb + (size_t)qc * DH, sl2, h, qf);
-    owner_frags<DH>(dO + ((size_t)b * T + qc) * d + hd * DH, 1.0f, h, dof);
+    if constexpr (OUT16) owner_frags16<DH>((const h16 *)dO + ((size_t)b * T + qc) * d + hd * DH, h, dof);
+    else owner_frags<DH>(dO + ((size_t)b * T + qc) * d + hd * DH, 1.0f, h, dof);
     const float lq = lse2[(size_t)bh * T + qc], dq_delta = delta[(size_t)bh * T + qc];
     f32x16 acc[ND];
 #pragma unroll
@@ -389,7 +392,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_bf16(
     constexpr int ES = IN16 ? 2 : 4;
     const char *qb = (const char *)q + (size_t)bh * T * DH * ES, *kb = (const char *)k + (size_t)bh * T * DH * ES,
                *vb = (const char *)v + (size_t)bh * T * DH * ES;
-    const float *dob = dO + (size_t)b * T * d + hd * DH;          // row stride d
+    const char *dob = (const char *)dO + ((size_t)b * T * d + hd * DH) * (OUT16 ? 2 : 4);          // row stride d elements
 
     bf16x8 kf[NS], vf[NS];
     if constexpr (IN16) {
@@ -404,7 +407,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_bf16(
 #pragma unroll
     for (int db = 0; db < ND; ++db) { dk[db] = zero16b(); dv[db] = zero16b(); }
 
-    StagerB<DH, IN16, false> sg;                                  // Q bf16 when IN16; dO always fp32
+    StagerB<DH, IN16, OUT16> sg;                                  // Q bf16 when IN16; dO bf16 when OUT16
     auto side = [&](TileB<DH> &t, int q0) __attribute__((always_inline)) {
         if (tid < 64) {
             const int qi = q0 + tid;

@@ -21,7 +21,7 @@ int vst_ln_bwd(const float *dy, const float *dsc, const float *score_w, int num_
                unsigned long long seed, unsigned site, float p, hipStream_t st);
 int vst_dropout_rows(float *x, int M, int cols, unsigned long long seed, unsigned site, float p, hipStream_t st);
 int vst_gate_bwd(float *g, const float *act, size_t n, float scale, hipStream_t st);
-int vst_head_rowdot(const float *dO, const float *O, float *delta, int M, int T, int H, int dh, hipStream_t st);
+int vst_head_rowdot(const float *dO, const float *O, float *delta, int M, int T, int H, int dh, hipStream_t st, int do16 = 0);      // do16 1: dO stored as bf16; 2: fp32 dO rounded to bf16 in the dot
 // part = [nblk = vst_ln_bwd_blocks(M)][d] partial sums of w[row*ws] * Y[row,:], then [nblk] partial sums of w[row*ws]
 int vst_weighted_colsum(const float *w, int ws, const float *Y, float *part, int M, int d, hipStream_t st);
 // dW[N,K] = dY[M,N]^T X[M,K] (+ db = column sums of dY when db0 != NULL); rows of the result are dealt to up to three

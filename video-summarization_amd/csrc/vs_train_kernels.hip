@@ -208,7 +208,10 @@ __global__ __launch_bounds__(256) void gate_bwd(float *__restrict__ g, const flo
 }
 
 // delta[(b*H + h)*T + t] = sum_c dO[m, h*dh + c] * O[m, h*dh + c],  m = b*T + t
-template <int NV>
+// DO16 1: dO is stored as bf16 (the bf16 training mode's out-projection input gradient); 2: dO is fp32 but enters the dot
+// rounded to bf16 - the value the bf16 attention backward multiplies (dP = dO V^T), so that dS = P (dP - delta) subtracts
+// like from like, and the two storage forms of that mode agree bit for bit
+template <int NV, int DO16 = 0>
 __global__ __launch_bounds__(256) void head_rowdot(const float *__restrict__ dO, const float *__restrict__ O,
                                                    float *__restrict__ delta, int M, int T, int H, int dh) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, d = H * dh, gl = dh / 4;   // gl lanes per head
@@ -219,7 +222,18 @@ __global__ __launch_bounds__(256) void head_rowdot(const float *__restrict__ dO,
             const int c = 4 * lane + 256 * u;
             float s = 0.f;
             if (c < d) {
-                const f32x4 x = *(const f32x4 *)(dO + (size_t)row * d + c), o = *(const f32x4 *)(O + (size_t)row * d + c);
+                f32x4 x;
+                if constexpr (DO16 == 2) {
+                    const f32x4 xf = *(const f32x4 *)(dO + (size_t)row * d + c);
+                    const unsigned x0 = pack_bf16(xf[0], xf[1]), x1 = pack_bf16(xf[2], xf[3]);
+                    x = f32x4{bits_f32(x0 << 16), bits_f32(x0 & 0xffff0000u), bits_f32(x1 << 16), bits_f32(x1 & 0xffff0000u)};
+                } else if constexpr (DO16 == 1) {
+                    const u32x2 xb = *(const u32x2 *)((const unsigned short *)dO + (size_t)row * d + c);
+                    const unsigned x0 = xb[0], x1 = xb[1];
+                    x = f32x4{bits_f32(x0 << 16), bits_f32(x0 & 0xffff0000u), bits_f32(x1 << 16), bits_f32(x1 & 0xffff0000u)};
+                } else
+                    x = *(const f32x4 *)(dO + (size_t)row * d + c);
+                const f32x4 o = *(const f32x4 *)(O + (size_t)row * d + c);
                 s = x[0] * o[0] + x[1] * o[1] + x[2] * o[2] + x[3] * o[3];
             }
             for (int off = 1; off < gl; off <<= 1) s += __shfl_xor(s, off);
@@ -726,11 +740,22 @@ int vst_gate_bwd(float *g, const float *act, size_t n, float scale, hipStream_t 
     return 0;
 }
 
-int vst_head_rowdot(const float *dO, const float *O, float *delta, int M, int T, int H, int dh, hipStream_t st) {
+int vst_head_rowdot(const float *dO, const float *O, float *delta, int M, int T, int H, int dh, hipStream_t st, int do16) {
     const int d = H * dh;
     if (d > 1024 || (dh != 32 && dh != 64 && dh != 128)) return -1;
     const dim3 grid((M + 3) / 4 < 4096 ? (M + 3) / 4 : 4096);
+#define VST_HRD(MODE_)                                                                                                   \
+    switch ((d + 255) / 256) {                                                                                           \
+        case 1: hipLaunchKernelGGL((head_rowdot<1, MODE_>), grid, dim3(256), 0, st, dO, O, delta, M, T, H, dh); break;   \
+        case 2: hipLaunchKernelGGL((head_rowdot<2, MODE_>), grid, dim3(256), 0, st, dO, O, delta, M, T, H, dh); break;   \
+        case 3: hipLaunchKernelGGL((head_rowdot<3, MODE_>), grid, dim3(256), 0, st, dO, O, delta, M, T, H, dh); break;   \
+        default: hipLaunchKernelGGL((head_rowdot<4, MODE_>), grid, dim3(256), 0, st, dO, O, delta, M, T, H, dh); break;  \
+    }
+    if (do16 == 1) { VST_HRD(1) }
+    else if (do16 == 2) { VST_HRD(2) }
+    else
     VST_NV_DISPATCH(d, head_rowdot, grid, dim3(256), 0, st, dO, O, delta, M, T, H, dh);
+#undef VST_HRD
     VSK_CHECK_LAUNCH();
     return 0;
 }
