@@ -259,7 +259,8 @@ def test_attention_forward_and_backward_kernels(vsa, B, H, T, dh, masked, p):
 
 @pytest.mark.parametrize("B,H,T,dh,masked,p", [(2, 4, 320, 64, False, 0.0), (1, 2, 777, 64, False, 0.0), (2, 4, 200, 64, True, 0.0),
                                                 (2, 8, 65, 32, True, 0.0), (1, 4, 1, 64, False, 0.0), (2, 4, 130, 64, True, 0.3),
-                                                (1, 8, 97, 32, False, 0.5), (1, 4, 513, 64, True, 0.2)])
+                                                (1, 8, 97, 32, False, 0.5), (1, 4, 513, 64, True, 0.2),
+                                                (2, 4, 200, 128, True, 0.0), (1, 2, 131, 128, False, 0.3), (1, 2, 64, 128, True, 0.5)])
 def test_attention_forward_and_backward_kernels_bf16(vsa, B, H, T, dh, masked, p):
     """The training attention on the bf16 matrix pipe (VS_TRAIN_FLAG_BF16_ATTENTION): forward (values + log-sum-exp) and
     backward (dq | dk | dv) against float64 torch autograd on UNROUNDED operands, the library's own dropout mask applied

@@ -171,13 +171,12 @@ __device__ __forceinline__ f32x16 rows_init(const float *c, int h) {
 // forward: owner = queries
 // ------------------------------------------------------------------------------------------
 template <int DH, bool DROP, bool IN16>          // IN16: q (pre-multiplied by scale * log2 e), k, v are bf16 in memory
-__global__ __launch_bounds__(256, 2) void attn_fwd_train_bf16(
+__global__ __launch_bounds__(256, DH == 128 ? 1 : 2) void attn_fwd_train_bf16(
     const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
     const uint8_t *__restrict__ mask, float *__restrict__ out, float *__restrict__ lse2, int H, int T, float scale,
     float drop_scale, const unsigned *__restrict__ dbits) {
     constexpr int NS = DH / 16, ND = DH / 32;
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    TileB<DH> *lds = reinterpret_cast<TileB<DH> *>(lds_raw);
+    __shared__ __attribute__((aligned(16))) TileB<DH> lds[2];        // static: 66.5 KB at head dim 128, above the dynamic default
     const int nq = (T + 127) / 128;
     const int bh = blockIdx.x / nq, qt = blockIdx.x - bh * nq, b = bh / H, hd = bh - b * H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
@@ -283,14 +282,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_train_bf16(
 // OUT16 ("gradient tensors are bf16"): dO [M][d] arrives as bf16 (written so by the out-projection's input-gradient GEMM) and
 // dq | dk | dv are written as bf16 [M][3 d] (their only readers - the QKV weight gradient and input gradient - are bf16 GEMMs)
 template <int DH, bool DROP, bool IN16, bool OUT16>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16(
+__global__ __launch_bounds__(256, DH == 128 ? 1 : 2) void attn_bwd_dq_bf16(
     const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
     const uint8_t *__restrict__ mask, const float *__restrict__ dO, const float *__restrict__ lse2,
     const float *__restrict__ delta, float *__restrict__ dqkv, int H, int T, float scale, float drop_scale,
     const unsigned *__restrict__ dbits) {
     constexpr int NS = DH / 16, ND = DH / 32;
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    TileB<DH> *lds = reinterpret_cast<TileB<DH> *>(lds_raw);
+    __shared__ __attribute__((aligned(16))) TileB<DH> lds[2];        // static: 66.5 KB at head dim 128, above the dynamic default
     const int nq = (T + 127) / 128, d = H * DH;
     const int bh = blockIdx.x / nq, qt = blockIdx.x - bh * nq, b = bh / H, hd = bh - b * H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
@@ -376,14 +374,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16(
 // backward, keys own: dK and dV
 // ------------------------------------------------------------------------------------------
 template <int DH, bool DROP, bool IN16, bool OUT16>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_bf16(
+__global__ __launch_bounds__(256, DH == 128 ? 1 : 2) void attn_bwd_dkdv_bf16(
     const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
     const uint8_t *__restrict__ mask, const float *__restrict__ dO, const float *__restrict__ lse2,
     const float *__restrict__ delta, float *__restrict__ dqkv, int H, int T, float scale, float drop_scale,
     const unsigned *__restrict__ dbits, int BH) {
     constexpr int NS = DH / 16, ND = DH / 32;
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    TileB<DH> *lds = reinterpret_cast<TileB<DH> *>(lds_raw);
+    __shared__ __attribute__((aligned(16))) TileB<DH> lds[2];        // static: 66.5 KB at head dim 128, above the dynamic default
     const int nk = (T + 127) / 128, d = H * DH;
     const int bh = blockIdx.x / nk, ktile = blockIdx.x - bh * nk, b = bh / H, hd = bh - b * H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
@@ -501,9 +498,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_bf16(
 
 #define VSTB_LAUNCH(KERNEL_, DH_, DROP_, IN16_, ...)                                                            \
     do {                                                                                                        \
-        constexpr size_t lds_bytes_ = 2 * sizeof(TileB<DH_>);                                                   \
-        static_assert(lds_bytes_ <= 64 * 1024, "static-size dynamic LDS below the 64 KB default limit");        \
-        hipLaunchKernelGGL((KERNEL_<DH_, DROP_, IN16_>), grid, dim3(256), lds_bytes_, st, __VA_ARGS__);         \
+        hipLaunchKernelGGL((KERNEL_<DH_, DROP_, IN16_>), grid, dim3(256), 0, st, __VA_ARGS__);                  \
     } while (0)
 #define VSTB_DISPATCH2(KERNEL_, DH_, ...)                                                                       \
     do {                                                                                                        \
@@ -517,10 +512,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_bf16(
         const bool drop = p > 0.f;                                                                              \
         if (dh == 32) VSTB_DISPATCH2(KERNEL_, 32, __VA_ARGS__);                                                 \
         else if (dh == 64) VSTB_DISPATCH2(KERNEL_, 64, __VA_ARGS__);                                            \
+        else if (dh == 128) VSTB_DISPATCH2(KERNEL_, 128, __VA_ARGS__);                                          \
         else return -1;                                                                                         \
     } while (0)
 
-bool vst_attention_bf16_supported(int dh) { return dh == 32 || dh == 64; }
+bool vst_attention_bf16_supported(int dh) { return dh == 32 || dh == 64 || dh == 128; }
 
 // in16: q (already times scale * log2 e), k, v are bf16 [B, H, T, dh] planes (the QKV GEMM's bf16 epilogue) instead of fp32
 int vst_attention_fwd_bf16(const float *q, const float *k, const float *v, const uint8_t *mask, float *out, float *lse2,
@@ -535,8 +531,7 @@ int vst_attention_fwd_bf16(const float *q, const float *k, const float *v, const
 
 #define VSTB_LAUNCH_B(KERNEL_, DH_, DROP_, IN16_, OUT16_, ...)                                                  \
     do {                                                                                                        \
-        constexpr size_t lds_bytes_ = 2 * sizeof(TileB<DH_>);                                                   \
-        hipLaunchKernelGGL((KERNEL_<DH_, DROP_, IN16_, OUT16_>), grid, dim3(256), lds_bytes_, st, __VA_ARGS__); \
+        hipLaunchKernelGGL((KERNEL_<DH_, DROP_, IN16_, OUT16_>), grid, dim3(256), 0, st, __VA_ARGS__);          \
     } while (0)
 #define VSTB_DISPATCH_B3(KERNEL_, DH_, DROP_, ...)                                                              \
     do {                                                                                                        \
@@ -550,6 +545,7 @@ int vst_attention_fwd_bf16(const float *q, const float *k, const float *v, const
         const bool drop = p > 0.f;                                                                              \
         if (dh == 32) { if (drop) VSTB_DISPATCH_B3(KERNEL_, 32, true, __VA_ARGS__); else VSTB_DISPATCH_B3(KERNEL_, 32, false, __VA_ARGS__); } \
         else if (dh == 64) { if (drop) VSTB_DISPATCH_B3(KERNEL_, 64, true, __VA_ARGS__); else VSTB_DISPATCH_B3(KERNEL_, 64, false, __VA_ARGS__); } \
+        else if (dh == 128) { if (drop) VSTB_DISPATCH_B3(KERNEL_, 128, true, __VA_ARGS__); else VSTB_DISPATCH_B3(KERNEL_, 128, false, __VA_ARGS__); } \
         else return -1;                                                                                         \
     } while (0)
 
