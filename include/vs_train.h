@@ -45,7 +45,7 @@ typedef struct vs_dropout_cfg {
  * pass the SAME flags to forward and backward.  Gradients then differ from the float64 truth by 1-3e-2 in relative L2
  * norm per tensor (tests/tolerances.py: TRAIN_LP_GRAD_L2), where the exact path is at 1e-6. */
 #define VS_TRAIN_FLAG_BF16_LINEAR 1u
-/* ... and the attention products too (S = q k^T, P v, and the five products of the backward), head dim 32 / 64: q * scale,
+/* ... and the attention products too (S = q k^T, P v, and the five products of the backward), head dim 32 / 64 / 128: q * scale,
  * k, v, dO, the probabilities and dS rounded to bf16, fp32 scores / softmax / lse / accumulation (head dim 128: exact). */
 #define VS_TRAIN_FLAG_BF16_ATTENTION 2u
 #define VS_TRAIN_FLAG_BF16 (VS_TRAIN_FLAG_BF16_LINEAR | VS_TRAIN_FLAG_BF16_ATTENTION)
@@ -143,7 +143,7 @@ int vs_train_attention_backward(const float *q, const float *k, const float *v, 
 size_t vs_train_attention_dropout_bits_bytes(int32_t B, int32_t H, int32_t T);
 int vs_train_attention_dropout_bits(void *dbits, int32_t B, int32_t H, int32_t T, uint64_t seed, uint32_t site, float p,
                                     void *stream);
-/* vs_train_attention_forward / _backward on the bf16 matrix pipe (VS_TRAIN_FLAG_BF16_ATTENTION); dh in {32, 64}; p > 0 needs
+/* vs_train_attention_forward / _backward on the bf16 matrix pipe (VS_TRAIN_FLAG_BF16_ATTENTION); dh in {32, 64, 128}; p > 0 needs
  * dbits (from vs_train_attention_dropout_bits with the same seed / site / p).  in16 != 0: q, k, v point to bf16 [B,H,T,dh]
  * planes, q already multiplied by scale * log2(e) - what the training forward stores when both low-precision flags are set
  * (results are bit-identical to the fp32-stored form, whose values the kernels round to the same bf16). */

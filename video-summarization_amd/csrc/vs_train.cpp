@@ -216,7 +216,7 @@ int vs_train_forward(const vs_weights *w, const float *x, const uint8_t *key_pad
     // low-precision training (VS_TRAIN_FLAG_BF16_LINEAR): every Linear / dgrad / wgrad GEMM on the bf16 matrix pipe, from the
     // batch size up where the LDS-tiled kernels beat the exact latency kernels (the threshold of the scoring path)
     const int lp = (drop && (drop->flags & VS_TRAIN_FLAG_BF16_LINEAR) && (long long)B * T > vsk_options().lp_min_rows) ? 1 : 0;
-    // ... and (VS_TRAIN_FLAG_BF16_ATTENTION) the attention products of the forward and the backward, head dim 32 / 64
+    // ... and (VS_TRAIN_FLAG_BF16_ATTENTION) the attention products of the forward and the backward (head dim 32 / 64 / 128)
     const bool lpa = drop && (drop->flags & VS_TRAIN_FLAG_BF16_ATTENTION) && (long long)B * T > vsk_options().lp_min_rows &&
                      vst_attention_bf16_supported(w->desc.d_model / w->desc.num_heads);
     // bf16 STORAGE of the tensors that are only ever bf16 matrix operands (VS_LP_STORE32 = 1 keeps them fp32: an A/B switch -
@@ -300,7 +300,7 @@ int vs_train_backward(vs_weights *w, const float *x, const uint8_t *key_pad_mask
     // low-precision training (VS_TRAIN_FLAG_BF16_LINEAR): every Linear / dgrad / wgrad GEMM on the bf16 matrix pipe, from the
     // batch size up where the LDS-tiled kernels beat the exact latency kernels (the threshold of the scoring path)
     const int lp = (drop && (drop->flags & VS_TRAIN_FLAG_BF16_LINEAR) && (long long)B * T > vsk_options().lp_min_rows) ? 1 : 0;
-    // ... and (VS_TRAIN_FLAG_BF16_ATTENTION) the attention products of the forward and the backward, head dim 32 / 64
+    // ... and (VS_TRAIN_FLAG_BF16_ATTENTION) the attention products of the forward and the backward (head dim 32 / 64 / 128)
     const bool lpa = drop && (drop->flags & VS_TRAIN_FLAG_BF16_ATTENTION) && (long long)B * T > vsk_options().lp_min_rows &&
                      vst_attention_bf16_supported(w->desc.d_model / w->desc.num_heads);
     // bf16 STORAGE of the tensors that are only ever bf16 matrix operands (VS_LP_STORE32 = 1 keeps them fp32: an A/B switch -

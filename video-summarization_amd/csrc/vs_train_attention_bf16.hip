@@ -1,6 +1,6 @@
 // vs_train_attention_bf16.hip — the training path's attention on the bf16 matrix pipe (low-precision training,
 // VS_TRAIN_FLAG_BF16_ATTENTION; reference simnet.py:155-161 under `amp.autocast()`, train.py:120): forward with dropout
-// and a saved log-sum-exp, and the flash-style backward, head dim 32 / 64.
+// and a saved log-sum-exp, and the flash-style backward, head dim 32 / 64 (two waves per SIMD) and 128 (one: 256 + registers).
 //
 // Same decomposition as the exact kernels of vs_train_attention.hip - three kernels, 4 waves x 32 "owner" rows per block,
 // the other sequence streamed through LDS, S and dP recomputed in both backward kernels so that every output element is

@@ -462,8 +462,9 @@ class SimNet(nn.Module):
         exact fp32 MFMA, gradients at 1e-6 of the float64 truth) or 'bf16' - the counterpart of the reference's
         ``with amp.autocast():`` (train.py:120, pretrain.py:59): operands rounded to bf16, fp32 accumulation, and - as
         under autocast - LayerNorm, softmax statistics and the loss in fp32.  The attention products (forward and both
-        backward kernels) run on the bf16 pipe too where a bf16 training attention exists (head dim 32 / 64; head dim
-        128 keeps the exact kernels).  Applies from 8192 frames per batch up.  Gradients within ~2e-2 relative L2 of
+        backward kernels) run on the bf16 pipe too (head dim 32 / 64 / 128), and the tensors that are only ever bf16 matrix
+        operands (q / k / v, the MLP hidden tensor and its gradient, the attention gradients) are stored as bf16.  Applies
+        from 8192 frames per batch up.  Gradients within ~2e-2 relative L2 of
         the float64 truth (tests/tolerances.py TRAIN_LP_*)."""
         if value not in ("fp32", "bf16"):
             raise ValueError("train dtype must be 'fp32' or 'bf16', got %r" % (value,))
