@@ -372,6 +372,31 @@ def test_bf16_training_storage_forms_agree_bit_for_bit(vsa, lp_train_everywhere,
             assert torch.equal(a, b), n
 
 
+@pytest.mark.parametrize("p,B,T", [(0.0, 2, 200), (0.3, 3, 171), (0.5, 1, 1)])
+def test_a_stationary_mlp_gemms_equal_the_tiled_ones_bit_for_bit(vsa, lp_train_everywhere, p, B, T):
+    """d_model 256 in the bf16 training mode: fc1 (+ ReLU + dropout) and the fc2 input gradient (+ gate) run A-stationary
+    (vs_train_gemm_rows.hip: a wave keeps its 32 rows of A in registers, W streams past, the bf16 result is written once).
+    Same operands, same rounding points, bias first and k ascending like gemm_nt_128: VS_LP_MLP_UNFUSED = 1 (the tiled
+    kernels) gives the same bits everywhere - logits, hidden states, every gradient; ragged row counts included."""
+    res = {}
+    try:
+        for tiled in (1, 0):
+            vsa._lib.set_option("VS_LP_MLP_UNFUSED", tiled)
+            m = vsa.SimNet(num_heads=4, d_model=256, num_layers=2, sparsity=0.0, dropout=p)
+            m.load_state_dict(vsa.synth.make_state_dict(256, 2, 3))
+            m = m.to(_dev()).train().set_train_dtype("bf16")
+            x = torch.randn(B, T, 1024, generator=torch.Generator().manual_seed(1)).to(_dev()).requires_grad_(True)
+            torch.manual_seed(5)
+            pred, hid = m(x, None)
+            ((pred ** 2).mean() + 1e-3 * hid.sum()).backward()
+            res[tiled] = [("pred", pred.detach().clone()), ("hidden", hid.detach().clone()), ("dx", x.grad.clone())] + \
+                         [(n, q.grad.clone()) for n, q in m.named_parameters()]
+    finally:
+        vsa._lib.set_option("VS_LP_MLP_UNFUSED", -1)
+    for (n, a), (_n, b) in zip(res[1], res[0]):
+        assert torch.equal(a, b), n
+
+
 @pytest.mark.parametrize("M,N,K", [(300, 256, 1024), (4096, 1024, 256), (77, 768, 256), (1000, 64, 192), (5000, 512, 2048),
                                    (16, 256, 256), (1, 128, 64)])
 def test_wgrad_kernel(vsa, M, N, K):

@@ -18,7 +18,7 @@ INCLUDE = os.path.join(ROOT, "include")
 LIB_PATH = os.path.join(HERE, "libvsscore.so")
 DIAG_LIB_PATH = os.path.join(HERE, "libvsscore_diag.so")
 SOURCES = ("vs_kernels.hip", "vs_attention.hip", "vs_mlp_fused.hip", "vs_gemm_ring.hip", "vs_scorer.cpp", "vs_eval.cpp",
-           "vs_train_kernels.hip", "vs_train_attention.hip", "vs_train_attention_bf16.hip", "vs_pretrain_kernels.hip",
+           "vs_train_kernels.hip", "vs_train_attention.hip", "vs_train_attention_bf16.hip", "vs_train_gemm_rows.hip", "vs_pretrain_kernels.hip",
            "vs_train.cpp")
 ABI_VERSION = 3
 

@@ -234,14 +234,16 @@ int vsw_ensure(const vs_weights *w, unsigned families, void *stream) {
                 pk &= vsk_pack_mlp_bf16(blob + L.wo, blob + L.w1, blob + L.w2, blob + L.b_mlp, (int)d, st) == 0;
                 pk &= vsk_pack_qkv_bf16(blob + L.wqkv, blob + L.b_qkv, (int)d, st) == 0;
             }
-        if (d > 256)
-            for (const auto &L : w->layers) {
-                pk &= vsk_to_bf16(blob + L.wqkv, blob + L.r_wqkv, 3 * d * d, st) == 0;
-                pk &= vsk_to_bf16(blob + L.wo, blob + L.r_wo, d * d, st) == 0;
-                pk &= vsk_to_bf16(blob + L.w1, blob + L.r_w1, 4 * d * d, st) == 0;
-                pk &= vsk_to_bf16(blob + L.w2, blob + L.r_w2, 4 * d * d, st) == 0;
-            }
         if (pk) w->b_version = w->version;
+    }
+    if ((families & VSW_ROWS16) && w->r_version != w->version) {
+        for (const auto &L : w->layers) {
+            pk &= vsk_to_bf16(blob + L.wqkv, blob + L.r_wqkv, 3 * d * d, st) == 0;
+            pk &= vsk_to_bf16(blob + L.wo, blob + L.r_wo, d * d, st) == 0;
+            pk &= vsk_to_bf16(blob + L.w1, blob + L.r_w1, 4 * d * d, st) == 0;
+            pk &= vsk_to_bf16(blob + L.w2, blob + L.r_w2, 4 * d * d, st) == 0;
+        }
+        if (pk) w->r_version = w->version;
     }
     if (!pk) return fail(VS_ERR_HIP, "weight image packing failed: %s", hipGetErrorString(hipGetLastError()));
     return VS_OK;
@@ -287,10 +289,9 @@ int vs_weights_pack(const vs_model_desc *desc, const vs_model_params *params, vo
             L.b_mlp = take(vsk_mlp_bf16_image_bytes((int)d) / sizeof(float));
             L.b_qkv = take(vsk_qkv_bf16_image_bytes((int)d) / sizeof(float));
         }
-    if (d > 256)
-        for (auto &L : w->layers) {
-            L.r_wqkv = take(3 * d * d / 2); L.r_wo = take(d * d / 2); L.r_w1 = take(4 * d * d / 2); L.r_w2 = take(4 * d * d / 2);
-        }
+    for (auto &L : w->layers) {
+        L.r_wqkv = take(3 * d * d / 2); L.r_wo = take(d * d / 2); L.r_w1 = take(4 * d * d / 2); L.r_w2 = take(4 * d * d / 2);
+    }
     w->has_b_embed = vsk_embed_bf16_image_bytes((int)d, (int)din) != 0;
     if (w->has_b_embed) w->b_embed = take(vsk_embed_bf16_image_bytes((int)d, (int)din) / sizeof(float));
     w->blob_floats = off;
@@ -394,7 +395,8 @@ int forward_core(const vs_weights *w, const float *x, const uint8_t *key_pad_mas
     const int lnbf = lbf;
     {   // kernel-layout weight images this forward reads, (re)built only if the parameters changed since their last use
         const int rows_min = cls ? B * Tf : M;
-        const unsigned fam = lbf == 1 ? VSW_BF16 : rows_min > vsk_skinny_max_rows() ? 0u : lbf == 2 ? VSW_F16X3 : VSW_FRAGMENTS;
+        const bool wide16 = lbf == 1 && d > 256;       // the bf16-operand GEMM's weight copies (ring path below)
+        const unsigned fam = lbf == 1 ? (VSW_BF16 | (wide16 ? VSW_ROWS16 : 0u)) : rows_min > vsk_skinny_max_rows() ? 0u : lbf == 2 ? VSW_F16X3 : VSW_FRAGMENTS;
         if (fam) if (int rc = vsw_ensure(w, fam, stream)) return rc;
     }
     // bf16 mode: the tensors that are only ever read as bf16 matrix operands are WRITTEN as bf16 by their producers

@@ -122,6 +122,7 @@ int ensure_transposed(vs_weights *w, hipStream_t st, bool frags) {
         w->tlayers.resize(w->desc.num_layers);
         for (auto &L : w->tlayers) {
             L.t_wqkv = take(3 * d * d); L.t_wo = take(d * d); L.t_w1 = take(4 * d * d); L.t_w2 = take(4 * d * d);
+            L.t16_w2 = take(4 * d * d / 2);
             L.tf_wqkv = take(3 * d * d); L.tf_wo = take(d * d); L.tf_w1 = take(4 * d * d); L.tf_w2 = take(4 * d * d);
         }
         const size_t nz = 4 * d > din ? 4 * d : din;
@@ -147,6 +148,7 @@ int ensure_transposed(vs_weights *w, hipStream_t st, bool frags) {
         VST_LAUNCH(both(w->p(P.wo), Q.t_wo, Q.tf_wo, (int)d, (int)d));
         VST_LAUNCH(both(w->p(P.w1), Q.t_w1, Q.tf_w1, (int)(4 * d), (int)d));                                 // [4d,d] -> [d,4d]
         VST_LAUNCH(both(w->p(P.w2), Q.t_w2, Q.tf_w2, (int)d, (int)(4 * d)));                                 // [d,4d] -> [4d,d]
+        if (do_t) VST_LAUNCH(vsk_to_bf16(w->tblob + Q.t_w2, w->tblob + Q.t16_w2, 4 * d * d, st));
     }
     if (do_t) w->t_version = w->version;
     if (do_f) w->tf_version = w->version;
@@ -223,6 +225,8 @@ int vs_train_forward(const vs_weights *w, const float *x, const uint8_t *key_pad
     // the kernels round the fp32-stored values to the same bf16, so every result is bit-identical either way)
     const bool qkv16 = lp && lpa && !vsk_options().lp_store32;     // q / k / v of the record are bf16 planes
     const bool h16 = lp && !vsk_options().lp_store32;              // ... and so is the MLP hidden tensor (and, in the backward, its gradient)
+    // ... which the A-stationary GEMM writes where it applies (K = d_model = 256; VS_LP_MLP_UNFUSED = 1: the tiled kernels, A/B switch)
+    const bool rows16 = h16 && !vsk_options().lp_mlp_unfused && vst_gemm_rows16_supported(B * T, 4 * w->desc.d_model, w->desc.d_model);
     const size_t kvs = qkv16 ? (size_t)B * T * w->desc.d_model / 2 : (size_t)B * T * w->desc.d_model;     // floats between the planes
     const unsigned long long seed = drop ? drop->seed : 0ull;
     const float scale = 1.0f / sqrtf((float)d);              // simnet.py:126: d_model ** -0.5
@@ -230,6 +234,7 @@ int vs_train_forward(const vs_weights *w, const float *x, const uint8_t *key_pad
     float *a = ws + W.a;
 
     if (M <= vsk_skinny_max_rows()) if (int rc = vsw_ensure(w, VSW_FRAGMENTS, stream)) return rc;
+    if (rows16) if (int rc = vsw_ensure(w, VSW_ROWS16, stream)) return rc;          // bf16 copy of W1 for the A-stationary fc1
     // Embedding + positional table + dropout(sparsity)   simnet.py:211, 237-238
     float *h0 = sv + S.h0;
     VST_LAUNCH(vsk_linear(x, w->p(w->embed_w), w->p(w->f_embed_w), w->p(w->embed_b), h0, M, d, D.in_features, 0,
@@ -259,7 +264,10 @@ int vs_train_forward(const vs_weights *w, const float *x, const uint8_t *key_pad
                                 seed, VS_SITE_LAYER(l, VS_SITE_DROP1), p, nullptr, nullptr, 0, nullptr, st));              // :107
         // bf16 GEMMs: the MLP hidden tensor (post ReLU, post dropout) is only ever a matrix operand or a sign - it is written
         // and saved as bf16 (h16), and fc2, its weight gradient and the backward's gate read it as such
-        if (p > 0.f)        // fc1 + ReLU + mlp.dropout in one GEMM epilogue (:181)
+        if (rows16)         // K = d_model = 256: the A-stationary form (vs_train_gemm_rows.hip), bit-identical to the tiled one
+            VST_LAUNCH(vst_gemm_rows16(sv + A.y1, w->p(P.r_w1), w->p(P.b1), sv + A.ffn, nullptr, M, 4 * d, d, p > 0.f ? 0 : 2, 0.f, seed,
+                                       VS_SITE_LAYER(l, VS_SITE_MLP), p, st));
+        else if (p > 0.f)   // fc1 + ReLU + mlp.dropout in one GEMM epilogue (:181)
             VST_LAUNCH(vsk_linear_relu_dropout(sv + A.y1, w->p(P.w1), w->p(P.f_w1), w->p(P.b1), sv + A.ffn, M, 4 * d, d, seed,
                                                VS_SITE_LAYER(l, VS_SITE_MLP), p, st, h16 ? (1 | VSK_STORE16) : lp));
         else
@@ -307,6 +315,8 @@ int vs_train_backward(vs_weights *w, const float *x, const uint8_t *key_pad_mask
     // the kernels round the fp32-stored values to the same bf16, so every result is bit-identical either way)
     const bool qkv16 = lp && lpa && !vsk_options().lp_store32;     // q / k / v of the record are bf16 planes
     const bool h16 = lp && !vsk_options().lp_store32;              // ... and so is the MLP hidden tensor (and, in the backward, its gradient)
+    // ... which the A-stationary GEMM writes where it applies (K = d_model = 256; VS_LP_MLP_UNFUSED = 1: the tiled kernels, A/B switch)
+    const bool rows16 = h16 && !vsk_options().lp_mlp_unfused && vst_gemm_rows16_supported(B * T, 4 * w->desc.d_model, w->desc.d_model);
     const size_t kvs = qkv16 ? (size_t)B * T * w->desc.d_model / 2 : (size_t)B * T * w->desc.d_model;     // floats between the planes
     const unsigned long long seed = drop ? drop->seed : 0ull;
     const float scale = 1.0f / sqrtf((float)d);
@@ -353,6 +363,10 @@ int vs_train_backward(vs_weights *w, const float *x, const uint8_t *key_pad_mask
         // the value through
         // (h16: the gate tensor is the bf16-stored activation, and the gated gradient gf - again only ever a matrix operand -
         // is written as bf16 too)
+        if (rows16)
+            VST_LAUNCH(vst_gemm_rows16(dm, w->tp(Q.t16_w2), zeros, gf, sv + A.ffn, M, 4 * d, d, 1, p > 0.f ? 1.0f / (1.0f - p) : 1.0f, 0ull, 0u,
+                                       0.f, st));
+        else
         VST_LAUNCH(vsk_linear_gate(dm, w->tp(Q.t_w2), w->tp(Q.tf_w2), zeros, sv + A.ffn, p > 0.f ? 1.0f / (1.0f - p) : 1.0f, gf, M, 4 * d, d, st,
                                    h16 ? (1 | VSK_STORE16) : lp));
         VST_LAUNCH(vst_wgrad(gf, 4 * d, sv + A.y1, d, M, 4 * d, d, G.w1, nullptr, nullptr, G.b1, nullptr, nullptr, 4 * d, wg, st,

@@ -13,13 +13,15 @@ struct LayerOff {
     size_t h_wqkv, h_wo, h_w1, h_w2;        // their fp16x3 counterparts (hi|lo f16 halves, same size)
     size_t b_mlp;                           // Wo, W1, W2 as the LDS images of the fused bf16 layer-tail kernel (vsk_pack_mlp_bf16)
     size_t b_qkv;                           // Wqkv as the LDS images of that kernel's QKV epilogue (vsk_pack_qkv_bf16)
-    size_t r_wqkv, r_wo, r_w1, r_w2;        // d_model > 256: plain row-major bf16 copies for the bf16-operand GEMM (vs_gemm_ring.hip)
+    size_t r_wqkv, r_wo, r_w1, r_w2;        // plain row-major bf16 copies (family VSW_ROWS16): the bf16-operand GEMM of d_model > 256
+                                            // (vs_gemm_ring.hip) and the training path's A-stationary GEMM (vs_train_gemm_rows.hip)
 };
 
 // transposed weights for the dgrad GEMMs of the training backward (dX = dY W is an NT GEMM against W^T); built
 // lazily by the first vs_train_backward after each pack / update, never for a scoring-only user
 struct LayerOffT {
     size_t t_wqkv, t_wo, t_w1, t_w2;          // W^T, row-major
+    size_t t16_w2;                            // W2^T as bf16 (the A-stationary fc2 input-gradient GEMM of the bf16 training mode)
     size_t tf_wqkv, tf_wo, tf_w1, tf_w2;      // the same in fragment-major order (latency kernels at small batch)
 };
 
@@ -40,6 +42,7 @@ struct vs_weights {
     mutable unsigned long long f_version = ~0ull;   // f_*: fragment-major fp32 copies (latency kernels, rows <= VS_SKINNY_ROWS)
     mutable unsigned long long h_version = ~0ull;   // h_*: their fp16x3 counterparts
     mutable unsigned long long b_version = ~0ull;   // b_*: LDS images of the fused bf16 layer kernels
+    mutable unsigned long long r_version = ~0ull;   // r_*: plain bf16 copies
 
     // ---- training side ----
     unsigned long long version = 0;       // bumped by every pack / update
@@ -55,5 +58,5 @@ int vs_fail_msg(int code, const char *msg);     // vs_scorer.cpp: sets the threa
 
 // (re)builds the image families in `families` that are older than the handle's parameters, stream-ordered on `st`.
 // A handle's calls must be issued on ONE stream at a time (or be ordered by the caller): include/vs_scorer.h.
-enum { VSW_FRAGMENTS = 1, VSW_F16X3 = 2, VSW_BF16 = 4 };
+enum { VSW_FRAGMENTS = 1, VSW_F16X3 = 2, VSW_BF16 = 4, VSW_ROWS16 = 8 };
 int vsw_ensure(const vs_weights *w, unsigned families, void *stream);
