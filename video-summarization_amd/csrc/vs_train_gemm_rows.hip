@@ -39,6 +39,8 @@ __global__ __launch_bounds__(512, 2) void gemm_rows16(
     constexpr int NLD = GR_NT * KT * 2 / 16 / 512;                 // 16-byte chunks per thread and stage (4 at K = 256)
     __shared__ __attribute__((aligned(16))) unsigned char wbuf[2][STAGE];
     __shared__ __attribute__((aligned(16))) unsigned char tbuf[8][32 * 144];      // per-wave transposition scratch: 32 rows x (64 bf16 + pad)
+    __shared__ __attribute__((aligned(16))) float bias_s[4096];                   // the whole bias vector (N <= 4096): an accumulator's
+                                                                                  // initial value must not wait for an L2 round trip per stage
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
     const int m0 = blockIdx.x * 256 + 32 * wave;
@@ -78,6 +80,7 @@ __global__ __launch_bounds__(512, 2) void gemm_rows16(
     const int nst = (N + GR_NT - 1) / GR_NT;
     const DropSite ds = drop_site(seed, site, p);
     const unsigned rkm = drop_rowkey(ds, (unsigned)(m0 + r));                // the owner lane's row
+    for (int i = tid; i < N / 4; i += 512) *(f32x4 *)&bias_s[4 * i] = *(const f32x4 *)(bias + 4 * i);
     wload(0);
     wstore(0);
     __syncthreads();
@@ -86,6 +89,15 @@ __global__ __launch_bounds__(512, 2) void gemm_rows16(
     for (int st = 0; st < nst; ++st) {
         const int buf = st & 1, n0 = st * GR_NT;
         if (st + 1 < nst) wload(st + 1);
+        u32x4 gpre[4];                              // this stage's gate values, requested before the MFMAs that they will mask
+        if (EPI == GR_GATE) {
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp) {
+                int row = m0 + trow + 8 * pp; row = row < M ? row : M - 1;
+                int col = n0 + tc8; col = col < N ? col : N - 8;
+                gpre[pp] = *(const u32x4 *)(gate + (size_t)row * N + col);
+            }
+        }
         // acc[nb][t] = C[m = r][n = n0 + 32 nb + 8 (t >> 2) + 4 h + (t & 3)]: starts at the bias
         f32x16 acc[2];
 #pragma unroll
@@ -93,7 +105,7 @@ __global__ __launch_bounds__(512, 2) void gemm_rows16(
 #pragma unroll
             for (int tg = 0; tg < 4; ++tg) {
                 const int c = n0 + 32 * nb + 8 * tg + 4 * h;
-                const f32x4 bv = c < N ? *(const f32x4 *)(bias + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+                const f32x4 bv = c < N ? *(const f32x4 *)&bias_s[c] : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[nb][4 * tg + e] = bv[e];
             }
@@ -130,7 +142,7 @@ __global__ __launch_bounds__(512, 2) void gemm_rows16(
             u32x4 pk = *(const u32x4 *)(tb + (trow + 8 * pp) * 144 + 2 * tc8);
             if (row < M && col < N) {
                 if (EPI == GR_GATE) {          // the bf16-stored activation: > 0 <=> its 16 bits are a positive integer
-                    const u32x4 g = *(const u32x4 *)(gate + (size_t)row * N + col);
+                    const u32x4 g = gpre[pp];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const unsigned gw = g[e], pw = pk[e];
@@ -150,7 +162,7 @@ __global__ __launch_bounds__(512, 2) void gemm_rows16(
 }  // namespace
 
 // (K = 512 would need 128 KB of W stages beside the scratch: not instantiated)
-bool vst_gemm_rows16_supported(int M, int N, int K) { return K == 256 && N % 8 == 0 && N >= GR_NT && M > 0; }
+bool vst_gemm_rows16_supported(int M, int N, int K) { return K == 256 && N % 8 == 0 && N >= GR_NT && N <= 4096 && M > 0; }
 
 // epi 0: dropout(relu(.)) (seed, site, p); 1: gate (gate16, scale); 2: relu.  A fp32 [M, K]; W16 bf16 [N, K]; C16 bf16 [M, N].
 int vst_gemm_rows16(const float *A, const void *W16, const float *bias, void *C16, const void *gate16, int M, int N, int K, int epi,
