@@ -249,6 +249,10 @@ int vs_train_forward(const vs_weights *w, const float *x, const uint8_t *key_pad
         // bf16 GEMMs + bf16 attention: q (times scale * log2 e), k, v are WRITTEN as bf16 by the QKV GEMM's epilogue (the
         // scoring path's form) - the attention kernels' only readers round them to bf16 anyway: same bits, half the
         // saved bytes, nothing to convert per streamed tile
+        if (rows16 && qkv16)       // A-stationary form (bit-identical to the tiled one)
+            VST_LAUNCH(vst_gemm_rows16(h_in, w->p(P.r_wqkv), w->p(P.bqkv), qkv, nullptr, M, 3 * d, d, 3, vsk_attention_qscale(scale), 0ull, 0u,
+                                       0.f, st, T, H, d / H));
+        else
         VST_LAUNCH(vsk_qkv(h_in, w->p(P.wqkv), w->p(P.f_wqkv), w->p(P.bqkv), qkv, B, T, d, H, qkv16 ? (1 | VSK_STORE16) : lp, st,
                            qkv16 ? vsk_attention_qscale(scale) : 1.0f));         // :148-153
         unsigned *dbits = p > 0.f ? (unsigned *)(sv + A.dbits) : nullptr;

@@ -2,6 +2,7 @@
 // backward): C16[M, N] = epilogue(A[M, K] W16[N, K]^T + bias), K = d_model = 256, N = 4 d_model, C written as bf16:
 //   EPI_RELU_DROP  mlp.fc1 + ReLU + mlp.dropout (forward)            -> the bf16-stored hidden tensor
 //   EPI_GATE       d(hidden) = (dY W2) gated by that tensor's sign, times 1 / (1 - p) (backward) -> the bf16-stored gradient
+//   EPI_QKV        the q / k / v projections (N = 3 d_model; simnet.py:148-153): bf16 [3][B][H][T][dh] planes, q times scale * log2 e
 //
 // Why not gemm_nt_128.  With K = 256 a 256 x 256 output tile is four k-tiles of work: its A panel is re-read by each of the
 // N / 256 column tiles and W by each of the M / 256 row tiles (all through L2, ~10 TB/s chip-wide), and its epilogue -
@@ -22,7 +23,7 @@
 namespace {
 
 typedef unsigned short h16;
-enum { GR_RELU_DROP = 0, GR_GATE = 1, GR_RELU = 2 };
+enum { GR_RELU_DROP = 0, GR_GATE = 1, GR_RELU = 2, GR_QKV = 3 };
 constexpr int GR_NT = 64;                       // output columns per stage
 
 // W image row (K bf16) in LDS: 16-byte chunk c at position c ^ (row & 15) (rows are 512 / 1024 B apart: without the XOR the
@@ -33,7 +34,7 @@ __device__ __forceinline__ int wimg_off(int row, int chunk) { return row * (2 * 
 template <int KT, int EPI, bool A16>      // A16: A is stored as bf16 (not used by the two call sites today; kept for the rows-copy form)
 __global__ __launch_bounds__(512, 2) void gemm_rows16(
     const float *__restrict__ A, const h16 *__restrict__ W, const float *__restrict__ bias, h16 *__restrict__ C,
-    const h16 *__restrict__ gate, int M, int N, float scale, unsigned long long seed, unsigned site, float p) {
+    const h16 *__restrict__ gate, int M, int N, float scale, unsigned long long seed, unsigned site, float p, int T, int H, int dh) {
     constexpr int NS = KT / 16;                                    // k-steps
     constexpr int STAGE = GR_NT * 2 * KT;                          // bytes
     constexpr int NLD = GR_NT * KT * 2 / 16 / 512;                 // 16-byte chunks per thread and stage (4 at K = 256)
@@ -129,6 +130,7 @@ __global__ __launch_bounds__(512, 2) void gemm_rows16(
                     v[e] = acc[nb][4 * tg + e];
                     if (EPI == GR_RELU_DROP || EPI == GR_RELU) v[e] = relu1(v[e]);
                     if (EPI == GR_GATE) v[e] *= scale;
+                    if (EPI == GR_QKV && n0 < H * dh) v[e] *= scale;        // q (a 64-column stage never straddles q | k | v: d % 64 == 0)
                 }
                 if (EPI == GR_RELU_DROP) {
 #pragma unroll
@@ -151,6 +153,11 @@ __global__ __launch_bounds__(512, 2) void gemm_rows16(
                         pk[e] = lo | hi;
                     }
                 }
+                if (EPI == GR_QKV) {       // head-major scatter: 8 consecutive columns stay inside one head (dh % 8 == 0)
+                    const int d = H * dh, which = col / d, c = col - which * d, head = c / dh, e0 = c - head * dh;
+                    const int b = row / T, t = row - b * T;
+                    *(u32x4 *)(C + (size_t)which * M * d + (((size_t)b * H + head) * T + t) * dh + e0) = pk;
+                } else
                 *(u32x4 *)(C + (size_t)row * N + col) = pk;
             }
         }
@@ -164,15 +171,17 @@ __global__ __launch_bounds__(512, 2) void gemm_rows16(
 // (K = 512 would need 128 KB of W stages beside the scratch: not instantiated)
 bool vst_gemm_rows16_supported(int M, int N, int K) { return K == 256 && N % 8 == 0 && N >= GR_NT && N <= 4096 && M > 0; }
 
-// epi 0: dropout(relu(.)) (seed, site, p); 1: gate (gate16, scale); 2: relu.  A fp32 [M, K]; W16 bf16 [N, K]; C16 bf16 [M, N].
+// epi 0: dropout(relu(.)) (seed, site, p); 1: gate (gate16, scale); 2: relu; 3: q / k / v planes (T, H, dh; scale = q's factor).
+// A fp32 [M, K]; W16 bf16 [N, K]; C16 bf16 [M, N] (epi 3: [3][M / T][H][T][dh]).
 int vst_gemm_rows16(const float *A, const void *W16, const float *bias, void *C16, const void *gate16, int M, int N, int K, int epi,
-                    float scale, unsigned long long seed, unsigned site, float p, hipStream_t st) {
+                    float scale, unsigned long long seed, unsigned site, float p, hipStream_t st, int T, int H, int dh) {
     if (!vst_gemm_rows16_supported(M, N, K)) return -1;
+    if (epi == GR_QKV && (T <= 0 || H <= 0 || dh % 8 || N != 3 * H * dh || (H * dh) % GR_NT || M % T)) return -1;
     const dim3 grid((M + 255) / 256);
     const h16 *w = (const h16 *)W16, *g = (const h16 *)gate16;
     h16 *c = (h16 *)C16;
-#define VST_GR(KT_, EPI_) hipLaunchKernelGGL((gemm_rows16<KT_, EPI_, false>), grid, dim3(512), 0, st, A, w, bias, c, g, M, N, scale, seed, site, p)
-    if (epi == GR_RELU_DROP) VST_GR(256, GR_RELU_DROP); else if (epi == GR_GATE) VST_GR(256, GR_GATE); else if (epi == GR_RELU) VST_GR(256, GR_RELU); else return -1;
+#define VST_GR(KT_, EPI_) hipLaunchKernelGGL((gemm_rows16<KT_, EPI_, false>), grid, dim3(512), 0, st, A, w, bias, c, g, M, N, scale, seed, site, p, T, H, dh)
+    if (epi == GR_RELU_DROP) VST_GR(256, GR_RELU_DROP); else if (epi == GR_GATE) VST_GR(256, GR_GATE); else if (epi == GR_RELU) VST_GR(256, GR_RELU); else if (epi == GR_QKV) VST_GR(256, GR_QKV); else return -1;
 #undef VST_GR
     VSK_CHECK_LAUNCH();
     return 0;
