@@ -381,7 +381,7 @@ def test_a_stationary_mlp_gemms_equal_the_tiled_ones_bit_for_bit(vsa, lp_train_e
     res = {}
     try:
         for tiled in (1, 0):
-            vsa._lib.set_option("VS_LP_MLP_UNFUSED", tiled)
+            vsa._lib.set_option("VS_LP_MLP_UNFUSED", 1 if tiled else 2)       # 2: A-stationary whatever the batch size
             m = vsa.SimNet(num_heads=4, d_model=256, num_layers=2, sparsity=0.0, dropout=p)
             m.load_state_dict(vsa.synth.make_state_dict(256, 2, 3))
             m = m.to(_dev()).train().set_train_dtype("bf16")

@@ -225,8 +225,10 @@ int vs_train_forward(const vs_weights *w, const float *x, const uint8_t *key_pad
     // the kernels round the fp32-stored values to the same bf16, so every result is bit-identical either way)
     const bool qkv16 = lp && lpa && !vsk_options().lp_store32;     // q / k / v of the record are bf16 planes
     const bool h16 = lp && !vsk_options().lp_store32;              // ... and so is the MLP hidden tensor (and, in the backward, its gradient)
-    // ... which the A-stationary GEMM writes where it applies (K = d_model = 256; VS_LP_MLP_UNFUSED = 1: the tiled kernels, A/B switch)
-    const bool rows16 = h16 && !vsk_options().lp_mlp_unfused && vst_gemm_rows16_supported(B * T, 4 * w->desc.d_model, w->desc.d_model);
+    // ... which the A-stationary GEMM writes where it applies (K = d_model = 256, batches that fill the chip; VS_LP_MLP_UNFUSED = 1: the
+    // tiled kernels, 2: the A-stationary kernel at every batch size - A/B and test switches)
+    const bool rows16 = h16 && vsk_options().lp_mlp_unfused != 1 &&
+                        vst_gemm_rows16_supported(B * T, 4 * w->desc.d_model, w->desc.d_model, vsk_options().lp_mlp_unfused == 2);
     const size_t kvs = qkv16 ? (size_t)B * T * w->desc.d_model / 2 : (size_t)B * T * w->desc.d_model;     // floats between the planes
     const unsigned long long seed = drop ? drop->seed : 0ull;
     const float scale = 1.0f / sqrtf((float)d);              // simnet.py:126: d_model ** -0.5
@@ -319,8 +321,10 @@ int vs_train_backward(vs_weights *w, const float *x, const uint8_t *key_pad_mask
     // the kernels round the fp32-stored values to the same bf16, so every result is bit-identical either way)
     const bool qkv16 = lp && lpa && !vsk_options().lp_store32;     // q / k / v of the record are bf16 planes
     const bool h16 = lp && !vsk_options().lp_store32;              // ... and so is the MLP hidden tensor (and, in the backward, its gradient)
-    // ... which the A-stationary GEMM writes where it applies (K = d_model = 256; VS_LP_MLP_UNFUSED = 1: the tiled kernels, A/B switch)
-    const bool rows16 = h16 && !vsk_options().lp_mlp_unfused && vst_gemm_rows16_supported(B * T, 4 * w->desc.d_model, w->desc.d_model);
+    // ... which the A-stationary GEMM writes where it applies (K = d_model = 256, batches that fill the chip; VS_LP_MLP_UNFUSED = 1: the
+    // tiled kernels, 2: the A-stationary kernel at every batch size - A/B and test switches)
+    const bool rows16 = h16 && vsk_options().lp_mlp_unfused != 1 &&
+                        vst_gemm_rows16_supported(B * T, 4 * w->desc.d_model, w->desc.d_model, vsk_options().lp_mlp_unfused == 2);
     const size_t kvs = qkv16 ? (size_t)B * T * w->desc.d_model / 2 : (size_t)B * T * w->desc.d_model;     // floats between the planes
     const unsigned long long seed = drop ? drop->seed : 0ull;
     const float scale = 1.0f / sqrtf((float)d);

@@ -169,13 +169,18 @@ __global__ __launch_bounds__(512, 2) void gemm_rows16(
 }  // namespace
 
 // (K = 512 would need 128 KB of W stages beside the scratch: not instantiated)
-bool vst_gemm_rows16_supported(int M, int N, int K) { return K == 256 && N % 8 == 0 && N >= GR_NT && N <= 4096 && M > 0; }
+// From 3/4 of a 256-row block per CU up (the grid is M / 256 blocks: at 16 384 rows it would fill a quarter of the chip and
+// measured 7 % slower per step than the tiled kernels' 256 tiles); MI355X: 256 CUs.
+// (any_rows: the kernel itself handles every M - tests pin it on small batches)
+bool vst_gemm_rows16_supported(int M, int N, int K, bool any_rows) {
+    return K == 256 && N % 8 == 0 && N >= GR_NT && N <= 4096 && M > 0 && (any_rows || M >= 192 * 256);
+}
 
 // epi 0: dropout(relu(.)) (seed, site, p); 1: gate (gate16, scale); 2: relu; 3: q / k / v planes (T, H, dh; scale = q's factor).
 // A fp32 [M, K]; W16 bf16 [N, K]; C16 bf16 [M, N] (epi 3: [3][M / T][H][T][dh]).
 int vst_gemm_rows16(const float *A, const void *W16, const float *bias, void *C16, const void *gate16, int M, int N, int K, int epi,
                     float scale, unsigned long long seed, unsigned site, float p, hipStream_t st, int T, int H, int dh) {
-    if (!vst_gemm_rows16_supported(M, N, K)) return -1;
+    if (!vst_gemm_rows16_supported(M, N, K, true)) return -1;
     if (epi == GR_QKV && (T <= 0 || H <= 0 || dh % 8 || N != 3 * H * dh || (H * dh) % GR_NT || M % T)) return -1;
     const dim3 grid((M + 255) / 256);
     const h16 *w = (const h16 *)W16, *g = (const h16 *)gate16;

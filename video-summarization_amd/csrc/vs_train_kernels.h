@@ -80,6 +80,6 @@ int vsp_head_backward(const float *feats, const float *scores, const uint8_t *ma
 
 // ---- vs_train_gemm_rows.hip: A-stationary bf16 GEMM for K = 256 with a bf16 C (fc1 forward, fc2 input gradient) ----
 // epi 0: dropout(relu(.)) (seed, site, p); 1: gate (gate16 = the bf16-stored activation, scale); 2: relu; 3: q / k / v planes
-bool vst_gemm_rows16_supported(int M, int N, int K);
+bool vst_gemm_rows16_supported(int M, int N, int K, bool any_rows = false);
 int vst_gemm_rows16(const float *A, const void *W16, const float *bias, void *C16, const void *gate16, int M, int N, int K, int epi,
                     float scale, unsigned long long seed, unsigned site, float p, hipStream_t st, int T = 0, int H = 0, int dh = 0);
