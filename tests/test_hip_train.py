@@ -372,9 +372,9 @@ def test_bf16_training_storage_forms_agree_bit_for_bit(vsa, lp_train_everywhere,
             assert torch.equal(a, b), n
 
 
-@pytest.mark.parametrize("p,B,T", [(0.0, 2, 200), (0.3, 3, 171), (0.5, 1, 1)])
-def test_a_stationary_mlp_gemms_equal_the_tiled_ones_bit_for_bit(vsa, lp_train_everywhere, p, B, T):
-    """d_model 256 in the bf16 training mode: fc1 (+ ReLU + dropout) and the fc2 input gradient (+ gate) run A-stationary
+@pytest.mark.parametrize("p,B,T,d", [(0.0, 2, 200, 256), (0.3, 3, 171, 256), (0.5, 1, 1, 256), (0.3, 2, 150, 512), (0.0, 1, 333, 512)])
+def test_a_stationary_mlp_gemms_equal_the_tiled_ones_bit_for_bit(vsa, lp_train_everywhere, p, B, T, d):
+    """d_model 256 / 512 in the bf16 training mode: fc1 (+ ReLU + dropout) and the fc2 input gradient (+ gate) run A-stationary
     (vs_train_gemm_rows.hip: a wave keeps its 32 rows of A in registers, W streams past, the bf16 result is written once).
     Same operands, same rounding points, bias first and k ascending like gemm_nt_128: VS_LP_MLP_UNFUSED = 1 (the tiled
     kernels) gives the same bits everywhere - logits, hidden states, every gradient; ragged row counts included."""
@@ -382,8 +382,8 @@ def test_a_stationary_mlp_gemms_equal_the_tiled_ones_bit_for_bit(vsa, lp_train_e
     try:
         for tiled in (1, 0):
             vsa._lib.set_option("VS_LP_MLP_UNFUSED", 1 if tiled else 2)       # 2: A-stationary whatever the batch size
-            m = vsa.SimNet(num_heads=4, d_model=256, num_layers=2, sparsity=0.0, dropout=p)
-            m.load_state_dict(vsa.synth.make_state_dict(256, 2, 3))
+            m = vsa.SimNet(num_heads=4, d_model=d, num_layers=2, sparsity=0.0, dropout=p)
+            m.load_state_dict(vsa.synth.make_state_dict(d, 2, 3))
             m = m.to(_dev()).train().set_train_dtype("bf16")
             x = torch.randn(B, T, 1024, generator=torch.Generator().manual_seed(1)).to(_dev()).requires_grad_(True)
             torch.manual_seed(5)

@@ -1,5 +1,5 @@
 // vs_train_gemm_rows.hip — the two widest GEMMs of a bf16 training step at small K (reference simnet.py:180-181 and its
-// backward): C16[M, N] = epilogue(A[M, K] W16[N, K]^T + bias), K = d_model = 256, N = 4 d_model, C written as bf16:
+// backward): C16[M, N] = epilogue(A[M, K] W16[N, K]^T + bias), K = d_model in {256, 512}, N = 4 d_model, C written as bf16:
 //   EPI_RELU_DROP  mlp.fc1 + ReLU + mlp.dropout (forward)            -> the bf16-stored hidden tensor
 //   EPI_GATE       d(hidden) = (dY W2) gated by that tensor's sign, times 1 / (1 - p) (backward) -> the bf16-stored gradient
 //   EPI_QKV        the q / k / v projections (N = 3 d_model; simnet.py:148-153): bf16 [3][B][H][T][dh] planes, q times scale * log2 e
@@ -24,20 +24,23 @@ namespace {
 
 typedef unsigned short h16;
 enum { GR_RELU_DROP = 0, GR_GATE = 1, GR_RELU = 2, GR_QKV = 3 };
-constexpr int GR_NT = 64;                       // output columns per stage
 
 // W image row (K bf16) in LDS: 16-byte chunk c at position c ^ (row & 15) (rows are 512 / 1024 B apart: without the XOR the
 // 16 lanes of a ds_read_b128 group - 16 different rows, one chunk each - would all hit the same four banks)
 template <int KT>
 __device__ __forceinline__ int wimg_off(int row, int chunk) { return row * (2 * KT) + ((chunk ^ (row & 15)) << 4); }
 
-template <int KT, int EPI, bool A16>      // A16: A is stored as bf16 (not used by the two call sites today; kept for the rows-copy form)
+// KT = 256: 64-column stages (two accumulator chains per wave); KT = 512 (d_model 512: the reference's default architecture):
+// 128 registers of A per lane and 32-column stages (one chain), so that two W stages still fit beside the scratch.
+template <int KT, int EPI, bool A16>      // A16: A is stored as bf16 (not used by the call sites today; kept for the rows-copy form)
 __global__ __launch_bounds__(512, 2) void gemm_rows16(
     const float *__restrict__ A, const h16 *__restrict__ W, const float *__restrict__ bias, h16 *__restrict__ C,
     const h16 *__restrict__ gate, int M, int N, float scale, unsigned long long seed, unsigned site, float p, int T, int H, int dh) {
     constexpr int NS = KT / 16;                                    // k-steps
-    constexpr int STAGE = GR_NT * 2 * KT;                          // bytes
-    constexpr int NLD = GR_NT * KT * 2 / 16 / 512;                 // 16-byte chunks per thread and stage (4 at K = 256)
+    constexpr int NB = KT == 256 ? 2 : 1, GR_NT = 32 * NB;         // 32-column blocks / output columns per stage
+    constexpr int STAGE = GR_NT * 2 * KT;                          // bytes (32 KB)
+    constexpr int NLD = GR_NT * KT * 2 / 16 / 512;                 // 16-byte chunks per thread and stage (4)
+    constexpr int LPR = 4 * NB, RPP = 64 / LPR, NPASS = 32 / RPP;  // read-back of the transposed stage: lanes per row, rows per pass, passes
     __shared__ __attribute__((aligned(16))) unsigned char wbuf[2][STAGE];
     __shared__ __attribute__((aligned(16))) unsigned char tbuf[8][32 * 144];      // per-wave transposition scratch: 32 rows x (64 bf16 + pad)
     __shared__ __attribute__((aligned(16))) float bias_s[4096];                   // the whole bias vector (N <= 4096): an accumulator's
@@ -86,23 +89,23 @@ __global__ __launch_bounds__(512, 2) void gemm_rows16(
     wstore(0);
     __syncthreads();
     unsigned char *tb = tbuf[wave];
-    const int trow = lane >> 3, tc8 = (lane & 7) * 8;
+    const int trow = lane / LPR, tc8 = (lane % LPR) * 8;
     for (int st = 0; st < nst; ++st) {
         const int buf = st & 1, n0 = st * GR_NT;
         if (st + 1 < nst) wload(st + 1);
-        u32x4 gpre[4];                              // this stage's gate values, requested before the MFMAs that they will mask
+        u32x4 gpre[NPASS];                          // this stage's gate values, requested before the MFMAs that they will mask
         if (EPI == GR_GATE) {
 #pragma unroll
-            for (int pp = 0; pp < 4; ++pp) {
-                int row = m0 + trow + 8 * pp; row = row < M ? row : M - 1;
+            for (int pp = 0; pp < NPASS; ++pp) {
+                int row = m0 + trow + RPP * pp; row = row < M ? row : M - 1;
                 int col = n0 + tc8; col = col < N ? col : N - 8;
                 gpre[pp] = *(const u32x4 *)(gate + (size_t)row * N + col);
             }
         }
         // acc[nb][t] = C[m = r][n = n0 + 32 nb + 8 (t >> 2) + 4 h + (t & 3)]: starts at the bias
-        f32x16 acc[2];
+        f32x16 acc[NB];
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
+        for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
             for (int tg = 0; tg < 4; ++tg) {
                 const int c = n0 + 32 * nb + 8 * tg + 4 * h;
@@ -113,7 +116,7 @@ __global__ __launch_bounds__(512, 2) void gemm_rows16(
 #pragma unroll
         for (int ks = 0; ks < NS; ++ks) {
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb) {
+            for (int nb = 0; nb < NB; ++nb) {
                 const bf16x8 wf = __builtin_bit_cast(bf16x8, *(const u32x4 *)(wbuf[buf] + wimg_off<KT>(32 * nb + r, 2 * ks + h)));
                 acc[nb] = MFMA_BF16(wf, af[ks], acc[nb]);
             }
@@ -121,7 +124,7 @@ __global__ __launch_bounds__(512, 2) void gemm_rows16(
         // ---- epilogue of this stage: the owner packs its 64 columns (ReLU here; dropout and gate need the transposed,
         // row-contiguous view), the wave transposes them through its scratch, 16-byte stores of whole 128-byte lines
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
+        for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
             for (int tg = 0; tg < 4; ++tg) {
                 f32x4 v;
@@ -139,9 +142,9 @@ __global__ __launch_bounds__(512, 2) void gemm_rows16(
                 *(u32x2 *)(tb + r * 144 + 64 * nb + 16 * tg + 8 * h) = u32x2{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
             }
 #pragma unroll
-        for (int pp = 0; pp < 4; ++pp) {
-            const int row = m0 + trow + 8 * pp, col = n0 + tc8;
-            u32x4 pk = *(const u32x4 *)(tb + (trow + 8 * pp) * 144 + 2 * tc8);
+        for (int pp = 0; pp < NPASS; ++pp) {
+            const int row = m0 + trow + RPP * pp, col = n0 + tc8;
+            u32x4 pk = *(const u32x4 *)(tb + (trow + RPP * pp) * 144 + 2 * tc8);
             if (row < M && col < N) {
                 if (EPI == GR_GATE) {          // the bf16-stored activation: > 0 <=> its 16 bits are a positive integer
                     const u32x4 g = gpre[pp];
@@ -168,12 +171,11 @@ __global__ __launch_bounds__(512, 2) void gemm_rows16(
 
 }  // namespace
 
-// (K = 512 would need 128 KB of W stages beside the scratch: not instantiated)
 // From 3/4 of a 256-row block per CU up (the grid is M / 256 blocks: at 16 384 rows it would fill a quarter of the chip and
 // measured 7 % slower per step than the tiled kernels' 256 tiles); MI355X: 256 CUs.
 // (any_rows: the kernel itself handles every M - tests pin it on small batches)
 bool vst_gemm_rows16_supported(int M, int N, int K, bool any_rows) {
-    return K == 256 && N % 8 == 0 && N >= GR_NT && N <= 4096 && M > 0 && (any_rows || M >= 192 * 256);
+    return (K == 256 || K == 512) && N % 8 == 0 && N >= 64 && N <= 4096 && M > 0 && (any_rows || M >= 192 * 256);
 }
 
 // epi 0: dropout(relu(.)) (seed, site, p); 1: gate (gate16, scale); 2: relu; 3: q / k / v planes (T, H, dh; scale = q's factor).
@@ -181,12 +183,16 @@ bool vst_gemm_rows16_supported(int M, int N, int K, bool any_rows) {
 int vst_gemm_rows16(const float *A, const void *W16, const float *bias, void *C16, const void *gate16, int M, int N, int K, int epi,
                     float scale, unsigned long long seed, unsigned site, float p, hipStream_t st, int T, int H, int dh) {
     if (!vst_gemm_rows16_supported(M, N, K, true)) return -1;
-    if (epi == GR_QKV && (T <= 0 || H <= 0 || dh % 8 || N != 3 * H * dh || (H * dh) % GR_NT || M % T)) return -1;
+    if (epi == GR_QKV && (T <= 0 || H <= 0 || dh % 8 || N != 3 * H * dh || (H * dh) % 64 || M % T)) return -1;
     const dim3 grid((M + 255) / 256);
     const h16 *w = (const h16 *)W16, *g = (const h16 *)gate16;
     h16 *c = (h16 *)C16;
 #define VST_GR(KT_, EPI_) hipLaunchKernelGGL((gemm_rows16<KT_, EPI_, false>), grid, dim3(512), 0, st, A, w, bias, c, g, M, N, scale, seed, site, p, T, H, dh)
-    if (epi == GR_RELU_DROP) VST_GR(256, GR_RELU_DROP); else if (epi == GR_GATE) VST_GR(256, GR_GATE); else if (epi == GR_RELU) VST_GR(256, GR_RELU); else if (epi == GR_QKV) VST_GR(256, GR_QKV); else return -1;
+    if (K == 256) {
+        if (epi == GR_RELU_DROP) VST_GR(256, GR_RELU_DROP); else if (epi == GR_GATE) VST_GR(256, GR_GATE); else if (epi == GR_RELU) VST_GR(256, GR_RELU); else if (epi == GR_QKV) VST_GR(256, GR_QKV); else return -1;
+    } else {
+        if (epi == GR_RELU_DROP) VST_GR(512, GR_RELU_DROP); else if (epi == GR_GATE) VST_GR(512, GR_GATE); else if (epi == GR_RELU) VST_GR(512, GR_RELU); else if (epi == GR_QKV) VST_GR(512, GR_QKV); else return -1;
+    }
 #undef VST_GR
     VSK_CHECK_LAUNCH();
     return 0;
