@@ -42,11 +42,15 @@ typedef struct vs_dropout_cfg {
  * (v_mfma_f32_32x32x16_bf16) with fp32 accumulation; tensors stay fp32 in HBM, and bias, residual, LayerNorm, softmax,
  * the attention products, dropout and the loss stay exact fp32 - what autocast keeps in fp32 (softmax, layer_norm, mse)
  * plus the attention matmuls.  Applied from 8192 frames per batch up (below, the exact latency kernels are faster);
- * pass the SAME flags to forward and backward.  Gradients then differ from the float64 truth by 1-3e-2 in relative L2
+ * pass the SAME flags to forward and backward.  With this flag the tensors of the activation record that are only ever
+ * bf16 matrix operands (the MLP hidden tensor; with VS_TRAIN_FLAG_BF16_ATTENTION also q / k / v) are STORED as bf16 (first
+ * half of their fields) - the same values their readers used to round to, so results do not change (the A/B switches
+ * VS_LP_STORE32 / VS_LP_MLP_UNFUSED of vs_set_option must not be flipped between a forward and its backward: they decide the
+ * record's format).  Gradients then differ from the float64 truth by 1-3e-2 in relative L2
  * norm per tensor (tests/tolerances.py: TRAIN_LP_GRAD_L2), where the exact path is at 1e-6. */
 #define VS_TRAIN_FLAG_BF16_LINEAR 1u
 /* ... and the attention products too (S = q k^T, P v, and the five products of the backward), head dim 32 / 64 / 128: q * scale,
- * k, v, dO, the probabilities and dS rounded to bf16, fp32 scores / softmax / lse / accumulation (head dim 128: exact). */
+ * k, v, dO, the probabilities and dS rounded to bf16, fp32 scores / softmax / lse / accumulation. */
 #define VS_TRAIN_FLAG_BF16_ATTENTION 2u
 #define VS_TRAIN_FLAG_BF16 (VS_TRAIN_FLAG_BF16_LINEAR | VS_TRAIN_FLAG_BF16_ATTENTION)
 
