@@ -26,6 +26,8 @@ Prints ONE JSON line on rank 0 with the contract fields plus
   emulated_f32  the same K steps again with every product EMULATED on the f16 matrix pipe ("fp16x3"): reported
                 beside `value`, never as `value`: the headline is the exact-fp32 MFMA path (--compute to change).
   bf16_mode     the same K steps on the bf16 matrix pipe (reduced precision, opt-in): context only.
+  training_step one training step on the same batch (HIP forward with dropout + masked MSE + HIP backward; SURVEY §8(f)
+                row 2), exact fp32 and under set_train_dtype("bf16"): context only.
 
 ``--workload`` selects the BASELINE.json configuration (same launcher, same JSON contract, one rank-0 line):
   batch  (default) configs[2]: B=64 x T=1024 x D=1024 per GPU, exact fp32, weak scaling - the headline metric
@@ -308,6 +310,7 @@ def main():
             low = (dt_low, diff)
 
         pcie_fps = pcie_overlap_fps = lat_ms = None
+        train_ms = None
         eval_ms = None
         if wl == "corpus":           # the consumer of the gathered scores: sharded keyshot evaluation + all_reduce of four sums
             harness = importlib.import_module("video-summarization_amd.harness")
@@ -342,6 +345,36 @@ def main():
                 model(x1)
             torch.cuda.synchronize()
             lat_ms = (time.perf_counter() - t1) / 200 * 1e3
+            # SURVEY §8(f) row 2, context only: one training step (HIP forward with dropout + masked-MSE loss + HIP backward) on
+            # the same batch, exact fp32 and under set_train_dtype("bf16") (the counterpart of the reference's autocast)
+            try:
+                tmodel = pkg.SimNet(num_heads=H, d_model=d, num_layers=L, sparsity=0.0, dropout=0.3)
+                tmodel.load_state_dict(sd)
+                tmodel = tmodel.to(dev).train()
+                ttarget = torch.rand(B, T, device=dev)
+                tmask = torch.zeros(B, T, dtype=torch.bool, device=dev)
+
+                def train_step():
+                    with torch.enable_grad():          # (this block sits inside the scoring legs' no_grad)
+                        pred, _h = tmodel(x, None)
+                        loss_ = pkg.mse_with_mask_loss(pred, ttarget, tmask)
+                        tmodel.zero_grad(set_to_none=True)
+                        loss_.backward()
+
+                train_ms = {}
+                for mode in ("fp32", "bf16"):
+                    tmodel.set_train_dtype(mode)
+                    for _ in range(3):
+                        train_step()
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    for _ in range(10):
+                        train_step()
+                    torch.cuda.synchronize()
+                    train_ms[mode] = (time.perf_counter() - t1) / 10 * 1e3
+                del tmodel
+            except Exception as exc:       # an extra must never cost the headline line
+                train_ms = {"error": repr(exc)}
 
     if dist is not None:
         t = torch.tensor([dt, emu[0] if emu else 0.0, emu[1] if emu else 0.0], dtype=torch.float64, device=dev)
@@ -464,6 +497,13 @@ def main():
         }
         if eval_ms is not None:
             out["eval_ms"] = round(eval_ms, 3)
+        if train_ms:
+            out["training_step"] = ({"workload": "forward under autograd (dropout 0.3) + masked MSE + backward on the same B x T batch, HIP "
+                                                 "kernels (include/vs_train.h); fp32 = exact, bf16 = SimNet.set_train_dtype('bf16')",
+                                     "fp32_ms": round(train_ms["fp32"], 3), "bf16_ms": round(train_ms["bf16"], 3),
+                                     "fp32_frames_per_s": round(B * T / train_ms["fp32"] * 1e3, 1),
+                                     "bf16_frames_per_s": round(B * T / train_ms["bf16"] * 1e3, 1)}
+                                    if "error" not in train_ms else train_ms)
         if emu:
             ev = frames / emu[0]
             out["emulated_f32"] = {
