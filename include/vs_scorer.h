@@ -223,6 +223,14 @@ int vs_attention_bf16(const float *q, const float *k, const float *v, const uint
                       float *out, int32_t B, int32_t H, int32_t T, int32_t dh, float scale,
                       void *stream);
 
+/* The bf16 mode's storage form of the same contract (what the fused bf16 layer kernels hand to the attention):
+ * q16 = bf16(q * scale * log2 e), k16, v16 head-major bf16 planes [B,H,T,dh]; out16 bf16 [B,T,H*dh]; dh in {32, 64, 128}.
+ * Head dim 64 runs on the one-wave-per-SIMD kernel (csrc/vs_attention_w64.hip) unless VS_ATTN_W64 = 0. */
+int vs_attention_bf16_stored(const void *q16, const void *k16, const void *v16, const uint8_t *key_pad_mask,
+                             void *out16, int32_t B, int32_t H, int32_t T, int32_t dh, void *stream);
+/* the factor a producer folds into q16: scale * log2 e */
+float vs_attention_qscale(float scale);
+
 /* The same contract emulated on the f16 matrix pipe (see VS_FLAG_F16X3_ATTENTION); dh in {32, 64}. */
 int vs_attention_f16x3(const float *q, const float *k, const float *v, const uint8_t *key_pad_mask,
                        float *out, int32_t B, int32_t H, int32_t T, int32_t dh, float scale,

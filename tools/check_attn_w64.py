@@ -1,0 +1,111 @@
+#!/usr/bin/env python3
+"""Quick check + timing of the one-wave-per-SIMD bf16 attention (csrc/vs_attention_w64.hip) against the 8-wave kernel
+(VS_ATTN_W64 = 0) and an fp64 reference that shares the rounded operands.
+
+    python tools/check_attn_w64.py            # correctness cases, then timings at the bench shapes
+    python tools/check_attn_w64.py time       # timings only"""
+import ctypes as C
+import importlib
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+pkg = importlib.import_module("video-summarization_amd")
+lib = pkg._lib.load()
+dev = torch.device("cuda:0")
+L2E = 1.4426950408889634
+
+
+def ref64(q16, k16, v16, mask):
+    s2 = torch.matmul(q16.double(), k16.double().transpose(2, 3))
+    if mask is not None:
+        s2 = s2.masked_fill(mask[:, None, None, :], float("-inf"))
+    p = torch.exp2(s2 - s2.max(dim=3, keepdim=True).values)
+    o = torch.matmul(p, v16.double()) / p.sum(dim=3, keepdim=True)
+    B, H, T, dh = q16.shape
+    return o.permute(0, 2, 1, 3).reshape(B, T, H * dh)
+
+
+def run(q16, k16, v16, mask, w64):
+    B, H, T, dh = q16.shape
+    pkg._lib.set_option("VS_ATTN_W64", 1 if w64 else 0)
+    out = torch.full((B, T, H * dh), float("nan"), device=dev, dtype=torch.bfloat16)
+    st = torch.cuda.current_stream().cuda_stream
+    pkg._lib.check(lib.vs_attention_bf16_stored(q16.data_ptr(), k16.data_ptr(), v16.data_ptr(),
+                                                mask.data_ptr() if mask is not None else None, out.data_ptr(), B, H, T, dh, st))
+    torch.cuda.synchronize()
+    pkg._lib.set_option("VS_ATTN_W64", -1)
+    return out
+
+
+def case(B, H, T, masked=False, sigma=2.0, seed=0, spike=False):
+    g = torch.Generator().manual_seed(seed + T)
+    q, k, v = (torch.randn(B, H, T, 64, generator=g) * sigma for _ in range(3))
+    if spike and T > 301:
+        k[:, :, 300] = q.mean(dim=2) * 50.0 + 20.0
+        k[:, :, 77] = -k[:, :, 300]
+    scale = (H * 64) ** -0.5 if not spike else 1.0
+    q16 = (q * (scale * L2E)).to(torch.bfloat16).to(dev)
+    k16, v16 = k.to(torch.bfloat16).to(dev), v.to(torch.bfloat16).to(dev)
+    mask = None
+    if masked:
+        mask = torch.rand(B, T, generator=g) < 0.3
+        mask[:, 0] = False
+        if T > 130:
+            mask[0, 64:128] = True              # a fully masked tile
+            mask[-1, T // 2:] = True            # suffix padding
+        mask = mask.to(dev)
+    ref = ref64(q16.cpu(), k16.cpu(), v16.cpu(), mask.cpu() if mask is not None else None)
+    new = run(q16, k16, v16, mask, True).cpu().double()
+    old = run(q16, k16, v16, mask, False).cpu().double()
+    en = (new - ref).abs().max().item() / ref.abs().max().item()
+    eo = (old - ref).abs().max().item() / ref.abs().max().item()
+    ok = bool(torch.isfinite(new).all()) and en < 6e-3
+    print("B=%d H=%d T=%5d masked=%d spike=%d: new rel err %.2e (old kernel %.2e) %s" % (B, H, T, masked, spike, en, eo, "ok" if ok else "FAIL"), flush=True)
+    return ok
+
+
+def timing(B, H, T, iters=20):
+    g = torch.Generator().manual_seed(1)
+    q, k, v = (torch.randn(B, H, T, 64, generator=g) for _ in range(3))
+    scale = (H * 64) ** -0.5
+    q16 = (q * (scale * L2E)).to(torch.bfloat16).to(dev)
+    k16, v16 = k.to(torch.bfloat16).to(dev), v.to(torch.bfloat16).to(dev)
+    out = torch.empty((B, T, H * 64), device=dev, dtype=torch.bfloat16)
+    st = torch.cuda.current_stream().cuda_stream
+    fl = 4.0 * B * H * T * T * 64
+    res = []
+    for w64 in (0, 1):
+        pkg._lib.set_option("VS_ATTN_W64", w64)
+        for _ in range(5):
+            lib.vs_attention_bf16_stored(q16.data_ptr(), k16.data_ptr(), v16.data_ptr(), None, out.data_ptr(), B, H, T, 64, st)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            lib.vs_attention_bf16_stored(q16.data_ptr(), k16.data_ptr(), v16.data_ptr(), None, out.data_ptr(), B, H, T, 64, st)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / iters
+        res.append(ms)
+        print("B=%d H=%d T=%d %s: %.4f ms  %.0f TF (%.3f of 2.5 PF)" % (B, H, T, "w64 (4 waves x 64 rows)" if w64 else "8-wave kernel        ", ms, fl / ms / 1e9, fl / ms / 1e9 / 2500), flush=True)
+    pkg._lib.set_option("VS_ATTN_W64", -1)
+    return res
+
+
+if __name__ == "__main__":
+    ok = True
+    if len(sys.argv) < 2 or sys.argv[1] != "time":
+        for args in [(1, 1, 64), (1, 1, 256), (2, 4, 320), (1, 4, 1024), (1, 2, 65), (1, 1, 1), (1, 4, 31), (2, 2, 513), (1, 2, 200),
+                     (1, 1, 2048)]:
+            ok &= case(*args)
+        for args in [(2, 4, 200), (2, 2, 513), (1, 1, 64), (3, 2, 1000)]:
+            ok &= case(*args, masked=True)
+        ok &= case(1, 4, 512, spike=True)
+        ok &= case(2, 2, 700, masked=True, spike=True)
+        ok &= case(1, 2, 640, sigma=8.0)
+    timing(8, 4, 8192)
+    timing(64, 4, 1024)
+    print("ALL OK" if ok else "FAILURES")
+    sys.exit(0 if ok else 1)

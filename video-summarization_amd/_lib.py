@@ -17,7 +17,7 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(ROOT, "include")
 LIB_PATH = os.path.join(HERE, "libvsscore.so")
 DIAG_LIB_PATH = os.path.join(HERE, "libvsscore_diag.so")
-SOURCES = ("vs_kernels.hip", "vs_attention.hip", "vs_mlp_fused.hip", "vs_gemm_ring.hip", "vs_scorer.cpp", "vs_eval.cpp",
+SOURCES = ("vs_kernels.hip", "vs_attention.hip", "vs_attention_w64.hip", "vs_mlp_fused.hip", "vs_gemm_ring.hip", "vs_scorer.cpp", "vs_eval.cpp",
            "vs_train_kernels.hip", "vs_train_attention.hip", "vs_train_attention_bf16.hip", "vs_train_gemm_rows.hip", "vs_pretrain_kernels.hip",
            "vs_train.cpp")
 ABI_VERSION = 3
@@ -35,7 +35,7 @@ VS_TRAIN_FLAG_BF16_ATTENTION = 2
 EXPORTS = ("vs_abi_version", "vs_last_error", "vs_weights_pack", "vs_weights_free", "vs_weights_update", "vs_set_option",
            "vs_scorer_workspace_bytes", "vs_scorer_forward", "vs_scorer_workspace_bytes_packed",
            "vs_scorer_forward_packed", "vs_scorer_workspace_bytes_cls", "vs_scorer_forward_cls", "vs_linear_f32", "vs_qkv_proj_f32",
-           "vs_attention_f32", "vs_attention_bf16", "vs_attention_f16x3", "vs_linear_residual_layernorm_f32",
+           "vs_attention_f32", "vs_attention_bf16", "vs_attention_bf16_stored", "vs_attention_qscale", "vs_attention_f16x3", "vs_linear_residual_layernorm_f32",
            "vs_linear_bf16", "vs_linear_residual_layernorm_bf16", "vs_linear_f16x3",
            "vs_linear_residual_layernorm_f16x3", "vs_mlp_block_bf16",
            "vs_linear_bf16_operands", "vs_qkv_proj_bf16_operands", "vs_to_bf16", "vs_linear_bf16_a16",
@@ -204,6 +204,10 @@ def load() -> C.CDLL:
         lib.vs_qkv_proj_f32.argtypes = [C.c_void_p] * 4 + [C.c_int32] * 4 + [C.c_void_p]
         lib.vs_attention_f32.restype = C.c_int
         lib.vs_attention_f32.argtypes = [C.c_void_p] * 5 + [C.c_int32] * 4 + [C.c_float, C.c_void_p]
+        lib.vs_attention_bf16_stored.restype = C.c_int
+        lib.vs_attention_bf16_stored.argtypes = [C.c_void_p] * 5 + [C.c_int32] * 4 + [C.c_void_p]
+        lib.vs_attention_qscale.restype = C.c_float
+        lib.vs_attention_qscale.argtypes = [C.c_float]
         lib.vs_attention_bf16.restype = C.c_int
         lib.vs_attention_bf16.argtypes = lib.vs_attention_f32.argtypes
         lib.vs_attention_f16x3.restype = C.c_int

@@ -1474,6 +1474,8 @@ int vsk_attention_packed(const float *q, const float *k, const float *v, float *
                          float scale, const int *cu, const int *work, int nwork, int nw, int prec, hipStream_t st) {
     const float sl2 = vsk_attention_qscale(scale);
     if (nwork <= 0) return 0;
+    if (prec == (1 | VSK_STORE16) && dh == 64 && nw == 8 && vsk_options().attn_w64)      // one wave per SIMD: the same 256-row work items
+        return vsk_attention_bf16_w64_packed(q, k, v, out, H, Mtot, cu, work, nwork, st);
     dim3 grid(nwork, H);
     const int2 *wk = (const int2 *)work;
 #define VSK_ATTN_PX(DH_, NW_) \
@@ -1540,6 +1542,10 @@ int vsk_attention_bf16(const float *q, const float *k, const float *v, const uin
     else                                                                                                                 \
         return -1;
     if (prec == (1 | VSK_STORE16)) {      // bf16 q (pre-scaled) / k / v in, bf16 out: the pipelined kernel only
+        if (dh == 64 && wide && vsk_options().attn_w64) {      // one wave per SIMD, 4 waves x 64 query rows (vs_attention_w64.hip)
+            const int rc = vsk_attention_bf16_w64(q, k, v, mask, out, B, H, T, st);
+            if (rc != -1) return rc;
+        }
         if (dh == 64 && wide)
             hipLaunchKernelGGL((attn_fwd_lp_pipe<64, 8, 1, false, true>), grid, dim3(512), 0, st, q, k, v, mask, out, H, T, sl2, BH);
         else if (dh == 64)

@@ -31,6 +31,12 @@ float vsk_attention_qscale(float scale);
 // prec 1: bf16 operands; 2: fp32 emulated with f16 hi+lo operand halves ("fp16x3")
 int vsk_attention_bf16(const float *q, const float *k, const float *v, const uint8_t *mask, float *out,
                        int B, int H, int T, int dh, float scale, int prec, hipStream_t st);
+// vs_attention_w64.hip: bf16 q (pre-scaled) / k / v planes in, bf16 out, head dim 64, one wave per SIMD (4 waves x 64 query
+// rows per block).  -1: shape outside this kernel (the caller uses attn_fwd_lp_pipe).
+int vsk_attention_bf16_w64(const void *q, const void *k, const void *v, const uint8_t *mask, void *out, int B, int H, int T,
+                           hipStream_t st);
+int vsk_attention_bf16_w64_packed(const void *q, const void *k, const void *v, void *out, int H, int Mtot, const int *cu,
+                                  const int *work, int nwork, hipStream_t st);
 int vsk_linear_res_ln(const float *A, const float *W, const float *Wf, const float *bias, const float *res,
                       const float *gamma, const float *beta, float *out, int M, int N, int K,
                       const float *score_w, const float *score_b, int num_classes, int sigmoid,
@@ -107,6 +113,7 @@ struct VskOptions {
     int gemm_nj2;         // VS_GEMM_NJ2      128-column GEMM tiles only
     int attn_nw4;         // VS_ATTN_NW4      4-wave attention blocks only
     int attn_lp_simple;   // VS_ATTN_LP_SIMPLE phase-aligned low-precision attention
+    int attn_w64;         // VS_ATTN_W64      (default 1) bf16-stored head-dim-64 attention on the one-wave-per-SIMD kernel (0: the 8-wave kernel, A/B)
     int lp_store32;       // VS_LP_STORE32    bf16 mode keeps q/k/v, the attention output and the MLP hidden tensor fp32 in HBM (A/B)
     int lp_mlp_unfused;   // VS_LP_MLP_UNFUSED bf16 mode runs fc1 and fc2 + LayerNorm as two kernels (A/B)
     int lp_tail_unfused;  // VS_LP_TAIL_UNFUSED bf16 mode runs the out-projection + norm1 as its own kernel in front of the fused MLP (A/B)

@@ -118,6 +118,7 @@ const OptionName kOptions[] = {
     {"VS_LP_MLP_UNFUSED", &VskOptions::lp_mlp_unfused, 0}, {"VS_LP_TAIL_UNFUSED", &VskOptions::lp_tail_unfused, 0},
     {"VS_LP_QKV_UNFUSED", &VskOptions::lp_qkv_unfused, 0}, {"VS_LP_EMBED_UNFUSED", &VskOptions::lp_embed_unfused, 0},
     {"VS_LP_MIN_ROWS_FUSED", &VskOptions::lp_min_rows_fused, 256}, {"VS_LP_TILE256", &VskOptions::lp_tile256, 0},
+    {"VS_ATTN_W64", &VskOptions::attn_w64, 1},
 };
 int option_from_env(const OptionName &o) {
     const char *e = getenv(o.name);
@@ -837,6 +838,18 @@ int vs_attention_bf16(const float *q, const float *k, const float *v, const uint
                       float *out, int32_t B, int32_t H, int32_t T, int32_t dh, float scale, void *stream) {
     return attention_lp_entry(q, k, v, key_pad_mask, out, B, H, T, dh, scale, 1, stream);
 }
+
+int vs_attention_bf16_stored(const void *q16, const void *k16, const void *v16, const uint8_t *key_pad_mask,
+                             void *out16, int32_t B, int32_t H, int32_t T, int32_t dh, void *stream) {
+    if (!q16 || !k16 || !v16 || !out16) return fail(VS_ERR_INVALID, "NULL pointer");
+    if (B <= 0 || H <= 0 || T <= 0) return fail(VS_ERR_INVALID, "B=%d H=%d T=%d", B, H, T);
+    if (dh != 32 && dh != 64 && dh != 128) return fail(VS_ERR_INVALID, "head_dim=%d unsupported on the bf16 path", dh);
+    VS_LAUNCH(vsk_attention_bf16((const float *)q16, (const float *)k16, (const float *)v16, key_pad_mask, (float *)out16, B, H, T, dh,
+                                 1.0f, 1 | VSK_STORE16, (hipStream_t)stream));
+    return VS_OK;
+}
+
+float vs_attention_qscale(float scale) { return vsk_attention_qscale(scale); }
 
 int vs_attention_f16x3(const float *q, const float *k, const float *v, const uint8_t *key_pad_mask,
                        float *out, int32_t B, int32_t H, int32_t T, int32_t dh, float scale, void *stream) {
