@@ -13,6 +13,8 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 pkg = importlib.import_module("video-summarization_amd")
+if len(sys.argv) > 1 and sys.argv[1] == "abl":      # timing ablations: the diagnostic library (tools/gen_attn_w64.py --abl ... first)
+    os.environ["VS_LIBRARY"] = pkg._lib.DIAG_LIB_PATH if os.path.exists(pkg._lib.DIAG_LIB_PATH) else pkg._lib.build(diag=True)
 lib = pkg._lib.load()
 dev = torch.device("cuda:0")
 L2E = 1.4426950408889634
@@ -67,7 +69,18 @@ def case(B, H, T, masked=False, sigma=2.0, seed=0, spike=False):
     return ok
 
 
-def timing(B, H, T, iters=20):
+def warm(seconds=0.5):
+    """the chip settles its clock over the first few hundred ms of load: keep it busy before a measurement"""
+    import time
+    a = torch.randn(4096, 4096, device=dev, dtype=torch.bfloat16)
+    t0 = time.time()
+    while time.time() - t0 < seconds:
+        for _ in range(10):
+            a = (a @ a).clamp_(-1, 1)
+        torch.cuda.synchronize()
+
+
+def timing(B, H, T, iters=50):
     g = torch.Generator().manual_seed(1)
     q, k, v = (torch.randn(B, H, T, 64, generator=g) for _ in range(3))
     scale = (H * 64) ** -0.5
@@ -79,6 +92,7 @@ def timing(B, H, T, iters=20):
     res = []
     for w64 in (0, 1):
         pkg._lib.set_option("VS_ATTN_W64", w64)
+        warm()
         for _ in range(5):
             lib.vs_attention_bf16_stored(q16.data_ptr(), k16.data_ptr(), v16.data_ptr(), None, out.data_ptr(), B, H, T, 64, st)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -94,7 +108,42 @@ def timing(B, H, T, iters=20):
     return res
 
 
+def ablations(B, H, T, iters=50):
+    """timing ablations of the stream (WRONG results by construction): what is left when a class of work is removed"""
+    g = torch.Generator().manual_seed(1)
+    q, k, v = (torch.randn(B, H, T, 64, generator=g) for _ in range(3))
+    q16 = (q * ((H * 64) ** -0.5 * L2E)).to(torch.bfloat16).to(dev)
+    k16, v16 = k.to(torch.bfloat16).to(dev), v.to(torch.bfloat16).to(dev)
+    out = torch.empty((B, T, H * 64), device=dev, dtype=torch.bfloat16)
+    st = torch.cuda.current_stream().cuda_stream
+    fl = 4.0 * B * H * T * T * 64
+    names = {0: "full kernel", 2: "no LDS-DMA", 4: "no fragment reads", 8: "no barrier", 14: "no DMA, no reads, no barrier",
+             15: "MFMAs only", 16: "exp2 -> mov", 32: "no packs, no OR chain", 64: "proportional distribution",
+             30: "exp2 -> mov, no DMA / reads / barrier"}
+    pkg._lib.set_option("VS_ATTN_W64", 1)
+    names.update({128: "no key-bias checks", 256: "no OR test (chain kept)", 384: "no bias checks, no OR test",
+                  398: "no checks, no DMA / reads / barrier"})
+    for abl in (0, 14, 15, 128, 256, 384, 398):
+        pkg._lib.set_option("VS_ATTN_W64_ABL", abl)
+        warm(0.3)
+        for _ in range(5):
+            lib.vs_attention_bf16_stored(q16.data_ptr(), k16.data_ptr(), v16.data_ptr(), None, out.data_ptr(), B, H, T, 64, st)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            lib.vs_attention_bf16_stored(q16.data_ptr(), k16.data_ptr(), v16.data_ptr(), None, out.data_ptr(), B, H, T, 64, st)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / iters
+        print("B=%d H=%d T=%d abl %2d %-30s %.4f ms  %5.0f TF" % (B, H, T, abl, names[abl], ms, fl / ms / 1e9), flush=True)
+    pkg._lib.set_option("VS_ATTN_W64_ABL", 0)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "abl":
+        ablations(8, 4, 8192)
+        ablations(64, 4, 1024)
+        sys.exit(0)
     ok = True
     if len(sys.argv) < 2 or sys.argv[1] != "time":
         for args in [(1, 1, 64), (1, 1, 256), (2, 4, 320), (1, 4, 1024), (1, 2, 65), (1, 1, 1), (1, 4, 31), (2, 2, 513), (1, 2, 200),

@@ -62,7 +62,7 @@ sNINF, sN32K, sP32K = 62, 63, 68
 sRAISE = 64                         # s[64:65]
 sMSK = 66                           # s[66:67]
 sTMP, sTMP2, sMB, sKB, sVB, sC4096, sOB = 69, 70, 71, 72, 73, 74, 75
-sLAST = 76
+sLAST, sKB1, sVB1, sR3 = 76, 77, 78, 79
 
 
 def vr(b, n=1):
@@ -213,50 +213,141 @@ def bias_block(g, x, name, ret):
     t.append("s_branch %s_%%=" % ret)
 
 
-def softmax_job(g, x, par, lo=0, hi=18):
-    """The filler groups lo..hi-1 of softmax(tile sT1, row block x) -> P[par] (18 groups, lists of instructions):
-    group 0 = checks, 1..16 = one exp2 pair each (+ the previous pair's pack, + the running OR), 17 = last pack, OR test.
-    The out-of-line rare blocks are generated only for the groups asked for."""
-    groups = []
-    if lo == 0:
-        sb, rb0 = g.site(), g.site()
-        g0 = ["s_lshr_b32 %s, %s, 5" % (sr(sTMP), sr(sT1)),
-          "v_readlane_b32 %s, %%[flags], %s" % (sr(sTMP2), sr(sTMP)),
-          "s_bitcmp1_b32 %s, %s" % (sr(sTMP2), sr(sT1)),
-          "s_cbranch_scc1 B%s_%%=" % sb,
-          "R%s_%%=:" % sb,
-          "v_cmp_eq_f32 vcc, %s, %s" % (sr(sNINF), vr(VM[x])),
-          "s_cbranch_vccnz B%s_%%=" % rb0,
-          "R%s_%%=:" % rb0]
-        bias_block(g, x, "B" + sb, "R" + sb)
-        rebase_block(g, x, None, "B" + rb0, "R" + rb0)
+MASKED = False   # which variant is being generated: generic tile flags (key mask) or "only the last tile can be ragged"
+
+
+class Item:
+    """an atomic group of filler instructions with its issue cost (cycles) and, optionally, the out-of-line blocks it needs"""
+    def __init__(self, ops, cost=None, blocks=None):
+        self.ops = ops
+        self.cost = cost if cost is not None else 4 * len([o for o in ops if not o.endswith(":")])
+        self.blocks = blocks
+
+    def emit(self, g):
+        for op in self.ops:
+            if (ABL & 16) and op.startswith("v_exp_f32"):
+                op = op.replace("v_exp_f32", "v_mov_b32")              # timing ablation: no transcendental unit
+            if (ABL & 32) and (op.startswith("v_cvt_pk") or op.startswith("v_or")):
+                continue                                               # timing ablation: no packs, no OR chain
+            if (ABL & 128) and (op.startswith("s_cmp_eq_u32") or op.startswith("s_cbranch_scc1 B")):
+                continue                                               # timing ablation: no key-bias check
+            if (ABL & 256) and (op.startswith("v_cmp_ne_u32 vcc") or op.startswith("s_cbranch_vccnz B") or op.startswith("v_and_b32")):
+                continue                                               # timing ablation: no OR test (the chain stays)
+            g.e(op)
+        if self.blocks is not None:
+            self.blocks()
+
+
+def tile0_prelude(g, x):
+    """no-mask variant, pre-iteration only: tile 0's key bias (a video shorter than one tile) and the rows' first constant"""
+    sb, rb0 = g.site(), g.site()
+    for op in ["s_cmp_eq_u32 %s, %s" % (sr(sT1), sr(sLAST)), "s_cbranch_scc1 B%s_%%=" % sb, "R%s_%%=:" % sb,
+               "v_cmp_eq_f32 vcc, %s, %s" % (sr(sNINF), vr(VM[x])), "s_cbranch_vccnz B%s_%%=" % rb0, "R%s_%%=:" % rb0]:
+        g.e(op)
+    bias_block(g, x, "B" + sb, "R" + sb)
+    rebase_block(g, x, None, "B" + rb0, "R" + rb0)
+
+
+def job_items(g, x, par, tile0):
+    """softmax(tile sT1, row block x) -> P[par] as an ordered list of Items: the checks, then per pair of keys two exp2 and
+    (one pair behind: the transcendental unit's result needs a wait state) the pack, the running OR, the OR test.
+    Key-mask variant: per-tile flag and "row without a constant" checks in every job.  No-mask variant: only the last
+    tile can need the key bias, and every row has its constant after tile 0 (tile0_prelude does both for tile 0; the job of
+    tile 0 then carries two nops in place of the check so that every job has the same cost profile - the B job is split
+    over two iterations and both halves must agree on where)."""
+    items = []
+    if not MASKED and tile0:
+        items.append(Item(["s_nop 0", "s_nop 0"]))
     else:
-        g0 = []
-    groups.append(g0)
+        sb = g.site()
+        if MASKED:
+            ops = ["s_lshr_b32 %s, %s, 5" % (sr(sTMP), sr(sT1)),
+                   "v_readlane_b32 %s, %%[flags], %s" % (sr(sTMP2), sr(sTMP)),
+                   "s_bitcmp1_b32 %s, %s" % (sr(sTMP2), sr(sT1))]
+        else:
+            ops = ["s_cmp_eq_u32 %s, %s" % (sr(sT1), sr(sLAST))]
+        ops += ["s_cbranch_scc1 B%s_%%=" % sb, "R%s_%%=:" % sb]
+        items.append(Item(ops, blocks=lambda: bias_block(g, x, "B" + sb, "R" + sb)))
+    if MASKED:
+        rb0 = g.site()
+        items.append(Item(["v_cmp_eq_f32 vcc, %s, %s" % (sr(sNINF), vr(VM[x])), "s_cbranch_vccnz B%s_%%=" % rb0, "R%s_%%=:" % rb0],
+                          blocks=lambda: rebase_block(g, x, None, "B" + rb0, "R" + rb0)))
     acc = VOR0
     for k in range(16):
-        grp = pair_exp(x, k)
+        e2 = pair_exp(x, k)
+        items.append(Item([e2[0]], 8))
+        items.append(Item([e2[1]], 8))
         if k > 0:
-            grp.append(pair_cvt(x, par, k - 1))
-        # running OR over the packed P: pairs <= k-2 are complete here
+            items.append(Item([pair_cvt(x, par, k - 1)]))
         if k == 4:
-            grp.append("v_or3_b32 %s, %s, %s, %s" % (vr(acc), vr(preg_of_pair(x, par, 0)), vr(preg_of_pair(x, par, 1)), vr(preg_of_pair(x, par, 2))))
+            items.append(Item(["v_or3_b32 %s, %s, %s, %s" % (vr(acc), vr(preg_of_pair(x, par, 0)), vr(preg_of_pair(x, par, 1)), vr(preg_of_pair(x, par, 2)))]))
         elif k in (6, 8, 10, 12, 14):
-            grp.append("v_or3_b32 %s, %s, %s, %s" % (vr(acc), vr(acc), vr(preg_of_pair(x, par, k - 3)), vr(preg_of_pair(x, par, k - 2))))
-        groups.append(grp)
-    if hi < 18:
-        return groups[lo:hi]
+            items.append(Item(["v_or3_b32 %s, %s, %s, %s" % (vr(acc), vr(acc), vr(preg_of_pair(x, par, k - 3)), vr(preg_of_pair(x, par, k - 2)))]))
     rb = g.site()
-    last = [pair_cvt(x, par, 15),
-            "v_or3_b32 %s, %s, %s, %s" % (vr(acc), vr(acc), vr(preg_of_pair(x, par, 13)), vr(preg_of_pair(x, par, 14))),
-            "v_or_b32 %s, %s, %s" % (vr(acc), vr(acc), vr(preg_of_pair(x, par, 15))),
-            "v_and_b32 %s, 0x40004000, %s" % (vr(acc), vr(acc)),
-            "v_cmp_ne_u32 vcc, 0, %s" % vr(acc),
-            "s_cbranch_vccnz B%s_%%=" % rb,
-            "R%s_%%=:" % rb]
-    rebase_block(g, x, par, "B" + rb, "R" + rb)
-    groups.append(last)
-    return groups[lo:hi]
+    items.append(Item([pair_cvt(x, par, 15)]))
+    items.append(Item(["v_or3_b32 %s, %s, %s, %s" % (vr(acc), vr(acc), vr(preg_of_pair(x, par, 13)), vr(preg_of_pair(x, par, 14))),
+                       "v_or_b32 %s, %s, %s" % (vr(acc), vr(acc), vr(preg_of_pair(x, par, 15))),
+                       "v_and_b32 %s, 0x40004000, %s" % (vr(acc), vr(acc)),
+                       "v_cmp_ne_u32 vcc, 0, %s" % vr(acc),
+                       "s_cbranch_vccnz B%s_%%=" % rb,
+                       "R%s_%%=:" % rb], blocks=lambda: rebase_block(g, x, par, "B" + rb, "R" + rb)))
+    return items
+
+
+BUDGET = 24      # cycles of filler issue a v_mfma_f32_32x32x16_bf16 gap hides (32 minus the MFMA's own 8)
+
+
+def distribute_quota(items, quota):
+    """items (ordered) over len(quota) MFMA gaps: gap i takes items until it holds quota[i] exp2 (and the non-exp2 items
+    that follow them); items before the first exp2 go to gap 0, what is left after the last quota to the next gap."""
+    n = len(quota)
+    out = [[] for _ in range(n)]
+    idx = 0
+    last_q = max(i for i in range(n) if quota[i] > 0)
+    for sl in range(n):
+        taken = 0
+        while idx < len(items):
+            is_exp = items[idx].ops[0].startswith("v_exp")
+            if is_exp and taken >= quota[sl]:
+                break
+            if not is_exp and sl > last_q:
+                pass
+            out[sl].append(items[idx])
+            taken += 1 if is_exp else 0
+            idx += 1
+            if sl <= last_q and taken >= quota[sl] and idx < len(items) and items[idx].ops[0].startswith("v_exp"):
+                break
+        if sl == last_q:
+            # the exp2 are placed; the remaining items (last pack, OR test) go to the next gap
+            pass
+    assert idx == len(items), (idx, len(items))
+    return out
+
+
+QUOTA_A = [1, 1, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2] + [2, 2, 2, 2, 2, 0, 0, 0]      # steps 2 + 3
+QUOTA_B = [1, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 1] + [2, 2, 2, 2, 2, 0, 0, 0]      # step 4 + the next step 1
+
+
+def distribute(items, fixed):
+    """items (ordered) over len(fixed) MFMA gaps; fixed[i] = issue cycles gap i already carries.  Every gap gets a share
+    of what is left in proportion to its room, so that an over-full phase is over-full evenly."""
+    n = len(fixed)
+    out = [[] for _ in range(n)]
+    idx = 0
+    remaining = sum(it.cost for it in items)
+    rooms = [max(BUDGET - f, 4) for f in fixed]
+    for sl in range(n):
+        if sl == n - 1:
+            out[sl] = items[idx:]
+            break
+        share = remaining * rooms[sl] / float(sum(rooms[sl:]))
+        taken = 0
+        while idx < len(items) and taken + items[idx].cost / 2.0 <= share:
+            out[sl].append(items[idx])
+            taken += items[idx].cost
+            idx += 1
+        remaining -= taken
+    return out
 
 
 def v_reads(f):
@@ -280,89 +371,121 @@ def k_addr_ops(ring):
             "v_xor_b32 %s, 0x60, %s" % (vr(VKA + 3), vr(VKA))]
 
 
-def dma_ops():
-    """K(t+4) -> ring slot (t+1) % 3, V(t+3) -> ring slot t % 3; this wave's pieces 2w and 2w+1 of each.  No instruction
-    offset: it would be added to the LDS address as well as to the source address."""
-    return [["s_add_u32 m0, %s, %s" % (sr(sKB0), sr(sR1)), "s_nop 0",
-             "buffer_load_dwordx4 %%[dk0], %s, %s offen lds" % (sr(KD, 4), sr(sKSO))],
-            ["s_add_u32 m0, m0, 0x400", "s_nop 0",
-             "buffer_load_dwordx4 %s, %s, %s offen lds" % (vr(VDK1), sr(KD, 4), sr(sKSO))],
-            ["s_add_u32 m0, %s, %s" % (sr(sVB0), sr(sR0)), "s_nop 0",
-             "buffer_load_dwordx4 %%[dv0], %s, %s offen lds" % (sr(VD, 4), sr(sVSO))],
-            ["s_add_u32 m0, m0, 0x400", "s_nop 0",
-             "buffer_load_dwordx4 %s, %s, %s offen lds" % (vr(VDV1), sr(VD, 4), sr(sVSO))]]
+def dma_piece(is_k, piece, ring):
+    """one LDS-DMA piece (1 KiB, 8 key rows) of this wave: K / V piece 0 / 1 into ring slot `ring` (an SGPR offset).
+    No instruction offset: it would be added to the LDS address as well as to the source address."""
+    base = (sKB0, sKB1, sVB0, sVB1)[(0 if is_k else 2) + piece]
+    voff = ("%[dk0]", vr(VDK1), "%[dv0]", vr(VDV1))[(0 if is_k else 2) + piece]
+    return ["s_add_u32 m0, %s, %s" % (sr(base), sr(ring)), "s_nop 0",
+            "buffer_load_dwordx4 %s, %s, %s offen lds" % (voff, sr(KD if is_k else VD, 4), sr(sKSO if is_k else sVSO))]
+
+
+DMA_COST = 16
+
+ABL = 0      # timing ablations (diagnostic library only; WRONG results): 1 no softmax work, 2 no LDS-DMA, 4 no fragment reads, 8 no barrier,
+             # 16 exp2 -> mov, 32 no packs / OR chain, 64 the proportional filler distribution instead of the exp2 quotas
 
 
 def iteration(g, par, do_pv, do_s):
     """One iteration t (see the kernel header); P(t, .) lives in P[par], softmax(t+1, .) writes P[par ^ 1].
-    do_pv False: the pre-iteration t = -1; do_s False: the last tile."""
+    do_pv False: the pre-iteration t = -1; do_s False: the last tile.
+    LDS-DMA: one piece per step, so that the four waves of a block never issue sixteen pieces at once behind the barrier:
+    step 4 K(t+4) piece 0; next iteration's steps 1 / 2 / 3: K(t+4) piece 1, V(t+3) piece 0, V(t+3) piece 1 - i.e. THIS
+    iteration's steps 1 / 2 / 3 carry K(t+3) piece 1 -> ring slot t % 3, V(t+2) pieces -> ring slot (t+2) % 3."""
     e = g.e
+    pre = not do_pv
+    late_dma = do_pv and do_s and not (ABL & 2)
+    gs = Gen() if (ABL & 1) else g                   # ablation 1: the softmax items and their rare blocks go nowhere
+
+    def emit_items(lst):
+        if not (ABL & 1):
+            for it in lst:
+                it.emit(g)
+
+    # the B job of tile t (second part here, first part in the previous iteration's step 4) and of tile t+1
+    fixed4 = [(DMA_COST + 4 if i == 0 else 0) + (4 if i < 8 else 0) + (12 if i == 10 else 0) + (28 if i == 11 else 0) for i in range(12)]
+    fixed1 = [8 + (4 if i == 0 else 0) + (DMA_COST if i == 7 else 0) for i in range(8)]
+    fixed2 = [(4 if i % 3 == 0 else 0) + (DMA_COST if i == 1 else 0) for i in range(12)]
+    fixed3 = [(20 if i == 6 else 0) + (DMA_COST + 8 if i == 7 else 0) for i in range(8)]
+    def dist(items, fixed, quota):
+        return distribute(items, fixed) if (ABL & 64) else distribute_quota(items, quota)
+
+    distB_prev = dist(job_items(gs, 1, par, False), fixed4 + fixed1, QUOTA_B) if do_pv else None
     # ---------------- step 1: S'(t+1, A) || softmax(t, B) second part; V(t) fragments ----------------
-    jobB_tail = softmax_job(g, 1, par, 12, 18) if do_pv else None
     if do_pv:
-        e("s_waitcnt lgkmcnt(0)")                    # K(t+1) fragments (requested in the previous step 4)
+        e("s_waitcnt lgkmcnt(0)")                    # K(t+1) fragments (requested in the previous step 4, slots 0..7)
     for i in range(8):
         if do_s:
             e(s_mfma(0, i))
         if do_pv:
-            for op in v_reads(i):
+            for op in ([] if (ABL & 4) else v_reads(i)):
                 e(op)
-            if i < len(jobB_tail):
-                for op in jobB_tail[i]:
+            if i == 6 and do_s:
+                # the ring moves on here (a gap that carries only fragment reads): (t, t+1, t+2) % 3 from now on
+                e("s_mov_b32 %s, %s" % (sr(sTMP), sr(sR0)))
+                e("s_mov_b32 %s, %s" % (sr(sR0), sr(sR1)))
+                e("s_mov_b32 %s, %s" % (sr(sR1), sr(sR2)))
+                e("s_mov_b32 %s, %s" % (sr(sR2), sr(sTMP)))
+                e("s_add_u32 %s, %s, 0x2000" % (sr(sVSO), sr(sVSO)))
+            if i == 7 and late_dma:
+                for op in dma_piece(True, 1, sR0):
                     e(op)
-    if do_s and not do_pv:
+            emit_items(distB_prev[12 + i])
+    if do_s and pre:
         e("s_nop 15"); e("s_nop 15"); e("s_nop 15")       # pre-iteration: no MFMAs behind which S'(0, A) could settle
+        if not MASKED and not (ABL & 1):
+            tile0_prelude(g, 0)
     # ---------------- step 2: O_A += V(t)^T P(t, A)^T || softmax(t+1, A) first part ----------------
-    jobA = softmax_job(g, 0, par ^ 1) if do_s else None
+    distA = dist(job_items(gs, 0, par ^ 1, pre), fixed2 + fixed3, QUOTA_A) if do_s else None
     for i in range(12):
         if do_pv:
             if i % 3 == 0:
                 e("s_waitcnt lgkmcnt(%d)" % (12 - 4 * (i // 3)))
             e(pv_mfma(0, par, i))
-        if do_s:
-            for op in jobA[i]:
+        if i == 1 and late_dma:
+            for op in dma_piece(False, 0, sR2):
                 e(op)
+        if do_s:
+            emit_items(distA[i])
     # ---------------- step 3: S'(t+1, B) || softmax(t+1, A) second part ----------------
     if do_s:
         for i in range(8):
             e(s_mfma(1, i))
-            if 12 + i < 18:
-                for op in jobA[12 + i]:
-                    e(op)
             if i == 6:
                 e("s_add_u32 %s, %s, %s" % (sr(sTMP), sr(sKB), sr(sR2)))
                 for op in k_addr_ops(None):
                     e(op)
-        if not do_pv:
+            if i == 7 and late_dma:
+                for op in dma_piece(False, 1, sR2):
+                    e(op)
+            emit_items(distA[12 + i])
+        if pre:
             e("s_nop 15"); e("s_nop 15"); e("s_nop 15")
+            if not MASKED and not (ABL & 1):
+                tile0_prelude(g, 1)
         e("s_waitcnt vmcnt(4)")                      # this wave's pieces of K(t+2) / V(t+1) have landed
-        e("s_barrier")
+        if not (ABL & 8):
+            e("s_barrier")
     # ---------------- step 4: O_B += V(t)^T P(t, B)^T || softmax(t+1, B) first part; K(t+2) fragments; DMA ----------------
-    jobB = softmax_job(g, 1, par ^ 1, 0, 12) if do_s else None
-    dma = dma_ops()
+    distB = dist(job_items(gs, 1, par ^ 1, pre), fixed4 + fixed1, QUOTA_B) if do_s else None
     for i in range(12):
         if do_pv:
             e(pv_mfma(1, par, i))
         if do_s:
-            if i < 4:
-                for op in dma[i]:
-                    e(op)
-            else:
-                e(k_read(i - 4))
-            for op in jobB[i]:
-                e(op)
-            if i == 11:
-                # next iteration's V read addresses (ring slot (t+1) % 3) and the ring / counters
+            if i == 0:
+                e("s_add_u32 %s, %s, 0x2000" % (sr(sKSO), sr(sKSO)))
+                if not (ABL & 2):
+                    for op in dma_piece(True, 0, sR1):
+                        e(op)
+            if i < 8 and not (ABL & 4):
+                e(k_read(i))
+            emit_items(distB[i])
+            if i == 10:
+                # next iteration's V read addresses: ring slot (t+1) % 3
                 e("s_add_u32 %s, %s, %s" % (sr(sTMP), sr(sVB), sr(sR1)))
                 e("v_add_u32 %s, %s, %%[voff]" % (vr(VVA), sr(sTMP)))
                 e("v_xor_b32 %s, 64, %s" % (vr(VVA + 1), vr(VVA)))
-                e("s_mov_b32 %s, %s" % (sr(sTMP), sr(sR0)))
-                e("s_mov_b32 %s, %s" % (sr(sR0), sr(sR1)))
-                e("s_mov_b32 %s, %s" % (sr(sR1), sr(sR2)))
-                e("s_mov_b32 %s, %s" % (sr(sR2), sr(sTMP)))
-                e("s_add_u32 %s, %s, 0x2000" % (sr(sKSO), sr(sKSO)))
-                e("s_add_u32 %s, %s, 0x2000" % (sr(sVSO), sr(sVSO)))
-                e("s_add_u32 %s, %s, 1" % (sr(sT), sr(sT)))
+            if i == 11:
                 e("s_add_u32 %s, %s, 1" % (sr(sT1), sr(sT1)))
 
 
@@ -387,6 +510,9 @@ def generate():
     e("s_lshl_b32 %s, %%[wave], 11" % sr(sTMP))                     # 2 w * 1024
     e("s_add_u32 %s, %s, %s" % (sr(sKB0), sr(sKB), sr(sTMP)))
     e("s_add_u32 %s, %s, %s" % (sr(sVB0), sr(sVB), sr(sTMP)))
+    e("s_add_u32 %s, %s, 0x400" % (sr(sKB1), sr(sKB0)))
+    e("s_add_u32 %s, %s, 0x400" % (sr(sVB1), sr(sVB0)))
+    e("s_mov_b32 %s, %%[lastf]" % sr(sLAST))
     # Q fragments straight into AGPRs (rows beyond the video read as zeros: buffer bounds)
     for ks in range(4):
         e("buffer_load_dwordx4 %s, %%[qoff], %s, 0 offen offset:%d" % (ar(Qf(0, ks), 4), sr(QD, 4), 32 * ks))
@@ -424,9 +550,8 @@ def generate():
     e("s_mov_b32 %s, 0x4000" % sr(sR0))
     e("s_mov_b32 %s, 0" % sr(sR1))
     e("s_mov_b32 %s, 0x2000" % sr(sR2))
-    e("s_mov_b32 %s, 0x6000" % sr(sKSO))             # K(3)
-    e("s_mov_b32 %s, 0x4000" % sr(sVSO))             # V(2)
-    e("s_mov_b32 %s, -1" % sr(sT))
+    e("s_mov_b32 %s, 0x4000" % sr(sKSO))             # (t + 3) * 8192 at t = -1; step 4 advances it to K(3)
+    e("s_mov_b32 %s, 0x2000" % sr(sVSO))             # (t + 2) * 8192
     e("s_mov_b32 %s, 0" % sr(sT1))
     e("s_waitcnt vmcnt(4)")                          # Q, K(0), V(0), K(1) have landed (this wave's pieces)
     e("s_barrier")
@@ -478,20 +603,34 @@ def generate():
 
 
 def main():
-    g = generate()
-    body = g.lines + ["s_branch END_%="] + g.tail + ["END_%=:"]
-    # the loop-carried B tail must be the same text whichever iteration produced it (checked, not assumed)
-    with open(OUT, "w") as f:
-        f.write("// GENERATED by tools/gen_attn_w64.py - do not edit.  %d instructions / labels.\n" % len(body))
-        f.write('R"ASM(\n')
-        for l in body:
-            f.write(l + "\n")
-        f.write(')ASM"\n')
+    global ABL, MASKED
+    if len(sys.argv) > 2 and sys.argv[1] == "--abl":       # tools/: timing ablations for the diagnostic library (not committed)
+        for a in sys.argv[2].split(","):
+            ABL = int(a)
+            g = generate()
+            body = g.lines + ["s_branch END_%="] + g.tail + ["END_%=:"]
+            path = OUT.replace("_asm.inc", "_asm_abl%d.inc" % ABL)
+            with open(path, "w") as f:
+                f.write("// GENERATED by tools/gen_attn_w64.py --abl: timing ablation %d, WRONG results by construction.\n" % ABL)
+                f.write('R"ASM(\n' + "\n".join(body) + '\n)ASM"\n')
+            print("wrote", path)
+        return
+    ABL = 0
+    for MASKED, path in ((False, OUT), (True, OUT.replace("_asm.inc", "_asm_mask.inc"))):
+        g = generate()
+        body = g.lines + ["s_branch END_%="] + g.tail + ["END_%=:"]
+        with open(path, "w") as f:
+            f.write("// GENERATED by tools/gen_attn_w64.py - do not edit.  %d instructions / labels.  Variant: %s.\n"
+                    % (len(body), "key mask (per-tile flags)" if MASKED else "no key mask (only the last tile can be ragged)"))
+            f.write('R"ASM(\n')
+            for l in body:
+                f.write(l + "\n")
+            f.write(')ASM"\n')
+        print("wrote", path, len(body), "lines")
     clob = ["memory", "vcc", "scc"] + ["v%d" % i for i in range(24, 256)] + ["a%d" % i for i in range(256)] + ["s%d" % i for i in range(36, 100)]
     with open(OUT.replace("_asm.inc", "_clobbers.inc"), "w") as f:
         f.write("// GENERATED by tools/gen_attn_w64.py - do not edit.\n")
         f.write(", ".join('"%s"' % c for c in clob) + "\n")
-    print("wrote", OUT, len(body), "lines")
 
 
 if __name__ == "__main__":

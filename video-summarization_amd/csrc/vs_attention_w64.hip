@@ -32,7 +32,8 @@ namespace {
 
 typedef unsigned short h16;
 
-template <bool VARLEN, bool HASMASK>
+// ABL (diagnostic library only): timing ablations of the stream with WRONG results (tools/gen_attn_w64.py --abl)
+template <bool VARLEN, bool HASMASK, int ABL = 0>
 __global__ __launch_bounds__(256, 1) void attn_fwd_bf16_w64(
     const h16 *__restrict__ Q, const h16 *__restrict__ Kg, const h16 *__restrict__ Vg, const uint8_t *__restrict__ mask,
     h16 *__restrict__ out, int H, int T, int BH, const int *__restrict__ cu, const int2 *__restrict__ work, int Mtot) {
@@ -73,6 +74,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_bf16_w64(
     }
     // tile flags: bit (t & 31) of lane (t >> 5) set <=> tile t has a masked key or runs past the end of the video
     unsigned flags = 0u;
+    int lastf = -1;                                  // no-mask stream: the one tile that needs the key bias (-1: none)
     unsigned mb_addr = (unsigned)(size_t)(__attribute__((address_space(3))) float *)mbias;
     if constexpr (HASMASK) {
         const int tpad = ntiles * KT;
@@ -93,7 +95,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_bf16_w64(
     } else {
         const int tl = ntiles - 1;
         if (tid < KT) mbias[tid] = (tl * KT + tid >= T) ? NEG_INF : 0.f;
-        if ((T & (KT - 1)) != 0 && lane == (tl >> 5)) flags = 1u << (tl & 31);
+        if ((T & (KT - 1)) != 0) lastf = tl;
         mb_addr -= (unsigned)tl * 256u;          // the stream addresses the table as mb + tile * 256
         __syncthreads();
     }
@@ -116,18 +118,86 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_bf16_w64(
     const unsigned vb = (unsigned)(size_t)(__attribute__((address_space(3))) h16 *)&Vb[0][0];
     // every "s" operand must be provably wave-uniform
     auto sc = [](unsigned v) __attribute__((always_inline)) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); };
-    asm volatile(
-        "s_nop 4\n"
-#include "vs_attention_w64_asm.inc"
-        :
-        : [qlo] "s"(sc((unsigned)qp)), [qhi] "s"(sc((unsigned)(qp >> 32))), [klo] "s"(sc((unsigned)kp)), [khi] "s"(sc((unsigned)(kp >> 32))),
-          [vlo] "s"(sc((unsigned)vp)), [vhi] "s"(sc((unsigned)(vp >> 32))), [olo] "s"(sc((unsigned)op)), [ohi] "s"(sc((unsigned)(op >> 32))),
-          [nrec] "s"(sc(nrec)), [nreco] "s"(sc(nreco)), [ntiles] "s"(sc((unsigned)ntiles)), [mb] "s"(sc(mb_addr)), [kb] "s"(sc(kb)),
-          [vb] "s"(sc(vb)), [orowb] "s"(sc((unsigned)(32 * H * 128))), [wave] "s"(wave),
+#define VS_W64_OPERANDS                                                                                                              \
+        : [qlo] "s"(sc((unsigned)qp)), [qhi] "s"(sc((unsigned)(qp >> 32))), [klo] "s"(sc((unsigned)kp)), [khi] "s"(sc((unsigned)(kp >> 32))), \
+          [vlo] "s"(sc((unsigned)vp)), [vhi] "s"(sc((unsigned)(vp >> 32))), [olo] "s"(sc((unsigned)op)), [ohi] "s"(sc((unsigned)(op >> 32))), \
+          [nrec] "s"(sc(nrec)), [nreco] "s"(sc(nreco)), [ntiles] "s"(sc((unsigned)ntiles)), [mb] "s"(sc(mb_addr)), [kb] "s"(sc(kb)),     \
+          [vb] "s"(sc(vb)), [orowb] "s"(sc((unsigned)(32 * H * 128))), [wave] "s"(wave), [lastf] "s"(sc((unsigned)lastf)),               \
           [koff] "v"(koff), [voff] "v"(voff), [dk0] "v"(dk0), [dv0] "v"(dv0), [qoff] "v"(qoff), [ooff] "v"(ooff), [flags] "v"(flags)
-        :
+    if constexpr (ABL == 0 && HASMASK) {      // per-tile flags, "row without a constant yet" checked on every tile
+        asm volatile(
+            "s_nop 4\n"
+#include "vs_attention_w64_asm_mask.inc"
+            : VS_W64_OPERANDS
+            :
 #include "vs_attention_w64_clobbers.inc"
-    );
+        );
+    } else if constexpr (ABL == 0) {          // only the last tile can be ragged
+        asm volatile(
+            "s_nop 4\n"
+#include "vs_attention_w64_asm.inc"
+            : VS_W64_OPERANDS
+            :
+#include "vs_attention_w64_clobbers.inc"
+        );
+    }
+#ifdef VS_WITH_DIAG
+    else if constexpr (ABL == 14) {
+        asm volatile(
+            "s_nop 4\n"
+#include "vs_attention_w64_asm_abl14.inc"
+            : VS_W64_OPERANDS
+            :
+#include "vs_attention_w64_clobbers.inc"
+        );
+    }
+    else if constexpr (ABL == 15) {
+        asm volatile(
+            "s_nop 4\n"
+#include "vs_attention_w64_asm_abl15.inc"
+            : VS_W64_OPERANDS
+            :
+#include "vs_attention_w64_clobbers.inc"
+        );
+    }
+    else if constexpr (ABL == 128) {
+        asm volatile(
+            "s_nop 4\n"
+#include "vs_attention_w64_asm_abl128.inc"
+            : VS_W64_OPERANDS
+            :
+#include "vs_attention_w64_clobbers.inc"
+        );
+    }
+    else if constexpr (ABL == 256) {
+        asm volatile(
+            "s_nop 4\n"
+#include "vs_attention_w64_asm_abl256.inc"
+            : VS_W64_OPERANDS
+            :
+#include "vs_attention_w64_clobbers.inc"
+        );
+    }
+    else if constexpr (ABL == 384) {
+        asm volatile(
+            "s_nop 4\n"
+#include "vs_attention_w64_asm_abl384.inc"
+            : VS_W64_OPERANDS
+            :
+#include "vs_attention_w64_clobbers.inc"
+        );
+    }
+    else if constexpr (ABL == 398) {
+        asm volatile(
+            "s_nop 4\n"
+#include "vs_attention_w64_asm_abl398.inc"
+            : VS_W64_OPERANDS
+            :
+#include "vs_attention_w64_clobbers.inc"
+        );
+    }
+#endif
+#undef VS_W64_OPERANDS
 }
 
 }  // namespace
@@ -144,8 +214,18 @@ int vsk_attention_bf16_w64(const void *q, const void *k, const void *v, const ui
         hipLaunchKernelGGL((attn_fwd_bf16_w64<false, true>), grid, dim3(256), dyn, st, (const h16 *)q, (const h16 *)k, (const h16 *)v,
                            mask, (h16 *)out, H, T, BH, nullptr, nullptr, 0);
     } else {
-        hipLaunchKernelGGL((attn_fwd_bf16_w64<false, false>), grid, dim3(256), 0, st, (const h16 *)q, (const h16 *)k, (const h16 *)v,
+#ifdef VS_WITH_DIAG
+#define VS_W64_LAUNCH_ABL(A_) case A_: hipLaunchKernelGGL((attn_fwd_bf16_w64<false, false, A_>), grid, dim3(256), 256, st, (const h16 *)q, (const h16 *)k, (const h16 *)v, nullptr, (h16 *)out, H, T, BH, nullptr, nullptr, 0); break;
+        switch (vsk_options().attn_w64_abl) {
+            VS_W64_LAUNCH_ABL(14) VS_W64_LAUNCH_ABL(15) VS_W64_LAUNCH_ABL(128) VS_W64_LAUNCH_ABL(256) VS_W64_LAUNCH_ABL(384) VS_W64_LAUNCH_ABL(398)
+            default:
+#endif
+        hipLaunchKernelGGL((attn_fwd_bf16_w64<false, false>), grid, dim3(256), 256, st, (const h16 *)q, (const h16 *)k, (const h16 *)v,
                            nullptr, (h16 *)out, H, T, BH, nullptr, nullptr, 0);
+#ifdef VS_WITH_DIAG
+        }
+#undef VS_W64_LAUNCH_ABL
+#endif
     }
     VSK_CHECK_LAUNCH();
     return 0;
@@ -155,7 +235,7 @@ int vsk_attention_bf16_w64(const void *q, const void *k, const void *v, const ui
 int vsk_attention_bf16_w64_packed(const void *q, const void *k, const void *v, void *out, int H, int Mtot, const int *cu,
                                   const int *work, int nwork, hipStream_t st) {
     if (nwork <= 0) return 0;
-    hipLaunchKernelGGL((attn_fwd_bf16_w64<true, false>), dim3(nwork, H), dim3(256), 0, st, (const h16 *)q, (const h16 *)k,
+    hipLaunchKernelGGL((attn_fwd_bf16_w64<true, false>), dim3(nwork, H), dim3(256), 256, st, (const h16 *)q, (const h16 *)k,
                        (const h16 *)v, nullptr, (h16 *)out, H, 0, 0, cu, (const int2 *)work, Mtot);
     VSK_CHECK_LAUNCH();
     return 0;

@@ -123,6 +123,7 @@ struct VskOptions {
     int mlp_fusion;       // VS_MLP_FUSION    (diagnostic builds only)
     int mlp_abl;          // VS_MLP_ABL       (diagnostic builds only)
     int attn_legacy;      // VS_ATTN_LEGACY   (diagnostic builds only)
+    int attn_w64_abl;     // VS_ATTN_W64_ABL  (diagnostic builds only) timing ablation of the one-wave-per-SIMD attention
 };
 VskOptions &vsk_options();
 // per-device cache of the CU count (one process may drive several GPUs)
