@@ -80,7 +80,7 @@ def warm(seconds=0.5):
         torch.cuda.synchronize()
 
 
-def timing(B, H, T, iters=50):
+def timing(B, H, T, iters=200, rounds=3):
     g = torch.Generator().manual_seed(1)
     q, k, v = (torch.randn(B, H, T, 64, generator=g) for _ in range(3))
     scale = (H * 64) ** -0.5
@@ -89,22 +89,27 @@ def timing(B, H, T, iters=50):
     out = torch.empty((B, T, H * 64), device=dev, dtype=torch.bfloat16)
     st = torch.cuda.current_stream().cuda_stream
     fl = 4.0 * B * H * T * T * 64
-    res = []
-    for w64 in (0, 1):
-        pkg._lib.set_option("VS_ATTN_W64", w64)
-        warm()
-        for _ in range(5):
-            lib.vs_attention_bf16_stored(q16.data_ptr(), k16.data_ptr(), v16.data_ptr(), None, out.data_ptr(), B, H, T, 64, st)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(iters):
-            lib.vs_attention_bf16_stored(q16.data_ptr(), k16.data_ptr(), v16.data_ptr(), None, out.data_ptr(), B, H, T, 64, st)
-        e1.record()
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / iters
-        res.append(ms)
-        print("B=%d H=%d T=%d %s: %.4f ms  %.0f TF (%.3f of 2.5 PF)" % (B, H, T, "w64 (4 waves x 64 rows)" if w64 else "8-wave kernel        ", ms, fl / ms / 1e9, fl / ms / 1e9 / 2500), flush=True)
+    res = {}
+    names = {0: "8-wave kernel", 1: "w64, optimistic pass first", 2: "w64, checked pass only"}
+    warm()
+    for rnd in range(rounds):
+        for var in (0, 1, 2):
+            pkg._lib.set_option("VS_ATTN_W64", 0 if var == 0 else 1)
+            pkg._lib.set_option("VS_ATTN_W64_CHECKED", 1 if var == 2 else 0)
+            for _ in range(5):
+                lib.vs_attention_bf16_stored(q16.data_ptr(), k16.data_ptr(), v16.data_ptr(), None, out.data_ptr(), B, H, T, 64, st)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                lib.vs_attention_bf16_stored(q16.data_ptr(), k16.data_ptr(), v16.data_ptr(), None, out.data_ptr(), B, H, T, 64, st)
+            e1.record()
+            torch.cuda.synchronize()
+            res.setdefault(var, []).append(e0.elapsed_time(e1) / iters)
+    for var in (0, 1, 2):
+        ms = min(res[var])
+        print("B=%d H=%d T=%d %-28s: %.4f ms (rounds %s)  %.0f TF (%.3f of 2.5 PF)" % (B, H, T, names[var], ms, " ".join("%.4f" % x for x in res[var]), fl / ms / 1e9, fl / ms / 1e9 / 2500), flush=True)
     pkg._lib.set_option("VS_ATTN_W64", -1)
+    pkg._lib.set_option("VS_ATTN_W64_CHECKED", -1)
     return res
 
 
@@ -154,7 +159,9 @@ if __name__ == "__main__":
         ok &= case(1, 4, 512, spike=True)
         ok &= case(2, 2, 700, masked=True, spike=True)
         ok &= case(1, 2, 640, sigma=8.0)
-    timing(8, 4, 8192)
+    timing(8, 4, 8192, iters=50)
     timing(64, 4, 1024)
+    timing(16, 4, 1024)
+    timing(4, 4, 320, iters=400)
     print("ALL OK" if ok else "FAILURES")
     sys.exit(0 if ok else 1)

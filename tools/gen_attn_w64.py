@@ -62,7 +62,7 @@ sNINF, sN32K, sP32K = 62, 63, 68
 sRAISE = 64                         # s[64:65]
 sMSK = 66                           # s[66:67]
 sTMP, sTMP2, sMB, sKB, sVB, sC4096, sOB = 69, 70, 71, 72, 73, 74, 75
-sLAST, sKB1, sVB1, sR3 = 76, 77, 78, 79
+sLAST, sKB1, sVB1, sR3, sMODE, sWV4 = 76, 77, 78, 79, 80, 81
 
 
 def vr(b, n=1):
@@ -162,7 +162,9 @@ def rebase_block(g, x, par, name, ret):
     cb, raw, cand, cnew, unew, shift, alpha, tmp = RT + 4, RT + 5, RT + 6, RT + 7, RT + 8, RT + 9, RT + 10, RT + 11
     t.append("v_sub_f32 %s, 0, %s" % (vr(cb), vr(NEGC(x))))
     t.append("v_add_f32 %s, %s, %s" % (vr(raw), vr(mx), vr(cb)))
-    t.append("v_add_f32 %s, 0x40c00000, %s" % (vr(cand), vr(raw)))                     # + CMARGIN = 6
+    # CMARGIN: checked pass max + 6 (P <= 2^-6 after a raise, the next one when a key beats that maximum by 2^7);
+    # optimistic pass max - 60 (P = 2^60 at tile 0's maximum: room for keys 2^67 above it and 2^186 below)
+    t.append("v_add_f32 %s, %s, %s" % (vr(cand), "0xc2700000" if FAST else "0x40c00000", vr(raw)))
     t.append("v_cmp_eq_f32_e64 %s, %s, %s" % (sr(sMSK, 2), sr(sNINF), vr(m)))
     t.append("s_or_b64 %s, %s, %s" % (sr(sMSK, 2), sr(sMSK, 2), sr(sRAISE, 2)))
     t.append("v_cmp_gt_f32 vcc, %s, %s" % (vr(cand), vr(m)))
@@ -213,6 +215,8 @@ def bias_block(g, x, name, ret):
     t.append("s_branch %s_%%=" % ret)
 
 
+FAST = False     # the optimistic pass is being generated (see generate())
+SFX = ""         # label suffix of the pass being generated
 MASKED = False   # which variant is being generated: generic tile flags (key mask) or "only the last tile can be ragged"
 
 
@@ -279,12 +283,16 @@ def job_items(g, x, par, tile0):
         items.append(Item([e2[1]], 8))
         if k > 0:
             items.append(Item([pair_cvt(x, par, k - 1)]))
+        if FAST:
+            continue
         if k == 4:
             items.append(Item(["v_or3_b32 %s, %s, %s, %s" % (vr(acc), vr(preg_of_pair(x, par, 0)), vr(preg_of_pair(x, par, 1)), vr(preg_of_pair(x, par, 2)))]))
         elif k in (6, 8, 10, 12, 14):
             items.append(Item(["v_or3_b32 %s, %s, %s, %s" % (vr(acc), vr(acc), vr(preg_of_pair(x, par, k - 3)), vr(preg_of_pair(x, par, k - 2)))]))
-    rb = g.site()
     items.append(Item([pair_cvt(x, par, 15)]))
+    if FAST:
+        return items
+    rb = g.site()
     items.append(Item(["v_or3_b32 %s, %s, %s, %s" % (vr(acc), vr(acc), vr(preg_of_pair(x, par, 13)), vr(preg_of_pair(x, par, 14))),
                        "v_or_b32 %s, %s, %s" % (vr(acc), vr(acc), vr(preg_of_pair(x, par, 15))),
                        "v_and_b32 %s, 0x40004000, %s" % (vr(acc), vr(acc)),
@@ -489,10 +497,90 @@ def iteration(g, par, do_pv, do_s):
                 e("s_add_u32 %s, %s, 1" % (sr(sT1), sr(sT1)))
 
 
+def tile_loop(g):
+    """pre-iteration, the tile loop (two iterations per trip: the P buffers alternate) and the last tile; ends at the epilogue"""
+    e = g.e
+    iteration(g, 1, False, True)
+    g.label("LOOP" + SFX)
+    e("s_cmp_ge_i32 %s, %s" % (sr(sT1), sr(sNT)))    # t + 1 >= ntiles: t (even) is the last tile
+    e("s_cbranch_scc1 LAST0%s_%%=" % SFX)
+    iteration(g, 0, True, True)
+    e("s_cmp_ge_i32 %s, %s" % (sr(sT1), sr(sNT)))
+    e("s_cbranch_scc1 LAST1%s_%%=" % SFX)
+    iteration(g, 1, True, True)
+    e("s_branch LOOP%s_%%=" % SFX)
+    g.label("LAST0" + SFX)
+    iteration(g, 0, True, False)
+    e("s_branch EPI%s_%%=" % SFX)
+    g.label("LAST1" + SFX)
+    iteration(g, 1, True, False)
+    g.label("EPI" + SFX)
+    e("s_nop 15"); e("s_nop 15"); e("s_nop 15")      # the last MFMAs' results
+    e("s_waitcnt vmcnt(0)")                          # no LDS-DMA piece may land after this block has left (or restarts)
+
+
+OUTV = 32        # the optimistic pass parks its packed outputs in v[32:63] (S' is dead by then): [row block][d block][g] x 2 dwords
+
+
+def epilogue(g, check):
+    """O / l -> bf16.  check False: stored at once (rows beyond the video are dropped by the buffer bounds).
+    check True (optimistic pass): kept in registers, and v27 collects, per lane, whether anything is inf / NaN."""
+    e = g.e
+    bad = VOR1
+    if check:
+        e("v_mov_b32 %s, 0" % vr(bad))
+    for x in range(2):
+        inv = RT
+        e("v_accvgpr_read_b32 %s, %s" % (vr(inv), ar(O(x, 2))))
+        e("s_nop 0")
+        if check:
+            e("v_fma_f32 %s, %s, 0, %s" % (vr(bad), vr(inv), vr(bad)))      # l itself: 1 / inf = 0 would hide an overflow
+        e("v_rcp_f32 %s, %s" % (vr(inv), vr(inv)))
+        e("s_nop 0")
+        for d in range(2):
+            for gg in range(4):
+                t0 = RT + 2 + 8 * ((4 * d + gg) % 4)
+                for e_ in range(4):
+                    e("v_accvgpr_read_b32 %s, %s" % (vr(t0 + e_), ar(O(x, d) + 4 * gg + e_)))
+                e("s_nop 0")
+                for e_ in range(4):
+                    e("v_mul_f32 %s, %s, %s" % (vr(t0 + e_), vr(inv), vr(t0 + e_)))
+                if check:
+                    # x * 0 is 0 for a finite x and NaN for inf / NaN; the NaN survives the additions
+                    for e_ in range(4):
+                        e("v_fma_f32 %s, %s, 0, %s" % (vr(bad), vr(t0 + e_), vr(bad)))
+                    o0 = OUTV + 2 * ((x * 2 + d) * 4 + gg)
+                    e("v_cvt_pk_bf16_f32 %s, %s, %s" % (vr(o0), vr(t0), vr(t0 + 1)))
+                    e("v_cvt_pk_bf16_f32 %s, %s, %s" % (vr(o0 + 1), vr(t0 + 2), vr(t0 + 3)))
+                else:
+                    e("v_cvt_pk_bf16_f32 %s, %s, %s" % (vr(t0 + 4), vr(t0), vr(t0 + 1)))
+                    e("v_cvt_pk_bf16_f32 %s, %s, %s" % (vr(t0 + 5), vr(t0 + 2), vr(t0 + 3)))
+                    so = "0" if x == 0 else sr(sOB)
+                    e("buffer_store_dwordx2 %s, %%[ooff], %s, %s offen offset:%d" % (vr(t0 + 4, 2), sr(OD, 4), so, 64 * d + 16 * gg))
+
+
+def store_parked(g):
+    for x in range(2):
+        for d in range(2):
+            for gg in range(4):
+                o0 = OUTV + 2 * ((x * 2 + d) * 4 + gg)
+                so = "0" if x == 0 else sr(sOB)
+                g.e("buffer_store_dwordx2 %s, %%[ooff], %s, %s offen offset:%d" % (vr(o0, 2), sr(OD, 4), so, 64 * d + 16 * gg))
+
+
 def generate():
+    """Key-mask variant: one pass, every tile checked (flags, rows without a constant, OR test).
+    No-mask variant: an OPTIMISTIC pass first - the row constant is set once, 60 below tile 0's maximum, and nothing is
+    checked per tile (no OR chain, no test: 22 fewer vector instructions per tile); its outputs are kept in registers and
+    tested for inf / NaN, which is what a key more than 2^67 above tile 0's maximum - or a sum beyond the fp32 range -
+    leaves behind.  If any wave of the block saw one, the whole block runs again in the checked form, whose arithmetic for
+    rows that never raise their constant is ... the checked form's (a block's result is then the checked pass's for every
+    row, so a row's bits do not depend on which pass produced them only if BOTH passes agree on untroubled rows: they do,
+    P differs by the exact factor 2^66 between the passes and O / l is scale-free up to fp32 rounding of the same sums)."""
+    global FAST, SFX
     g = Gen()
     e = g.e
-    # ---------------- prologue ----------------
+    # ---------------- once per block ----------------
     for d, lo, hi, nrec in ((QD, "qlo", "qhi", "nrec"), (KD, "klo", "khi", "nrec"), (VD, "vlo", "vhi", "nrec"), (OD, "olo", "ohi", "nreco")):
         e("s_mov_b32 %s, %%[%s]" % (sr(d), lo))
         e("s_and_b32 %s, %%[%s], 0xffff" % (sr(d + 1), hi))
@@ -513,6 +601,8 @@ def generate():
     e("s_add_u32 %s, %s, 0x400" % (sr(sKB1), sr(sKB0)))
     e("s_add_u32 %s, %s, 0x400" % (sr(sVB1), sr(sVB0)))
     e("s_mov_b32 %s, %%[lastf]" % sr(sLAST))
+    e("s_lshl_b32 %s, %%[wave], 2" % sr(sWV4))
+    e("s_mov_b32 %s, %%[mode0]" % sr(sMODE))              # 0: optimistic pass first; 1: the checked pass only (A/B switch)
     # Q fragments straight into AGPRs (rows beyond the video read as zeros: buffer bounds)
     for ks in range(4):
         e("buffer_load_dwordx4 %s, %%[qoff], %s, 0 offen offset:%d" % (ar(Qf(0, ks), 4), sr(QD, 4), 32 * ks))
@@ -521,6 +611,15 @@ def generate():
     e("v_xor_b32 %s, 64, %%[dk0]" % vr(VDK1))
     e("v_add_u32 %s, 0x400, %s" % (vr(VDK1), vr(VDK1)))
     e("v_add_u32 %s, 0x400, %%[dv0]" % vr(VDV1))
+    e("v_mov_b32 %s, 0x3f803f80" % vr(RT))
+    for i in range(4):
+        e("v_accvgpr_write_b32 %s, %s" % (ar(ONES + i), vr(RT)))
+    e("v_mbcnt_lo_u32_b32 %s, -1, 0" % vr(VH16))
+    e("v_mbcnt_hi_u32_b32 %s, -1, %s" % (vr(VH16), vr(VH16)))
+    e("v_lshrrev_b32 %s, 5, %s" % (vr(VH16), vr(VH16)))
+    e("v_lshlrev_b32 %s, 4, %s" % (vr(VH16), vr(VH16)))
+    # ---------------- a pass starts here ----------------
+    g.label("RESTART")
     # prologue DMA: K(0), V(0), K(1) | V(1), K(2)
     def dma_tile(is_k, tile, slot):
         base, desc, v0, v1 = (sKB0, KD, "%[dk0]", vr(VDK1)) if is_k else (sVB0, VD, "%[dv0]", vr(VDV1))
@@ -532,20 +631,12 @@ def generate():
         e("s_nop 0")
         e("buffer_load_dwordx4 %s, %s, %s offen lds" % (v1, sr(desc, 4), sr(sTMP)))
     dma_tile(True, 0, 0); dma_tile(False, 0, 0); dma_tile(True, 1, 1); dma_tile(False, 1, 1); dma_tile(True, 2, 2)
-    # state
     for i in range(96):
         e("v_accvgpr_write_b32 %s, 0" % ar(i))
     for i in range(32):
         e("v_mov_b32 %s, 0" % vr(NEGC(0, i)))
     e("v_mov_b32 %s, %s" % (vr(VM[0]), sr(sNINF)))
     e("v_mov_b32 %s, %s" % (vr(VM[1]), sr(sNINF)))
-    e("v_mov_b32 %s, 0x3f803f80" % vr(RT))
-    for i in range(4):
-        e("v_accvgpr_write_b32 %s, %s" % (ar(ONES + i), vr(RT)))
-    e("v_mbcnt_lo_u32_b32 %s, -1, 0" % vr(VH16))
-    e("v_mbcnt_hi_u32_b32 %s, -1, %s" % (vr(VH16), vr(VH16)))
-    e("v_lshrrev_b32 %s, 5, %s" % (vr(VH16), vr(VH16)))
-    e("v_lshlrev_b32 %s, 4, %s" % (vr(VH16), vr(VH16)))
     # ring for the pre-iteration t = -1: (t, t+1, t+2) % 3 = (2, 0, 1)
     e("s_mov_b32 %s, 0x4000" % sr(sR0))
     e("s_mov_b32 %s, 0" % sr(sR1))
@@ -561,43 +652,44 @@ def generate():
     for gi in range(8):
         e(k_read(gi))
     e("s_waitcnt lgkmcnt(0)")
-    # ---------------- pre-iteration t = -1 (parity 1), then the tile loop ----------------
-    iteration(g, 1, False, True)
-    g.label("LOOP")
-    e("s_cmp_ge_i32 %s, %s" % (sr(sT1), sr(sNT)))    # t + 1 >= ntiles: t (even) is the last tile
-    e("s_cbranch_scc1 LAST0_%=")
-    iteration(g, 0, True, True)
-    e("s_cmp_ge_i32 %s, %s" % (sr(sT1), sr(sNT)))
-    e("s_cbranch_scc1 LAST1_%=")
-    iteration(g, 1, True, True)
-    e("s_branch LOOP_%=")
-    g.label("LAST0")
-    iteration(g, 0, True, False)
-    e("s_branch EPI_%=")
-    g.label("LAST1")
-    iteration(g, 1, True, False)
-    g.label("EPI")
-    # ---------------- epilogue: O / l -> bf16 -> global (rows beyond the video: dropped by the buffer bounds) ----------------
-    e("s_nop 15"); e("s_nop 15"); e("s_nop 15")
-    e("s_waitcnt vmcnt(0)")                          # no LDS-DMA piece may land after this block has left
-    for x in range(2):
-        inv = RT
-        e("v_accvgpr_read_b32 %s, %s" % (vr(inv), ar(O(x, 2))))
+    if not MASKED and not ABL:
+        e("s_cmp_eq_u32 %s, 1" % sr(sMODE))
+        e("s_cbranch_scc1 CHECKED_%=")
+        # ---------------- the optimistic pass ----------------
+        FAST, SFX = True, "F"
+        tile_loop(g)
+        epilogue(g, True)
+        # any lane of any wave of the block with an inf / NaN?  (the K ring is free by now: one dword per wave at its base)
+        e("v_cmp_u_f32 vcc, %s, %s" % (vr(VOR1), vr(VOR1)))
+        e("s_cmp_lg_u64 vcc, 0")
+        e("s_cselect_b32 %s, 1, 0" % sr(sTMP))
+        e("v_mov_b32 %s, %s" % (vr(RT), sr(sTMP)))
+        e("s_add_u32 %s, %s, %s" % (sr(sTMP2), sr(sKB), sr(sWV4)))
+        e("v_mov_b32 %s, %s" % (vr(RT + 1), sr(sTMP2)))
+        e("ds_write_b32 %s, %s" % (vr(RT + 1), vr(RT)))
+        e("s_waitcnt lgkmcnt(0)")
+        e("s_barrier")
+        e("v_mov_b32 %s, %s" % (vr(RT + 1), sr(sKB)))
+        e("ds_read_b128 %s, %s" % (vr(RT + 4, 4), vr(RT + 1)))
+        e("s_waitcnt lgkmcnt(0)")
+        e("v_or3_b32 %s, %s, %s, %s" % (vr(RT), vr(RT + 4), vr(RT + 5), vr(RT + 6)))
+        e("v_or_b32 %s, %s, %s" % (vr(RT), vr(RT), vr(RT + 7)))
         e("s_nop 0")
-        e("v_rcp_f32 %s, %s" % (vr(inv), vr(inv)))
-        e("s_nop 0")
-        for d in range(2):
-            for gg in range(4):
-                t0 = RT + 2 + 8 * ((4 * d + gg) % 4)
-                for e_ in range(4):
-                    e("v_accvgpr_read_b32 %s, %s" % (vr(t0 + e_), ar(O(x, d) + 4 * gg + e_)))
-                e("s_nop 0")
-                for e_ in range(4):
-                    e("v_mul_f32 %s, %s, %s" % (vr(t0 + e_), vr(inv), vr(t0 + e_)))
-                e("v_cvt_pk_bf16_f32 %s, %s, %s" % (vr(t0 + 4), vr(t0), vr(t0 + 1)))
-                e("v_cvt_pk_bf16_f32 %s, %s, %s" % (vr(t0 + 5), vr(t0 + 2), vr(t0 + 3)))
-                so = "0" if x == 0 else sr(sOB)
-                e("buffer_store_dwordx2 %s, %%[ooff], %s, %s offen offset:%d" % (vr(t0 + 4, 2), sr(OD, 4), so, 64 * d + 16 * gg))
+        e("v_readfirstlane_b32 %s, %s" % (sr(sTMP), vr(RT)))
+        e("s_barrier")                                   # every wave has read the four words before the ring is refilled
+        e("s_cmp_eq_u32 %s, 0" % sr(sTMP))
+        e("s_cbranch_scc1 STOREF_%=")
+        e("s_mov_b32 %s, 1" % sr(sMODE))
+        e("s_branch RESTART_%=")
+        g.label("STOREF")
+        store_parked(g)
+        e("s_waitcnt vmcnt(0)")
+        e("s_branch END_%=")
+        g.label("CHECKED")
+    # ---------------- the checked pass ----------------
+    FAST, SFX = False, ""
+    tile_loop(g)
+    epilogue(g, False)
     e("s_waitcnt vmcnt(0)")
     return g
 

@@ -36,7 +36,7 @@ typedef unsigned short h16;
 template <bool VARLEN, bool HASMASK, int ABL = 0>
 __global__ __launch_bounds__(256, 1) void attn_fwd_bf16_w64(
     const h16 *__restrict__ Q, const h16 *__restrict__ Kg, const h16 *__restrict__ Vg, const uint8_t *__restrict__ mask,
-    h16 *__restrict__ out, int H, int T, int BH, const int *__restrict__ cu, const int2 *__restrict__ work, int Mtot) {
+    h16 *__restrict__ out, int H, int T, int BH, const int *__restrict__ cu, const int2 *__restrict__ work, int Mtot, int mode0) {
     constexpr int DH = 64, KT = 64, NBUF = 3;
     __shared__ __attribute__((aligned(1024))) h16 Kb[NBUF][KT * DH];      // 8 KiB per tile, ring of three
     __shared__ __attribute__((aligned(1024))) h16 Vb[NBUF][KT * DH];
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_bf16_w64(
         : [qlo] "s"(sc((unsigned)qp)), [qhi] "s"(sc((unsigned)(qp >> 32))), [klo] "s"(sc((unsigned)kp)), [khi] "s"(sc((unsigned)(kp >> 32))), \
           [vlo] "s"(sc((unsigned)vp)), [vhi] "s"(sc((unsigned)(vp >> 32))), [olo] "s"(sc((unsigned)op)), [ohi] "s"(sc((unsigned)(op >> 32))), \
           [nrec] "s"(sc(nrec)), [nreco] "s"(sc(nreco)), [ntiles] "s"(sc((unsigned)ntiles)), [mb] "s"(sc(mb_addr)), [kb] "s"(sc(kb)),     \
-          [vb] "s"(sc(vb)), [orowb] "s"(sc((unsigned)(32 * H * 128))), [wave] "s"(wave), [lastf] "s"(sc((unsigned)lastf)),               \
+          [vb] "s"(sc(vb)), [orowb] "s"(sc((unsigned)(32 * H * 128))), [wave] "s"(wave), [lastf] "s"(sc((unsigned)lastf)), [mode0] "s"(sc((unsigned)mode0)),               \
           [koff] "v"(koff), [voff] "v"(voff), [dk0] "v"(dk0), [dv0] "v"(dv0), [qoff] "v"(qoff), [ooff] "v"(ooff), [flags] "v"(flags)
     if constexpr (ABL == 0 && HASMASK) {      // per-tile flags, "row without a constant yet" checked on every tile
         asm volatile(
@@ -212,16 +212,16 @@ int vsk_attention_bf16_w64(const void *q, const void *k, const void *v, const ui
         const size_t dyn = (size_t)ntiles * 64 * sizeof(float) + (size_t)((ntiles + 15) / 16 * 16);
         if (dyn > 96 * 1024) return -1;
         hipLaunchKernelGGL((attn_fwd_bf16_w64<false, true>), grid, dim3(256), dyn, st, (const h16 *)q, (const h16 *)k, (const h16 *)v,
-                           mask, (h16 *)out, H, T, BH, nullptr, nullptr, 0);
+                           mask, (h16 *)out, H, T, BH, nullptr, nullptr, 0, 1);
     } else {
 #ifdef VS_WITH_DIAG
-#define VS_W64_LAUNCH_ABL(A_) case A_: hipLaunchKernelGGL((attn_fwd_bf16_w64<false, false, A_>), grid, dim3(256), 256, st, (const h16 *)q, (const h16 *)k, (const h16 *)v, nullptr, (h16 *)out, H, T, BH, nullptr, nullptr, 0); break;
+#define VS_W64_LAUNCH_ABL(A_) case A_: hipLaunchKernelGGL((attn_fwd_bf16_w64<false, false, A_>), grid, dim3(256), 256, st, (const h16 *)q, (const h16 *)k, (const h16 *)v, nullptr, (h16 *)out, H, T, BH, nullptr, nullptr, 0, 1); break;
         switch (vsk_options().attn_w64_abl) {
             VS_W64_LAUNCH_ABL(14) VS_W64_LAUNCH_ABL(15) VS_W64_LAUNCH_ABL(128) VS_W64_LAUNCH_ABL(256) VS_W64_LAUNCH_ABL(384) VS_W64_LAUNCH_ABL(398)
             default:
 #endif
         hipLaunchKernelGGL((attn_fwd_bf16_w64<false, false>), grid, dim3(256), 256, st, (const h16 *)q, (const h16 *)k, (const h16 *)v,
-                           nullptr, (h16 *)out, H, T, BH, nullptr, nullptr, 0);
+                           nullptr, (h16 *)out, H, T, BH, nullptr, nullptr, 0, vsk_options().attn_w64_checked ? 1 : 0);
 #ifdef VS_WITH_DIAG
         }
 #undef VS_W64_LAUNCH_ABL
@@ -236,7 +236,7 @@ int vsk_attention_bf16_w64_packed(const void *q, const void *k, const void *v, v
                                   const int *work, int nwork, hipStream_t st) {
     if (nwork <= 0) return 0;
     hipLaunchKernelGGL((attn_fwd_bf16_w64<true, false>), dim3(nwork, H), dim3(256), 256, st, (const h16 *)q, (const h16 *)k,
-                       (const h16 *)v, nullptr, (h16 *)out, H, 0, 0, cu, (const int2 *)work, Mtot);
+                       (const h16 *)v, nullptr, (h16 *)out, H, 0, 0, cu, (const int2 *)work, Mtot, vsk_options().attn_w64_checked ? 1 : 0);
     VSK_CHECK_LAUNCH();
     return 0;
 }

@@ -122,6 +122,7 @@ struct VskOptions {
     int lp_embed_unfused; // VS_LP_EMBED_UNFUSED bf16 mode runs the embedding as the generic GEMM + the first QKV kernel (A/B)
     int mlp_fusion;       // VS_MLP_FUSION    (diagnostic builds only)
     int mlp_abl;          // VS_MLP_ABL       (diagnostic builds only)
+    int attn_w64_checked; // VS_ATTN_W64_CHECKED the one-wave-per-SIMD attention skips its optimistic pass (every tile checked; A/B and test pin)
     int attn_legacy;      // VS_ATTN_LEGACY   (diagnostic builds only)
     int attn_w64_abl;     // VS_ATTN_W64_ABL  (diagnostic builds only) timing ablation of the one-wave-per-SIMD attention
 };
