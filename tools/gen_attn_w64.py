@@ -62,7 +62,7 @@ sNINF, sN32K, sP32K = 62, 63, 68
 sRAISE = 64                         # s[64:65]
 sMSK = 66                           # s[66:67]
 sTMP, sTMP2, sMB, sKB, sVB, sC4096, sOB = 69, 70, 71, 72, 73, 74, 75
-sLAST, sKB1, sVB1, sR3, sMODE, sWV4 = 76, 77, 78, 79, 80, 81
+sLAST, sKB1, sVB1, sR3, sMODE, sWV4, sNPADN = 76, 77, 78, 79, 80, 81, 82
 
 
 def vr(b, n=1):
@@ -132,7 +132,7 @@ def preg_of_pair(x, par, k):
     return P(par, x, n, ss, j)
 
 
-def rebase_block(g, x, par, name, ret):
+def rebase_block(g, x, par, name, ret, o_is_zero=False):
     """Out-of-line rare path.  par None: the tile's first look at a row without a constant (no raise request, P not
     computed yet); else: some P reached 2 (lanes in vcc) - raise, rescale, recompute the tile's P into buffer par."""
     t = g.tail
@@ -182,7 +182,7 @@ def rebase_block(g, x, par, name, ret):
         t.append("v_add_f32 %s, %s, %s" % (vr(r), vr(shift), vr(r)))
     for i in range(16):
         t.append("v_sub_f32 %s, 0, %s" % (vr(NEGC(x, i)), vr(unew)))
-    for i in range(48):
+    for i in range(0 if o_is_zero else 48):
         a = (OA if x == 0 else OB) + i
         t.append("v_accvgpr_read_b32 %s, %s" % (vr(tmp), ar(a)))
         t.append("s_nop 0")
@@ -249,7 +249,7 @@ def tile0_prelude(g, x):
                "v_cmp_eq_f32 vcc, %s, %s" % (sr(sNINF), vr(VM[x])), "s_cbranch_vccnz B%s_%%=" % rb0, "R%s_%%=:" % rb0]:
         g.e(op)
     bias_block(g, x, "B" + sb, "R" + sb)
-    rebase_block(g, x, None, "B" + rb0, "R" + rb0)
+    rebase_block(g, x, None, "B" + rb0, "R" + rb0, o_is_zero=True)
 
 
 def job_items(g, x, par, tile0):
@@ -260,7 +260,9 @@ def job_items(g, x, par, tile0):
     tile 0 then carries two nops in place of the check so that every job has the same cost profile - the B job is split
     over two iterations and both halves must agree on where)."""
     items = []
-    if not MASKED and tile0:
+    if FAST:
+        pass          # nothing is checked per tile (the ragged last tile is corrected in the epilogue; see generate())
+    elif not MASKED and tile0:
         items.append(Item(["s_nop 0", "s_nop 0"]))
     else:
         sb = g.site()
@@ -497,6 +499,134 @@ def iteration(g, par, do_pv, do_s):
                 e("s_add_u32 %s, %s, 1" % (sr(sT1), sr(sT1)))
 
 
+VF2 = 196                            # second V^T fragment buffer (optimistic pass: fragments of tile t+1 are read while tile t's are in use)
+KAS, VAS = 244, 202                  # optimistic pass: read addresses of the three ring slots, K v[244:255] (slot * 4 + ks), V v[202:207] (slot * 2 + d)
+QUOTA_FA = [1, 1, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2] + [2, 2, 2, 2, 1, 1, 0, 0]      # exp2 per gap, job A: steps 2 + 3
+QUOTA_FB = [1, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 1] + [1, 1, 2, 2, 2, 2, 0, 0]      # job B: step 4 + the next step 1
+
+
+def iteration_fast(g, par, ring, do_pv, do_s):
+    """The optimistic pass's iteration t (t % 2 = par, t % 3 = ring: six bodies per loop trip, every ring offset an
+    immediate).  Differences from iteration(): nothing is checked; V^T fragments are double-buffered (first half of tile
+    t+1's in step 4, second half in the next step 1); the read addresses of the three ring slots sit in registers."""
+    e = g.e
+    pre = not do_pv
+    r0, r1, r2 = ring, (ring + 1) % 3, (ring + 2) % 3
+    vfb, vfn = (VF, VF2) if par == 0 else (VF2, VF)          # V^T fragments of tile t / where tile t+1's go
+
+    def emit_items(lst):
+        for it in lst:
+            it.emit(g)
+
+    def pv(x, i):
+        gq, w = i // 3, i % 3
+        p = vr(P(par, x, gq >> 1, gq & 1), 4)
+        if w < 2:
+            return mfma(ar(O(x, w), 16), ar(vfb + 4 * (2 * gq + w), 4), p, ar(O(x, w), 16))
+        return mfma(ar(O(x, 2), 16), ar(ONES, 4), p, ar(O(x, 2), 16))
+
+    def vread(buf, slot, f):
+        n, s_, d = f >> 2, (f >> 1) & 1, f & 1
+        off = (32 * n + 16 * s_) * 128
+        a = buf + 4 * f
+        return ["ds_read_b64_tr_b16 %s, %s offset:%d" % (ar(a, 2), vr(VAS + 2 * slot + d), off),
+                "ds_read_b64_tr_b16 %s, %s offset:%d" % (ar(a + 2, 2), vr(VAS + 2 * slot + d), off + 1024)]
+
+    def kread(slot, gi):
+        n, ks = gi // 4, gi % 4
+        return "ds_read_b128 %s, %s offset:%d" % (ar(KF + 4 * gi, 4), vr(KAS + 4 * slot + ks), 4096 * n)
+
+    def dma(is_k, piece, slot):
+        base = (sKB0, sKB1, sVB0, sVB1)[(0 if is_k else 2) + piece]
+        voff = ("%[dk0]", vr(VDK1), "%[dv0]", vr(VDV1))[(0 if is_k else 2) + piece]
+        return ["s_add_u32 m0, %s, 0x%x" % (sr(base), slot * 8192), "s_nop 0",
+                "buffer_load_dwordx4 %s, %s, %s offen lds" % (voff, sr(KD if is_k else VD, 4), sr(sKSO if is_k else sVSO))]
+
+    late_dma = do_pv and do_s
+    distB_prev = distribute_quota(job_items(g, 1, par, False), QUOTA_FB) if do_pv else None
+    # ---------------- step 1: S'(t+1, A) || softmax(t, B) second part; second half of V(t)'s fragments ----------------
+    if do_pv:
+        e("s_waitcnt lgkmcnt(8)")                    # K(t+1) fragments (the eight younger reads are V(t)'s first half)
+    for i in range(8):
+        if do_s:
+            e(s_mfma(0, i))
+        if do_pv:
+            if i < 4:
+                for op in vread(vfb, r0, 4 + i):
+                    e(op)
+            if i == 6 and do_s:
+                e("s_add_u32 %s, %s, 0x2000" % (sr(sVSO), sr(sVSO)))
+            if i == 7 and late_dma:
+                for op in dma(True, 1, r0):
+                    e(op)
+            emit_items(distB_prev[12 + i])
+    if do_s and pre:
+        e("s_nop 15"); e("s_nop 15"); e("s_nop 15")
+        tile0_prelude(g, 0)
+    # ---------------- step 2: O_A += V(t)^T P(t, A)^T || softmax(t+1, A) first part ----------------
+    distA = distribute_quota(job_items(g, 0, par ^ 1, pre), QUOTA_FA) if do_s else None
+    for i in range(12):
+        if do_pv:
+            if i == 0:
+                e("s_waitcnt lgkmcnt(0)")
+            e(pv(0, i))
+        if i == 1 and late_dma:
+            for op in dma(False, 0, r2):
+                e(op)
+        if do_s:
+            emit_items(distA[i])
+    # ---------------- step 3: S'(t+1, B) || softmax(t+1, A) second part ----------------
+    if do_s:
+        for i in range(8):
+            e(s_mfma(1, i))
+            if i == 7 and late_dma:
+                for op in dma(False, 1, r2):
+                    e(op)
+            emit_items(distA[12 + i])
+        if pre:
+            e("s_nop 15"); e("s_nop 15"); e("s_nop 15")
+            tile0_prelude(g, 1)
+        e("s_waitcnt vmcnt(4)")
+        e("s_barrier")
+    # ---------------- step 4: O_B += V(t)^T P(t, B)^T || softmax(t+1, B) first part; K(t+2), first half of V(t+1) ----------------
+    distB = distribute_quota(job_items(g, 1, par ^ 1, pre), QUOTA_FB) if do_s else None
+    for i in range(12):
+        if do_pv:
+            e(pv(1, i))
+        if do_s:
+            if i == 0:
+                e("s_add_u32 %s, %s, 0x2000" % (sr(sKSO), sr(sKSO)))
+                for op in dma(True, 0, r1):
+                    e(op)
+            if i < 8:
+                e(kread(r2, i))
+            else:
+                for op in vread(vfn, r1, i - 8):
+                    e(op)
+            emit_items(distB[i])
+            if i == 11:
+                e("s_add_u32 %s, %s, 1" % (sr(sT1), sr(sT1)))
+
+
+def tile_loop_fast(g):
+    e = g.e
+    iteration_fast(g, 1, 2, False, True)             # pre-iteration t = -1
+    g.label("LOOPF")
+    for k in range(6):
+        e("s_cmp_ge_i32 %s, %s" % (sr(sT1), sr(sNT)))
+        e("s_cbranch_scc1 LASTF%d_%%=" % k)
+        iteration_fast(g, k % 2, k % 3, True, True)
+    e("s_branch LOOPF_%=")
+    for k in range(6):
+        g.label("LASTF%d" % k)
+        iteration_fast(g, k % 2, k % 3, True, False)
+        if k < 5:
+            e("s_branch EPIF_%=")
+    g.label("EPIF")
+    e("s_nop 15"); e("s_nop 15"); e("s_nop 15")
+    e("s_waitcnt vmcnt(0)")
+
+
 def tile_loop(g):
     """pre-iteration, the tile loop (two iterations per trip: the P buffers alternate) and the last tile; ends at the epilogue"""
     e = g.e
@@ -534,6 +664,13 @@ def epilogue(g, check):
         e("v_accvgpr_read_b32 %s, %s" % (vr(inv), ar(O(x, 2))))
         e("s_nop 0")
         if check:
+            # keys beyond the end of the video in a ragged last tile: their K rows are zeros (buffer bounds), so each of
+            # them added exactly bf16(exp2(-c)) to l and nothing to O (their V rows are zeros too): take it out again
+            e("v_exp_f32 %s, %s" % (vr(RT + 1), vr(NEGC(x))))
+            e("s_nop 0")
+            e("v_cvt_pk_bf16_f32 %s, %s, %s" % (vr(RT + 1), vr(RT + 1), vr(RT + 1)))
+            e("v_lshlrev_b32 %s, 16, %s" % (vr(RT + 1), vr(RT + 1)))
+            e("v_fma_f32 %s, %s, %s, %s" % (vr(inv), sr(sNPADN), vr(RT + 1), vr(inv)))
             e("v_fma_f32 %s, %s, 0, %s" % (vr(bad), vr(inv), vr(bad)))      # l itself: 1 / inf = 0 would hide an overflow
         e("v_rcp_f32 %s, %s" % (vr(inv), vr(inv)))
         e("s_nop 0")
@@ -602,6 +739,7 @@ def generate():
     e("s_add_u32 %s, %s, 0x400" % (sr(sVB1), sr(sVB0)))
     e("s_mov_b32 %s, %%[lastf]" % sr(sLAST))
     e("s_lshl_b32 %s, %%[wave], 2" % sr(sWV4))
+    e("s_mov_b32 %s, %%[npadn]" % sr(sNPADN))          # -(keys beyond the end in a ragged last tile that is not tile 0), as a float
     e("s_mov_b32 %s, %%[mode0]" % sr(sMODE))              # 0: optimistic pass first; 1: the checked pass only (A/B switch)
     # Q fragments straight into AGPRs (rows beyond the video read as zeros: buffer bounds)
     for ks in range(4):
@@ -657,7 +795,18 @@ def generate():
         e("s_cbranch_scc1 CHECKED_%=")
         # ---------------- the optimistic pass ----------------
         FAST, SFX = True, "F"
-        tile_loop(g)
+        # read addresses of the three ring slots (the K ones are recomputed here on purpose: the checked pass's own
+        # address registers are different ones)
+        for slot in range(3):
+            e("s_add_u32 %s, %s, 0x%x" % (sr(sTMP), sr(sKB), slot * 8192))
+            e("v_add_u32 %s, %s, %%[koff]" % (vr(KAS + 4 * slot), sr(sTMP)))
+            e("v_xor_b32 %s, 32, %s" % (vr(KAS + 4 * slot + 1), vr(KAS + 4 * slot)))
+            e("v_xor_b32 %s, 64, %s" % (vr(KAS + 4 * slot + 2), vr(KAS + 4 * slot)))
+            e("v_xor_b32 %s, 0x60, %s" % (vr(KAS + 4 * slot + 3), vr(KAS + 4 * slot)))
+            e("s_add_u32 %s, %s, 0x%x" % (sr(sTMP), sr(sVB), slot * 8192))
+            e("v_add_u32 %s, %s, %%[voff]" % (vr(VAS + 2 * slot), sr(sTMP)))
+            e("v_xor_b32 %s, 64, %s" % (vr(VAS + 2 * slot + 1), vr(VAS + 2 * slot)))
+        tile_loop_fast(g)
         epilogue(g, True)
         # any lane of any wave of the block with an inf / NaN?  (the K ring is free by now: one dword per wave at its base)
         e("v_cmp_u_f32 vcc, %s, %s" % (vr(VOR1), vr(VOR1)))

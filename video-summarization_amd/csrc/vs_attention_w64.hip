@@ -75,6 +75,8 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_bf16_w64(
     // tile flags: bit (t & 31) of lane (t >> 5) set <=> tile t has a masked key or runs past the end of the video
     unsigned flags = 0u;
     int lastf = -1;                                  // no-mask stream: the one tile that needs the key bias (-1: none)
+    // optimistic pass: minus the number of keys beyond the end of the video in a ragged last tile that is not tile 0
+    const float npadn = (ntiles > 1 && (T & (KT - 1)) != 0) ? -(float)(KT - (T & (KT - 1))) : 0.f;
     unsigned mb_addr = (unsigned)(size_t)(__attribute__((address_space(3))) float *)mbias;
     if constexpr (HASMASK) {
         const int tpad = ntiles * KT;
@@ -122,7 +124,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_bf16_w64(
         : [qlo] "s"(sc((unsigned)qp)), [qhi] "s"(sc((unsigned)(qp >> 32))), [klo] "s"(sc((unsigned)kp)), [khi] "s"(sc((unsigned)(kp >> 32))), \
           [vlo] "s"(sc((unsigned)vp)), [vhi] "s"(sc((unsigned)(vp >> 32))), [olo] "s"(sc((unsigned)op)), [ohi] "s"(sc((unsigned)(op >> 32))), \
           [nrec] "s"(sc(nrec)), [nreco] "s"(sc(nreco)), [ntiles] "s"(sc((unsigned)ntiles)), [mb] "s"(sc(mb_addr)), [kb] "s"(sc(kb)),     \
-          [vb] "s"(sc(vb)), [orowb] "s"(sc((unsigned)(32 * H * 128))), [wave] "s"(wave), [lastf] "s"(sc((unsigned)lastf)), [mode0] "s"(sc((unsigned)mode0)),               \
+          [vb] "s"(sc(vb)), [orowb] "s"(sc((unsigned)(32 * H * 128))), [wave] "s"(wave), [lastf] "s"(sc((unsigned)lastf)), [mode0] "s"(sc((unsigned)mode0)), [npadn] "s"(sc(__builtin_bit_cast(unsigned, npadn))),               \
           [koff] "v"(koff), [voff] "v"(voff), [dk0] "v"(dk0), [dv0] "v"(dv0), [qoff] "v"(qoff), [ooff] "v"(ooff), [flags] "v"(flags)
     if constexpr (ABL == 0 && HASMASK) {      // per-tile flags, "row without a constant yet" checked on every tile
         asm volatile(
