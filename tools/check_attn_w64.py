@@ -13,7 +13,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 pkg = importlib.import_module("video-summarization_amd")
-if len(sys.argv) > 1 and sys.argv[1] == "abl":      # timing ablations: the diagnostic library (tools/gen_attn_w64.py --abl ... first)
+if len(sys.argv) > 1 and sys.argv[1] in ("abl", "ablone"):      # timing ablations: the diagnostic library (tools/gen_attn_w64.py --abl ... first)
     os.environ["VS_LIBRARY"] = pkg._lib.DIAG_LIB_PATH if os.path.exists(pkg._lib.DIAG_LIB_PATH) else pkg._lib.build(diag=True)
 lib = pkg._lib.load()
 dev = torch.device("cuda:0")
@@ -128,7 +128,8 @@ def ablations(B, H, T, iters=50):
     pkg._lib.set_option("VS_ATTN_W64", 1)
     names.update({128: "no key-bias checks", 256: "no OR test (chain kept)", 384: "no bias checks, no OR test",
                   398: "no checks, no DMA / reads / barrier"})
-    for abl in (0, 14, 15, 128, 256, 384, 398):
+    names.update({1: "no softmax work", 512: "no softmax beside S' MFMAs", 1024: "no softmax beside P.V MFMAs"})
+    for abl in (0, 1, 2, 4, 8, 14, 15, 512, 1024):
         pkg._lib.set_option("VS_ATTN_W64_ABL", abl)
         warm(0.3)
         for _ in range(5):
@@ -145,6 +146,20 @@ def ablations(B, H, T, iters=50):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[1] == "ablone":      # one ablation, for a counter run: python tools/check_attn_w64.py ablone 2
+        B, H, T = 8, 4, 8192
+        g = torch.Generator().manual_seed(1)
+        q, k, v = (torch.randn(B, H, T, 64, generator=g) for _ in range(3))
+        q16 = (q * ((H * 64) ** -0.5 * L2E)).to(torch.bfloat16).to(dev)
+        k16, v16 = k.to(torch.bfloat16).to(dev), v.to(torch.bfloat16).to(dev)
+        out = torch.empty((B, T, H * 64), device=dev, dtype=torch.bfloat16)
+        st = torch.cuda.current_stream().cuda_stream
+        pkg._lib.set_option("VS_ATTN_W64_ABL", int(sys.argv[2]))
+        warm(0.3)
+        for _ in range(30):
+            lib.vs_attention_bf16_stored(q16.data_ptr(), k16.data_ptr(), v16.data_ptr(), None, out.data_ptr(), B, H, T, 64, st)
+        torch.cuda.synchronize()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "abl":
         ablations(8, 4, 8192)
         ablations(64, 4, 1024)

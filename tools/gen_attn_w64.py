@@ -98,8 +98,11 @@ def mfma(dst, a, b, c):
     return "v_mfma_f32_32x32x16_bf16 %s, %s, %s, %s" % (dst, a, b, c)
 
 
-def s_mfma(x, i):
-    """MFMA i (= n*4 + ks) of S'(., x): K fragment i, Q fragment ks, accumulator started from -c"""
+def s_mfma(x, j):
+    """The j-th MFMA of S'(., x).  The two key blocks' chains alternate (n0 k0, n1 k0, n0 k1, ...): measured, a chain of
+    dependent v_mfma_f32_32x32x16_bf16 with VGPR accumulators issues every ~34.5 cycles, not 32 (MFMA-only ablation:
+    1381 cycles per 40 MFMAs).  MFMA (n, ks) takes K fragment n*4 + ks, Q fragment ks; ks = 0 starts from -c."""
+    i = (j % 2) * 4 + j // 2
     n, ks = i // 4, i % 4
     c = vr(NEGC(x), 16) if ks == 0 else vr(S(x, n), 16)
     return mfma(vr(S(x, n), 16), ar(KF + 4 * i, 4), ar(Qf(x, ks), 4), c)
@@ -393,7 +396,8 @@ def dma_piece(is_k, piece, ring):
 DMA_COST = 16
 
 ABL = 0      # timing ablations (diagnostic library only; WRONG results): 1 no softmax work, 2 no LDS-DMA, 4 no fragment reads, 8 no barrier,
-             # 16 exp2 -> mov, 32 no packs / OR chain, 64 the proportional filler distribution instead of the exp2 quotas
+             # 16 exp2 -> mov, 32 no packs / OR chain, 64 the proportional filler distribution instead of the exp2 quotas,
+             # 512 / 1024 (optimistic pass) no softmax items beside the S' MFMAs / beside the P.V MFMAs
 
 
 def iteration(g, par, do_pv, do_s):
@@ -499,6 +503,7 @@ def iteration(g, par, do_pv, do_s):
                 e("s_add_u32 %s, %s, 1" % (sr(sT1), sr(sT1)))
 
 
+LATE_MEM = False     # A/B (measured slower: 0.980 vs 0.956 of the checked pass): inside an MFMA gap vector instructions first, LDS reads / LDS-DMA last
 VF2 = 196                            # second V^T fragment buffer (optimistic pass: fragments of tile t+1 are read while tile t's are in use)
 KAS, VAS = 244, 202                  # optimistic pass: read addresses of the three ring slots, K v[244:255] (slot * 4 + ks), V v[202:207] (slot * 2 + d)
 QUOTA_FA = [1, 1, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2] + [2, 2, 2, 2, 1, 1, 0, 0]      # exp2 per gap, job A: steps 2 + 3
@@ -515,8 +520,9 @@ def iteration_fast(g, par, ring, do_pv, do_s):
     vfb, vfn = (VF, VF2) if par == 0 else (VF2, VF)          # V^T fragments of tile t / where tile t+1's go
 
     def emit_items(lst):
-        for it in lst:
-            it.emit(g)
+        if not (ABL & 1):
+            for it in lst:
+                it.emit(g)
 
     def pv(x, i):
         gq, w = i // 3, i % 3
@@ -551,15 +557,20 @@ def iteration_fast(g, par, ring, do_pv, do_s):
         if do_s:
             e(s_mfma(0, i))
         if do_pv:
-            if i < 4:
+            if not (ABL & 512) and not LATE_MEM:
+                pass
+            if LATE_MEM and not (ABL & 512):
+                emit_items(distB_prev[12 + i])
+            if i < 4 and not (ABL & 4):
                 for op in vread(vfb, r0, 4 + i):
                     e(op)
             if i == 6 and do_s:
                 e("s_add_u32 %s, %s, 0x2000" % (sr(sVSO), sr(sVSO)))
-            if i == 7 and late_dma:
+            if i == 7 and late_dma and not (ABL & 2):
                 for op in dma(True, 1, r0):
                     e(op)
-            emit_items(distB_prev[12 + i])
+            if not LATE_MEM and not (ABL & 512):
+                emit_items(distB_prev[12 + i])
     if do_s and pre:
         e("s_nop 15"); e("s_nop 15"); e("s_nop 15")
         tile0_prelude(g, 0)
@@ -568,42 +579,52 @@ def iteration_fast(g, par, ring, do_pv, do_s):
     for i in range(12):
         if do_pv:
             if i == 0:
-                e("s_waitcnt lgkmcnt(0)")
+                e("s_waitcnt lgkmcnt(0)")            # V(t)^T fragments (second half asked for in step 1's gaps 0..3)
             e(pv(0, i))
-        if i == 1 and late_dma:
+        if LATE_MEM and do_s and not (ABL & 1024):
+            emit_items(distA[i])
+        if i == 1 and late_dma and not (ABL & 2):
             for op in dma(False, 0, r2):
                 e(op)
-        if do_s:
+        if not LATE_MEM and do_s and not (ABL & 1024):
             emit_items(distA[i])
     # ---------------- step 3: S'(t+1, B) || softmax(t+1, A) second part ----------------
     if do_s:
         for i in range(8):
             e(s_mfma(1, i))
-            if i == 7 and late_dma:
+            if LATE_MEM and not (ABL & 512):
+                emit_items(distA[12 + i])
+            if i == 7 and late_dma and not (ABL & 2):
                 for op in dma(False, 1, r2):
                     e(op)
-            emit_items(distA[12 + i])
+            if not LATE_MEM and not (ABL & 512):
+                emit_items(distA[12 + i])
         if pre:
             e("s_nop 15"); e("s_nop 15"); e("s_nop 15")
             tile0_prelude(g, 1)
         e("s_waitcnt vmcnt(4)")
-        e("s_barrier")
+        if not (ABL & 8):
+            e("s_barrier")
     # ---------------- step 4: O_B += V(t)^T P(t, B)^T || softmax(t+1, B) first part; K(t+2), first half of V(t+1) ----------------
     distB = distribute_quota(job_items(g, 1, par ^ 1, pre), QUOTA_FB) if do_s else None
     for i in range(12):
         if do_pv:
             e(pv(1, i))
         if do_s:
+            if LATE_MEM and not (ABL & 1024):
+                emit_items(distB[i])
             if i == 0:
                 e("s_add_u32 %s, %s, 0x2000" % (sr(sKSO), sr(sKSO)))
-                for op in dma(True, 0, r1):
+                for op in ([] if (ABL & 2) else dma(True, 0, r1)):
                     e(op)
-            if i < 8:
-                e(kread(r2, i))
-            else:
-                for op in vread(vfn, r1, i - 8):
-                    e(op)
-            emit_items(distB[i])
+            if not (ABL & 4):
+                if i < 8:
+                    e(kread(r2, i))
+                else:
+                    for op in vread(vfn, r1, i - 8):
+                        e(op)
+            if not LATE_MEM and not (ABL & 1024):
+                emit_items(distB[i])
             if i == 11:
                 e("s_add_u32 %s, %s, 1" % (sr(sT1), sr(sT1)))
 
@@ -790,7 +811,7 @@ def generate():
     for gi in range(8):
         e(k_read(gi))
     e("s_waitcnt lgkmcnt(0)")
-    if not MASKED and not ABL:
+    if not MASKED:
         e("s_cmp_eq_u32 %s, 1" % sr(sMODE))
         e("s_cbranch_scc1 CHECKED_%=")
         # ---------------- the optimistic pass ----------------
@@ -826,6 +847,8 @@ def generate():
         e("s_nop 0")
         e("v_readfirstlane_b32 %s, %s" % (sr(sTMP), vr(RT)))
         e("s_barrier")                                   # every wave has read the four words before the ring is refilled
+        if ABL:
+            e("s_mov_b32 %s, 0" % sr(sTMP))              # timing ablations: wrong values on purpose, never a second pass
         e("s_cmp_eq_u32 %s, 0" % sr(sTMP))
         e("s_cbranch_scc1 STOREF_%=")
         e("s_mov_b32 %s, 1" % sr(sMODE))

@@ -144,6 +144,42 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_bf16_w64(
         );
     }
 #ifdef VS_WITH_DIAG
+    else if constexpr (ABL == 1) {
+        asm volatile(
+            "s_nop 4\n"
+#include "vs_attention_w64_asm_abl1.inc"
+            : VS_W64_OPERANDS
+            :
+#include "vs_attention_w64_clobbers.inc"
+        );
+    }
+    else if constexpr (ABL == 2) {
+        asm volatile(
+            "s_nop 4\n"
+#include "vs_attention_w64_asm_abl2.inc"
+            : VS_W64_OPERANDS
+            :
+#include "vs_attention_w64_clobbers.inc"
+        );
+    }
+    else if constexpr (ABL == 4) {
+        asm volatile(
+            "s_nop 4\n"
+#include "vs_attention_w64_asm_abl4.inc"
+            : VS_W64_OPERANDS
+            :
+#include "vs_attention_w64_clobbers.inc"
+        );
+    }
+    else if constexpr (ABL == 8) {
+        asm volatile(
+            "s_nop 4\n"
+#include "vs_attention_w64_asm_abl8.inc"
+            : VS_W64_OPERANDS
+            :
+#include "vs_attention_w64_clobbers.inc"
+        );
+    }
     else if constexpr (ABL == 14) {
         asm volatile(
             "s_nop 4\n"
@@ -162,37 +198,19 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_bf16_w64(
 #include "vs_attention_w64_clobbers.inc"
         );
     }
-    else if constexpr (ABL == 128) {
+    else if constexpr (ABL == 512) {
         asm volatile(
             "s_nop 4\n"
-#include "vs_attention_w64_asm_abl128.inc"
+#include "vs_attention_w64_asm_abl512.inc"
             : VS_W64_OPERANDS
             :
 #include "vs_attention_w64_clobbers.inc"
         );
     }
-    else if constexpr (ABL == 256) {
+    else if constexpr (ABL == 1024) {
         asm volatile(
             "s_nop 4\n"
-#include "vs_attention_w64_asm_abl256.inc"
-            : VS_W64_OPERANDS
-            :
-#include "vs_attention_w64_clobbers.inc"
-        );
-    }
-    else if constexpr (ABL == 384) {
-        asm volatile(
-            "s_nop 4\n"
-#include "vs_attention_w64_asm_abl384.inc"
-            : VS_W64_OPERANDS
-            :
-#include "vs_attention_w64_clobbers.inc"
-        );
-    }
-    else if constexpr (ABL == 398) {
-        asm volatile(
-            "s_nop 4\n"
-#include "vs_attention_w64_asm_abl398.inc"
+#include "vs_attention_w64_asm_abl1024.inc"
             : VS_W64_OPERANDS
             :
 #include "vs_attention_w64_clobbers.inc"
@@ -217,9 +235,9 @@ int vsk_attention_bf16_w64(const void *q, const void *k, const void *v, const ui
                            mask, (h16 *)out, H, T, BH, nullptr, nullptr, 0, 1);
     } else {
 #ifdef VS_WITH_DIAG
-#define VS_W64_LAUNCH_ABL(A_) case A_: hipLaunchKernelGGL((attn_fwd_bf16_w64<false, false, A_>), grid, dim3(256), 256, st, (const h16 *)q, (const h16 *)k, (const h16 *)v, nullptr, (h16 *)out, H, T, BH, nullptr, nullptr, 0, 1); break;
+#define VS_W64_LAUNCH_ABL(A_) case A_: hipLaunchKernelGGL((attn_fwd_bf16_w64<false, false, A_>), grid, dim3(256), 256, st, (const h16 *)q, (const h16 *)k, (const h16 *)v, nullptr, (h16 *)out, H, T, BH, nullptr, nullptr, 0, 0); break;
         switch (vsk_options().attn_w64_abl) {
-            VS_W64_LAUNCH_ABL(14) VS_W64_LAUNCH_ABL(15) VS_W64_LAUNCH_ABL(128) VS_W64_LAUNCH_ABL(256) VS_W64_LAUNCH_ABL(384) VS_W64_LAUNCH_ABL(398)
+            VS_W64_LAUNCH_ABL(1) VS_W64_LAUNCH_ABL(2) VS_W64_LAUNCH_ABL(4) VS_W64_LAUNCH_ABL(8) VS_W64_LAUNCH_ABL(14) VS_W64_LAUNCH_ABL(15) VS_W64_LAUNCH_ABL(512) VS_W64_LAUNCH_ABL(1024)
             default:
 #endif
         hipLaunchKernelGGL((attn_fwd_bf16_w64<false, false>), grid, dim3(256), 256, st, (const h16 *)q, (const h16 *)k, (const h16 *)v,
