@@ -547,6 +547,135 @@ def test_attention_bf16_rescale_branch(vsa):
     assert (out.double() - ref).abs().max().item() < 4e-3 * ref.abs().max().item()
 
 
+# ---- the bf16 mode's storage form (bf16 q * scale * log2 e / k / v planes in, bf16 out): head dim 64 runs on the
+# one-wave-per-SIMD kernel (csrc/vs_attention_w64.hip), everything else on attn_fwd_lp_pipe<.., IO16> ----
+def _stored_operands(q, k, v, scale):
+    return ((q * (scale * 1.4426950408889634)).to(torch.bfloat16), k.to(torch.bfloat16), v.to(torch.bfloat16))
+
+
+def _attn_ref_stored(q16, k16, v16, mask):
+    """fp64 attention over the stored bf16 operands (q16 already carries scale * log2 e)"""
+    s2 = torch.matmul(q16.double(), k16.double().transpose(2, 3))
+    if mask is not None:
+        s2 = s2.masked_fill(mask[:, None, None, :], float("-inf"))
+    p = torch.exp2(s2 - s2.max(dim=3, keepdim=True).values)
+    o = torch.matmul(p, v16.double()) / p.sum(dim=3, keepdim=True)
+    B, H, T, dh = q16.shape
+    return o.permute(0, 2, 1, 3).reshape(B, T, H * dh)
+
+
+def _run_attn_stored(vsa, q16, k16, v16, mask, w64=1, checked=0):
+    lib = vsa._lib.load()
+    B, H, T, dh = q16.shape
+    dq, dk, dv = q16.to(_dev()), k16.to(_dev()), v16.to(_dev())
+    dm = mask.to(_dev()) if mask is not None else None
+    out = torch.full((B, T, H * dh), float("nan"), device=_dev(), dtype=torch.bfloat16)
+    try:
+        vsa._lib.set_option("VS_ATTN_W64", w64)
+        vsa._lib.set_option("VS_ATTN_W64_CHECKED", checked)
+        vsa._lib.check(lib.vs_attention_bf16_stored(dq.data_ptr(), dk.data_ptr(), dv.data_ptr(),
+                                                    dm.data_ptr() if dm is not None else None, out.data_ptr(), B, H, T, dh,
+                                                    _stream()))
+        torch.cuda.synchronize()
+    finally:
+        vsa._lib.set_option("VS_ATTN_W64", -1)
+        vsa._lib.set_option("VS_ATTN_W64_CHECKED", -1)
+    return out.cpu()
+
+
+BF16_STORED_REL = 6e-3      # against fp64 on the SAME stored operands: P and the output are rounded to bf16 (2^-9 each)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,T,masked", [(1, 1, 64, False), (2, 4, 320, False), (1, 4, 1024, False), (1, 2, 65, False),
+                                          (1, 1, 1, False), (1, 4, 31, False), (2, 2, 513, False), (1, 2, 200, False),
+                                          (1, 1, 2048, False), (3, 2, 1000, False), (1, 1, 257, False),
+                                          (2, 4, 200, True), (2, 2, 513, True), (1, 1, 64, True), (3, 2, 1000, True)])
+@pytest.mark.parametrize("checked", [0, 1])
+def test_attention_bf16_stored_w64_kernel(vsa, B, H, T, masked, checked):
+    """One wave per SIMD, both passes (optimistic first / every tile checked): every tile count modulo the ring and the
+    loop unrolling, ragged last tiles (corrected in the epilogue / key bias), one-tile videos, arbitrary key masks with a
+    fully masked tile and suffix padding, against fp64 on the stored operands and against the 8-wave kernel."""
+    g = torch.Generator().manual_seed(1000 * T + B)
+    q, k, v = (torch.randn(B, H, T, 64, generator=g) * 2.0 for _ in range(3))
+    q16, k16, v16 = _stored_operands(q, k, v, (H * 64) ** -0.5)
+    mask = None
+    if masked:
+        mask = torch.rand(B, T, generator=g) < 0.3
+        mask[:, 0] = False
+        if T > 130:
+            mask[0, 64:128] = True
+            mask[-1, T // 2:] = True
+    ref = _attn_ref_stored(q16, k16, v16, mask)
+    out = _run_attn_stored(vsa, q16, k16, v16, mask, 1, checked)
+    assert torch.isfinite(out).all()
+    assert (out.double() - ref).abs().max().item() < BF16_STORED_REL * ref.abs().max().item()
+    old = _run_attn_stored(vsa, q16, k16, v16, mask, 0)
+    assert (out.double() - old.double()).abs().max().item() < 2 * BF16_STORED_REL * ref.abs().max().item()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T", [64, 200, 513, 1100])
+@pytest.mark.parametrize("checked", [0, 1])
+def test_attention_bf16_stored_w64_operand_layout_is_exact_on_a_permutation(vsa, T, checked):
+    """Every index map of the one-wave-per-SIMD kernel (LDS-DMA pieces and their swizzles, both fragment reads, the
+    accumulator-as-operand key order, both row blocks, the double-buffered V^T fragments, the epilogue), checked exactly:
+    query i is a scaled copy of key pi(i), so its softmax row is one-hot to ~2^-30 and its output row must be V[pi(i)]
+    (small integers: exact in bf16)."""
+    B, H = 2, 2
+    g = torch.Generator().manual_seed(T)
+    k = (torch.randint(0, 2, (B, H, T, 64), generator=g) * 2 - 1).float()
+    idx = torch.arange(T)
+    k[..., :12] = ((idx[:, None] >> torch.arange(12)[None, :]) & 1).float() * 2 - 1
+    perm = torch.stack([torch.randperm(T, generator=g) for _ in range(B * H)]).view(B, H, T)
+    q = torch.gather(k, 2, perm[..., None].expand(-1, -1, -1, 64))
+    v = torch.randint(-8, 9, (B, H, T, 64), generator=g).float()
+    out = _run_attn_stored(vsa, (q * 16.0).to(torch.bfloat16), k.to(torch.bfloat16), v.to(torch.bfloat16), None, 1, checked)
+    want = torch.gather(v, 2, perm[..., None].expand(-1, -1, -1, 64)).permute(0, 2, 1, 3).reshape(B, T, H * 64)
+    assert (out.float() - want).abs().max().item() < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("masked", [False, True])
+def test_attention_bf16_stored_w64_rescue_and_raise(vsa, masked):
+    """Scores of several hundred that rise late in the video: the optimistic pass overflows (its row constant is set once,
+    from tile 0), finds the inf / NaN in its outputs and the block runs again in the checked form, whose rare path raises
+    the constants; with a key mask the checked form runs alone.  Both against fp64 on the stored operands."""
+    B, H, T = 2, 2, 700
+    g = torch.Generator().manual_seed(99)
+    q, k, v = (torch.randn(B, H, T, 64, generator=g) for _ in range(3))
+    k[:, :, 300] = q.mean(dim=2) * 50.0 + 20.0
+    k[:, :, 77] = -k[:, :, 300]
+    k[:, :, 650] = q.mean(dim=2) * 120.0 + 40.0
+    q16, k16, v16 = (q * 1.4426950408889634).to(torch.bfloat16), k.to(torch.bfloat16), v.to(torch.bfloat16)
+    mask = None
+    if masked:
+        mask = torch.rand(B, T, generator=g) < 0.2
+        mask[:, 0] = False
+    ref = _attn_ref_stored(q16, k16, v16, mask)
+    for checked in (0, 1):
+        out = _run_attn_stored(vsa, q16, k16, v16, mask, 1, checked)
+        assert torch.isfinite(out).all()
+        assert (out.double() - ref).abs().max().item() < BF16_STORED_REL * ref.abs().max().item()
+
+
+@pytest.mark.gpu
+def test_attention_bf16_stored_w64_is_deterministic_and_batch_invariant(vsa):
+    """A video's rows depend on that video alone: the same video scored in a batch of three and alone gives the same bits
+    (blocks never span videos, and the pass a block ends up in depends on its own rows only), run to run as well."""
+    H, T = 4, 448
+    g = torch.Generator().manual_seed(5)
+    q, k, v = (torch.randn(3, H, T, 64, generator=g) * 2.0 for _ in range(3))
+    k[1, :, 400] = q[1].mean(dim=1) * 60.0 + 30.0         # video 1 takes the rescue path, videos 0 and 2 do not
+    q16, k16, v16 = (q * 1.4426950408889634 * 0.25).to(torch.bfloat16), k.to(torch.bfloat16), v.to(torch.bfloat16)
+    full = _run_attn_stored(vsa, q16, k16, v16, None)
+    again = _run_attn_stored(vsa, q16, k16, v16, None)
+    assert torch.equal(full, again)
+    for b in range(3):
+        one = _run_attn_stored(vsa, q16[b:b + 1].contiguous(), k16[b:b + 1].contiguous(), v16[b:b + 1].contiguous(), None)
+        assert torch.equal(one[0], full[b])
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("cfg", ["M-A", "M-B", "M-B512"])
 def test_bf16_attention_mode_end_to_end(vsa, cfg):
@@ -822,6 +951,9 @@ def test_bf16_storage_is_bit_identical_to_fp32_storage(vsa, lp_linear_everywhere
 
     try:
         vsa._lib.set_option("VS_LP_MLP_UNFUSED", 1)      # (the fused MLP / layer-tail kernels have their own tests below)
+        # the storage forms of ONE attention kernel are compared: the bf16-stored head-dim-64 form otherwise runs on the
+        # one-wave-per-SIMD kernel (other summation order; its own tests: test_attention_bf16_stored_*)
+        vsa._lib.set_option("VS_ATTN_W64", 0)
         vsa._lib.set_option("VS_LP_STORE32", 1)
         ref = run()
         vsa._lib.set_option("VS_LP_STORE32", -1)
@@ -829,6 +961,7 @@ def test_bf16_storage_is_bit_identical_to_fp32_storage(vsa, lp_linear_everywhere
     finally:
         vsa._lib.set_option("VS_LP_STORE32", -1)
         vsa._lib.set_option("VS_LP_MLP_UNFUSED", -1)
+        vsa._lib.set_option("VS_ATTN_W64", -1)
     for g, r in zip(got, ref):
         assert torch.isfinite(g).all() and torch.equal(g, r)
 

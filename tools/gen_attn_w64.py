@@ -333,7 +333,7 @@ def distribute_quota(items, quota):
         if sl == last_q:
             # the exp2 are placed; the remaining items (last pack, OR test) go to the next gap
             pass
-    assert idx == len(items), (idx, len(items))
+    assert idx == len(items) and sum(quota) == sum(1 for it in items if it.ops[0].startswith("v_exp")), (idx, len(items), sum(quota))
     return out
 
 
@@ -506,8 +506,8 @@ def iteration(g, par, do_pv, do_s):
 LATE_MEM = False     # A/B (measured slower: 0.980 vs 0.956 of the checked pass): inside an MFMA gap vector instructions first, LDS reads / LDS-DMA last
 VF2 = 196                            # second V^T fragment buffer (optimistic pass: fragments of tile t+1 are read while tile t's are in use)
 KAS, VAS = 244, 202                  # optimistic pass: read addresses of the three ring slots, K v[244:255] (slot * 4 + ks), V v[202:207] (slot * 2 + d)
-QUOTA_FA = [1, 1, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2] + [2, 2, 2, 2, 1, 1, 0, 0]      # exp2 per gap, job A: steps 2 + 3
-QUOTA_FB = [1, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 1] + [1, 1, 2, 2, 2, 2, 0, 0]      # job B: step 4 + the next step 1
+QUOTA_FA = [2, 1, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2] + [2, 2, 2, 2, 1, 0, 0, 0]      # exp2 per gap, job A: steps 2 + 3
+QUOTA_FB = [0, 2, 2, 2, 2, 2, 2, 2, 1, 1, 1, 0] + [1, 2, 2, 2, 2, 2, 2, 2]      # job B: step 4 + the next step 1
 
 
 def iteration_fast(g, par, ring, do_pv, do_s):
@@ -548,6 +548,17 @@ def iteration_fast(g, par, ring, do_pv, do_s):
         return ["s_add_u32 m0, %s, 0x%x" % (sr(base), slot * 8192), "s_nop 0",
                 "buffer_load_dwordx4 %s, %s, %s offen lds" % (voff, sr(KD if is_k else VD, 4), sr(sKSO if is_k else sVSO))]
 
+    def gap_with_dma(dma_ops3, items):
+        """M0 write, one of the gap's own vector instructions (the wait state the LDS-DMA needs after an M0 write), the load"""
+        e(dma_ops3[0])
+        rest = list(items)
+        if rest and not (ABL & 1) and len(rest[0].ops) == 1:
+            rest.pop(0).emit(g)
+        else:
+            e(dma_ops3[1])
+        e(dma_ops3[2])
+        emit_items(rest)
+
     late_dma = do_pv and do_s
     distB_prev = distribute_quota(job_items(g, 1, par, False), QUOTA_FB) if do_pv else None
     # ---------------- step 1: S'(t+1, A) || softmax(t, B) second part; second half of V(t)'s fragments ----------------
@@ -566,9 +577,6 @@ def iteration_fast(g, par, ring, do_pv, do_s):
                     e(op)
             if i == 6 and do_s:
                 e("s_add_u32 %s, %s, 0x2000" % (sr(sVSO), sr(sVSO)))
-            if i == 7 and late_dma and not (ABL & 2):
-                for op in dma(True, 1, r0):
-                    e(op)
             if not LATE_MEM and not (ABL & 512):
                 emit_items(distB_prev[12 + i])
     if do_s and pre:
@@ -583,9 +591,6 @@ def iteration_fast(g, par, ring, do_pv, do_s):
             e(pv(0, i))
         if LATE_MEM and do_s and not (ABL & 1024):
             emit_items(distA[i])
-        if i == 1 and late_dma and not (ABL & 2):
-            for op in dma(False, 0, r2):
-                e(op)
         if not LATE_MEM and do_s and not (ABL & 1024):
             emit_items(distA[i])
     # ---------------- step 3: S'(t+1, B) || softmax(t+1, A) second part ----------------
@@ -594,10 +599,11 @@ def iteration_fast(g, par, ring, do_pv, do_s):
             e(s_mfma(1, i))
             if LATE_MEM and not (ABL & 512):
                 emit_items(distA[12 + i])
-            if i == 7 and late_dma and not (ABL & 2):
-                for op in dma(False, 1, r2):
-                    e(op)
-            if not LATE_MEM and not (ABL & 512):
+            if i >= 5 and late_dma and not (ABL & 2):
+                # the rest of the batch whose first piece went out in the previous step 4: K(t+3) piece 1 -> slot t % 3,
+                # V(t+2) pieces -> slot (t+2) % 3 (any time in steps 1..3 is safe; these gaps carry no exp2)
+                gap_with_dma(dma(True, 1, r0) if i == 5 else dma(False, i - 6, r2), [] if (ABL & 512) else distA[12 + i])
+            elif not LATE_MEM and not (ABL & 512):
                 emit_items(distA[12 + i])
         if pre:
             e("s_nop 15"); e("s_nop 15"); e("s_nop 15")
@@ -614,9 +620,12 @@ def iteration_fast(g, par, ring, do_pv, do_s):
             if LATE_MEM and not (ABL & 1024):
                 emit_items(distB[i])
             if i == 0:
-                e("s_add_u32 %s, %s, 0x2000" % (sr(sKSO), sr(sKSO)))
-                for op in ([] if (ABL & 2) else dma(True, 0, r1)):
-                    e(op)
+                d3 = dma(True, 0, r1)
+                if not (ABL & 2):
+                    e(d3[0])
+                e("s_add_u32 %s, %s, 0x2000" % (sr(sKSO), sr(sKSO)))      # (also the wait state between the M0 write and the load)
+                if not (ABL & 2):
+                    e(d3[2])
             if not (ABL & 4):
                 if i < 8:
                     e(kread(r2, i))
