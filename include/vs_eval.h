@@ -46,6 +46,28 @@ int vs_eval_fscore(const int8_t *summary, int32_t summary_len, const int8_t *use
 int vs_eval_rank_correlation(const float *frame_scores, int32_t n, const double *user_scores,
                              int32_t n_users, double *kendall, double *spearman);
 
+/* One video's inputs to the evaluation: the scorer's output and the user record of the reference's
+ * UserSummaries (data/dataset.py:146-154).  user_scores may be NULL (no rank correlation for that video: NaN). */
+typedef struct vs_eval_video {
+    const float *scores;          /* [n_scores] per sub-sampled frame */
+    const int32_t *positions;     /* [n_positions] picks */
+    const int32_t *change_points; /* [n_shots][2] inclusive ends */
+    const int8_t *user_summary;   /* [n_users][user_len] 0/1 */
+    const void *user_scores;      /* [n_score_users][n_frames] double (or float, see below), or NULL */
+    int32_t n_scores, n_positions, n_frames, n_shots, n_users, user_len, n_score_users;
+    int32_t use_max;              /* != 0: 'max' protocol (SumMe), else 'avg' (TVSum) */
+    int32_t user_scores_f32;      /* != 0: user_scores is float (the datasets' own type: no widened copy, half the bytes) */
+} vs_eval_video;
+
+/* Replaces: the loop of eval_metrics(data, user_dict) (compute_metrics.py:42-92) over a shard's videos: per video
+ * generate_summary -> evaluate_summary, upsample -> evaluate_scores.  All videos run on ONE pool of at most max_threads
+ * host threads (<= 0: the hardware's count, capped at 32) that first takes the per-video work (summary, F-score,
+ * prediction ranks) and then the (video, user) rank correlations - no nested pools, no per-video thread start.  Per-user
+ * results are summed in user order: the outputs do not depend on the scheduling.
+ * f_score, kendall, spearman: out, [n_videos] each.  A video whose inputs are invalid fails the whole call. */
+int vs_eval_corpus(const vs_eval_video *videos, int32_t n_videos, int32_t max_threads,
+                   double *f_score, double *kendall, double *spearman);
+
 #ifdef __cplusplus
 }
 #endif

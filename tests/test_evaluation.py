@@ -92,6 +92,65 @@ def test_eval_metrics_drop_in(ev):
     assert np.allclose(got, G["eval_metrics"], rtol=0, atol=1e-9)
 
 
+def test_eval_videos_one_call_equals_the_per_video_entry_points(ev):
+    """vs_eval_corpus (one bounded pool for every video and every (video, user) pair) against the per-video entry
+    points it replaces and the reference goldens: 'avg' and 'max' protocols, 1 thread and many, any key order."""
+    data, users = {}, {}
+    for i in (3, 0, 4, 1, 2):
+        v = _video(i)
+        data[NAMES[i]] = v["scores"]
+        users[NAMES[i]] = Rec(user_summary=v["user_summary"], user_scores=v["user_scores"], change_points=v["cps"],
+                              n_frames=v["n_frames"], picks=v["picks"], name=NAMES[i])
+    for threads in (1, 3, 0):
+        for method, col in (("avg", 0), ("max", 1)):
+            f, kt, sp = ev.eval_videos(data, users, method, max_threads=threads)
+            for j, n in enumerate(data):
+                m = _video(NAMES.index(n))["metrics"]
+                assert abs(f[j] - m[col]) < 1e-9 and abs(kt[j] - m[2]) < 1e-9 and abs(sp[j] - m[3]) < 1e-9
+    # bit-equal to the per-video path whatever the thread count
+    f1, k1, s1 = ev.eval_videos(data, users, "avg", max_threads=1)
+    f8, k8, s8 = ev.eval_videos(data, users, "avg", max_threads=8)
+    assert np.array_equal(f1, f8) and np.array_equal(k1, k8) and np.array_equal(s1, s8)
+    for j, n in enumerate(data):
+        u = users[n]
+        kk, ss = ev.evaluate_scores(ev.upsample(data[n], u.n_frames, u.picks), u.user_scores)
+        assert kk == k1[j] and ss == s1[j]
+    # float32 user scores (the datasets' type) go in without a widened copy: the same results
+    users32 = {n: u._replace(user_scores=np.asarray(u.user_scores, dtype=np.float32)) for n, u in users.items()} if hasattr(users[NAMES[0]], "_replace") else None
+    if users32 is not None and all(np.array_equal(np.asarray(users32[n].user_scores, dtype=np.float64), np.asarray(users[n].user_scores, dtype=np.float64)) for n in users):
+        f32, k32, s32 = ev.eval_videos(data, users32, "avg")
+        assert np.array_equal(f32, f1) and np.array_equal(k32, k1) and np.array_equal(s32, s1)
+    assert ev.eval_videos({}, {})[0].size == 0
+    bad = dict(users)
+    bad[NAMES[0]] = bad[NAMES[0]]._replace(user_scores=np.zeros((2, 7))) if hasattr(bad[NAMES[0]], "_replace") else bad[NAMES[0]]
+    if hasattr(users[NAMES[0]], "_replace"):
+        with pytest.raises(ValueError):
+            ev.eval_videos(data, bad)
+
+
+def test_rank_correlation_on_runs_equals_the_per_frame_oracle(ev):
+    """The library ranks run-length-compressed vectors (weighted pair counts); the oracle ranks frame by frame with
+    scipy: long runs, no runs at all, few / many distinct values, constant users (tau = nan), n from 2 up."""
+    rng = np.random.default_rng(5)
+    for trial in range(60):
+        n = int(rng.integers(2, 400))
+        def vec(kind):
+            if kind == 0:
+                return rng.standard_normal(n)                                                   # no ties, no runs
+            if kind == 1:
+                return rng.integers(0, 4, n).astype(np.float64)                                  # many ties, short runs
+            if kind == 2:
+                return np.repeat(rng.integers(1, 6, n // 7 + 1), 7)[:n].astype(np.float64)       # runs (the users' format)
+            return np.repeat(rng.standard_normal(n // 15 + 1), 15)[:n]                           # runs of distinct values (the prediction's format)
+        x = vec(int(rng.integers(0, 4))).astype(np.float32)
+        us = np.stack([vec(int(rng.integers(0, 4))) for _ in range(3)])
+        if np.all(x == x[0]) or any(np.all(u == u[0]) for u in us):
+            continue
+        k, s_ = ev.evaluate_scores(x, us)
+        ok, os_ = eval_oracle.rank_correlation(x, us)
+        assert abs(k - ok) < 1e-12 and abs(s_ - os_) < 1e-12, (trial, n)
+
+
 def test_edge_cases(ev):
     # picks ending exactly at n_frames (no append), scores shorter than segments (tail = 0)
     up = ev.upsample(np.array([0.5, 0.25], np.float32), 6, np.array([0, 2, 4, 6]))

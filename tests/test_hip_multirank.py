@@ -91,7 +91,28 @@ def _rccl_worker(port, q):
                                        force_collective=True)
         t = torch.tensor([1.0, 2.0, 3.0, 4.0], dtype=torch.float64, device=dev)
         dist.all_reduce(t)
-    ok = dist.get_backend() == "nccl" and all(torch.equal(plain[i], gathered[i]) for i in range(len(vids))) and t.tolist() == [1.0, 2.0, 3.0, 4.0]
+        # the scores stay on the device through the gather: with the videos resident, one pass uploads the
+        # two index tensors of the scatter (+ the packed plan's lengths, one per batch) and reads back ONCE - no copy per video
+        from torch.profiler import ProfilerActivity, profile
+        dvids = [v.to(dev) for v in vids]
+        nb = len(corpus.bucket_batches(list(range(len(vids))), [int(v.shape[0]) for v in vids], 4096))
+        counts = {}
+        for name, kw in (("padded", {}), ("packed", {"packed_fn": lambda x, ln: m.score_packed(x, ln)})):
+            corpus.score_corpus(lambda x, mk: m.score(x, mk), dvids, rank=0, world=1, device=dev, max_frames=4096,
+                                force_collective=True, **kw)
+            torch.cuda.synchronize()
+            with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+                again = corpus.score_corpus(lambda x, mk: m.score(x, mk), dvids, rank=0, world=1, device=dev, max_frames=4096,
+                                            force_collective=True, **kw)
+                torch.cuda.synchronize()
+            ev = [e.name for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA]
+            counts[name] = (sum("Memcpy HtoD" in n for n in ev), sum("Memcpy DtoH" in n for n in ev))
+            ok_again = all(torch.equal(plain[i], again[i]) for i in range(len(vids)))
+            counts[name + "_ok"] = ok_again
+    few = all(counts[k][0] <= 2 + 2 * nb and counts[k][1] == 1 for k in ("padded", "packed")) and counts["padded_ok"] and counts["packed_ok"]
+    if not few:
+        print("copy counts (HtoD, DtoH):", counts, "batches", nb, flush=True)
+    ok = few and dist.get_backend() == "nccl" and all(torch.equal(plain[i], gathered[i]) for i in range(len(vids))) and t.tolist() == [1.0, 2.0, 3.0, 4.0]
     q.put(bool(ok))
     dist.barrier()
     dist.destroy_process_group()

@@ -42,7 +42,7 @@ EXPORTS = ("vs_abi_version", "vs_last_error", "vs_weights_pack", "vs_weights_fre
            "vs_profile_enable", "vs_profile_collect", "vs_stage_name")
 # include/vs_eval.h
 EVAL_EXPORTS = ("vs_eval_upsample", "vs_eval_knapsack", "vs_eval_generate_summary", "vs_eval_fscore",
-                "vs_eval_rank_correlation")
+                "vs_eval_rank_correlation", "vs_eval_corpus")
 # include/vs_train.h
 TRAIN_EXPORTS = ("vs_train_prepare", "vs_train_saved_bytes", "vs_train_workspace_bytes", "vs_train_forward", "vs_train_backward",
                  "vs_mse_mask_loss_forward", "vs_mse_mask_loss_backward", "vs_train_attention_forward",
@@ -74,6 +74,12 @@ class ModelParams(C.Structure):
 
 class DropoutCfg(C.Structure):
     _fields_ = [("p_embed", C.c_float), ("p", C.c_float), ("seed", C.c_uint64), ("flags", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class EvalVideo(C.Structure):   # vs_eval_video (include/vs_eval.h)
+    _fields_ = [("scores", C.c_void_p), ("positions", C.c_void_p), ("change_points", C.c_void_p), ("user_summary", C.c_void_p),
+                ("user_scores", C.c_void_p)] + [(n, C.c_int32) for n in ("n_scores", "n_positions", "n_frames", "n_shots", "n_users",
+                                                                        "user_len", "n_score_users", "use_max", "user_scores_f32")]
 
 
 LayerGrads = LayerParams        # vs_layer_grads: same field names, destinations instead of sources
@@ -244,6 +250,8 @@ def load() -> C.CDLL:
                                        C.POINTER(C.c_double)]
         lib.vs_eval_rank_correlation.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_double),
                                                  C.POINTER(C.c_double)]
+        lib.vs_eval_corpus.restype = C.c_int
+        lib.vs_eval_corpus.argtypes = [C.POINTER(EvalVideo), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
         # include/vs_train.h
         lib.vs_train_prepare.restype = C.c_int
         lib.vs_train_prepare.argtypes = [C.c_void_p, C.c_void_p]

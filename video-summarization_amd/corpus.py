@@ -83,49 +83,61 @@ def score_corpus(score_fn: ScoreFn, videos: Sequence[torch.Tensor], rank: int = 
     rank (CPU tensors).  `score_fn` is `SimNet.score` on a GPU box.  With world == 1 no
     `torch.distributed` call is made (unless `force_collective`: the gather then runs over a one-rank group - how the
     RCCL branch is exercised on a one-GPU box).  With `packed_fn` (`SimNet.score_packed`) the batches are PACKED - the
-    videos' frames concatenated, no sentinel padding, no mask - instead of padded; the scores are the same bits."""
+    videos' frames concatenated, no sentinel padding, no mask - instead of padded; the scores are the same bits.
+
+    The scores stay on the scorer's device until the end: the batches' outputs are concatenated, ONE indexed copy
+    moves every valid frame into its row of the send buffer [n_max, t_max] (the index is built on the host from the
+    lengths: two small uploads per call, none per video), ONE all_gather_into_tensor exchanges the shards and ONE
+    device-to-host copy brings the result back.  No video ids travel: every rank derives the same plan."""
     lengths = [int(v.shape[0]) for v in videos]
-    mine = plan_shards(lengths, world)[rank]
-    local: Dict[int, torch.Tensor] = {}
-    pending = []
+    shards = plan_shards(lengths, world)
+    mine = shards[rank]
+    n_max = max((len(s) for s in shards), default=0)
+    t_max = max(lengths) if lengths else 0
+    pending, src, dst = [], [], []
+    base = 0                                            # offset of the current batch in the concatenated outputs
+    slot_of = {i: k for k, i in enumerate(mine)}
     for batch in bucket_batches(mine, lengths, max_frames):
         if packed_fn is not None:
             x = torch.cat([videos[i].to(device=device, dtype=torch.float32) for i in batch], dim=0)
-            pending.append((batch, packed_fn(x, [lengths[i] for i in batch]).detach().float()))
+            out = packed_fn(x, [lengths[i] for i in batch]).detach().float().reshape(-1)
+            row = 0
+            for i in batch:
+                src.append(torch.arange(base + row, base + row + lengths[i]))
+                row += lengths[i]
         else:
             x, mask = pad_batch([videos[i] for i in batch], device)
-            pending.append((batch, score_fn(x, mask).detach().float()))  # stays on the device: no sync per batch
-    for batch, s in pending:                                            # one D2H per batch, after all launches
-        sh = s.cpu()
-        row = 0
-        for b, i in enumerate(batch):
-            if packed_fn is not None:
-                local[i] = sh[row: row + lengths[i]].clone()
-                row += lengths[i]
-            else:
-                local[i] = sh[b, : lengths[i]].clone()
-    if world == 1 and not force_collective:
-        return local
-    import torch.distributed as dist
-    # one padded all_gather: [n_max, 1 + t_max] rows = (video id, scores...), -1 id = empty slot
-    shards = plan_shards(lengths, world)
-    n_max = max(len(s) for s in shards)
-    t_max = max(lengths) if lengths else 0
-    comm_dev = device if (device is not None and dist.get_backend(group) == "nccl") else torch.device("cpu")
-    send = torch.zeros((n_max, 1 + t_max), dtype=torch.float32, device=comm_dev)
-    send[:, 0] = -1.0
-    for slot, i in enumerate(mine):
-        send[slot, 0] = float(i)
-        send[slot, 1: 1 + lengths[i]] = local[i].to(comm_dev)
-    recv = torch.empty((world * n_max, 1 + t_max), dtype=torch.float32, device=comm_dev)
+            out2 = score_fn(x, mask).detach().float()    # stays on the device: no sync per batch
+            tb = out2.shape[1]
+            out = out2.reshape(-1)
+            for b, i in enumerate(batch):
+                src.append(torch.arange(base + b * tb, base + b * tb + lengths[i]))
+        for i in batch:
+            dst.append(torch.arange(slot_of[i] * t_max, slot_of[i] * t_max + lengths[i]))
+        pending.append(out)
+        base += out.numel()
+    collective = world > 1 or force_collective
+    if collective:
+        import torch.distributed as dist
+        on_dev = device is not None and dist.get_backend(group) == "nccl"
+    out_dev = pending[0].device if pending else (torch.device(device) if device is not None else torch.device("cpu"))
+    send = torch.zeros((n_max, t_max), dtype=torch.float32, device=out_dev)
+    if pending:
+        flat = pending[0] if len(pending) == 1 else torch.cat(pending)
+        src_i, dst_i = torch.cat(src).to(out_dev), torch.cat(dst).to(out_dev)
+        send.view(-1).index_copy_(0, dst_i, flat.index_select(0, src_i))
+    if not collective:
+        host = send.cpu()                               # the one device-to-host copy
+        return {i: host[slot_of[i], : lengths[i]].clone() for i in mine}
+    if not on_dev:
+        send = send.cpu()
+    recv = torch.empty((world * n_max, t_max), dtype=torch.float32, device=send.device)
     dist.all_gather_into_tensor(recv, send, group=group)      # concatenated along dim 0 (gloo and nccl)
-    recv = recv.view(world, n_max, 1 + t_max).cpu()
+    recv = recv.view(world, n_max, t_max).cpu()
     out: Dict[int, torch.Tensor] = {}
     for r in range(world):
-        for slot in range(n_max):
-            i = int(recv[r, slot, 0].item())
-            if i >= 0:
-                out[i] = recv[r, slot, 1: 1 + lengths[i]].clone()
+        for slot, i in enumerate(shards[r]):
+            out[i] = recv[r, slot, : lengths[i]].clone()
     return out
 
 

@@ -5,6 +5,9 @@
 #include "vs_eval.h"
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdlib>
 #include <cmath>
 #include <cstdio>
 #include <numeric>
@@ -94,98 +97,127 @@ bool knapsack(int W, const int32_t *wt, const double *val, int n, std::vector<in
     return true;
 }
 
-// scipy.stats.rankdata(-x) with method 'average', as doubles
+// ---- rank correlations on RUN-LENGTH-COMPRESSED frame vectors ----
+// Both inputs of evaluate_scores are piecewise constant: the prediction is up-sampled from one score per pick (15 frames,
+// compute_metrics.py:30-37) and the users' importance scores are per-shot integers (TVSum: 1..5 over 2-second shots).  A
+// frame vector is therefore held as runs (start, value), ranks are taken over run VALUES with the run lengths as weights,
+// and Kendall's pair counts / Spearman's sums become weighted sums over the joint runs of the two vectors.  Every pair
+// count is an exact integer and every Spearman sum an exact multiple of 1/4 (far below 2^53), so the results are the
+// ones of the per-frame computation (scipy.stats.rankdata(-x, 'average'), kendalltau variant 'b', np.corrcoef) bit for
+// bit; vectors without runs cost what the per-frame form costs.
+struct Ranked {
+    int n = 0;                          // frames
+    std::vector<int> start;             // run r covers frames [start[r], start[r+1]); start.back() == n
+    std::vector<int> dense;             // per run: index of its value among the distinct values, largest value first (rank order)
+    std::vector<long long> gweight;     // per distinct value: frames holding it
+    std::vector<double> grank;          // per distinct value: the average rank of those frames
+};
+
+// per-thread work vectors: they keep their capacity from task to task (a fresh std::vector per task grows its thread's
+// malloc arena by system calls, which serialise on the process' address-space lock: measured, no speed-up at all from
+// 8 threads before this)
+struct Scratch {
+    std::vector<double> val;
+    std::vector<int> order, cnt, cx;
+    std::vector<long long> bit;
+    struct Seg { long long w; int x, y; };
+    std::vector<Seg> seg, tmp;
+};
+
 template <class T>
-void rank_neg_average(const T *x, int n, std::vector<double> &rk) {
-    std::vector<std::pair<double, int>> kv(n);          // (key, index) pairs sort ~3x faster than indirect compares
-    for (int i = 0; i < n; ++i) kv[i] = {-(double)x[i], i};
-    std::sort(kv.begin(), kv.end(), [](const std::pair<double, int> &a, const std::pair<double, int> &b) { return a.first < b.first; });
-    rk.assign(n, 0.0);
-    for (int i = 0; i < n;) {
-        int j = i;
-        while (j + 1 < n && kv[j + 1].first == kv[i].first) ++j;
-        const double r = 0.5 * ((i + 1) + (j + 1));     // average rank of the tie group (order inside it is irrelevant)
-        for (int k = i; k <= j; ++k) rk[kv[k].second] = r;
-        i = j + 1;
+void rank_runs(const T *x, int n, Ranked &R, Scratch &W) {
+    R.n = n;
+    R.start.clear();
+    std::vector<double> &val = W.val;
+    val.clear();
+    for (int i = 0; i < n; ++i)
+        if (i == 0 || !((double)x[i] == (double)x[i - 1])) { R.start.push_back(i); val.push_back((double)x[i]); }
+    const int m = (int)val.size();
+    R.start.push_back(n);
+    std::vector<int> &order = W.order;
+    order.resize(m);
+    std::iota(order.begin(), order.end(), 0);
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return val[a] > val[b]; });      // rankdata(-x): largest first
+    R.dense.assign(m, 0);
+    R.gweight.clear();
+    for (int k = 0; k < m; ++k) {
+        const int r = order[k];
+        if (k == 0 || !(val[r] == val[order[k - 1]])) R.gweight.push_back(0);
+        R.dense[r] = (int)R.gweight.size() - 1;
+        R.gweight.back() += R.start[r + 1] - R.start[r];
+    }
+    R.grank.resize(R.gweight.size());
+    long long before = 0;
+    for (size_t g = 0; g < R.gweight.size(); ++g) {
+        R.grank[g] = (double)before + 0.5 * (double)(R.gweight[g] + 1);          // average of before+1 .. before+c
+        before += R.gweight[g];
     }
 }
 
-// Pearson r of two rank vectors, the way np.corrcoef computes it (means, centred products, in double)
-double pearson(const std::vector<double> &a, const std::vector<double> &b) {
-    const int n = (int)a.size();
-    double ma = 0, mb = 0;
-    for (int i = 0; i < n; ++i) { ma += a[i]; mb += b[i]; }
-    ma /= n; mb /= n;
-    double sab = 0, saa = 0, sbb = 0;
-    for (int i = 0; i < n; ++i) {
-        const double da = a[i] - ma, db = b[i] - mb;
-        sab += da * db; saa += da * da; sbb += db * db;
+// mean Kendall tau-b and Spearman rho ingredients for one (prediction, user) pair
+void correlate(const Ranked &X, const Ranked &Y, double &tau, double &rho, Scratch &W) {
+    const int n = X.n;
+    const int gx = (int)X.gweight.size(), gy = (int)Y.gweight.size();
+    // joint runs: (weight, x group, y group)
+    typedef Scratch::Seg Seg;
+    std::vector<Seg> &seg = W.seg, &tmp = W.tmp;
+    seg.clear();
+    for (size_t rx = 0, ry = 0; rx < X.dense.size() && ry < Y.dense.size();) {
+        const int lo = std::max(X.start[rx], Y.start[ry]), hi = std::min(X.start[rx + 1], Y.start[ry + 1]);
+        if (hi > lo) seg.push_back(Seg{hi - lo, X.dense[rx], Y.dense[ry]});
+        if (X.start[rx + 1] <= Y.start[ry + 1]) ++rx; else ++ry;
     }
-    return sab / std::sqrt(saa * sbb);
-}
-
-// number of discordant pairs of (x, y), x sorted ascending with ties broken by y (merge-sort inversion count)
-long long count_discordant(std::vector<int> &y) {
-    const int n = (int)y.size();
-    std::vector<int> tmp(n);
-    long long inv = 0;
-    for (int width = 1; width < n; width *= 2) {
-        for (int lo = 0; lo < n; lo += 2 * width) {
-            const int mid = std::min(lo + width, n), hi = std::min(lo + 2 * width, n);
-            int i = lo, j = mid, k = lo;
-            while (i < mid && j < hi) {
-                if (y[j] < y[i]) { tmp[k++] = y[j++]; inv += mid - i; }
-                else tmp[k++] = y[i++];
-            }
-            while (i < mid) tmp[k++] = y[i++];
-            while (j < hi) tmp[k++] = y[j++];
-            std::copy(tmp.begin() + lo, tmp.begin() + hi, y.begin() + lo);
-        }
-    }
-    return inv;
-}
-
-// scipy.stats.kendalltau (variant 'b') on two rank vectors
-double kendall_tau_b(const std::vector<double> &xr, const std::vector<double> &yr) {
-    const int n = (int)xr.size();
-    if (n < 2) return NAN;
-    // one sort by (x, y) gives x ascending with ties in x ordered by y (what scipy's two stable sorts build);
-    // ranks are multiples of 0.5, so 2*rank is an exact integer key
-    std::vector<std::pair<long long, int>> kv(n);
-    for (int i = 0; i < n; ++i) kv[i] = {(long long)(2.0 * xr[i]) * (4LL * n + 4) + (long long)(2.0 * yr[i]), i};
-    std::sort(kv.begin(), kv.end());
-    std::vector<int> xs(n), ys(n);
+    const int m = (int)seg.size();
+    // stable counting sorts: by y group, then by x group -> x ascending, y ascending inside an x group
+    tmp.resize(m);
     {
-        std::vector<std::pair<long long, int>> ykv(n);
-        for (int i = 0; i < n; ++i) ykv[i] = {(long long)(2.0 * yr[i]), i};
-        std::sort(ykv.begin(), ykv.end());
-        std::vector<int> ydense(n);
-        int d = 0;
-        for (int i = 0; i < n; ++i) { if (i > 0 && ykv[i].first != ykv[i - 1].first) ++d; ydense[ykv[i].second] = d; }
-        d = 0;
-        for (int i = 0; i < n; ++i) {
-            if (i > 0 && xr[kv[i].second] != xr[kv[i - 1].second]) ++d;
-            xs[i] = d; ys[i] = ydense[kv[i].second];
-        }
+        std::vector<int> &cnt = W.cnt, &cx = W.cx;
+        cnt.assign(gy + 1, 0);
+        for (const Seg &q : seg) ++cnt[q.y + 1];
+        for (int g = 0; g < gy; ++g) cnt[g + 1] += cnt[g];
+        for (const Seg &q : seg) tmp[cnt[q.y]++] = q;
+        cx.assign(gx + 1, 0);
+        for (const Seg &q : tmp) ++cx[q.x + 1];
+        for (int g = 0; g < gx; ++g) cx[g + 1] += cx[g];
+        for (const Seg &q : tmp) seg[cx[q.x]++] = q;
     }
-    auto tie_pairs = [&](const std::vector<int> &v_sorted) {
-        long long t = 0;
-        for (int i = 0; i < n;) { int j = i; while (j + 1 < n && v_sorted[j + 1] == v_sorted[i]) ++j; const long long c = j - i + 1; t += c * (c - 1) / 2; i = j + 1; }
-        return t;
-    };
-    long long ntie = 0;     // joint ties: runs equal in both x and y (adjacent after the double sort)
-    for (int i = 0; i < n;) { int j = i; while (j + 1 < n && xs[j + 1] == xs[i] && ys[j + 1] == ys[i]) ++j; const long long c = j - i + 1; ntie += c * (c - 1) / 2; i = j + 1; }
-    const long long xtie = tie_pairs(xs);
-    std::vector<int> ysorted(ys);
-    std::sort(ysorted.begin(), ysorted.end());
-    const long long ytie = tie_pairs(ysorted);
-    std::vector<int> ycopy(ys);
-    const long long dis = count_discordant(ycopy);
-    const long long tot = (long long)n * (n - 1) / 2;
-    if (xtie == tot || ytie == tot) return NAN;
-    const double con_minus_dis = (double)(tot - xtie - ytie + ntie - 2 * dis);
-    double tau = con_minus_dis / std::sqrt((double)(tot - xtie)) / std::sqrt((double)(tot - ytie));
-    return std::min(1.0, std::max(-1.0, tau));
+    auto pairs = [](long long c) { return c * (c - 1) / 2; };
+    const long long tot = pairs(n);
+    long long xtie = 0, ytie = 0, ntie = 0, dis = 0;
+    for (long long c : X.gweight) xtie += pairs(c);
+    for (long long c : Y.gweight) ytie += pairs(c);
+    for (int i = 0; i < m;) {
+        int k = i;
+        long long c = 0;
+        while (k < m && seg[k].x == seg[i].x && seg[k].y == seg[i].y) c += seg[k++].w;
+        ntie += pairs(c);
+        i = k;
+    }
+    // discordant pairs: x groups in ascending order; a frame pair is discordant when the later x group holds the smaller y
+    // group.  Fenwick tree over y groups holding the weight seen so far.
+    std::vector<long long> &bit = W.bit;
+    bit.assign(gy + 1, 0);
+    long long seen = 0;
+    auto add = [&](int y, long long w) { for (int i = y + 1; i <= gy; i += i & -i) bit[i] += w; };
+    auto upto = [&](int y) { long long t = 0; for (int i = y + 1; i > 0; i -= i & -i) t += bit[i]; return t; };     // weight with group <= y
+    for (int i = 0; i < m;) {
+        int k = i;
+        while (k < m && seg[k].x == seg[i].x) { dis += seg[k].w * (seen - upto(seg[k].y)); ++k; }
+        for (int q = i; q < k; ++q) { add(seg[q].y, seg[q].w); seen += seg[q].w; }
+        i = k;
+    }
+    if (xtie == tot || ytie == tot) tau = NAN;
+    else {
+        const double con_minus_dis = (double)(tot - xtie - ytie + ntie - 2 * dis);
+        tau = std::min(1.0, std::max(-1.0, con_minus_dis / std::sqrt((double)(tot - xtie)) / std::sqrt((double)(tot - ytie))));
+    }
+    // Spearman = Pearson of the average ranks (np.corrcoef): both means are (n + 1) / 2
+    const double mean = 0.5 * (double)(n + 1);
+    double sab = 0, saa = 0, sbb = 0;
+    for (const Seg &q : seg) sab += (double)q.w * (X.grank[q.x] - mean) * (Y.grank[q.y] - mean);
+    for (int g = 0; g < gx; ++g) saa += (double)X.gweight[g] * (X.grank[g] - mean) * (X.grank[g] - mean);
+    for (int g = 0; g < gy; ++g) sbb += (double)Y.gweight[g] * (Y.grank[g] - mean) * (Y.grank[g] - mean);
+    rho = sab / std::sqrt(saa * sbb);
 }
 
 }  // namespace
@@ -264,31 +296,107 @@ int vs_eval_fscore(const int8_t *summary, int32_t summary_len, const int8_t *use
 int vs_eval_rank_correlation(const float *frame_scores, int32_t n, const double *user_scores, int32_t n_users,
                              double *kendall, double *spearman) {
     if (!frame_scores || !user_scores || !kendall || !spearman || n < 2 || n_users < 1) return bad("rank_correlation: bad arguments");
-    std::vector<double> pr;
-    rank_neg_average(frame_scores, n, pr);
-    // users are independent: a few host threads, results summed in user order (deterministic)
-    std::vector<double> kt(n_users), sp(n_users);
-    auto work = [&](int u0, int u1) {
-        std::vector<double> ur;
-        for (int u = u0; u < u1; ++u) {
-            rank_neg_average(user_scores + (size_t)u * n, n, ur);
-            sp[u] = pearson(pr, ur);                                          // compute_correlation.py:9-11
-            kt[u] = kendall_tau_b(pr, ur);                                    // :12-14
-        }
-    };
-    const int hw = (int)std::thread::hardware_concurrency();
-    const int nth = std::max(1, std::min({n_users, hw > 0 ? hw : 1, 8}));
-    if (nth == 1 || (size_t)n * n_users < 20000) {
-        work(0, n_users);
-    } else {
-        std::vector<std::thread> pool;
-        for (int t = 0; t < nth; ++t) pool.emplace_back(work, (int)((long long)n_users * t / nth), (int)((long long)n_users * (t + 1) / nth));
-        for (auto &th : pool) th.join();
-    }
+    Ranked X, Y;
+    Scratch W;
+    rank_runs(frame_scores, n, X, W);
     double ksum = 0, ssum = 0;
-    for (int u = 0; u < n_users; ++u) { ksum += kt[u]; ssum += sp[u]; }
+    for (int u = 0; u < n_users; ++u) {          // users in order: the sums do not depend on any scheduling (vs_eval_corpus: the parallel form)
+        double kt, sp;
+        rank_runs(user_scores + (size_t)u * n, n, Y, W);
+        correlate(X, Y, kt, sp, W);                  // compute_correlation.py:9-14
+        ksum += kt; ssum += sp;
+    }
     *kendall = ksum / n_users;
     *spearman = ssum / n_users;
+    return VS_OK;
+}
+
+int vs_eval_corpus(const vs_eval_video *videos, int32_t n_videos, int32_t max_threads, double *f_score, double *kendall,
+                   double *spearman) {
+    if (n_videos < 0 || (n_videos > 0 && (!videos || !f_score || !kendall || !spearman))) return bad("eval_corpus: bad arguments");
+    if (n_videos == 0) return VS_OK;
+    for (int v = 0; v < n_videos; ++v) {
+        const vs_eval_video &V = videos[v];
+        if (!V.scores || !V.positions || !V.change_points || !V.user_summary || V.n_shots < 1 || V.n_users < 1 || V.n_frames < 0)
+            return bad("eval_corpus: a video record has a NULL pointer or an empty field");
+        if (V.user_scores && (V.n_score_users < 1 || V.n_frames < 2)) return bad("eval_corpus: user_scores needs n_score_users >= 1 and n_frames >= 2");
+    }
+    const int hw = (int)std::thread::hardware_concurrency();
+    int nth = max_threads > 0 ? max_threads : std::min(hw > 0 ? hw : 1, 32);
+    // phase 2 tasks: (video, user) pairs, heaviest videos first (a long video's users should not start last)
+    struct Task { int v, u; };
+    std::vector<Task> tasks;
+    std::vector<int> order(n_videos);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return videos[a].n_frames > videos[b].n_frames; });
+    std::vector<size_t> uoff(n_videos + 1, 0);
+    for (int v = 0; v < n_videos; ++v) uoff[v + 1] = uoff[v] + (videos[v].user_scores ? (size_t)videos[v].n_score_users : 0);
+    for (int v : order)
+        if (videos[v].user_scores)
+            for (int u = 0; u < videos[v].n_score_users; ++u) tasks.push_back(Task{v, u});
+    nth = std::max(1, std::min<int>(nth, (int)std::max<size_t>(tasks.size(), (size_t)n_videos)));
+    std::vector<Ranked> pr(n_videos);                            // prediction ranks per video (phase 1 -> phase 2)
+    std::vector<double> kt(uoff[n_videos]), sp(uoff[n_videos]);
+    std::vector<int> rc(n_videos, VS_OK);
+    std::atomic<int> next1{0}, next2{0};
+    auto phase1 = [&]() {
+        Scratch W;
+        std::vector<float> fs;
+        std::vector<int8_t> summary;
+        for (;;) {
+            const int i = next1.fetch_add(1);
+            if (i >= n_videos) break;
+            const int v = order[i];
+            const vs_eval_video &V = videos[v];
+            const int last_end = V.change_points[2 * (V.n_shots - 1) + 1];
+            if (last_end < 0) { rc[v] = VS_ERR_INVALID; continue; }
+            summary.resize((size_t)last_end + 1);
+            rc[v] = vs_eval_generate_summary(V.scores, V.n_scores, V.positions, V.n_positions, V.n_frames, V.change_points, V.n_shots,
+                                             summary.data(), last_end + 1);
+            if (rc[v] == VS_OK)
+                rc[v] = vs_eval_fscore(summary.data(), last_end + 1, V.user_summary, V.n_users, V.user_len, V.use_max, &f_score[v]);
+            if (rc[v] == VS_OK && V.user_scores) {
+                fs.resize((size_t)V.n_frames);
+                rc[v] = upsample(V.scores, V.n_scores, V.positions, V.n_positions, V.n_frames, fs.data());
+                if (rc[v] == VS_OK) rank_runs(fs.data(), V.n_frames, pr[v], W);
+            }
+        }
+    };
+    auto phase2 = [&]() {
+        Ranked ur;
+        Scratch W;
+        for (;;) {
+            const int i = next2.fetch_add(1);
+            if (i >= (int)tasks.size()) break;
+            const Task t = tasks[i];
+            if (rc[t.v] != VS_OK) continue;
+            const vs_eval_video &V = videos[t.v];
+            if (V.user_scores_f32) rank_runs((const float *)V.user_scores + (size_t)t.u * V.n_frames, V.n_frames, ur, W);
+            else rank_runs((const double *)V.user_scores + (size_t)t.u * V.n_frames, V.n_frames, ur, W);
+            correlate(pr[t.v], ur, kt[uoff[t.v] + t.u], sp[uoff[t.v] + t.u], W);
+        }
+    };
+    auto run = [&](auto &fn) {
+        if (nth == 1) { fn(); return; }
+        std::vector<std::thread> pool;
+        for (int t = 0; t < nth; ++t) pool.emplace_back(fn);
+        for (auto &th : pool) th.join();
+    };
+    auto T0 = std::chrono::steady_clock::now();
+    run(phase1);
+    auto T1 = std::chrono::steady_clock::now();
+    for (int v = 0; v < n_videos; ++v)
+        if (rc[v] != VS_OK) return bad("eval_corpus: a video failed in generate_summary / evaluate_summary (see the per-video entry points for the cause)");
+    run(phase2);
+    auto T2 = std::chrono::steady_clock::now();
+    if (getenv("VS_EVAL_DEBUG")) fprintf(stderr, "phase1 %.2f ms phase2 %.2f ms nth %d tasks %zu\n", std::chrono::duration<double, std::milli>(T1 - T0).count(), std::chrono::duration<double, std::milli>(T2 - T1).count(), nth, tasks.size());
+    for (int v = 0; v < n_videos; ++v) {
+        if (!videos[v].user_scores) { kendall[v] = NAN; spearman[v] = NAN; continue; }
+        double ks = 0, ss = 0;
+        for (int u = 0; u < videos[v].n_score_users; ++u) { ks += kt[uoff[v] + u]; ss += sp[uoff[v] + u]; }
+        kendall[v] = ks / videos[v].n_score_users;
+        spearman[v] = ss / videos[v].n_score_users;
+    }
     return VS_OK;
 }
 

@@ -11,8 +11,6 @@ from __future__ import annotations
 
 import ctypes as C
 
-import concurrent.futures
-
 import numpy as np
 
 from . import _lib
@@ -87,24 +85,38 @@ def evaluate_scores(predicted_scores, user_scores):
     return k.value, s.value
 
 
-def eval_metrics(data, user_dict):
-    """compute_metrics.py:42-92 -> (mean F-score ['avg' protocol, :43], mean Kendall tau, mean Spearman rho).
-    Videos are independent: they are evaluated on a few host threads (the C++ calls release the GIL) and the
-    means are taken in key order, so the result does not depend on the scheduling."""
+def eval_videos(data, user_dict, eval_method="avg", max_threads=0):
+    """The per-video results of eval_metrics: (f_score, kendall, spearman) arrays in the key order of `data`.
+    ONE C call (vs_eval_corpus): every video and every (video, user) rank correlation runs on one bounded pool of host
+    threads inside the library - no Python per video in the timed part, no nested pools."""
+    lib = _lib.load()
     keys = list(data.keys())
-
-    def one(k):
+    n = len(keys)
+    recs = (_lib.EvalVideo * max(n, 1))()
+    keep = []                                       # the arrays the records point into
+    for j, k in enumerate(keys):
         u = user_dict[k]
-        sc = np.asarray(data[k])
-        summary = generate_summary([u.change_points], [sc], [u.n_frames], [u.picks])[0]
-        f = evaluate_summary(summary, u.user_summary, "avg")
-        kt, sp = evaluate_scores(upsample(sc, u.n_frames, u.picks), u.user_scores)
-        return f, kt, sp
+        sc, pos, cp = _f32(data[k]).reshape(-1), _i32(u.picks).reshape(-1), _i32(u.change_points)
+        us = np.ascontiguousarray(np.asarray(u.user_summary), dtype=np.int8)
+        uf = np.asarray(u.user_scores)
+        uf = np.ascontiguousarray(uf, dtype=np.float32 if uf.dtype == np.float32 else np.float64)      # float32 (the datasets' type) goes in as it is
+        if uf.ndim != 2 or uf.shape[1] != int(u.n_frames):
+            raise ValueError("user_scores of %r has shape %r, n_frames %d" % (k, uf.shape, int(u.n_frames)))
+        keep.append((sc, pos, cp, us, uf))
+        r = recs[j]
+        r.scores, r.positions, r.change_points, r.user_summary, r.user_scores = _p(sc), _p(pos), _p(cp), _p(us), _p(uf)
+        r.n_scores, r.n_positions, r.n_frames, r.n_shots = sc.size, pos.size, int(u.n_frames), cp.shape[0]
+        r.n_users, r.user_len, r.n_score_users, r.use_max = us.shape[0], us.shape[1], uf.shape[0], 1 if eval_method == "max" else 0
+        r.user_scores_f32 = 1 if uf.dtype == np.float32 else 0
+    f, kt, sp = (np.empty(n, dtype=np.float64) for _ in range(3))
+    _lib.check(lib.vs_eval_corpus(recs, n, int(max_threads), _p(f), _p(kt), _p(sp)))
+    return f, kt, sp
 
-    if len(keys) > 1:
-        with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, len(keys))) as pool:
-            res = list(pool.map(one, keys))
-    else:
-        res = [one(k) for k in keys]
-    f, kt, sp = zip(*res) if res else ((), (), ())
+
+def eval_metrics(data, user_dict):
+    """compute_metrics.py:42-92 -> (mean F-score ['avg' protocol, :43], mean Kendall tau, mean Spearman rho);
+    the means are taken in key order (the result does not depend on the threads' scheduling)."""
+    if not len(data):
+        return float(np.mean(())), float(np.mean(())), float(np.mean(()))
+    f, kt, sp = eval_videos(data, user_dict, "avg")
     return float(np.mean(f)), float(np.mean(kt)), float(np.mean(sp))

@@ -14,13 +14,11 @@ from __future__ import annotations
 
 from typing import Iterable, Sequence
 
-import concurrent.futures
-
 import torch
 import torch.nn.functional as F
 
 from .corpus import plan_shards, score_corpus
-from .evaluation import eval_metrics
+from .evaluation import eval_metrics, eval_videos
 
 
 @torch.no_grad()
@@ -40,6 +38,19 @@ def val_step(model, loader: Iterable, device):
     return loss_sum / max(n, 1), f_score, ktau, spr
 
 
+def evaluate_shard(scores, targets, users, order):
+    """[sum MSE loss, sum F-score, sum Kendall tau, sum Spearman rho] over the videos `order` (indices): the keyshot
+    evaluation of a rank's shard as ONE library call (`evaluation.eval_videos` -> vs_eval_corpus: one bounded host thread
+    pool over every video and every (video, user) pair), sums in index order."""
+    if not order:
+        return [0.0, 0.0, 0.0, 0.0]
+    f, k, s = eval_videos({i: scores[i].numpy() for i in order}, {i: users[i] for i in order}, "avg")
+    loss = 0.0
+    for i in order:
+        loss += F.mse_loss(scores[i].view(1, -1), targets[i].detach().float().cpu().view(1, -1)).item()
+    return [loss, float(f.sum()), float(k.sum()), float(s.sum())]
+
+
 @torch.no_grad()
 def val_step_batched(model, features: Sequence[torch.Tensor], targets: Sequence[torch.Tensor], users: Sequence,
                      device, rank: int = 0, world: int = 1, group=None, max_frames: int = 16384):
@@ -56,21 +67,7 @@ def val_step_batched(model, features: Sequence[torch.Tensor], targets: Sequence[
     mine = plan_shards(lengths, world)[rank] if world > 1 else list(range(len(users)))
     order = sorted(mine)
 
-    def one(i):
-        u = users[i]
-        f, k, s = eval_metrics({u.name: scores[i].numpy()}, {u.name: u})
-        return F.mse_loss(scores[i].view(1, -1), targets[i].detach().float().cpu().view(1, -1)).item(), f, k, s
-
-    # videos are independent: a few host threads (the C++ evaluation releases the GIL), sums in index order
-    if len(order) > 1:
-        with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, len(order))) as pool:
-            res = list(pool.map(one, order))
-    else:
-        res = [one(i) for i in order]
-    sums = [0.0, 0.0, 0.0, 0.0]
-    for r in res:
-        for j in range(4):
-            sums[j] += r[j]
+    sums = evaluate_shard(scores, targets, users, order)
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor(sums, dtype=torch.float64,
