@@ -177,6 +177,14 @@ int vs_train_dropout_mask_rows(uint8_t *keep, int32_t M, int32_t cols, uint64_t 
  * may switch the other way in float64); 1: attention output [B*T, d]; 2: y1 [B*T, d]; 3: y2 [B*T, d]. */
 int vs_train_saved_field(const vs_weights *w, int32_t B, int32_t T, int32_t layer, int32_t field, size_t *offset_bytes,
                          size_t *count);
+/* The form of the activation record the LAST vs_train_forward of the calling thread wrote: bit 31 set (valid), bit 0 bf16
+ * Linear / dgrad / wgrad products, bit 1 bf16 attention products, bits 2..4 which tensors of the record are bf16 planes
+ * (q/k/v; MLP hidden; written by the A-stationary GEMM).  Bits 0 and 1 both clear = the exact fp32 path ran, whatever
+ * vs_dropout_cfg.flags asked for (low-precision training applies from VS_LP_MIN_ROWS frames per batch up).
+ * Pass the value to vs_train_backward in vs_dropout_cfg.reserved: the backward then reads the record in the form it was
+ * written in even if a library switch (vs_set_option) changed in between; reserved == 0 derives the form again. */
+uint32_t vs_train_last_format(void);
+
 /* module numbers (`site`) of the dropouts: embedding = 0; layer l: 1 + 4*l + {0 attention, 1 dropout1, 2 mlp, 3 dropout2} */
 uint32_t vs_train_dropout_site(int32_t layer, int32_t which);
 

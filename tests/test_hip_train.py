@@ -372,6 +372,55 @@ def test_bf16_training_storage_forms_agree_bit_for_bit(vsa, lp_train_everywhere,
             assert torch.equal(a, b), n
 
 
+def test_backward_reads_the_record_in_the_form_the_forward_wrote(vsa, lp_train_everywhere):
+    """the forward publishes the form of its activation record (vs_train_last_format) and the backward
+    takes it back through vs_dropout_cfg.reserved.  Flipping the storage / kernel-choice switches BETWEEN a forward and its
+    backward (another model, a retained graph, a test harness) therefore changes nothing: every gradient is bit-identical to
+    the undisturbed step.  Before, the backward derived the form again and read bf16 planes as fp32."""
+    def step(flip):
+        m = vsa.SimNet(num_heads=4, d_model=256, num_layers=2, sparsity=0.0, dropout=0.0)
+        m.load_state_dict(vsa.synth.make_state_dict(256, 2, 3))
+        m = m.to(_dev()).train().set_train_dtype("bf16")
+        x = torch.randn(2, 200, 1024, generator=torch.Generator().manual_seed(1)).to(_dev()).requires_grad_(True)
+        pred, hid = m(x, None)
+        loss = (pred ** 2).mean() + 1e-3 * hid.sum()
+        try:
+            if flip:
+                vsa._lib.set_option("VS_LP_STORE32", 1)
+                vsa._lib.set_option("VS_LP_MLP_UNFUSED", 1)
+            loss.backward()
+            torch.cuda.synchronize()
+        finally:
+            vsa._lib.set_option("VS_LP_STORE32", -1)
+            vsa._lib.set_option("VS_LP_MLP_UNFUSED", -1)
+        assert m.last_train_dtype == "bf16"
+        return [("dx", x.grad.clone())] + [(n, q.grad.clone()) for n, q in m.named_parameters()]
+    for (n, a), (_n, b) in zip(step(False), step(True)):
+        assert torch.isfinite(a).all() and torch.equal(a, b), n
+
+
+def test_low_precision_request_below_the_threshold_says_so(vsa):
+    """below VS_LP_MIN_ROWS frames per batch the exact kernels run whatever set_train_dtype asked for -
+    the model now records what ran (last_train_dtype) and warns once instead of doing so silently."""
+    import warnings
+    m = vsa.SimNet(num_heads=4, d_model=256, num_layers=1, sparsity=0.0, dropout=0.0)
+    m.load_state_dict(vsa.synth.make_state_dict(256, 1, 3))
+    m = m.to(_dev()).train().set_train_dtype("bf16")
+    x = torch.randn(2, 100, 1024, generator=torch.Generator().manual_seed(1)).to(_dev())
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        m(x, None)[0].sum().backward()
+        m(x, None)[0].sum().backward()
+    assert m.last_train_dtype == "fp32"
+    assert sum("exact fp32 kernels" in str(w.message) for w in rec) == 1
+    try:
+        vsa._lib.set_option("VS_LP_MIN_ROWS", 0)
+        m(x, None)[0].sum().backward()
+        assert m.last_train_dtype == "bf16"
+    finally:
+        vsa._lib.set_option("VS_LP_MIN_ROWS", -1)
+
+
 @pytest.mark.parametrize("p,B,T,d", [(0.0, 2, 200, 256), (0.3, 3, 171, 256), (0.5, 1, 1, 256), (0.3, 2, 150, 512), (0.0, 1, 333, 512)])
 def test_a_stationary_mlp_gemms_equal_the_tiled_ones_bit_for_bit(vsa, lp_train_everywhere, p, B, T, d):
     """d_model 256 / 512 in the bf16 training mode: fc1 (+ ReLU + dropout) and the fc2 input gradient (+ gate) run A-stationary

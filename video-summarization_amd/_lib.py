@@ -48,7 +48,7 @@ TRAIN_EXPORTS = ("vs_train_prepare", "vs_train_saved_bytes", "vs_train_workspace
                  "vs_mse_mask_loss_forward", "vs_mse_mask_loss_backward", "vs_train_attention_forward",
                  "vs_train_attention_backward", "vs_train_attention_dropout_bits_bytes", "vs_train_attention_dropout_bits",
                  "vs_train_attention_forward_bf16", "vs_train_attention_backward_bf16", "vs_train_wgrad_scratch_floats", "vs_train_wgrad", "vs_train_wgrad_bf16",
-                 "vs_train_dropout_mask_attention", "vs_train_dropout_mask_rows", "vs_train_dropout_site", "vs_train_saved_field",
+                 "vs_train_dropout_mask_attention", "vs_train_dropout_mask_rows", "vs_train_dropout_site", "vs_train_saved_field", "vs_train_last_format",
                  "vs_pretrain_head_state_bytes", "vs_pretrain_head_workspace_bytes", "vs_pretrain_head_forward",
                  "vs_pretrain_head_backward")
 NUM_STAGES = 6
@@ -250,6 +250,8 @@ def load() -> C.CDLL:
                                        C.POINTER(C.c_double)]
         lib.vs_eval_rank_correlation.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_double),
                                                  C.POINTER(C.c_double)]
+        lib.vs_train_last_format.restype = C.c_uint32
+        lib.vs_train_last_format.argtypes = []
         lib.vs_eval_corpus.restype = C.c_int
         lib.vs_eval_corpus.argtypes = [C.POINTER(EvalVideo), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
         # include/vs_train.h

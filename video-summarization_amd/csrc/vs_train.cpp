@@ -40,6 +40,35 @@ int failf(int code, const char *fmt, ...) {
 
 size_t align_floats(size_t n) { return (n + 63) / 64 * 64; }      // 256-byte granules
 
+// The FORM of an activation record: which tensors of it are bf16 planes / which arithmetic wrote it.  The forward derives it
+// from the request (vs_dropout_cfg.flags), the batch size and the library's switches; the backward must read the record in
+// the form it was WRITTEN in.  The forward therefore publishes the form (vs_train_last_format(), per calling thread) and the
+// backward takes it back through vs_dropout_cfg.reserved - a switch flipped between the two calls (another model, a retained
+// graph, a test) can no longer make the backward read bf16 planes as fp32.  reserved == 0: derived again (older callers).
+struct RecordForm {
+    int lp; bool lpa, qkv16, h16, rows16;
+    uint32_t bits() const { return 0x80000000u | (lp ? 1u : 0u) | (lpa ? 2u : 0u) | (qkv16 ? 4u : 0u) | (h16 ? 8u : 0u) | (rows16 ? 16u : 0u); }
+};
+thread_local uint32_t g_last_format = 0;
+RecordForm derive_form(const vs_weights *w, const vs_dropout_cfg *drop, int B, int T) {
+    RecordForm f{};
+    // low-precision training (VS_TRAIN_FLAG_BF16_LINEAR): every Linear / dgrad / wgrad GEMM on the bf16 matrix pipe, from the
+    // batch size up where the LDS-tiled kernels beat the exact latency kernels (the threshold of the scoring path)
+    f.lp = (drop && (drop->flags & VS_TRAIN_FLAG_BF16_LINEAR) && (long long)B * T > vsk_options().lp_min_rows) ? 1 : 0;
+    // ... and (VS_TRAIN_FLAG_BF16_ATTENTION) the attention products of the forward and the backward (head dim 32 / 64 / 128)
+    f.lpa = drop && (drop->flags & VS_TRAIN_FLAG_BF16_ATTENTION) && (long long)B * T > vsk_options().lp_min_rows &&
+            vst_attention_bf16_supported(w->desc.d_model / w->desc.num_heads);
+    // bf16 STORAGE of the tensors that are only ever bf16 matrix operands (VS_LP_STORE32 = 1 keeps them fp32: an A/B switch -
+    // the kernels round the fp32-stored values to the same bf16, so every result is bit-identical either way)
+    f.qkv16 = f.lp && f.lpa && !vsk_options().lp_store32;     // q / k / v of the record are bf16 planes
+    f.h16 = f.lp && !vsk_options().lp_store32;                // ... and so is the MLP hidden tensor (and, in the backward, its gradient)
+    // ... which the A-stationary GEMM writes where it applies (K = d_model = 256, batches that fill the chip; VS_LP_MLP_UNFUSED = 1: the
+    // tiled kernels, 2: the A-stationary kernel at every batch size - A/B and test switches)
+    f.rows16 = f.h16 && vsk_options().lp_mlp_unfused != 1 &&
+               vst_gemm_rows16_supported(B * T, 4 * w->desc.d_model, w->desc.d_model, vsk_options().lp_mlp_unfused == 2);
+    return f;
+}
+
 // ---- activation record (floats) ----
 struct LayerSaved { size_t qkv, att, lse, z1, st1, y1, ffn, z2, st2, y2, dbits; };
 struct SavedLayout {
@@ -194,6 +223,8 @@ int vs_train_saved_field(const vs_weights *w, int32_t B, int32_t T, int32_t laye
     return VS_OK;
 }
 
+uint32_t vs_train_last_format(void) { return g_last_format; }
+
 uint32_t vs_train_dropout_site(int32_t layer, int32_t which) { return layer < 0 ? VS_SITE_EMBED : VS_SITE_LAYER(layer, which); }
 
 int vs_train_forward(const vs_weights *w, const float *x, const uint8_t *key_pad_mask, int32_t B, int32_t T,
@@ -215,20 +246,10 @@ int vs_train_forward(const vs_weights *w, const float *x, const uint8_t *key_pad
     const float p = drop ? drop->p : 0.f;
     // the embedding dropout lives INSIDE PositionalEncoding (simnet.py:224,237): a use_pos=False model has none
     const float p_embed = (drop && w->has_pe) ? drop->p_embed : 0.f;
-    // low-precision training (VS_TRAIN_FLAG_BF16_LINEAR): every Linear / dgrad / wgrad GEMM on the bf16 matrix pipe, from the
-    // batch size up where the LDS-tiled kernels beat the exact latency kernels (the threshold of the scoring path)
-    const int lp = (drop && (drop->flags & VS_TRAIN_FLAG_BF16_LINEAR) && (long long)B * T > vsk_options().lp_min_rows) ? 1 : 0;
-    // ... and (VS_TRAIN_FLAG_BF16_ATTENTION) the attention products of the forward and the backward (head dim 32 / 64 / 128)
-    const bool lpa = drop && (drop->flags & VS_TRAIN_FLAG_BF16_ATTENTION) && (long long)B * T > vsk_options().lp_min_rows &&
-                     vst_attention_bf16_supported(w->desc.d_model / w->desc.num_heads);
-    // bf16 STORAGE of the tensors that are only ever bf16 matrix operands (VS_LP_STORE32 = 1 keeps them fp32: an A/B switch -
-    // the kernels round the fp32-stored values to the same bf16, so every result is bit-identical either way)
-    const bool qkv16 = lp && lpa && !vsk_options().lp_store32;     // q / k / v of the record are bf16 planes
-    const bool h16 = lp && !vsk_options().lp_store32;              // ... and so is the MLP hidden tensor (and, in the backward, its gradient)
-    // ... which the A-stationary GEMM writes where it applies (K = d_model = 256, batches that fill the chip; VS_LP_MLP_UNFUSED = 1: the
-    // tiled kernels, 2: the A-stationary kernel at every batch size - A/B and test switches)
-    const bool rows16 = h16 && vsk_options().lp_mlp_unfused != 1 &&
-                        vst_gemm_rows16_supported(B * T, 4 * w->desc.d_model, w->desc.d_model, vsk_options().lp_mlp_unfused == 2);
+    const RecordForm form = derive_form(w, drop, B, T);
+    g_last_format = form.bits();
+    const int lp = form.lp;
+    const bool lpa = form.lpa, qkv16 = form.qkv16, h16 = form.h16, rows16 = form.rows16;
     const size_t kvs = qkv16 ? (size_t)B * T * w->desc.d_model / 2 : (size_t)B * T * w->desc.d_model;     // floats between the planes
     const unsigned long long seed = drop ? drop->seed : 0ull;
     const float scale = 1.0f / sqrtf((float)d);              // simnet.py:126: d_model ** -0.5
@@ -311,20 +332,19 @@ int vs_train_backward(vs_weights *w, const float *x, const uint8_t *key_pad_mask
     const float p = drop ? drop->p : 0.f;
     // the embedding dropout lives INSIDE PositionalEncoding (simnet.py:224,237): a use_pos=False model has none
     const float p_embed = (drop && w->has_pe) ? drop->p_embed : 0.f;
-    // low-precision training (VS_TRAIN_FLAG_BF16_LINEAR): every Linear / dgrad / wgrad GEMM on the bf16 matrix pipe, from the
-    // batch size up where the LDS-tiled kernels beat the exact latency kernels (the threshold of the scoring path)
-    const int lp = (drop && (drop->flags & VS_TRAIN_FLAG_BF16_LINEAR) && (long long)B * T > vsk_options().lp_min_rows) ? 1 : 0;
-    // ... and (VS_TRAIN_FLAG_BF16_ATTENTION) the attention products of the forward and the backward (head dim 32 / 64 / 128)
-    const bool lpa = drop && (drop->flags & VS_TRAIN_FLAG_BF16_ATTENTION) && (long long)B * T > vsk_options().lp_min_rows &&
-                     vst_attention_bf16_supported(w->desc.d_model / w->desc.num_heads);
-    // bf16 STORAGE of the tensors that are only ever bf16 matrix operands (VS_LP_STORE32 = 1 keeps them fp32: an A/B switch -
-    // the kernels round the fp32-stored values to the same bf16, so every result is bit-identical either way)
-    const bool qkv16 = lp && lpa && !vsk_options().lp_store32;     // q / k / v of the record are bf16 planes
-    const bool h16 = lp && !vsk_options().lp_store32;              // ... and so is the MLP hidden tensor (and, in the backward, its gradient)
-    // ... which the A-stationary GEMM writes where it applies (K = d_model = 256, batches that fill the chip; VS_LP_MLP_UNFUSED = 1: the
-    // tiled kernels, 2: the A-stationary kernel at every batch size - A/B and test switches)
-    const bool rows16 = h16 && vsk_options().lp_mlp_unfused != 1 &&
-                        vst_gemm_rows16_supported(B * T, 4 * w->desc.d_model, w->desc.d_model, vsk_options().lp_mlp_unfused == 2);
+    // the form the record was written in: handed back by the caller (vs_dropout_cfg.reserved = vs_train_last_format() of the
+    // forward), else derived again from the same inputs
+    RecordForm form = derive_form(w, drop, B, T);
+    if (drop && (drop->reserved & 0x80000000u)) {
+        const uint32_t fb = drop->reserved;
+        form.lp = (fb & 1u) ? 1 : 0; form.lpa = (fb & 2u) != 0; form.qkv16 = (fb & 4u) != 0; form.h16 = (fb & 8u) != 0; form.rows16 = (fb & 16u) != 0;
+        if ((form.qkv16 && !(form.lp && form.lpa)) || (form.h16 && !form.lp) || (form.rows16 && !form.h16) ||
+            (form.lpa && !vst_attention_bf16_supported(w->desc.d_model / w->desc.num_heads)) ||
+            (form.rows16 && !vst_gemm_rows16_supported(B * T, 4 * w->desc.d_model, w->desc.d_model, true)))
+            return failf(VS_ERR_INVALID, "vs_dropout_cfg.reserved = 0x%08x is not a record form this model / batch can have", fb);
+    }
+    const int lp = form.lp;
+    const bool lpa = form.lpa, qkv16 = form.qkv16, h16 = form.h16, rows16 = form.rows16;
     const size_t kvs = qkv16 ? (size_t)B * T * w->desc.d_model / 2 : (size_t)B * T * w->desc.d_model;     // floats between the planes
     const unsigned long long seed = drop ? drop->seed : 0ull;
     const float scale = 1.0f / sqrtf((float)d);

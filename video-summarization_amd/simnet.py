@@ -140,8 +140,10 @@ class _TrainForward(torch.autograd.Function):
             _lib.check(lib.vs_train_forward(packed.handle, x.data_ptr(), _ptr(m), B, T, C.byref(cfg), scores.data_ptr(),
                                             hidden.data_ptr(), saved.data_ptr(), saved.numel(), ws.data_ptr(), ws.numel(),
                                             stream))
+            fmt = int(lib.vs_train_last_format())        # the form this record was written in: handed back to the backward
         ctx.save_for_backward(x, m, saved)
-        ctx.module, ctx.cfg, ctx.packed, ctx.packed_key = module, (float(p_embed), float(p), int(seed), int(tflags), 0), packed, module._packed_key
+        ctx.module, ctx.cfg, ctx.packed, ctx.packed_key = module, (float(p_embed), float(p), int(seed), int(tflags), fmt), packed, module._packed_key
+        module._note_train_arithmetic(int(tflags), fmt, B * T)
         ctx.set_materialize_grads(False)
         return scores, hidden
 
@@ -155,7 +157,13 @@ class _TrainForward(torch.autograd.Function):
             raise RuntimeError("SimNet parameters were modified between forward and backward")
         B, T, _ = x.shape
         params = [t for t in module._tensors() if isinstance(t, nn.Parameter)]
-        grads = [torch.empty_like(t, dtype=torch.float32, memory_format=torch.contiguous_format) for t in params]
+        # ONE allocation for every gradient, viewed per parameter (was ~70 torch.empty_like per backward)
+        sizes = [t.numel() for t in params]
+        offs = [0]
+        for n_ in sizes:
+            offs.append(offs[-1] + (n_ + 63) // 64 * 64)          # 256-byte aligned views
+        flat = torch.empty((offs[-1],), dtype=torch.float32, device=x.device)
+        grads = [flat[o: o + n_].view(t.shape) for o, n_, t in zip(offs, sizes, params)]
         it = iter(grads)
         G = _lib.ModelGrads()
         G.embed_w, G.embed_b = next(it).data_ptr(), next(it).data_ptr()
@@ -245,6 +253,7 @@ class SimNet(nn.Module):
         self._attention_dtype = "fp32"
         self._linear_dtype = "fp32"       # "bf16": every Linear multiplies bf16-rounded operands (fp32 storage/accumulate)
         self._train_dtype = "fp32"        # set_train_dtype("bf16"): the training path's counterpart of the reference's autocast
+        self.last_train_dtype = None      # what the last training forward actually computed in ("fp32" / "bf16")
         self._packed: Optional[_Packed] = None
         self._packed_key = None
         self._packed_shape = None
@@ -456,6 +465,17 @@ class SimNet(nn.Module):
             self.attention_dtype = value if (head_ok or value == "fp32") else "fp32"
         self.linear_dtype = value
         return self
+
+    def _note_train_arithmetic(self, tflags: int, fmt: int, frames: int) -> None:
+        """Records which arithmetic the last training forward actually ran (``last_train_dtype``) and says so - once - when a
+        low-precision request was not honoured (the library keeps batches below VS_LP_MIN_ROWS frames on the exact kernels)."""
+        self.last_train_dtype = "bf16" if (fmt & 3) else "fp32"
+        if tflags and not (fmt & 3) and not getattr(self, "_warned_train_dtype", False):
+            import warnings
+            self._warned_train_dtype = True
+            warnings.warn("set_train_dtype(%r) was requested but this batch (%d frames) ran on the exact fp32 kernels: the "
+                          "low-precision training kernels apply above VS_LP_MIN_ROWS frames per batch (see "
+                          "SimNet.last_train_dtype after any training forward)" % (self._train_dtype, frames), RuntimeWarning)
 
     def set_train_dtype(self, value: str) -> "SimNet":
         """Arithmetic of the TRAINING path's matrix products (forward Linears, dgrad and wgrad GEMMs): 'fp32' (default:
