@@ -169,7 +169,7 @@ const char *vs_stage_name(int32_t stage);
 
 /* A/B and test switches (DESIGN.md "Environment switches"; none selects a fallback).  Their defaults come from
  * environment variables of the same name, read ONCE when the library is first used - no forward calls getenv.
- * value < 0 restores the environment / built-in default.  Names: VS_SKINNY_ROWS, VS_LP_MIN_ROWS, VS_LP_MIN_ROWS_FUSED, VS_GEMM_NWM2,
+ * value < 0 restores the environment / built-in default.  Names: VS_SKINNY_ROWS, VS_LP_MIN_ROWS, VS_LP_MIN_ROWS_FUSED, VS_TRAIN_LP_MIN_ROWS, VS_ATTN_W64, VS_ATTN_W64_CHECKED, VS_GEMM_NWM2,
  * VS_GEMM_NJ2, VS_ATTN_NW4, VS_ATTN_LP_SIMPLE, VS_LP_STORE32, VS_LP_MLP_UNFUSED, VS_LP_TAIL_UNFUSED, VS_LP_QKV_UNFUSED, VS_LP_EMBED_UNFUSED, VS_LP_TILE256 (+ VS_MLP_FUSION, VS_MLP_ABL, VS_ATTN_LEGACY, which only the
  * diagnostic build of the library acts on).  Process-wide; not meant to be flipped while forwards are in flight. */
 int vs_set_option(const char *name, int32_t value);

@@ -180,7 +180,7 @@ int vs_train_saved_field(const vs_weights *w, int32_t B, int32_t T, int32_t laye
 /* The form of the activation record the LAST vs_train_forward of the calling thread wrote: bit 31 set (valid), bit 0 bf16
  * Linear / dgrad / wgrad products, bit 1 bf16 attention products, bits 2..4 which tensors of the record are bf16 planes
  * (q/k/v; MLP hidden; written by the A-stationary GEMM).  Bits 0 and 1 both clear = the exact fp32 path ran, whatever
- * vs_dropout_cfg.flags asked for (low-precision training applies from VS_LP_MIN_ROWS frames per batch up).
+ * vs_dropout_cfg.flags asked for (low-precision training applies above VS_TRAIN_LP_MIN_ROWS frames per batch, default 1024).
  * Pass the value to vs_train_backward in vs_dropout_cfg.reserved: the backward then reads the record in the form it was
  * written in even if a library switch (vs_set_option) changed in between; reserved == 0 derives the form again. */
 uint32_t vs_train_last_format(void);

@@ -400,7 +400,7 @@ def test_backward_reads_the_record_in_the_form_the_forward_wrote(vsa, lp_train_e
 
 
 def test_low_precision_request_below_the_threshold_says_so(vsa):
-    """below VS_LP_MIN_ROWS frames per batch the exact kernels run whatever set_train_dtype asked for -
+    """below VS_TRAIN_LP_MIN_ROWS frames per batch the exact kernels run whatever set_train_dtype asked for -
     the model now records what ran (last_train_dtype) and warns once instead of doing so silently."""
     import warnings
     m = vsa.SimNet(num_heads=4, d_model=256, num_layers=1, sparsity=0.0, dropout=0.0)
@@ -414,11 +414,11 @@ def test_low_precision_request_below_the_threshold_says_so(vsa):
     assert m.last_train_dtype == "fp32"
     assert sum("exact fp32 kernels" in str(w.message) for w in rec) == 1
     try:
-        vsa._lib.set_option("VS_LP_MIN_ROWS", 0)
+        vsa._lib.set_option("VS_TRAIN_LP_MIN_ROWS", 0)
         m(x, None)[0].sum().backward()
         assert m.last_train_dtype == "bf16"
     finally:
-        vsa._lib.set_option("VS_LP_MIN_ROWS", -1)
+        vsa._lib.set_option("VS_TRAIN_LP_MIN_ROWS", -1)
 
 
 @pytest.mark.parametrize("p,B,T,d", [(0.0, 2, 200, 256), (0.3, 3, 171, 256), (0.5, 1, 1, 256), (0.3, 2, 150, 512), (0.0, 1, 333, 512)])
@@ -496,10 +496,10 @@ def test_wgrad_bf16_kernel(vsa, M, N, K):
 
 @pytest.fixture
 def lp_train_everywhere(vsa):
-    """low-precision GEMMs from the first row on (default: from 8192 frames per batch)"""
-    vsa._lib.set_option("VS_LP_MIN_ROWS", 0)
+    """low-precision GEMMs from the first row on (default: above 1024 frames per batch)"""
+    vsa._lib.set_option("VS_TRAIN_LP_MIN_ROWS", 0)
     yield
-    vsa._lib.set_option("VS_LP_MIN_ROWS", -1)
+    vsa._lib.set_option("VS_TRAIN_LP_MIN_ROWS", -1)
 
 
 @pytest.mark.parametrize("case", train_cases(), ids=lambda c: c["name"])

@@ -36,7 +36,7 @@ ATOL, RTOL = tht.ATOL, tht.RTOL          # tests/tolerances.py: TRAIN_GRAD_ATOL 
 def run(budget, seed, progress=True, lp=False):
     dev = torch.device("cuda:0")
     if lp:
-        pkg._lib.set_option("VS_LP_MIN_ROWS", 0)
+        pkg._lib.set_option("VS_TRAIN_LP_MIN_ROWS", 0)
     rng = np.random.Generator(np.random.PCG64(seed))
     torch.set_num_threads(16)
     t_end, n, worst, t_print, nrisky = time.time() + budget, 0, 0.0, time.time() + 30, 0

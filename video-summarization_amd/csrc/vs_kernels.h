@@ -108,6 +108,8 @@ int vsk_skinny_max_rows();      // rows up to which the skinny (latency) kernels
 struct VskOptions {
     int skinny_rows;      // VS_SKINNY_ROWS   (default 16384)
     int lp_min_rows;      // VS_LP_MIN_ROWS   (default 8192)
+    int train_lp_min_rows;// VS_TRAIN_LP_MIN_ROWS (default 1024): frames per batch above which a low-precision TRAINING request is honoured
+                          // (profiles/r04_lp_min_rows_sweep.txt: break-even at ~1280 frames, 1.1x at 2560, 1.7x at 8192)
     int lp_min_rows_fused;// VS_LP_MIN_ROWS_FUSED (default 256): the same threshold where the fused bf16 layer kernels apply
     int gemm_nwm2;        // VS_GEMM_NWM2     128x128 four-wave GEMM blocks only
     int gemm_nj2;         // VS_GEMM_NJ2      128-column GEMM tiles only

@@ -118,7 +118,7 @@ const OptionName kOptions[] = {
     {"VS_LP_MLP_UNFUSED", &VskOptions::lp_mlp_unfused, 0}, {"VS_LP_TAIL_UNFUSED", &VskOptions::lp_tail_unfused, 0},
     {"VS_LP_QKV_UNFUSED", &VskOptions::lp_qkv_unfused, 0}, {"VS_LP_EMBED_UNFUSED", &VskOptions::lp_embed_unfused, 0},
     {"VS_LP_MIN_ROWS_FUSED", &VskOptions::lp_min_rows_fused, 256}, {"VS_LP_TILE256", &VskOptions::lp_tile256, 0},
-    {"VS_ATTN_W64_CHECKED", &VskOptions::attn_w64_checked, 0},
+    {"VS_ATTN_W64_CHECKED", &VskOptions::attn_w64_checked, 0}, {"VS_TRAIN_LP_MIN_ROWS", &VskOptions::train_lp_min_rows, 1024},
     {"VS_ATTN_W64", &VskOptions::attn_w64, 1},           {"VS_ATTN_W64_ABL", &VskOptions::attn_w64_abl, 0},
 };
 int option_from_env(const OptionName &o) {

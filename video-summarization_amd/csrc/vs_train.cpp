@@ -53,10 +53,11 @@ thread_local uint32_t g_last_format = 0;
 RecordForm derive_form(const vs_weights *w, const vs_dropout_cfg *drop, int B, int T) {
     RecordForm f{};
     // low-precision training (VS_TRAIN_FLAG_BF16_LINEAR): every Linear / dgrad / wgrad GEMM on the bf16 matrix pipe, from the
-    // batch size up where the LDS-tiled kernels beat the exact latency kernels (the threshold of the scoring path)
-    f.lp = (drop && (drop->flags & VS_TRAIN_FLAG_BF16_LINEAR) && (long long)B * T > vsk_options().lp_min_rows) ? 1 : 0;
+    // batch size up where that pays (VS_TRAIN_LP_MIN_ROWS, default 1024 frames: tools/sweep_lp_min_rows.py,
+    // profiles/r04_lp_min_rows_sweep.txt - break-even at ~1280 frames, never slower; rounds 2-3 used the scoring path's 8192)
+    f.lp = (drop && (drop->flags & VS_TRAIN_FLAG_BF16_LINEAR) && (long long)B * T > vsk_options().train_lp_min_rows) ? 1 : 0;
     // ... and (VS_TRAIN_FLAG_BF16_ATTENTION) the attention products of the forward and the backward (head dim 32 / 64 / 128)
-    f.lpa = drop && (drop->flags & VS_TRAIN_FLAG_BF16_ATTENTION) && (long long)B * T > vsk_options().lp_min_rows &&
+    f.lpa = drop && (drop->flags & VS_TRAIN_FLAG_BF16_ATTENTION) && (long long)B * T > vsk_options().train_lp_min_rows &&
             vst_attention_bf16_supported(w->desc.d_model / w->desc.num_heads);
     // bf16 STORAGE of the tensors that are only ever bf16 matrix operands (VS_LP_STORE32 = 1 keeps them fp32: an A/B switch -
     // the kernels round the fp32-stored values to the same bf16, so every result is bit-identical either way)

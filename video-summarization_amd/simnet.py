@@ -468,13 +468,13 @@ class SimNet(nn.Module):
 
     def _note_train_arithmetic(self, tflags: int, fmt: int, frames: int) -> None:
         """Records which arithmetic the last training forward actually ran (``last_train_dtype``) and says so - once - when a
-        low-precision request was not honoured (the library keeps batches below VS_LP_MIN_ROWS frames on the exact kernels)."""
+        low-precision request was not honoured (the library keeps batches below VS_TRAIN_LP_MIN_ROWS frames on the exact kernels)."""
         self.last_train_dtype = "bf16" if (fmt & 3) else "fp32"
         if tflags and not (fmt & 3) and not getattr(self, "_warned_train_dtype", False):
             import warnings
             self._warned_train_dtype = True
             warnings.warn("set_train_dtype(%r) was requested but this batch (%d frames) ran on the exact fp32 kernels: the "
-                          "low-precision training kernels apply above VS_LP_MIN_ROWS frames per batch (see "
+                          "low-precision training kernels apply above VS_TRAIN_LP_MIN_ROWS frames per batch (see "
                           "SimNet.last_train_dtype after any training forward)" % (self._train_dtype, frames), RuntimeWarning)
 
     def set_train_dtype(self, value: str) -> "SimNet":
