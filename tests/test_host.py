@@ -209,6 +209,69 @@ def test_fused_mlp_chunk_loop_has_only_its_counted_dma_on_the_vector_memory_coun
         assert full >= 2
 
 
+def _device_functions(vsa, tmp_path):
+    """{kernel name: [(address, instruction text, branch-target offset or None)]} of every gfx950 code object in the built
+    library (llvm-objdump --offloading unbundles them next to a COPY of the .so)."""
+    import shutil
+    import subprocess
+    od = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(od):
+        pytest.skip("llvm-objdump not found")
+    vsa._lib.build()
+    lib = str(tmp_path / "lib.so")
+    shutil.copy(vsa._lib.LIB_PATH, lib)
+    subprocess.run([od, "--offloading", lib], capture_output=True, check=True)
+    funcs = {}
+    for f in sorted(os.listdir(str(tmp_path))):
+        if "gfx950" not in f:
+            continue
+        txt = subprocess.run([od, "-d", "--no-show-raw-insn", str(tmp_path / f)], capture_output=True, text=True, check=True).stdout
+        cur = None
+        for line in txt.split("\n"):
+            m = re.match(r"^[0-9a-f]+ <(.+)>:$", line.strip())
+            if m:
+                cur = funcs.setdefault(m.group(1), [])
+                continue
+            m = re.match(r"^\s+(\S.*?)\s*// ([0-9A-Fa-f]+):(.*)$", line)
+            if m and cur is not None:
+                t = re.search(r"\+0x([0-9a-f]+)>", m.group(3))
+                cur.append((int(m.group(2), 16), m.group(1), int(t.group(1), 16) if t else None))
+    assert len(funcs) > 50
+    return funcs
+
+
+def test_no_kernel_touches_scratch_inside_its_innermost_mfma_loop(vsa, tmp_path):
+    """a register spill inside a k-loop costs a memory round trip per MFMA step and falsifies counted
+    `vmcnt` waits.  Every backward branch of every kernel of the built library is a loop; the innermost loops that hold
+    MFMAs must hold no scratch_ instruction.  (Known and kept, outside the k-loops, once per output tile: the 64-wide-k
+    bf16 GEMM instantiations park their store addresses around the k-loop - DESIGN section 17.)"""
+    funcs = _device_functions(vsa, tmp_path)
+    offenders, outer = [], {}
+    seen_mfma_kernels = 0
+    for name, ins in funcs.items():
+        if not any(i.startswith("v_mfma") for _, i, _ in ins):
+            continue
+        seen_mfma_kernels += 1
+        base = ins[0][0]
+        loops = [(base + t, a) for a, i, t in ins if (i.startswith("s_cbranch") or i.startswith("s_branch")) and t is not None and base + t <= a]
+        count = lambda lo, hi, pfx: sum(1 for a, i, _ in ins if lo <= a <= hi and i.startswith(pfx))
+        mf = [l for l in loops if count(l[0], l[1], "v_mfma") > 0]
+        inner = [l for l in mf if not any(o != l and o[0] >= l[0] and o[1] <= l[1] for o in mf)]
+        for lo, hi in inner:
+            if count(lo, hi, "scratch_"):
+                offenders.append((name, count(lo, hi, "v_mfma"), count(lo, hi, "scratch_")))
+        tot = count(ins[0][0], ins[-1][0], "scratch_")
+        if tot:
+            outer[name] = tot
+    assert seen_mfma_kernels > 100
+    assert not offenders, offenders
+    # the spills that exist are the documented ones (DESIGN section 17): gemm_nt_128's 64-wide-k forms (per output tile,
+    # around the k-loop), gemm_rows16<512> (prologue: its 128 registers of A) and the fused layer-tail kernel (2 / 6 in
+    # the prologue); a NEW kernel with scratch fails here and has to be looked at
+    assert all(("gemm_nt_128" in n or "gemm_rows16ILi512" in n or "mlp_fused_bf16ILb1" in n) for n in outer), sorted(outer)
+    assert max(outer.values()) <= 80, outer
+
+
 def test_every_documented_switch_is_a_known_option_and_unknown_names_are_refused(vsa):
     """include/vs_scorer.h names the A/B switches vs_set_option accepts; each must be known to the library (value -1 =
     back to the environment / built-in default: a no-op here), a misspelt one must be an error, not a silent no-op."""
