@@ -25,15 +25,19 @@ TRAIN_GRAD_ATOL = 1e-4          # per tensor, max |g - g64| absolute ...
 TRAIN_GRAD_RTOL = 1e-3          # ... and relative to the tensor's largest entry (+1e-6 for analytically-zero sums)
 # low-precision training (set_train_dtype("bf16" | "fp16"): MFMA operands rounded, fp32 accumulate / softmax / LayerNorm /
 # loss) - the counterpart of the reference's fp16 autocast (train.py:120)
-TRAIN_LP_GRAD_L2 = 5e-2         # per tensor, relative L2 error ||g - g64|| / ||g64|| over the golden's sampled rows
+TRAIN_LP_GRAD_L2 = 3.5e-2       # per tensor, relative L2 error ||g - g64|| / ||g64|| over the golden's sampled rows
                                 # (measured over the seven golden cases: 1.2e-2 ... 2.6e-2; 8-bit mantissas through ~10
-                                # GEMMs and two LayerNorm backwards per layer)
-                                # - with ONE sampled row per tensor set aside when it alone breaks the bound: a flipped ReLU
-                                # unit's whole fc1.weight row moves (measured: 78 % of the squared error in one of 8 rows)
+                                # GEMMs and two LayerNorm backwards per layer; round 3 allowed 5e-2)
+                                # - for mlp.fc1.weight ONLY, one sampled row is set aside when it alone breaks the bound: a ReLU
+                                # unit whose pre-activation lies within bf16 rounding of zero flips, and that unit's whole
+                                # fc1.weight row moves (measured: 78 % of the squared error in one of 8 sampled rows); every
+                                # other tensor meets the bound with all its rows (round 3 allowed the set-aside everywhere)
                                 # - the soak (tools/fuzz_train.py bf16) holds the q / k projection gradients relative to the
                                 # same layer's v projection gradient: dS = P (dP - delta) is a difference, the bf16 rounding
                                 # of dO and V enters at the scale of dP, and with diffuse attention little of dP is left
                                 # (measured: 35 % of a q.weight gradient that is itself 1/30 of the layer's others)
+TRAIN_LP_FC1_L2 = 5e-2          # mlp.fc1.weight after the set-aside (round 3's bound, kept for this tensor alone: the d_model 768
+                                # golden has two flipped units among its sampled rows - 4.7e-2 with one of them set aside)
 TRAIN_LP_GRAD_RTOL = 2e-1       # per tensor, LARGEST element error relative to the tensor's largest entry: a gross-error
                                 # bound only - a ReLU unit whose pre-activation lies within bf16 rounding of zero flips and
                                 # moves one row of d_fc1 / one entry of its bias, by up to 14 % of the maximum in the
