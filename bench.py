@@ -18,7 +18,7 @@ Prints ONE JSON line on rank 0 with the contract fields plus
   roofline      the dominant kernel: algorithmic FLOPs per launch / its mean launch duration, from HIP events the
                 library records around every launch in a SEPARATE profiled pass of the same K steps (the headline
                 `value` is timed with profiling off); `traffic` = HBM bytes per launch from the committed PMC passes
-                (profiles/r03_hbm_traffic.json, stamped with the kernel-source hash it was measured on; null when
+                (profiles/r04_hbm_traffic.json, stamped with the kernel-source hash it was measured on; null when
                 the loaded sources differ)
   cpu_baseline  the oracle (CPU restatement of the reference, "port") timed on this box's host cores:
                 B=8,T=1024 (throughput leg, = `value`'s unit) and B=1,T=320 x20 (SURVEY §8(d) latency leg)
@@ -55,7 +55,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense fp32 matrix peak 
 PEAK_F16_MFMA_TFLOPS = 2500.0     # dense f16 / bf16 matrix peak; an fp16x3 product costs 3 f16 products
 # HBM bytes per launch per kernel come from separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; see
 # tools/collect_traffic.sh), committed under profiles/: counters cannot be read from inside the timed run.
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_hbm_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r04_hbm_traffic.json")
 STAGE_KERNEL = {"attention": "attn_fwd_pipe", "embed_pe": "gemm_nt_128<2", "qkv_proj": "gemm_nt_128<3",
                 "fc1_relu": "gemm_nt_128<1", "outproj_ln": "gemm_ln_rows", "fc2_ln_score": "gemm_ln_rows"}
 

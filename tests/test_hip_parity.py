@@ -590,7 +590,8 @@ BF16_STORED_REL = 6e-3      # against fp64 on the SAME stored operands: P and th
 @pytest.mark.parametrize("B,H,T,masked", [(1, 1, 64, False), (2, 4, 320, False), (1, 4, 1024, False), (1, 2, 65, False),
                                           (1, 1, 1, False), (1, 4, 31, False), (2, 2, 513, False), (1, 2, 200, False),
                                           (1, 1, 2048, False), (3, 2, 1000, False), (1, 1, 257, False),
-                                          (2, 4, 200, True), (2, 2, 513, True), (1, 1, 64, True), (3, 2, 1000, True)])
+                                          (2, 4, 200, True), (2, 2, 513, True), (1, 1, 64, True), (3, 2, 1000, True),
+                                          (1, 1, 8200, True), (1, 1, 8200, False)])
 @pytest.mark.parametrize("checked", [0, 1])
 def test_attention_bf16_stored_w64_kernel(vsa, B, H, T, masked, checked):
     """One wave per SIMD, both passes (optimistic first / every tile checked): every tile count modulo the ring and the

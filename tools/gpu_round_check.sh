@@ -3,7 +3,7 @@
 # usage: gpu_round_check.sh [tag] [part]   part 1 = parity + headline measurements, part 2 = the other modes' profiles,
 # no part = both (longer than one 20-minute gpurun call since round 3)
 set -e
-TAG=${1:-r03z}
+TAG=${1:-r04z}
 PART=${2:-0}
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/$TAG
@@ -11,7 +11,7 @@ if [ "$PART" != "2" ]; then
 # HBM-traffic passes first: the bench contract test below wants a traffic file measured on the sources that are loaded
 bash tools/collect_traffic.sh > gpurun_out/$TAG/traffic.log 2>&1
 cp gpurun_out/traffic.json gpurun_out/$TAG/traffic.json
-cp gpurun_out/traffic.json profiles/r03_hbm_traffic.json      # (on the box; copy gpurun_out/$TAG/traffic.json home as well)
+cp gpurun_out/traffic.json profiles/r04_hbm_traffic.json      # (on the box; copy gpurun_out/$TAG/traffic.json home as well)
 python -m pytest tests -x -q -m gpu > gpurun_out/$TAG/gputest.log 2>&1 || { tail -40 gpurun_out/$TAG/gputest.log; exit 1; }
 tail -3 gpurun_out/$TAG/gputest.log
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1

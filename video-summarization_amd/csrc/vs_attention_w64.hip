@@ -21,6 +21,8 @@
 // ds_read_b128, V^T fragments by ds_read_b64_tr_b16, the S' accumulator registers packed pairwise ARE the B operand of
 // the second product.  Softmax: P = exp2(S') against a row constant c kept >= max - 1 (raised to max + 6 when a P
 // reaches 2: OR test on the packed P; rare path), l from the rounded P on the matrix pipe.
+#include <atomic>
+
 #include "vs_device.h"
 #include "vs_kernels.h"
 
@@ -229,8 +231,18 @@ int vsk_attention_bf16_w64(const void *q, const void *k, const void *v, const ui
     const int BH = B * H, nq = (T + 255) / 256, ntiles = (T + 63) / 64;
     dim3 grid(8 * ((BH + 7) / 8) * nq);
     if (mask != nullptr) {
+        // key-bias table of the whole row + one flag byte per tile behind the 48 KiB of K / V ring: beyond the 64 KiB a
+        // launch may use by default, so the limit of this kernel is raised once (gfx950: 160 KiB per workgroup)
         const size_t dyn = (size_t)ntiles * 64 * sizeof(float) + (size_t)((ntiles + 15) / 16 * 16);
-        if (dyn > 96 * 1024) return -1;
+        if (dyn > 96 * 1024 || ntiles > 2048) return -1;
+        static std::atomic<int> raised{0};
+        if (!raised.load(std::memory_order_acquire)) {
+            if (hipFuncSetAttribute((const void *)attn_fwd_bf16_w64<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess) {
+                (void)hipGetLastError();
+                return -1;
+            }
+            raised.store(1, std::memory_order_release);
+        }
         hipLaunchKernelGGL((attn_fwd_bf16_w64<false, true>), grid, dim3(256), dyn, st, (const h16 *)q, (const h16 *)k, (const h16 *)v,
                            mask, (h16 *)out, H, T, BH, nullptr, nullptr, 0, 1);
     } else {

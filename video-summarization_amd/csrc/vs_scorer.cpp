@@ -845,6 +845,8 @@ int vs_attention_bf16_stored(const void *q16, const void *k16, const void *v16, 
     if (!q16 || !k16 || !v16 || !out16) return fail(VS_ERR_INVALID, "NULL pointer");
     if (B <= 0 || H <= 0 || T <= 0) return fail(VS_ERR_INVALID, "B=%d H=%d T=%d", B, H, T);
     if (dh != 32 && dh != 64 && dh != 128) return fail(VS_ERR_INVALID, "head_dim=%d unsupported on the bf16 path", dh);
+    if ((((uintptr_t)q16 | (uintptr_t)k16 | (uintptr_t)v16 | (uintptr_t)out16) & 15) != 0)
+        return fail(VS_ERR_INVALID, "q16 / k16 / v16 / out16 must be 16-byte aligned");
     VS_LAUNCH(vsk_attention_bf16((const float *)q16, (const float *)k16, (const float *)v16, key_pad_mask, (float *)out16, B, H, T, dh,
                                  1.0f, 1 | VSK_STORE16, (hipStream_t)stream));
     return VS_OK;
