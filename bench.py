@@ -238,7 +238,7 @@ def main():
 
         def step():
             corpus_mod.score_corpus(lambda xx, mm: model.score(xx, mm), videos, rank=rank, world=world, device=dev,
-                                    max_frames=16384, packed_fn=(lambda xx, ll: model.score_packed(xx, ll)) if can_pack else None,
+                                    max_frames=int(os.environ.get("VS_BENCH_CORPUS_FRAMES", "65536")), packed_fn=(lambda xx, ll: model.score_packed(xx, ll)) if can_pack else None,
                                     force_collective=dist is not None)
             return None
     else:

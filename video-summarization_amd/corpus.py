@@ -36,12 +36,25 @@ def plan_shards(lengths: Sequence[int], world: int, **cost_kw) -> List[List[int]
 
 
 def bucket_batches(indices: Sequence[int], lengths: Sequence[int], max_frames: int = 65536,
-                   max_waste: float = 0.25) -> List[List[int]]:
+                   max_waste: float = 0.25, packed: bool = False) -> List[List[int]]:
     """Groups a shard's videos (sorted by length) into padded batches of at most `max_frames`
-    padded frames whose padding waste stays under `max_waste`."""
+    padded frames whose padding waste stays under `max_waste`.  `packed`: the batches will be scored PACKED (frames
+    concatenated, nothing padded), so only the frame budget counts - a 75-video shard of 30 k frames is ONE batch
+    (one set of launches) instead of a dozen."""
     order = sorted(indices, key=lambda i: (lengths[i], i))
     batches: List[List[int]] = []
     cur: List[int] = []
+    if packed:
+        total = 0
+        for i in order:
+            if cur and total + lengths[i] > max_frames:
+                batches.append(cur)
+                cur, total = [], 0
+            cur.append(i)
+            total += lengths[i]
+        if cur:
+            batches.append(cur)
+        return batches
     for i in order:
         if cur:
             tmax = lengths[i]                       # sorted ascending: newest is the longest
@@ -97,7 +110,7 @@ def score_corpus(score_fn: ScoreFn, videos: Sequence[torch.Tensor], rank: int = 
     pending, src, dst = [], [], []
     base = 0                                            # offset of the current batch in the concatenated outputs
     slot_of = {i: k for k, i in enumerate(mine)}
-    for batch in bucket_batches(mine, lengths, max_frames):
+    for batch in bucket_batches(mine, lengths, max_frames, packed=packed_fn is not None):
         if packed_fn is not None:
             x = torch.cat([videos[i].to(device=device, dtype=torch.float32) for i in batch], dim=0)
             out = packed_fn(x, [lengths[i] for i in batch]).detach().float().reshape(-1)

@@ -53,7 +53,7 @@ def evaluate_shard(scores, targets, users, order):
 
 @torch.no_grad()
 def val_step_batched(model, features: Sequence[torch.Tensor], targets: Sequence[torch.Tensor], users: Sequence,
-                     device, rank: int = 0, world: int = 1, group=None, max_frames: int = 16384):
+                     device, rank: int = 0, world: int = 1, group=None, max_frames: int = 65536):
     """Same result as ``val_step`` over (features[i] [T_i,1024], targets[i] [T_i], users[i])."""
     model.eval()
     # models with head dim 32 / 64 score PACKED batches (no sentinel padding, no mask; the same bits)
