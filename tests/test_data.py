@@ -160,6 +160,22 @@ def test_feeder_producer_exits_when_the_consumer_stops_early(data):
     f3 = data.RaggedFeeder(videos, max_frames=60, slots=2)
     f3.close()
     assert not f3.alive
+    # iterating a feeder that was closed (the producer's final sentinel may have been dropped) ends at once
+    # instead of blocking for good; so does an iteration whose feeder is closed from another thread
+    import threading
+    t0 = time.time()
+    assert len(list(f3)) <= 2 and len(list(f2)) <= 2 and time.time() - t0 < 2.0      # (what was already queued, then the end)
+    f4 = data.RaggedFeeder(videos, max_frames=60, slots=2)
+    got = []
+    def consume():
+        for slot, *_ in f4:                 # never hands a slot back: blocks on the queue after two batches
+            got.append(slot)
+    th = threading.Thread(target=consume, daemon=True)
+    th.start()
+    time.sleep(0.3)
+    f4.close()
+    th.join(timeout=3.0)
+    assert not th.is_alive() and not f4.alive
 
 
 @pytest.mark.gpu

@@ -290,7 +290,16 @@ class RaggedFeeder:
     def __iter__(self) -> Iterator[Tuple[int, torch.Tensor, List[int], List[int]]]:
         try:
             while True:
-                item = self._q.get()
+                # never block for good: after close() the producer's final sentinel may have been dropped (a closed feeder
+                # iterated again, or close() from another thread while this one waits)
+                try:
+                    item = self._q.get(timeout=0.1)
+                except queue.Empty:
+                    if self._stop.is_set() or not self._thread.is_alive():
+                        if self._err:
+                            raise self._err[0]
+                        return
+                    continue
                 if item is None:
                     if self._err:
                         raise self._err[0]
