@@ -107,8 +107,9 @@ void vs_weights_free(vs_weights *w);
  * vs_weights_pack; no allocation, no free), stream-ordered on `stream`: one batched copy launch per encoder layer.
  * params->pos_embedding may be NULL here: the table already packed is kept (it is a buffer, not a parameter).  The
  * kernel-layout copies (fragment-major, fp16x3, bf16 images, transposes) are NOT rebuilt here: each family is rebuilt
- * by the first forward / backward that reads it after the update, on that call's stream - so a handle's calls must be
- * issued on ONE stream at a time or be ordered by the caller. */
+ * by the first forward / backward that reads it after the update, on that call's stream.  Calls on DIFFERENT streams are
+ * ordered by the library on the device (an event is recorded behind every parameter write / image rebuild and a call on
+ * another stream waits for it - no host synchronisation); two host THREADS must still not use one handle at the same time. */
 int vs_weights_update(vs_weights *w, const vs_model_params *params, void *stream);
 
 /* Bytes of scratch vs_scorer_forward needs for a [B,T] batch (0 on invalid arguments). */

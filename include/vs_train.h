@@ -8,8 +8,9 @@
  * (and of the input).  Same conventions as vs_scorer.h: device pointers, work enqueued on the caller's stream, int
  * status + vs_last_error().  ONE allocation exists on this path: the transposed weights of the dgrad GEMMs, made by
  * vs_train_prepare() (or, if that was never called, by the first vs_train_backward).  A handle's calls (forward,
- * backward, vs_weights_update) must be issued on ONE stream at a time, or be ordered by the caller: the lazily rebuilt
- * weight images are ordered on the stream of the call that rebuilds them.  All arithmetic is exact fp32 (v_mfma_f32_32x32x2_f32); every
+ * backward, vs_weights_update) may use different streams: the lazily rebuilt weight images are ordered on the stream of the
+ * call that rebuilds them and a call on another stream waits, on the device, for the event recorded behind that work
+ * (vs_scorer.h); one host thread per handle at a time.  All arithmetic is exact fp32 (v_mfma_f32_32x32x2_f32); every
  * reduction runs in a fixed order, so a step is bitwise reproducible for a given dropout seed.
  */
 #ifndef VS_TRAIN_H

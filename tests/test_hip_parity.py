@@ -1475,6 +1475,32 @@ def test_class_token_scoring_launches_no_torch_kernels_after_the_first_call(vsa)
         assert (lb.cpu() - rl).abs().max().item() < tol.BF16_LOGIT_TOL
 
 
+def test_weight_images_built_on_one_stream_are_ordered_for_calls_on_another(vsa):
+    """the kernel-layout images of the parameters are rebuilt lazily by the first call that needs them, on THAT
+    call's stream, and the host-side version stamp is set at enqueue time.  A second call on another stream used to see
+    the stamp as current and could read images whose pack kernels were still running.  The library now records an event
+    behind every parameter write / rebuild and makes a call on another stream wait for it on the device."""
+    sd = vsa.synth.make_state_dict(1024, 4, 9)
+    m = vsa.SimNet(num_heads=16, d_model=1024, num_layers=4, sparsity=0.0, dropout=0.0)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(_dev()).eval()
+    x = vsa.synth.make_features(1, 96, 3, "randn").to(_dev())
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    for mode in ("fp16x3", "bf16", "fp32"):
+        m.set_compute_dtype(mode)
+        with torch.no_grad():
+            for rep in range(3):
+                for p in m.parameters():
+                    p.mul_(1.0 + 1e-4)                      # new parameter version: every image family is stale
+                torch.cuda.synchronize()
+                with torch.cuda.stream(s1):
+                    y1 = m(x)[0]                            # parameter copy + image rebuild + forward on s1
+                with torch.cuda.stream(s2):
+                    y2 = m(x)[0]                            # same version: no rebuild - must wait for s1's images
+                torch.cuda.synchronize()
+                assert torch.isfinite(y2).all() and torch.equal(y1, y2), (mode, rep)
+
+
 @pytest.mark.parametrize("name", ["mb_t320", "mb_pad_t150", "d768_h12_t200_pad", "d1024_h8_t150", "d1024_h16_randmask_t96"])
 def test_bf16_mode_on_wide_models_matches_reference_golden(vsa, lp_linear_everywhere, name):
     """Round 3: ``set_compute_dtype("bf16")`` for d_model > 256 (M-B = the reference's argparse default, train.py:169-173;

@@ -203,9 +203,32 @@ static int fill_weights(vs_weights *w, const vs_model_params *params, hipStream_
 namespace { std::mutex g_wmu; }
 
 // kernel-layout images, built on first use after each pack / update (see vs_weights_impl.h)
+void vsw_mark(const vs_weights *w, void *stream) {
+    if (!w->order_event) {
+        hipEvent_t ev = nullptr;
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return; }
+        w->order_event = (void *)ev;
+    }
+    if (hipEventRecord((hipEvent_t)w->order_event, (hipStream_t)stream) == hipSuccess) {
+        w->order_stream = stream;
+        w->order_recorded = true;
+    } else {
+        (void)hipGetLastError();
+    }
+}
+
+void vsw_order(const vs_weights *w, void *stream) {
+    if (w->order_recorded && w->order_stream != stream)
+        if (hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)w->order_event, 0) != hipSuccess) (void)hipGetLastError();
+}
+
 int vsw_ensure(const vs_weights *w, unsigned families, void *stream) {
     hipStream_t st = (hipStream_t)stream;
     std::lock_guard<std::mutex> lk(g_wmu);
+    vsw_order(w, stream);       // parameters written / images built on another stream: wait for them on the device
+    const bool rebuilt = ((families & VSW_FRAGMENTS) && w->f_version != w->version) || ((families & VSW_F16X3) && w->h_version != w->version) ||
+                         ((families & VSW_BF16) && w->b_version != w->version) || ((families & VSW_ROWS16) && w->r_version != w->version);
+    struct Mark { const vs_weights *w; void *s; bool on; ~Mark() { if (on) vsw_mark(w, s); } } mark{w, stream, rebuilt};
     const size_t d = w->desc.d_model, din = w->desc.in_features;
     float *blob = w->blob;
     bool pk = true;
@@ -306,6 +329,7 @@ int vs_weights_pack(const vs_model_desc *desc, const vs_model_params *params, vo
         return rc;
     }
     w->version = 1;
+    vsw_mark(w, stream);
     *out = w;
     return VS_OK;
 }
@@ -316,13 +340,17 @@ int vs_weights_update(vs_weights *w, const vs_model_params *params, void *stream
     if (hipGetDevice(&dev) != hipSuccess || dev != w->device)
         return fail(VS_ERR_INVALID, "vs_weights_update on device %d, handle was packed on device %d", dev, w->device);
     ++w->version;        // every image family (and the training side's transposes) is rebuilt on its next use
-    return fill_weights(w, params, (hipStream_t)stream, true);
+    vsw_order(w, stream);   // (images still being read / built on another stream)
+    const int rc = fill_weights(w, params, (hipStream_t)stream, true);
+    vsw_mark(w, stream);
+    return rc;
 }
 
 void vs_weights_free(vs_weights *w) {
     if (!w) return;
     if (w->blob) (void)hipFree(w->blob);
     if (w->tblob) (void)hipFree(w->tblob);
+    if (w->order_event) (void)hipEventDestroy((hipEvent_t)w->order_event);
     delete w;
 }
 
@@ -399,6 +427,7 @@ int forward_core(const vs_weights *w, const float *x, const uint8_t *key_pad_mas
         const int rows_min = cls ? B * Tf : M;
         const bool wide16 = lbf == 1 && d > 256;       // the bf16-operand GEMM's weight copies (ring path below)
         const unsigned fam = lbf == 1 ? (VSW_BF16 | (wide16 ? VSW_ROWS16 : 0u)) : rows_min > vsk_skinny_max_rows() ? 0u : lbf == 2 ? VSW_F16X3 : VSW_FRAGMENTS;
+        vsw_order(w, stream);       // parameters written on another stream (vs_weights_update): ordered on the device
         if (fam) if (int rc = vsw_ensure(w, fam, stream)) return rc;
     }
     // bf16 mode: the tensors that are only ever read as bf16 matrix operands are WRITTEN as bf16 by their producers

@@ -163,8 +163,10 @@ int ensure_transposed(vs_weights *w, hipStream_t st, bool frags) {
         w->tf_version = ~0ull;
     }
     // W [N,K] -> W^T [K,N] row-major, and its fragment-major copy for the latency kernels (as vsw_ensure does for W)
+    vsw_order(w, (void *)st);
     const bool do_t = w->t_version != w->version, do_f = frags && w->tf_version != w->version;
     if (!do_t && !do_f) return VS_OK;
+    struct Mark { const vs_weights *w; void *s; ~Mark() { vsw_mark(w, s); } } mark{w, (void *)st};
     auto both = [&](const float *W, size_t t_off, size_t tf_off, int N, int K) -> int {
         if (do_t) if (int rc = vst_transpose(W, w->tblob + t_off, N, K, st)) return rc;
         if (do_f) return vsk_pack_fragments(w->tblob + t_off, w->tblob + tf_off, K, N, st);
@@ -257,6 +259,7 @@ int vs_train_forward(const vs_weights *w, const float *x, const uint8_t *key_pad
     float *sv = (float *)saved, *ws = (float *)workspace;
     float *a = ws + W.a;
 
+    vsw_order(w, stream);
     if (M <= vsk_skinny_max_rows()) if (int rc = vsw_ensure(w, VSW_FRAGMENTS, stream)) return rc;
     if (rows16) if (int rc = vsw_ensure(w, VSW_ROWS16, stream)) return rc;          // bf16 copy of W1 for the A-stationary fc1
     // Embedding + positional table + dropout(sparsity)   simnet.py:211, 237-238

@@ -44,6 +44,13 @@ struct vs_weights {
     mutable unsigned long long b_version = ~0ull;   // b_*: LDS images of the fused bf16 layer kernels
     mutable unsigned long long r_version = ~0ull;   // r_*: plain bf16 copies
 
+    // Stream ordering of everything above and below: the last stream that wrote the parameters or (re)built an
+    // image, and an event recorded behind that work.  A call on ANOTHER stream first waits for the event
+    // (hipStreamWaitEvent: no host synchronisation), so the host-side version stamps never run ahead of the device.
+    mutable void *order_event = nullptr;  // hipEvent_t, created on first use
+    mutable void *order_stream = nullptr; // hipStream_t of the recorded work (meaningful only while order_event != nullptr)
+    mutable bool order_recorded = false;
+
     // ---- training side ----
     unsigned long long version = 0;       // bumped by every pack / update
     float *tblob = nullptr;               // second device allocation: transposed weights + a zero vector
@@ -60,3 +67,7 @@ int vs_fail_msg(int code, const char *msg);     // vs_scorer.cpp: sets the threa
 // A handle's calls must be issued on ONE stream at a time (or be ordered by the caller): include/vs_scorer.h.
 enum { VSW_FRAGMENTS = 1, VSW_F16X3 = 2, VSW_BF16 = 4, VSW_ROWS16 = 8 };
 int vsw_ensure(const vs_weights *w, unsigned families, void *stream);
+// stream ordering helpers (vs_scorer.cpp): vsw_mark() after parameter writes / image rebuilds were enqueued on `stream`;
+// vsw_order() before a call on `stream` reads them (a no-op when it is the same stream)
+void vsw_mark(const vs_weights *w, void *stream);
+void vsw_order(const vs_weights *w, void *stream);
