@@ -357,7 +357,7 @@ def main():
             torch.cuda.synchronize()
             lat_ms = (time.perf_counter() - t1) / 200 * 1e3
             # SURVEY §8(f) row 2, context only: one training step (HIP forward with dropout + masked-MSE loss + HIP backward) on
-            # the same batch, exact fp32 and under set_train_dtype("bf16") (the counterpart of the reference's autocast)
+            # the same batch, exact fp32 and under set_train_dtype("bf16" / "fp16") (the counterparts of the reference's autocast)
             try:
                 tmodel = pkg.SimNet(num_heads=H, d_model=d, num_layers=L, sparsity=0.0, dropout=0.3)
                 tmodel.load_state_dict(sd)
@@ -373,7 +373,7 @@ def main():
                         loss_.backward()
 
                 train_ms = {}
-                for mode in ("fp32", "bf16"):
+                for mode in ("fp32", "bf16", "fp16"):
                     tmodel.set_train_dtype(mode)
                     for _ in range(3):
                         train_step()
@@ -510,7 +510,7 @@ def main():
             out["eval_ms"] = round(eval_ms, 3)
         if train_ms:
             out["training_step"] = ({"workload": "forward under autograd (dropout 0.3) + masked MSE + backward on the same B x T batch, HIP "
-                                                 "kernels (include/vs_train.h); fp32 = exact, bf16 = SimNet.set_train_dtype('bf16')",
+                                                 "kernels (include/vs_train.h); fp32 = exact, bf16 / fp16 = SimNet.set_train_dtype(...)",
                                      "fp32_ms": round(train_ms["fp32"], 3), "bf16_ms": round(train_ms["bf16"], 3),
                                      "fp32_frames_per_s": round(B * T / train_ms["fp32"] * 1e3, 1),
                                      "bf16_frames_per_s": round(B * T / train_ms["bf16"] * 1e3, 1)}

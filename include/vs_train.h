@@ -54,6 +54,16 @@ typedef struct vs_dropout_cfg {
  * k, v, dO, the probabilities and dS rounded to bf16, fp32 scores / softmax / lse / accumulation. */
 #define VS_TRAIN_FLAG_BF16_ATTENTION 2u
 #define VS_TRAIN_FLAG_BF16 (VS_TRAIN_FLAG_BF16_LINEAR | VS_TRAIN_FLAG_BF16_ATTENTION)
+/* Modifier of the two flags above: the 16-bit type - of every rounded operand and of every 16-bit-stored tensor of the
+ * record - is IEEE fp16 (v_mfma_f32_32x32x16_f16), the reference's own autocast type on CUDA (train.py:120), instead of
+ * bf16: 11 significant bits against 8, so the gradients sit ~8x closer to the float64 truth (tests/tolerances.py:
+ * TRAIN_FP16_GRAD_L2), but the range ends at 65 504 and values under 6e-8 vanish - use it the way the reference does,
+ * with a loss scale (torch.amp.GradScaler, train.py:60,126-128): an operand that overflows becomes inf in the operand
+ * and inf / NaN in the gradients it reaches, which is exactly what GradScaler's check looks for before it skips the step.
+ * Accumulation, bias, residual, LayerNorm, softmax and the loss stay fp32 as in the bf16 mode.  The A-stationary fc1 / QKV
+ * kernels are bf16-only: this mode runs the tiled GEMMs everywhere. */
+#define VS_TRAIN_FLAG_FP16 4u
+#define VS_TRAIN_FLAG_FP16_ALL (VS_TRAIN_FLAG_BF16 | VS_TRAIN_FLAG_FP16)
 
 /* Gradient destinations: the mirror of vs_layer_params / vs_model_params (nn.Linear layout [out, in]); every
  * pointer is a device buffer of the parameter's shape that the backward OVERWRITES (it does not accumulate). */
@@ -180,7 +190,7 @@ int vs_train_saved_field(const vs_weights *w, int32_t B, int32_t T, int32_t laye
                          size_t *count);
 /* The form of the activation record the LAST vs_train_forward of the calling thread wrote: bit 31 set (valid), bit 0 bf16
  * Linear / dgrad / wgrad products, bit 1 bf16 attention products, bits 2..4 which tensors of the record are bf16 planes
- * (q/k/v; MLP hidden; written by the A-stationary GEMM).  Bits 0 and 1 both clear = the exact fp32 path ran, whatever
+ * (q/k/v; MLP hidden; written by the A-stationary GEMM), bit 5 the 16-bit type is fp16 (VS_TRAIN_FLAG_FP16).  Bits 0 and 1 both clear = the exact fp32 path ran, whatever
  * vs_dropout_cfg.flags asked for (low-precision training applies above VS_TRAIN_LP_MIN_ROWS frames per batch, default 1024).
  * Pass the value to vs_train_backward in vs_dropout_cfg.reserved: the backward then reads the record in the form it was
  * written in even if a library switch (vs_set_option) changed in between; reserved == 0 derives the form again. */

@@ -556,7 +556,7 @@ def test_bf16_training_gradients_within_the_low_precision_tolerance(vsa, lp_trai
             l2 = sq[keep_rows].sum().sqrt().item() / (want_g[keep_rows].norm().item() + 1e-30)
             assert l2 <= tol.TRAIN_LP_FC1_L2, "%s: relative L2 error %.3e with the flipped unit's row set aside" % (k, l2)
             l2 = 0.0        # (not counted into the worst figure below)
-        assert l2 <= tol.TRAIN_LP_GRAD_L2, "%s: relative L2 error %.3e" % (k, l2)
+        assert l2 <= (tol.TRAIN_LP_FC1_L2 if k.endswith("mlp.fc1.bias") else tol.TRAIN_LP_GRAD_L2), "%s: relative L2 error %.3e" % (k, l2)
         assert abs(g.double().norm().item() - nrm) <= 2e-2 * nrm + 1e-7, k
         if gmax > 1e-6 and err / gmax > worst:
             worst, worst_k = err / gmax, k
@@ -564,6 +564,127 @@ def test_bf16_training_gradients_within_the_low_precision_tolerance(vsa, lp_trai
             worst_l2 = l2
     assert worst > 1e-5, "the low-precision path did not run (gradients at exact-fp32 accuracy)"
     print("%s: bf16 training, worst gradient error relative to the tensor's max: %.2e (%s); worst relative L2 error %.2e" % (c["name"], worst, worst_k, worst_l2))
+
+
+@pytest.mark.parametrize("case", train_cases(), ids=lambda c: c["name"])
+def test_fp16_training_gradients_under_a_loss_scale(vsa, lp_train_everywhere, case):
+    """``set_train_dtype("fp16")`` - the reference's own autocast type (train.py:120) - used the way the reference uses it,
+    under a loss scale (GradScaler, train.py:60,126-128): loss and every unscaled gradient against the float64 goldens of the
+    IMPORTED reference at tests/tolerances.py's TRAIN_FP16_*: 11 significant bits instead of bf16's 8, and the bounds are
+    that much tighter than TRAIN_LP_*."""
+    c = case
+    z = np.load(os.path.join(GOLDEN, c["name"] + ".npz"))
+    sd = vsa.synth.make_state_dict(c["d"], c["L"], c["wseed"])
+    x, mask, target, R = _inputs(vsa.synth, c)
+    m = vsa.SimNet(num_heads=c["H"], d_model=c["d"], num_layers=c["L"], sparsity=0.0, dropout=0.0)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(_dev()).train().set_train_dtype("fp16")
+    xd = x.to(_dev()).requires_grad_(True)
+    md = None if mask is None else mask.to(_dev())
+    pred, hidden = m(xd, md)
+    assert m.last_train_dtype == "fp16"
+    mk = md if md is not None else torch.zeros(x.shape[:2], dtype=torch.bool, device=_dev())
+    loss = vsa.mse_with_mask_loss(pred, target.to(_dev()), mk)
+    if c["hidden_w"]:
+        loss = loss + c["hidden_w"] * (hidden * R.to(_dev())).sum()
+    S = tol.TRAIN_FP16_LOSS_SCALE
+    (loss * S).backward()
+    torch.cuda.synchronize()
+    want = float(z["loss"])
+    assert abs(loss.item() - want) <= tol.TRAIN_FP16_LOSS_RTOL * max(1.0, abs(want)), (loss.item(), want)
+    grads = {"x": xd.grad}
+    grads.update({k: p.grad for k, p in m.named_parameters()})
+    worst, worst_k, worst_l2, worst_l2k = 0.0, None, 0.0, None
+    for k in json.loads(str(z["keys"])):
+        g = grads[k]
+        assert g is not None and torch.isfinite(g).all(), k
+        g = g / S
+        g2 = g.reshape(-1, g.shape[-1]) if g.dim() > 1 else g.reshape(1, -1)
+        rows = torch.from_numpy(z["r:" + k])
+        want_g = torch.from_numpy(z["g:" + k]).double()
+        tot, nrm, gmax, ref32 = z["s:" + k]
+        diff = g2[rows.to(g2.device)].double().cpu() - want_g
+        err = diff.abs().max().item()
+        l2 = diff.norm().item() / (want_g.norm().item() + 1e-30)
+        if gmax < 1e-6:       # analytically zero (k.bias)
+            assert g.double().norm().item() <= tol.TRAIN_FP16_ZERO_ATOL, "%s: |g| %.3e" % (k, g.double().norm().item())
+            continue
+        assert err <= tol.TRAIN_FP16_GRAD_RTOL * gmax + 1e-7, "%s: err %.3e, max|g| %.3e" % (k, err, gmax)
+        fc1 = k.endswith("mlp.fc1.weight") or k.endswith("mlp.fc1.bias")
+        assert l2 <= (tol.TRAIN_FP16_FC1_L2 if fc1 else tol.TRAIN_FP16_GRAD_L2), "%s: relative L2 error %.3e" % (k, l2)
+        if err / gmax > worst:
+            worst, worst_k = err / gmax, k
+        if l2 > worst_l2:
+            worst_l2, worst_l2k = l2, k
+    assert worst > 1e-5, "the low-precision path did not run (gradients at exact-fp32 accuracy)"
+    print("%s: fp16 training (loss scale %g), worst gradient error relative to the tensor's max: %.2e (%s); worst relative L2 error %.2e (%s)"
+          % (c["name"], S, worst, worst_k, worst_l2, worst_l2k))
+
+
+def test_fp16_training_overflow_reaches_gradscaler(vsa, lp_train_everywhere):
+    """What the fp16 range costs, and that it fails the way the reference's loop expects (train.py:126-128:
+    ``scaler.scale(loss).backward(); scaler.step(optim); scaler.update()``): with a loss scale that pushes the score
+    gradient past 65 504 the operands round to inf, the gradients come out non-finite, GradScaler skips the step (the
+    parameters do not move) and backs the scale off; at a sane scale the same loop steps."""
+    torch.manual_seed(3)
+    sd = vsa.synth.make_state_dict(256, 2, 31)
+    m = vsa.SimNet(num_heads=4, d_model=256, num_layers=2, sparsity=0.0, dropout=0.1)
+    m.load_state_dict(sd)
+    m = m.to(_dev()).train().set_train_dtype("fp16")
+    opt = torch.optim.Adam(m.parameters(), lr=1e-4)
+    x = vsa.synth.make_features(4, 200, 9, "pool5", [200, 150, 180, 120]).to(_dev())
+    mask = vsa.synth.padding_mask(x)
+    tgt = torch.rand(4, 200, generator=torch.Generator().manual_seed(3)).to(_dev())
+
+    def step(scaler):
+        before = [p.detach().clone() for p in m.parameters()]
+        pred, _h = m(x, mask)
+        loss = vsa.mse_with_mask_loss(pred, tgt, mask)
+        opt.zero_grad(set_to_none=True)
+        scaler.scale(loss).backward()
+        finite = all(bool(torch.isfinite(p.grad).all()) for p in m.parameters())
+        scaler.step(opt)
+        scaler.update()
+        moved = any(not torch.equal(a, p.detach()) for a, p in zip(before, m.parameters()))
+        return finite, moved
+
+    big = torch.amp.GradScaler("cuda", init_scale=2.0 ** 40)
+    finite, moved = step(big)
+    assert not finite and not moved and big.get_scale() == 2.0 ** 39, (finite, moved, big.get_scale())
+    sane = torch.amp.GradScaler("cuda", init_scale=2.0 ** 10)
+    finite, moved = step(sane)
+    assert finite and moved and sane.get_scale() == 2.0 ** 10, (finite, moved, sane.get_scale())
+
+
+def test_fp16_training_loss_curve_tracks_the_exact_path(vsa, lp_train_everywhere):
+    """The reference's loop shape (autocast + GradScaler, train.py:118-128) for 40 Adam steps, exact fp32 against the fp16 mode
+    from one initialisation and one dropout seed stream: every step's loss within 1 % of the exact run's."""
+    def run(dtype):
+        torch.manual_seed(7)
+        sd = vsa.synth.make_state_dict(256, 2, 31)
+        m = vsa.SimNet(num_heads=4, d_model=256, num_layers=2, sparsity=0.0, dropout=0.1)
+        m.load_state_dict(sd)
+        m = m.to(_dev()).train().set_train_dtype(dtype)
+        opt = torch.optim.Adam(m.parameters(), lr=2e-4)
+        scaler = torch.amp.GradScaler("cuda", init_scale=2.0 ** 12, enabled=dtype == "fp16")
+        x = vsa.synth.make_features(4, 200, 9, "pool5", [200, 150, 180, 120]).to(_dev())
+        mask = vsa.synth.padding_mask(x)
+        tgt = torch.rand(4, 200, generator=torch.Generator().manual_seed(3)).to(_dev())
+        out = []
+        for _ in range(40):
+            pred, _h = m(x, mask)
+            loss = vsa.mse_with_mask_loss(pred, tgt, mask)
+            opt.zero_grad(set_to_none=True)
+            scaler.scale(loss).backward()
+            scaler.step(opt)
+            scaler.update()
+            out.append(loss.item())
+        return out
+    a, b = run("fp32"), run("fp16")
+    assert a[-1] < 0.7 * a[0] and b[-1] < 0.7 * b[0], (a[0], a[-1], b[0], b[-1])
+    rel = max(abs(u - v) / u for u, v in zip(a, b))
+    print("loss curves: exact %.4f -> %.4f, fp16 %.4f -> %.4f, worst step-wise relative difference %.2e" % (a[0], a[-1], b[0], b[-1], rel))
+    assert rel < 1e-2 and a != b
 
 
 def test_bf16_training_loss_curve_tracks_the_exact_path(vsa, lp_train_everywhere):

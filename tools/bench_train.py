@@ -92,6 +92,9 @@ for shape in args.shapes.split(","):
     m.set_train_dtype("bf16")           # the autocast counterpart: bf16 Linear / dgrad / wgrad GEMMs
     s16 = timed(step, args.iters)
     fs16 = timed(full_step, args.iters)
+    m.set_train_dtype("fp16")           # ... and with the reference's own 16-bit type (tiled GEMMs everywhere, no A-stationary form)
+    sh16 = timed(step, args.iters)
+    fsh16 = timed(full_step, args.iters)
     m.set_train_dtype("fp32")
     flops_f = B * T * (2 * 1024 * d + L * (24 * d * d + 4 * T * d))
     # backward: 2x the Linear flops (dgrad + wgrad) + 3.5x the attention flops (7 products for the forward's 2)
@@ -99,6 +102,7 @@ for shape in args.shapes.split(","):
     line = "B=%3d T=%4d  scoring fwd %.3f ms | train fwd %.3f ms | fwd+loss+bwd %.3f ms (bwd %.3f ms) | %.1f TF fwd, %.1f TF bwd, %.0f frames/s | WHOLE train_step (autocast + GradScaler + Adam + re-pack) %.3f ms = %.0f frames/s trained" % (
         B, T, ev, f, s, s - f, flops_f / f / 1e9, flops_b / (s - f) / 1e9, B * T / s * 1e3, fs, B * T / fs * 1e3)
     line += " | bf16 GEMMs (set_train_dtype): fwd+loss+bwd %.3f ms, whole train_step %.3f ms = %.0f frames/s" % (s16, fs16, B * T / fs16 * 1e3)
+    line += " | fp16 GEMMs: fwd+loss+bwd %.3f ms, whole train_step %.3f ms = %.0f frames/s" % (sh16, fsh16, B * T / fsh16 * 1e3)
     if args.torch:
         import torch_ref
         params = {k: v.to(dev).clone().requires_grad_(v.dtype.is_floating_point and "pos_embedding" not in k) for k, v in sd.items()}

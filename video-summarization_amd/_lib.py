@@ -30,6 +30,7 @@ VS_FLAG_F16X3_LINEAR = 8
 VS_FLAG_F16X3_ATTENTION = 16
 VS_TRAIN_FLAG_BF16_LINEAR = 1
 VS_TRAIN_FLAG_BF16_ATTENTION = 2
+VS_TRAIN_FLAG_FP16 = 4          # modifier: the 16-bit type is IEEE fp16 (the reference's own autocast type) instead of bf16
 
 # every symbol include/vs_scorer.h declares
 EXPORTS = ("vs_abi_version", "vs_last_error", "vs_weights_pack", "vs_weights_free", "vs_weights_update", "vs_set_option",

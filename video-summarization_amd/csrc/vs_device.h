@@ -88,6 +88,30 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 constexpr float F16X3_WS = 1024.0f;
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 #define MFMA_F16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+// ---- ONE 16-bit operand type per kernel instantiation: bf16 (F16 = 0) or IEEE f16 (F16 = 1; round 4: the training path's
+// "fp16" mode - the reference's own autocast type, train.py:120 - 11 significant bits against bf16's 8, range 65 504:
+// an overflowing operand becomes inf and travels to the gradients, which is what the reference's GradScaler looks for) ----
+__device__ __forceinline__ unsigned pack_f16(float lo, float hi) {
+    const f32x2 f = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f, f16x2));
+}
+template <int F16>
+__device__ __forceinline__ unsigned pack_lp(float lo, float hi) {
+    if constexpr (F16) return pack_f16(lo, hi);
+    else return pack_bf16(lo, hi);
+}
+template <int F16>
+__device__ __forceinline__ f32x16 mfma_lp(const u32x4 &a, const u32x4 &b, const f32x16 &c) {
+    if constexpr (F16) return MFMA_F16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c);
+    else return MFMA_BF16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c);
+}
+// the two values of a packed pair as floats
+template <int F16>
+__device__ __forceinline__ f32x2 unpack_lp(unsigned u) {
+    if constexpr (F16) return __builtin_convertvector(__builtin_bit_cast(f16x2, u), f32x2);
+    else return f32x2{bits_f32(u << 16), bits_f32(u & 0xffff0000u)};
+}
+
 __device__ __forceinline__ void split_f16(float x0, float x1, unsigned &hi, unsigned &lo) {
     const f32x2 x = {x0, x1};
     const f16x2 hv = __builtin_convertvector(x, f16x2);

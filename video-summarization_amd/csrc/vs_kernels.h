@@ -8,7 +8,8 @@
 // bf16 == (1 | VSK_STORE16): additionally the tensors that are ONLY ever consumed as bf16 matrix operands live in HBM
 // as bf16: C of vsk_qkv and of vsk_linear(relu), A of vsk_linear_res_ln, q/k/v/out of the bf16 attention.  The
 // rounding happens in the producer instead of the consumer: same bits, half the bytes.
-enum { VSK_STORE16 = 16, VSK_A16 = 32 };      // VSK_A16 (training path): A of vsk_linear is stored as bf16
+enum { VSK_STORE16 = 16, VSK_A16 = 32, VSK_F16 = 64 };      // VSK_A16 (training path): A of vsk_linear is stored as bf16;
+// VSK_F16 (training path's fp16 mode): the 16-bit type of this call - operands, stored C, stored A - is IEEE f16, not bf16
 // Wf: the weight in fragment-major order (vsk_pack_fragments) or nullptr; enables the packed latency kernels
 int vsk_linear(const float *A, const float *W, const float *Wf, const float *bias, float *C, int M, int N, int K,
                int relu, const float *pe, int T, int bf16, hipStream_t st);

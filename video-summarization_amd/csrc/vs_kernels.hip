@@ -74,8 +74,11 @@ __global__ __launch_bounds__(128 * NWM, 2) void gemm_nt_128(
     const float *__restrict__ A, const float *__restrict__ W, const float *__restrict__ bias,
     float *__restrict__ C, int M, int N, int K, const float *__restrict__ pe, int T, int H, int dh,
     unsigned long long *__restrict__ diag = nullptr, EpiArgs ea = EpiArgs{0ull, 0u, 0.f, 0.f}) {
-    static_assert(KW == 32 || (KW == 64 && PREC == 1), "64-wide k-tiles exist for the bf16 operands only");
-    static_assert(A16 == 0 || PREC == 1, "bf16-stored A belongs to the bf16 mode");
+    static_assert(KW == 32 || (KW == 64 && (PREC == 1 || PREC == 3)), "64-wide k-tiles exist for the 16-bit operands only");
+    static_assert(A16 == 0 || PREC == 1 || PREC == 3, "16-bit-stored A belongs to the 16-bit operand modes");
+    constexpr bool LP1 = PREC == 1 || PREC == 3;      // ONE 16-bit plane per operand: bf16 (1) or f16 (3: the training path's fp16 mode)
+    constexpr int F16 = PREC == 3 ? 1 : 0;
+    (void)LP1; (void)F16;
     typedef unsigned short a16_t;
     constexpr int BM = 64 * NWM, BN = 64 * NJ, BK = KW, LD = 36;
     constexpr int NT = 128 * NWM;                       // threads
@@ -155,17 +158,17 @@ __global__ __launch_bounds__(128 * NWM, 2) void gemm_nt_128(
                 *(u32x2 *)&Ws[(lrow + RS * i) * LD + lc4 / 2] = hi;
                 *(u32x2 *)&Ws[(lrow + RS * i) * LD + 16 + lc4 / 2] = lo;
             }
-        } else if constexpr (PREC == 1) {
+        } else if constexpr (LP1) {
 #pragma unroll
             for (int i = 0; i < LA; ++i) {
                 u32x2 u;
                 if constexpr (A16 != 0) { u[0] = f32_bits(pa[i][0]); u[1] = f32_bits(pa[i][1]); }
-                else { u[0] = pack_bf16(pa[i][0], pa[i][1]); u[1] = pack_bf16(pa[i][2], pa[i][3]); }
+                else { u[0] = pack_lp<F16>(pa[i][0], pa[i][1]); u[1] = pack_lp<F16>(pa[i][2], pa[i][3]); }
                 *(u32x2 *)&As[(lrow + RS * i) * LDB + lc4 / 2] = u;
             }
 #pragma unroll
             for (int i = 0; i < LW; ++i) {
-                u32x2 u; u[0] = pack_bf16(pw[i][0], pw[i][1]); u[1] = pack_bf16(pw[i][2], pw[i][3]);
+                u32x2 u; u[0] = pack_lp<F16>(pw[i][0], pw[i][1]); u[1] = pack_lp<F16>(pw[i][2], pw[i][3]);
                 *(u32x2 *)&Ws[(lrow + RS * i) * LDB + lc4 / 2] = u;
             }
         } else {
@@ -219,7 +222,7 @@ __global__ __launch_bounds__(128 * NWM, 2) void gemm_nt_128(
             fpar ^= 1;
             return;
         }
-        if constexpr (PREC == 1) {
+        if constexpr (LP1) {
             // BK / 16 k-steps of 16: lane (r,h) supplies k = 16ks + 8h .. +7 (one b128 of the bf16 row)
             const float *ap = As + (64 * wr + r) * LDB + 4 * h;
             const float *wp = Ws + (32 * NJ * wc + r) * LDB + 4 * h;
@@ -229,15 +232,15 @@ __global__ __launch_bounds__(128 * NWM, 2) void gemm_nt_128(
             for (int i = 0; i < LW; ++i) pw[i] = *(const f32x4 *)(wptr[i] + koff);
 #pragma unroll
             for (int ks = 0; ks < BK / 16; ++ks) {
-                bf16x8 fa[2], fw[NJ];
+                u32x4 fa[2], fw[NJ];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) fa[i] = __builtin_bit_cast(bf16x8, *(const u32x4 *)(ap + 32 * i * LDB + 8 * ks));
+                for (int i = 0; i < 2; ++i) fa[i] = *(const u32x4 *)(ap + 32 * i * LDB + 8 * ks);
 #pragma unroll
-                for (int jj = 0; jj < NJ; ++jj) fw[jj] = __builtin_bit_cast(bf16x8, *(const u32x4 *)(wp + 32 * jj * LDB + 8 * ks));
+                for (int jj = 0; jj < NJ; ++jj) fw[jj] = *(const u32x4 *)(wp + 32 * jj * LDB + 8 * ks);
 #pragma unroll
                 for (int jj = 0; jj < NJ; ++jj) {
-                    acc[0][jj] = MFMA_BF16(fw[jj], fa[0], acc[0][jj]);
-                    acc[1][jj] = MFMA_BF16(fw[jj], fa[1], acc[1][jj]);
+                    acc[0][jj] = mfma_lp<F16>(fw[jj], fa[0], acc[0][jj]);
+                    acc[1][jj] = mfma_lp<F16>(fw[jj], fa[1], acc[1][jj]);
                 }
             }
             stage(fpar ^ 1);
@@ -399,7 +402,7 @@ __global__ __launch_bounds__(128 * NWM, 2) void gemm_nt_128(
                         }
                         if constexpr (C16 != 0) {
                             if (EPI == EPI_QKV && which == 0) v *= ea.scale;
-                            u32x2 u; u[0] = pack_bf16(v[0], v[1]); u[1] = pack_bf16(v[2], v[3]);
+                            u32x2 u; u[0] = pack_lp<F16>(v[0], v[1]); u[1] = pack_lp<F16>(v[2], v[3]);
                             unsigned short *C2 = (unsigned short *)C;
                             if (EPI == EPI_QKV)
                                 *(u32x2 *)(C2 + (size_t)which * M * (H * dh) + (((size_t)bb * H + head) * T + tt) * dh + e0 + tc4) = u;
@@ -1828,7 +1831,8 @@ static int allow_big_lds_on_device(const void *kernel, std::atomic<unsigned char
         return allow_big_lds_on_device((const void *)(kernel_), done_);     \
     }())
 
-template <int EPI>
+// LPP: the PREC of the 16-bit-operand branch - 1 bf16, 3 f16 (the training path's fp16 mode; bf16 flag | VSK_F16)
+template <int EPI, int LPP = 1>
 static int launch_gemm(const float *A, const float *W, const float *Wf, const float *bias, float *C, int M, int N, int K,
                        const float *pe, int T, int H, int dh, int bf16, hipStream_t st,
                        EpiArgs ea = EpiArgs{0ull, 0u, 0.f, 0.f}) {
@@ -1861,9 +1865,9 @@ static int launch_gemm(const float *A, const float *W, const float *Wf, const fl
             const bool big = N % 256 == 0 && M > 128;
             const int blocks = big ? persistent_blocks(((M + 255) / 256) * (N / 256), 1) : persistent_blocks(((M + 127) / 128) * ((N + 127) / 128), 2);
             if (blocks < 0) return (int)hipErrorInvalidDevice;
-            if (big && kw64) hipLaunchKernelGGL((gemm_nt_128<EPI, 4, 0, 4, 1, 1, 64>), dim3(blocks), dim3(512), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr, ea);
-            else if (big) hipLaunchKernelGGL((gemm_nt_128<EPI, 4, 0, 4, 1, 1>), dim3(blocks), dim3(512), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr, ea);
-            else hipLaunchKernelGGL((gemm_nt_128<EPI, 2, 0, 2, 1, 1>), dim3(blocks), dim3(256), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr, ea);
+            if (big && kw64) hipLaunchKernelGGL((gemm_nt_128<EPI, 4, 0, 4, LPP, 1, 64>), dim3(blocks), dim3(512), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr, ea);
+            else if (big) hipLaunchKernelGGL((gemm_nt_128<EPI, 4, 0, 4, LPP, 1>), dim3(blocks), dim3(512), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr, ea);
+            else hipLaunchKernelGGL((gemm_nt_128<EPI, 2, 0, 2, LPP, 1>), dim3(blocks), dim3(256), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr, ea);
             VSK_CHECK_LAUNCH();
             return 0;
         }
@@ -1873,9 +1877,9 @@ static int launch_gemm(const float *A, const float *W, const float *Wf, const fl
             const bool big = N % 256 == 0 && M > 128;
             const int blocks = big ? persistent_blocks(((M + 255) / 256) * (N / 256), 1) : persistent_blocks(((M + 127) / 128) * ((N + 127) / 128), 2);
             if (blocks < 0) return (int)hipErrorInvalidDevice;
-            if (big && kw64) hipLaunchKernelGGL((gemm_nt_128<EPI, 4, 0, 4, 1, 0, 64, 1>), dim3(blocks), dim3(512), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr, ea);
-            else if (big) hipLaunchKernelGGL((gemm_nt_128<EPI, 4, 0, 4, 1, 0, 32, 1>), dim3(blocks), dim3(512), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr, ea);
-            else hipLaunchKernelGGL((gemm_nt_128<EPI, 2, 0, 2, 1, 0, 32, 1>), dim3(blocks), dim3(256), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr, ea);
+            if (big && kw64) hipLaunchKernelGGL((gemm_nt_128<EPI, 4, 0, 4, LPP, 0, 64, 1>), dim3(blocks), dim3(512), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr, ea);
+            else if (big) hipLaunchKernelGGL((gemm_nt_128<EPI, 4, 0, 4, LPP, 0, 32, 1>), dim3(blocks), dim3(512), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr, ea);
+            else hipLaunchKernelGGL((gemm_nt_128<EPI, 2, 0, 2, LPP, 0, 32, 1>), dim3(blocks), dim3(256), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr, ea);
             VSK_CHECK_LAUNCH();
             return 0;
         }
@@ -1886,13 +1890,13 @@ static int launch_gemm(const float *A, const float *W, const float *Wf, const fl
             if (N % 256 == 0 && M > 128) {
                 const int blocks = persistent_blocks(((M + 255) / 256) * (N / 256), 1);
                 if (blocks < 0) return (int)hipErrorInvalidDevice;
-                if (kw64) hipLaunchKernelGGL((gemm_nt_128<EPI, 4, 0, 4, 1, 1, 64>), dim3(blocks), dim3(512), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr, ea);
-                else hipLaunchKernelGGL((gemm_nt_128<EPI, 4, 0, 4, 1, 1>), dim3(blocks), dim3(512), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr, ea);
+                if (kw64) hipLaunchKernelGGL((gemm_nt_128<EPI, 4, 0, 4, LPP, 1, 64>), dim3(blocks), dim3(512), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr, ea);
+                else hipLaunchKernelGGL((gemm_nt_128<EPI, 4, 0, 4, LPP, 1>), dim3(blocks), dim3(512), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr, ea);
             } else {
                 const int blocks = persistent_blocks(((M + 127) / 128) * ((N + 127) / 128), 2);
                 if (blocks < 0) return (int)hipErrorInvalidDevice;
-                if (kw64) hipLaunchKernelGGL((gemm_nt_128<EPI, 2, 0, 2, 1, 1, 64>), dim3(blocks), dim3(256), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr, ea);
-                else hipLaunchKernelGGL((gemm_nt_128<EPI, 2, 0, 2, 1, 1>), dim3(blocks), dim3(256), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr, ea);
+                if (kw64) hipLaunchKernelGGL((gemm_nt_128<EPI, 2, 0, 2, LPP, 1, 64>), dim3(blocks), dim3(256), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr, ea);
+                else hipLaunchKernelGGL((gemm_nt_128<EPI, 2, 0, 2, LPP, 1>), dim3(blocks), dim3(256), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr, ea);
             }
             VSK_CHECK_LAUNCH();
             return 0;
@@ -1903,13 +1907,13 @@ static int launch_gemm(const float *A, const float *W, const float *Wf, const fl
         if (N % 256 == 0 && M > 128) {
             const int blocks = persistent_blocks(((M + 255) / 256) * (N / 256), 1);
             if (blocks < 0) return (int)hipErrorInvalidDevice;
-            if (kw64) hipLaunchKernelGGL((gemm_nt_128<EPI, 4, 0, 4, 1, 0, 64>), dim3(blocks), dim3(512), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr, ea);
-            else hipLaunchKernelGGL((gemm_nt_128<EPI, 4, 0, 4, 1>), dim3(blocks), dim3(512), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr, ea);
+            if (kw64) hipLaunchKernelGGL((gemm_nt_128<EPI, 4, 0, 4, LPP, 0, 64>), dim3(blocks), dim3(512), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr, ea);
+            else hipLaunchKernelGGL((gemm_nt_128<EPI, 4, 0, 4, LPP>), dim3(blocks), dim3(512), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr, ea);
         } else {
             const int blocks = persistent_blocks(((M + 127) / 128) * ((N + 127) / 128), 2);
             if (blocks < 0) return (int)hipErrorInvalidDevice;
-            if (kw64) hipLaunchKernelGGL((gemm_nt_128<EPI, 2, 0, 2, 1, 0, 64>), dim3(blocks), dim3(256), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr, ea);
-            else hipLaunchKernelGGL((gemm_nt_128<EPI, 2, 0, 2, 1>), dim3(blocks), dim3(256), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr, ea);
+            if (kw64) hipLaunchKernelGGL((gemm_nt_128<EPI, 2, 0, 2, LPP, 0, 64>), dim3(blocks), dim3(256), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr, ea);
+            else hipLaunchKernelGGL((gemm_nt_128<EPI, 2, 0, 2, LPP>), dim3(blocks), dim3(256), 0, st, A, W, bias, C, M, N, K, pe, T, H, dh, nullptr, ea);
         }
         VSK_CHECK_LAUNCH();
         return 0;
@@ -1946,6 +1950,12 @@ static int launch_gemm(const float *A, const float *W, const float *Wf, const fl
 
 int vsk_linear(const float *A, const float *W, const float *Wf, const float *bias, float *C, int M, int N, int K,
                int relu, const float *pe, int T, int bf16, hipStream_t st) {
+    if (bf16 & VSK_F16) {          // f16 operands (training path's fp16 mode): the same kernels, PREC 3
+        bf16 &= ~VSK_F16;
+        if (pe != nullptr) return launch_gemm<EPI_PE, 3>(A, W, Wf, bias, C, M, N, K, pe, T, 0, 0, bf16, st);
+        if (relu) return launch_gemm<EPI_RELU, 3>(A, W, Wf, bias, C, M, N, K, nullptr, 1, 0, 0, bf16, st);
+        return launch_gemm<EPI_BIAS, 3>(A, W, Wf, bias, C, M, N, K, nullptr, 1, 0, 0, bf16, st);
+    }
     if (pe != nullptr) return launch_gemm<EPI_PE>(A, W, Wf, bias, C, M, N, K, pe, T, 0, 0, bf16, st);
     if (relu) return launch_gemm<EPI_RELU>(A, W, Wf, bias, C, M, N, K, nullptr, 1, 0, 0, bf16, st);
     return launch_gemm<EPI_BIAS>(A, W, Wf, bias, C, M, N, K, nullptr, 1, 0, 0, bf16, st);
@@ -1955,12 +1965,14 @@ int vsk_linear(const float *A, const float *W, const float *Wf, const float *bia
 // epilogue of the fc2 dgrad GEMM (exact fp32 kernels only)
 int vsk_linear_gate(const float *A, const float *W, const float *Wf, const float *bias, const float *gate, float scale,
                     float *C, int M, int N, int K, hipStream_t st, int bf16) {
+    if (bf16 & VSK_F16) return launch_gemm<EPI_GATE, 3>(A, W, Wf, bias, C, M, N, K, gate, 1, 0, 0, bf16 & ~VSK_F16, st, EpiArgs{0ull, 0u, 0.f, scale});
     return launch_gemm<EPI_GATE>(A, W, Wf, bias, C, M, N, K, gate, 1, 0, 0, bf16, st, EpiArgs{0ull, 0u, 0.f, scale});
 }
 
 // training path: C = dropout_{seed,site,p}(relu(A W^T + bias)) - mlp.fc1 + ReLU + mlp.dropout in one GEMM
 int vsk_linear_relu_dropout(const float *A, const float *W, const float *Wf, const float *bias, float *C, int M, int N,
                             int K, unsigned long long seed, unsigned site, float p, hipStream_t st, int bf16) {
+    if (bf16 & VSK_F16) return launch_gemm<EPI_RELU_DROP, 3>(A, W, Wf, bias, C, M, N, K, nullptr, 1, 0, 0, bf16 & ~VSK_F16, st, EpiArgs{seed, site, p, 0.f});
     return launch_gemm<EPI_RELU_DROP>(A, W, Wf, bias, C, M, N, K, nullptr, 1, 0, 0, bf16, st, EpiArgs{seed, site, p, 0.f});
 }
 
@@ -2040,6 +2052,9 @@ int vsk_diag_gemm(const float *A, const float *W, const float *bias, float *C, i
 // bf16 | VSK_STORE16: q (times qscale), k, v are written as bf16, three [B,H,T,dh] planes of M*d 2-byte elements
 int vsk_qkv(const float *h, const float *Wqkv, const float *Wf, const float *bqkv, float *qkv, int B, int T, int d,
             int H, int bf16, hipStream_t st, float qscale) {
+    if (bf16 & VSK_F16)
+        return launch_gemm<EPI_QKV, 3>(h, Wqkv, Wf, bqkv, qkv, B * T, 3 * d, d, nullptr, T, H, d / H, bf16 & ~VSK_F16, st,
+                                       EpiArgs{0ull, 0u, 0.f, qscale});
     return launch_gemm<EPI_QKV>(h, Wqkv, Wf, bqkv, qkv, B * T, 3 * d, d, nullptr, T, H, d / H, bf16, st,
                                 EpiArgs{0ull, 0u, 0.f, qscale});
 }

@@ -46,8 +46,10 @@ size_t align_floats(size_t n) { return (n + 63) / 64 * 64; }      // 256-byte gr
 // backward takes it back through vs_dropout_cfg.reserved - a switch flipped between the two calls (another model, a retained
 // graph, a test) can no longer make the backward read bf16 planes as fp32.  reserved == 0: derived again (older callers).
 struct RecordForm {
-    int lp; bool lpa, qkv16, h16, rows16;
-    uint32_t bits() const { return 0x80000000u | (lp ? 1u : 0u) | (lpa ? 2u : 0u) | (qkv16 ? 4u : 0u) | (h16 ? 8u : 0u) | (rows16 ? 16u : 0u); }
+    int lp; bool lpa, qkv16, h16, rows16, f16;      // f16: the 16-bit type of everything above is IEEE f16 (VS_TRAIN_FLAG_FP16)
+    uint32_t bits() const {
+        return 0x80000000u | (lp ? 1u : 0u) | (lpa ? 2u : 0u) | (qkv16 ? 4u : 0u) | (h16 ? 8u : 0u) | (rows16 ? 16u : 0u) | (f16 ? 32u : 0u);
+    }
 };
 thread_local uint32_t g_last_format = 0;
 RecordForm derive_form(const vs_weights *w, const vs_dropout_cfg *drop, int B, int T) {
@@ -65,7 +67,9 @@ RecordForm derive_form(const vs_weights *w, const vs_dropout_cfg *drop, int B, i
     f.h16 = f.lp && !vsk_options().lp_store32;                // ... and so is the MLP hidden tensor (and, in the backward, its gradient)
     // ... which the A-stationary GEMM writes where it applies (K = d_model = 256, batches that fill the chip; VS_LP_MLP_UNFUSED = 1: the
     // tiled kernels, 2: the A-stationary kernel at every batch size - A/B and test switches)
-    f.rows16 = f.h16 && vsk_options().lp_mlp_unfused != 1 &&
+    f.f16 = (f.lp || f.lpa) && (drop->flags & VS_TRAIN_FLAG_FP16) != 0;
+    // (the A-stationary kernels and their pre-rounded weight copies exist in bf16 only: the fp16 mode runs the tiled GEMMs)
+    f.rows16 = f.h16 && !f.f16 && vsk_options().lp_mlp_unfused != 1 &&
                vst_gemm_rows16_supported(B * T, 4 * w->desc.d_model, w->desc.d_model, vsk_options().lp_mlp_unfused == 2);
     return f;
 }
@@ -251,7 +255,8 @@ int vs_train_forward(const vs_weights *w, const float *x, const uint8_t *key_pad
     const float p_embed = (drop && w->has_pe) ? drop->p_embed : 0.f;
     const RecordForm form = derive_form(w, drop, B, T);
     g_last_format = form.bits();
-    const int lp = form.lp;
+    const int F = form.f16 ? VSK_F16 : 0;            // fp16 mode: rides on every 16-bit precision word below
+    const int lp = form.lp ? (1 | F) : 0;
     const bool lpa = form.lpa, qkv16 = form.qkv16, h16 = form.h16, rows16 = form.rows16;
     const size_t kvs = qkv16 ? (size_t)B * T * w->desc.d_model / 2 : (size_t)B * T * w->desc.d_model;     // floats between the planes
     const unsigned long long seed = drop ? drop->seed : 0ull;
@@ -280,13 +285,13 @@ int vs_train_forward(const vs_weights *w, const float *x, const uint8_t *key_pad
             VST_LAUNCH(vst_gemm_rows16(h_in, w->p(P.r_wqkv), w->p(P.bqkv), qkv, nullptr, M, 3 * d, d, 3, vsk_attention_qscale(scale), 0ull, 0u,
                                        0.f, st, T, H, d / H));
         else
-        VST_LAUNCH(vsk_qkv(h_in, w->p(P.wqkv), w->p(P.f_wqkv), w->p(P.bqkv), qkv, B, T, d, H, qkv16 ? (1 | VSK_STORE16) : lp, st,
+        VST_LAUNCH(vsk_qkv(h_in, w->p(P.wqkv), w->p(P.f_wqkv), w->p(P.bqkv), qkv, B, T, d, H, qkv16 ? (1 | VSK_STORE16 | F) : lp, st,
                            qkv16 ? vsk_attention_qscale(scale) : 1.0f));         // :148-153
         unsigned *dbits = p > 0.f ? (unsigned *)(sv + A.dbits) : nullptr;
         if (dbits) VST_LAUNCH(vst_attention_dropout_bits(dbits, B, H, T, seed, VS_SITE_LAYER(l, VS_SITE_ATTN), p, st));
         if (lpa)
             VST_LAUNCH(vst_attention_fwd_bf16(qkv, qkv + kvs, qkv + 2 * kvs, key_pad_mask, sv + A.att,
-                                              sv + A.lse, B, H, T, d / H, scale, p, dbits, st, qkv16));
+                                              sv + A.lse, B, H, T, d / H, scale, p, dbits, st, (qkv16 ? 1 : 0) | F));
         else
         VST_LAUNCH(vst_attention_fwd(qkv, qkv + (size_t)M * d, qkv + 2 * (size_t)M * d, key_pad_mask, sv + A.att,
                                      sv + A.lse, B, H, T, d / H, scale, seed, VS_SITE_LAYER(l, VS_SITE_ATTN), p, st, dbits));   // :155-161
@@ -300,11 +305,11 @@ int vs_train_forward(const vs_weights *w, const float *x, const uint8_t *key_pad
                                        VS_SITE_LAYER(l, VS_SITE_MLP), p, st));
         else if (p > 0.f)   // fc1 + ReLU + mlp.dropout in one GEMM epilogue (:181)
             VST_LAUNCH(vsk_linear_relu_dropout(sv + A.y1, w->p(P.w1), w->p(P.f_w1), w->p(P.b1), sv + A.ffn, M, 4 * d, d, seed,
-                                               VS_SITE_LAYER(l, VS_SITE_MLP), p, st, h16 ? (1 | VSK_STORE16) : lp));
+                                               VS_SITE_LAYER(l, VS_SITE_MLP), p, st, h16 ? (1 | VSK_STORE16 | F) : lp));
         else
             VST_LAUNCH(vsk_linear(sv + A.y1, w->p(P.w1), w->p(P.f_w1), w->p(P.b1), sv + A.ffn, M, 4 * d, d, 1, nullptr, 1,
-                                  h16 ? (1 | VSK_STORE16) : lp, st));
-        VST_LAUNCH(vsk_linear(sv + A.ffn, w->p(P.w2), w->p(P.f_w2), w->p(P.b2), a, M, d, 4 * d, 0, nullptr, 1, h16 ? (1 | VSK_A16) : lp, st));  // :182
+                                  h16 ? (1 | VSK_STORE16 | F) : lp, st));
+        VST_LAUNCH(vsk_linear(sv + A.ffn, w->p(P.w2), w->p(P.f_w2), w->p(P.b2), a, M, d, 4 * d, 0, nullptr, 1, h16 ? (1 | VSK_A16 | F) : lp, st));  // :182
         VST_LAUNCH(vst_rows_fwd(a, sv + A.y1, w->p(P.ln2g), w->p(P.ln2b), sv + A.z2, sv + A.y2, last ? hidden : nullptr,
                                 sv + A.st2, M, d, seed, VS_SITE_LAYER(l, VS_SITE_DROP2), p,
                                 last ? w->p(w->final_w) : nullptr, last ? w->p(w->final_b) : nullptr, D.num_classes,
@@ -342,12 +347,15 @@ int vs_train_backward(vs_weights *w, const float *x, const uint8_t *key_pad_mask
     if (drop && (drop->reserved & 0x80000000u)) {
         const uint32_t fb = drop->reserved;
         form.lp = (fb & 1u) ? 1 : 0; form.lpa = (fb & 2u) != 0; form.qkv16 = (fb & 4u) != 0; form.h16 = (fb & 8u) != 0; form.rows16 = (fb & 16u) != 0;
+        form.f16 = (fb & 32u) != 0;
         if ((form.qkv16 && !(form.lp && form.lpa)) || (form.h16 && !form.lp) || (form.rows16 && !form.h16) ||
+            (form.f16 && (form.rows16 || !(form.lp || form.lpa))) || (fb & 0x7fffffc0u) ||
             (form.lpa && !vst_attention_bf16_supported(w->desc.d_model / w->desc.num_heads)) ||
             (form.rows16 && !vst_gemm_rows16_supported(B * T, 4 * w->desc.d_model, w->desc.d_model, true)))
             return failf(VS_ERR_INVALID, "vs_dropout_cfg.reserved = 0x%08x is not a record form this model / batch can have", fb);
     }
-    const int lp = form.lp;
+    const int F = form.f16 ? VSK_F16 : 0;            // fp16 mode: rides on every 16-bit precision word below
+    const int lp = form.lp ? (1 | F) : 0;
     const bool lpa = form.lpa, qkv16 = form.qkv16, h16 = form.h16, rows16 = form.rows16;
     const size_t kvs = qkv16 ? (size_t)B * T * w->desc.d_model / 2 : (size_t)B * T * w->desc.d_model;     // floats between the planes
     const unsigned long long seed = drop ? drop->seed : 0ull;
@@ -390,7 +398,7 @@ int vs_train_backward(vs_weights *w, const float *x, const uint8_t *key_pad_mask
         const float *dm = p > 0.f ? dbr : dz;
         // mlp.fc2: weight/bias gradient, then the gradient of its input
         VST_LAUNCH(vst_wgrad(dm, d, sv + A.ffn, 4 * d, M, d, 4 * d, G.w2, nullptr, nullptr, G.b2, nullptr, nullptr, d, wg, st,
-                             h16 ? (1 | VST_WGRAD_X16) : lp));
+                             h16 ? (1 | VST_WGRAD_X16 | F) : lp));
         // ... through mlp.dropout + ReLU in the GEMM's epilogue: the saved activation is > 0 exactly where both let
         // the value through
         // (h16: the gate tensor is the bf16-stored activation, and the gated gradient gf - again only ever a matrix operand -
@@ -400,11 +408,11 @@ int vs_train_backward(vs_weights *w, const float *x, const uint8_t *key_pad_mask
                                        0.f, st));
         else
         VST_LAUNCH(vsk_linear_gate(dm, w->tp(Q.t_w2), w->tp(Q.tf_w2), zeros, sv + A.ffn, p > 0.f ? 1.0f / (1.0f - p) : 1.0f, gf, M, 4 * d, d, st,
-                                   h16 ? (1 | VSK_STORE16) : lp));
+                                   h16 ? (1 | VSK_STORE16 | F) : lp));
         VST_LAUNCH(vst_wgrad(gf, 4 * d, sv + A.y1, d, M, 4 * d, d, G.w1, nullptr, nullptr, G.b1, nullptr, nullptr, 4 * d, wg, st,
-                             h16 ? (1 | VST_WGRAD_Y16) : lp));
+                             h16 ? (1 | VST_WGRAD_Y16 | F) : lp));
         // d y1 = dz2 (residual) + d(fc1 input): the residual rides in the GEMM epilogue
-        VST_LAUNCH(vsk_linear(gf, w->tp(Q.t_w1), w->tp(Q.tf_w1), zeros, dy1, M, d, 4 * d, 0, dz, M, h16 ? (1 | VSK_A16) : lp, st));
+        VST_LAUNCH(vsk_linear(gf, w->tp(Q.t_w1), w->tp(Q.tf_w1), zeros, dy1, M, d, 4 * d, 0, dz, M, h16 ? (1 | VSK_A16 | F) : lp, st));
         // norm1; d(feature_projection output) = dropout1 mask on dz1
         VST_LAUNCH(vst_ln_bwd(dy1, nullptr, nullptr, 0, sv + A.z1, sv + A.st1, w->p(P.ln1g), dz, p > 0.f ? dbr : nullptr, part,
                               M, d, seed, VS_SITE_LAYER(l, VS_SITE_DROP1), p, st));
@@ -413,14 +421,14 @@ int vs_train_backward(vs_weights *w, const float *x, const uint8_t *key_pad_mask
         VST_LAUNCH(vst_wgrad(da, d, sv + A.att, d, M, d, d, G.wo, nullptr, nullptr, G.bo, nullptr, nullptr, d, wg, st, lp));
         // (qkv16: d(attention output) is written as bf16 - the attention backward multiplies bf16 operands, and delta is then the
         // row dot of the SAME rounded dO with the saved fp32 output)
-        VST_LAUNCH(vsk_linear(da, w->tp(Q.t_wo), w->tp(Q.tf_wo), zeros, datt, M, d, d, 0, nullptr, 1, qkv16 ? (1 | VSK_STORE16) : lp, st));
+        VST_LAUNCH(vsk_linear(da, w->tp(Q.t_wo), w->tp(Q.tf_wo), zeros, datt, M, d, d, 0, nullptr, 1, qkv16 ? (1 | VSK_STORE16 | F) : lp, st));
         // attention
         const float *qkv = sv + A.qkv;
-        VST_LAUNCH(vst_head_rowdot(datt, sv + A.att, delta, M, T, H, d / H, st, qkv16 ? 1 : lpa ? 2 : 0));
+        VST_LAUNCH(vst_head_rowdot(datt, sv + A.att, delta, M, T, H, d / H, st, qkv16 ? (1 | F) : lpa ? (2 | F) : 0));
         if (lpa)
             VST_LAUNCH(vst_attention_bwd_bf16(qkv, qkv + kvs, qkv + 2 * kvs, key_pad_mask, datt, sv + A.lse,
                                               delta, dqkv, B, H, T, d / H, scale, p,
-                                              p > 0.f ? (const unsigned *)(sv + A.dbits) : nullptr, st, qkv16, qkv16));
+                                              p > 0.f ? (const unsigned *)(sv + A.dbits) : nullptr, st, (qkv16 ? 1 : 0) | F, qkv16));
         else
         VST_LAUNCH(vst_attention_bwd(qkv, qkv + (size_t)M * d, qkv + 2 * (size_t)M * d, key_pad_mask, datt, sv + A.lse, delta,
                                      dqkv, B, H, T, d / H, scale, seed, VS_SITE_LAYER(l, VS_SITE_ATTN), p, st,
@@ -428,9 +436,9 @@ int vs_train_backward(vs_weights *w, const float *x, const uint8_t *key_pad_mask
         // q / k / v projections: one [3d, d] weight gradient dealt to the three parameters
         // (qkv16: dq | dk | dv arrive as bf16 - only ever matrix operands of the two GEMMs below)
         VST_LAUNCH(vst_wgrad(dqkv, 3 * d, h_in, d, M, 3 * d, d, G.wq, G.wk, G.wv, G.bq, G.bk, G.bv, d, wg, st,
-                             qkv16 ? (1 | VST_WGRAD_Y16) : lp));
+                             qkv16 ? (1 | VST_WGRAD_Y16 | F) : lp));
         // gradient of the layer input = dz1 (residual) + dqkv Wqkv
-        VST_LAUNCH(vsk_linear(dqkv, w->tp(Q.t_wqkv), w->tp(Q.tf_wqkv), zeros, g[cur ^ 1], M, d, 3 * d, 0, dz, M, qkv16 ? (1 | VSK_A16) : lp, st));
+        VST_LAUNCH(vsk_linear(dqkv, w->tp(Q.t_wqkv), w->tp(Q.tf_wqkv), zeros, g[cur ^ 1], M, d, 3 * d, 0, dz, M, qkv16 ? (1 | VSK_A16 | F) : lp, st));
         cur ^= 1;
     }
     // Embedding (simnet.py:211, 237-238): dropout(sparsity) mask, then the Linear

@@ -40,19 +40,19 @@ __device__ __forceinline__ int img_off(int row, int chunk) { return row * (2 * D
 
 // row fragment: lane (r, h) <- columns 16 ks + 8 h .. + 7 of row rbase + r
 template <int DH>
-__device__ __forceinline__ bf16x8 row_frag(const unsigned char *img, int rbase, int ks, int r, int h) {
-    return __builtin_bit_cast(bf16x8, *(const u32x4 *)(img + img_off<DH>(rbase + r, 2 * ks + h)));
+__device__ __forceinline__ u32x4 row_frag(const unsigned char *img, int rbase, int ks, int r, int h) {
+    return __builtin_bit_cast(u32x4, *(const u32x4 *)(img + img_off<DH>(rbase + r, 2 * ks + h)));
 }
 // transposed fragment: lane (r, h) <- rows r0 + {4h .. 4h+3, 8 + 4h .. 8 + 4h+3} of column 32 db + r
 template <int DH>
-__device__ __forceinline__ bf16x8 tr_frag(const unsigned char *img, int r0, int db, int lane) {
+__device__ __forceinline__ u32x4 tr_frag(const unsigned char *img, int r0, int db, int lane) {
     const int i16 = lane & 15, qq = i16 >> 2, p = i16 & 3, g2 = (lane >> 4) & 1, h = lane >> 5;
     const int row = r0 + 4 * h + qq, chunk = 4 * db + 2 * g2 + (p >> 1), sub = 8 * (p & 1);
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(img + img_off<DH>(row, chunk) + sub));
     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(img + img_off<DH>(row + 8, chunk) + sub));
     const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
     const u32x4 v = {l2[0], l2[1], h2[0], h2[1]};
-    return __builtin_bit_cast(bf16x8, v);
+    return __builtin_bit_cast(u32x4, v);
 }
 
 template <int DH>
@@ -66,7 +66,7 @@ struct TileB {                                  // one staged 64-row tile pair +
 // global -> registers -> bf16 LDS image of a 64 x DH tile pair by 256 threads.  A16 / B16: that matrix already IS bf16 in
 // memory (q * scale * log2 e, k, v as the QKV GEMM's bf16 epilogue writes them: nothing to convert, 16-byte chunks go
 // straight into the image); otherwise fp32, rounded here (DH / 16 float4 per thread).
-template <int DH, bool A16 = false, bool B16 = false>
+template <int DH, bool A16 = false, bool B16 = false, int F16 = 0>     // F16: the 16-bit type is IEEE f16 (fp16 training mode)
 struct StagerB {
     static constexpr int NV = DH / 16, NC = DH / 32;       // float4 per thread (fp32 source) | 16-byte chunks per thread (bf16 source)
     f32x4 va[A16 ? 1 : NV], vb[B16 ? 1 : NV];
@@ -108,8 +108,8 @@ struct StagerB {
             for (int i = 0; i < NV; ++i) {
                 const int idx = tid + 256 * i, row = idx / (DH / 4), c4 = (idx % (DH / 4)) * 4;
                 const int off = img_off<DH>(row, c4 >> 3) + ((c4 & 4) << 1);
-                if constexpr (!A16) { u32x2 ua; ua[0] = pack_bf16(va[i][0], va[i][1]); ua[1] = pack_bf16(va[i][2], va[i][3]); *(u32x2 *)(t.a + off) = ua; }
-                if constexpr (!B16) { u32x2 ub; ub[0] = pack_bf16(vb[i][0], vb[i][1]); ub[1] = pack_bf16(vb[i][2], vb[i][3]); *(u32x2 *)(t.b + off) = ub; }
+                if constexpr (!A16) { u32x2 ua; ua[0] = pack_lp<F16>(va[i][0], va[i][1]); ua[1] = pack_lp<F16>(va[i][2], va[i][3]); *(u32x2 *)(t.a + off) = ua; }
+                if constexpr (!B16) { u32x2 ub; ub[0] = pack_lp<F16>(vb[i][0], vb[i][1]); ub[1] = pack_lp<F16>(vb[i][2], vb[i][3]); *(u32x2 *)(t.b + off) = ub; }
             }
         }
     }
@@ -123,26 +123,27 @@ __device__ __forceinline__ f32x16 zero16b() {
 }
 
 // the owner's own rows as B-operand fragments: lane (r, h) <- src[16 ks + 8 h .. + 7] * mul, rounded to bf16
-template <int DH>
-__device__ __forceinline__ void owner_frags(const float *src, float mul, int h, bf16x8 (&f)[DH / 16]) {
+template <int DH, int F16>
+__device__ __forceinline__ void owner_frags(const float *src, float mul, int h, u32x4 (&f)[DH / 16]) {
 #pragma unroll
     for (int ks = 0; ks < DH / 16; ++ks) {
         const f32x4 v0 = *(const f32x4 *)(src + 16 * ks + 8 * h) * mul, v1 = *(const f32x4 *)(src + 16 * ks + 8 * h + 4) * mul;
-        const u32x4 u = {pack_bf16(v0[0], v0[1]), pack_bf16(v0[2], v0[3]), pack_bf16(v1[0], v1[1]), pack_bf16(v1[2], v1[3])};
-        f[ks] = __builtin_bit_cast(bf16x8, u);
+        const u32x4 u = {pack_lp<F16>(v0[0], v0[1]), pack_lp<F16>(v0[2], v0[3]), pack_lp<F16>(v1[0], v1[1]), pack_lp<F16>(v1[2], v1[3])};
+        f[ks] = __builtin_bit_cast(u32x4, u);
     }
 }
 // ... from a row that already is bf16 in memory: lane (r, h) <- the 16-byte chunk 2 ks + h of the row
 template <int DH>
-__device__ __forceinline__ void owner_frags16(const h16 *src, int h, bf16x8 (&f)[DH / 16]) {
+__device__ __forceinline__ void owner_frags16(const h16 *src, int h, u32x4 (&f)[DH / 16]) {
 #pragma unroll
-    for (int ks = 0; ks < DH / 16; ++ks) f[ks] = __builtin_bit_cast(bf16x8, *(const u32x4 *)(src + 16 * ks + 8 * h));
+    for (int ks = 0; ks < DH / 16; ++ks) f[ks] = __builtin_bit_cast(u32x4, *(const u32x4 *)(src + 16 * ks + 8 * h));
 }
 // registers 8 s .. 8 s + 7 of a 32x32 result -> the B operand of the next product's 16-row step s
-__device__ __forceinline__ bf16x8 pack_step(const f32x16 &x, int s) {
-    const u32x4 u = {pack_bf16(x[8 * s], x[8 * s + 1]), pack_bf16(x[8 * s + 2], x[8 * s + 3]),
-                     pack_bf16(x[8 * s + 4], x[8 * s + 5]), pack_bf16(x[8 * s + 6], x[8 * s + 7])};
-    return __builtin_bit_cast(bf16x8, u);
+template <int F16>
+__device__ __forceinline__ u32x4 pack_step(const f32x16 &x, int s) {
+    const u32x4 u = {pack_lp<F16>(x[8 * s], x[8 * s + 1]), pack_lp<F16>(x[8 * s + 2], x[8 * s + 3]),
+                     pack_lp<F16>(x[8 * s + 4], x[8 * s + 5]), pack_lp<F16>(x[8 * s + 6], x[8 * s + 7])};
+    return __builtin_bit_cast(u32x4, u);
 }
 
 // keep decision `bit` of a lane's dropout word as a multiplier: 1 / (1 - p) or 0  (v_bfe_i32 + v_and)
@@ -170,7 +171,7 @@ __device__ __forceinline__ f32x16 rows_init(const float *c, int h) {
 // ------------------------------------------------------------------------------------------
 // forward: owner = queries
 // ------------------------------------------------------------------------------------------
-template <int DH, bool DROP, bool IN16>          // IN16: q (pre-multiplied by scale * log2 e), k, v are bf16 in memory
+template <int DH, bool DROP, bool IN16, int F16 = 0>          // F16: 16-bit operands / storage are IEEE f16; IN16: q (pre-multiplied by scale * log2 e), k, v are bf16 in memory
 __global__ __launch_bounds__(256, DH == 128 ? 1 : 2) void attn_fwd_train_bf16(
     const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
     const uint8_t *__restrict__ mask, float *__restrict__ out, float *__restrict__ lse2, int H, int T, float scale,
@@ -186,15 +187,15 @@ __global__ __launch_bounds__(256, DH == 128 ? 1 : 2) void attn_fwd_train_bf16(
     const char *qb = (const char *)q + (size_t)bh * T * DH * ES, *kb = (const char *)k + (size_t)bh * T * DH * ES,
                *vb = (const char *)v + (size_t)bh * T * DH * ES;
 
-    bf16x8 qf[NS];
+    u32x4 qf[NS];
     if constexpr (IN16) owner_frags16<DH>((const h16 *)qb + (size_t)qc * DH, h, qf);
-    else owner_frags<DH>((const float *)qb + (size_t)qc * DH, sl2, h, qf);
+    else owner_frags<DH, F16>((const float *)qb + (size_t)qc * DH, sl2, h, qf);
     f32x16 o[ND];
 #pragma unroll
     for (int db = 0; db < ND; ++db) o[db] = zero16b();
     float m_run = NEG_INF_B, l_run = 0.f;
 
-    StagerB<DH, IN16, IN16> sg;
+    StagerB<DH, IN16, IN16, F16> sg;
     auto side = [&](TileB<DH> &t, int key0) __attribute__((always_inline)) {
         if (tid < 64) {
             const int key = key0 + tid;
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(256, DH == 128 ? 1 : 2) void attn_fwd_train_bf16(
         for (int n = 0; n < 2; ++n) {
             s[n] = rows_init(&t.s0[32 * n], h);              // the key bias (0 / -inf) is the accumulator's initial value
 #pragma unroll
-            for (int ks = 0; ks < NS; ++ks) s[n] = MFMA_BF16(row_frag<DH>(t.a, 32 * n, ks, r, h), qf[ks], s[n]);
+            for (int ks = 0; ks < NS; ++ks) s[n] = mfma_lp<F16>(row_frag<DH>(t.a, 32 * n, ks, r, h), qf[ks], s[n]);
         }
         float mx = s[0][0];
 #pragma unroll
@@ -252,9 +253,9 @@ __global__ __launch_bounds__(256, DH == 128 ? 1 : 2) void attn_fwd_train_bf16(
         for (int n = 0; n < 2; ++n)
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                const bf16x8 pf = pack_step(s[n], s2);
+                const u32x4 pf = pack_step<F16>(s[n], s2);
 #pragma unroll
-                for (int db = 0; db < ND; ++db) o[db] = MFMA_BF16(tr_frag<DH>(t.b, 32 * n + 16 * s2, db, lane), pf, o[db]);
+                for (int db = 0; db < ND; ++db) o[db] = mfma_lp<F16>(tr_frag<DH>(t.b, 32 * n + 16 * s2, db, lane), pf, o[db]);
             }
         if (kt + 1 < nkt) { sg.store(lds[(kt + 1) & 1]); side(lds[(kt + 1) & 1], 64 * (kt + 1)); }
         __syncthreads();
@@ -281,7 +282,7 @@ __global__ __launch_bounds__(256, DH == 128 ? 1 : 2) void attn_fwd_train_bf16(
 // ------------------------------------------------------------------------------------------
 // OUT16 ("gradient tensors are bf16"): dO [M][d] arrives as bf16 (written so by the out-projection's input-gradient GEMM) and
 // dq | dk | dv are written as bf16 [M][3 d] (their only readers - the QKV weight gradient and input gradient - are bf16 GEMMs)
-template <int DH, bool DROP, bool IN16, bool OUT16>
+template <int DH, bool DROP, bool IN16, bool OUT16, int F16 = 0>
 __global__ __launch_bounds__(256, DH == 128 ? 1 : 2) void attn_bwd_dq_bf16(
     const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
     const uint8_t *__restrict__ mask, const float *__restrict__ dO, const float *__restrict__ lse2,
@@ -298,17 +299,17 @@ __global__ __launch_bounds__(256, DH == 128 ? 1 : 2) void attn_bwd_dq_bf16(
     const char *qb = (const char *)q + (size_t)bh * T * DH * ES, *kb = (const char *)k + (size_t)bh * T * DH * ES,
                *vb = (const char *)v + (size_t)bh * T * DH * ES;
 
-    bf16x8 qf[NS], dof[NS];
+    u32x4 qf[NS], dof[NS];
     if constexpr (IN16) owner_frags16<DH>((const h16 *)qb + (size_t)qc * DH, h, qf);
-    else owner_frags<DH>((const float *)qb + (size_t)qc * DH, sl2, h, qf);
+    else owner_frags<DH, F16>((const float *)qb + (size_t)qc * DH, sl2, h, qf);
     if constexpr (OUT16) owner_frags16<DH>((const h16 *)dO + ((size_t)b * T + qc) * d + hd * DH, h, dof);
-    else owner_frags<DH>(dO + ((size_t)b * T + qc) * d + hd * DH, 1.0f, h, dof);
+    else owner_frags<DH, F16>(dO + ((size_t)b * T + qc) * d + hd * DH, 1.0f, h, dof);
     const float lq = lse2[(size_t)bh * T + qc], dq_delta = delta[(size_t)bh * T + qc];
     f32x16 acc[ND];
 #pragma unroll
     for (int db = 0; db < ND; ++db) acc[db] = zero16b();
 
-    StagerB<DH, IN16, IN16> sg;
+    StagerB<DH, IN16, IN16, F16> sg;
     auto side = [&](TileB<DH> &t, int key0) __attribute__((always_inline)) {
         if (tid < 64) {
             const int key = key0 + tid;
@@ -334,8 +335,8 @@ __global__ __launch_bounds__(256, DH == 128 ? 1 : 2) void attn_bwd_dq_bf16(
             f32x16 s = rows_init(&t.s0[32 * n], h), dp = zero16b();        // key bias = initial accumulator
 #pragma unroll
             for (int ks = 0; ks < NS; ++ks) {
-                s = MFMA_BF16(row_frag<DH>(t.a, 32 * n, ks, r, h), qf[ks], s);
-                dp = MFMA_BF16(row_frag<DH>(t.b, 32 * n, ks, r, h), dof[ks], dp);
+                s = mfma_lp<F16>(row_frag<DH>(t.a, 32 * n, ks, r, h), qf[ks], s);
+                dp = mfma_lp<F16>(row_frag<DH>(t.b, 32 * n, ks, r, h), dof[ks], dp);
             }
             const unsigned kwh = kw[n] >> (4 * h);
 #pragma unroll
@@ -346,9 +347,9 @@ __global__ __launch_bounds__(256, DH == 128 ? 1 : 2) void attn_bwd_dq_bf16(
             }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                const bf16x8 dsf = pack_step(s, s2);
+                const u32x4 dsf = pack_step<F16>(s, s2);
 #pragma unroll
-                for (int db = 0; db < ND; ++db) acc[db] = MFMA_BF16(tr_frag<DH>(t.a, 32 * n + 16 * s2, db, lane), dsf, acc[db]);
+                for (int db = 0; db < ND; ++db) acc[db] = mfma_lp<F16>(tr_frag<DH>(t.a, 32 * n + 16 * s2, db, lane), dsf, acc[db]);
             }
         }
         if (kt + 1 < nkt) { sg.store(lds[(kt + 1) & 1]); side(lds[(kt + 1) & 1], 64 * (kt + 1)); }
@@ -364,7 +365,7 @@ __global__ __launch_bounds__(256, DH == 128 ? 1 : 2) void attn_bwd_dq_bf16(
                 f32x4 w;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) w[e] = acc[db][4 * tg + e] * scale;
-                if constexpr (OUT16) *(u32x2 *)(op16 + 32 * db + 8 * tg + 4 * h) = u32x2{pack_bf16(w[0], w[1]), pack_bf16(w[2], w[3])};
+                if constexpr (OUT16) *(u32x2 *)(op16 + 32 * db + 8 * tg + 4 * h) = u32x2{pack_lp<F16>(w[0], w[1]), pack_lp<F16>(w[2], w[3])};
                 else *(f32x4 *)(op + 32 * db + 8 * tg + 4 * h) = w;
             }
     }
@@ -373,7 +374,7 @@ __global__ __launch_bounds__(256, DH == 128 ? 1 : 2) void attn_bwd_dq_bf16(
 // ------------------------------------------------------------------------------------------
 // backward, keys own: dK and dV
 // ------------------------------------------------------------------------------------------
-template <int DH, bool DROP, bool IN16, bool OUT16>
+template <int DH, bool DROP, bool IN16, bool OUT16, int F16 = 0>
 __global__ __launch_bounds__(256, DH == 128 ? 1 : 2) void attn_bwd_dkdv_bf16(
     const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
     const uint8_t *__restrict__ mask, const float *__restrict__ dO, const float *__restrict__ lse2,
@@ -391,13 +392,13 @@ __global__ __launch_bounds__(256, DH == 128 ? 1 : 2) void attn_bwd_dkdv_bf16(
                *vb = (const char *)v + (size_t)bh * T * DH * ES;
     const char *dob = (const char *)dO + ((size_t)b * T * d + hd * DH) * (OUT16 ? 2 : 4);          // row stride d elements
 
-    bf16x8 kf[NS], vf[NS];
+    u32x4 kf[NS], vf[NS];
     if constexpr (IN16) {
         owner_frags16<DH>((const h16 *)kb + (size_t)kc * DH, h, kf);
         owner_frags16<DH>((const h16 *)vb + (size_t)kc * DH, h, vf);
     } else {
-        owner_frags<DH>((const float *)kb + (size_t)kc * DH, 1.0f, h, kf);
-        owner_frags<DH>((const float *)vb + (size_t)kc * DH, 1.0f, h, vf);
+        owner_frags<DH, F16>((const float *)kb + (size_t)kc * DH, 1.0f, h, kf);
+        owner_frags<DH, F16>((const float *)vb + (size_t)kc * DH, 1.0f, h, vf);
     }
     const bool kmasked = mask != nullptr && mask[(size_t)b * T + kc];
     f32x16 dk[ND], dv[ND];
@@ -434,8 +435,8 @@ __global__ __launch_bounds__(256, DH == 128 ? 1 : 2) void attn_bwd_dkdv_bf16(
             f32x16 s = rows_init(&t.s0[32 * qblk], h), dp = DROP ? zero16b() : rows_init(&t.s1[32 * qblk], h);
 #pragma unroll
             for (int ks = 0; ks < NS; ++ks) {
-                s = MFMA_BF16(row_frag<DH>(t.a, 32 * qblk, ks, r, h), kf[ks], s);
-                dp = MFMA_BF16(row_frag<DH>(t.b, 32 * qblk, ks, r, h), vf[ks], dp);
+                s = mfma_lp<F16>(row_frag<DH>(t.a, 32 * qblk, ks, r, h), kf[ks], s);
+                dp = mfma_lp<F16>(row_frag<DH>(t.b, 32 * qblk, ks, r, h), vf[ks], dp);
             }
             // (a masked owner key needs no bias here: its lane is one COLUMN of every product below, so whatever it
             // computes stays in its own dK / dV row, which is written as zero at the end)
@@ -461,11 +462,11 @@ __global__ __launch_bounds__(256, DH == 128 ? 1 : 2) void attn_bwd_dkdv_bf16(
             }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                const bf16x8 pdf = pack_step(pd, s2), dsf = pack_step(s, s2);
+                const u32x4 pdf = pack_step<F16>(pd, s2), dsf = pack_step<F16>(s, s2);
 #pragma unroll
                 for (int db = 0; db < ND; ++db) {
-                    dv[db] = MFMA_BF16(tr_frag<DH>(t.b, 32 * qblk + 16 * s2, db, lane), pdf, dv[db]);
-                    dk[db] = MFMA_BF16(tr_frag<DH>(t.a, 32 * qblk + 16 * s2, db, lane), dsf, dk[db]);
+                    dv[db] = mfma_lp<F16>(tr_frag<DH>(t.b, 32 * qblk + 16 * s2, db, lane), pdf, dv[db]);
+                    dk[db] = mfma_lp<F16>(tr_frag<DH>(t.a, 32 * qblk + 16 * s2, db, lane), dsf, dk[db]);
                 }
             }
         }
@@ -484,8 +485,8 @@ __global__ __launch_bounds__(256, DH == 128 ? 1 : 2) void attn_bwd_dkdv_bf16(
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { wk[e] = kmasked ? 0.f : dk[db][4 * tg + e] * ln2; wv[e] = kmasked ? 0.f : dv[db][4 * tg + e]; }
                 if constexpr (OUT16) {
-                    *(u32x2 *)(op16 + d + 32 * db + 8 * tg + 4 * h) = u32x2{pack_bf16(wk[0], wk[1]), pack_bf16(wk[2], wk[3])};
-                    *(u32x2 *)(op16 + 2 * d + 32 * db + 8 * tg + 4 * h) = u32x2{pack_bf16(wv[0], wv[1]), pack_bf16(wv[2], wv[3])};
+                    *(u32x2 *)(op16 + d + 32 * db + 8 * tg + 4 * h) = u32x2{pack_lp<F16>(wk[0], wk[1]), pack_lp<F16>(wk[2], wk[3])};
+                    *(u32x2 *)(op16 + 2 * d + 32 * db + 8 * tg + 4 * h) = u32x2{pack_lp<F16>(wv[0], wv[1]), pack_lp<F16>(wv[2], wv[3])};
                 } else {
                 *(f32x4 *)(op + d + 32 * db + 8 * tg + 4 * h) = wk;
                 *(f32x4 *)(op + 2 * d + 32 * db + 8 * tg + 4 * h) = wv;
@@ -498,7 +499,8 @@ __global__ __launch_bounds__(256, DH == 128 ? 1 : 2) void attn_bwd_dkdv_bf16(
 
 #define VSTB_LAUNCH(KERNEL_, DH_, DROP_, IN16_, ...)                                                            \
     do {                                                                                                        \
-        hipLaunchKernelGGL((KERNEL_<DH_, DROP_, IN16_>), grid, dim3(256), 0, st, __VA_ARGS__);                  \
+        if (f16) hipLaunchKernelGGL((KERNEL_<DH_, DROP_, IN16_, 1>), grid, dim3(256), 0, st, __VA_ARGS__);      \
+        else hipLaunchKernelGGL((KERNEL_<DH_, DROP_, IN16_, 0>), grid, dim3(256), 0, st, __VA_ARGS__);          \
     } while (0)
 #define VSTB_DISPATCH2(KERNEL_, DH_, ...)                                                                       \
     do {                                                                                                        \
@@ -522,6 +524,8 @@ bool vst_attention_bf16_supported(int dh) { return dh == 32 || dh == 64 || dh ==
 int vst_attention_fwd_bf16(const float *q, const float *k, const float *v, const uint8_t *mask, float *out, float *lse2,
                            int B, int H, int T, int dh, float scale, float p, const unsigned *dbits, hipStream_t st, int in16) {
     if (p < 0.f || p >= 1.f || (p > 0.f && dbits == nullptr)) return -1;
+    const bool f16 = (in16 & VSK_F16) != 0;          // fp16 training mode: operands (and the stored planes) are IEEE f16
+    in16 &= ~VSK_F16;
     const float ds = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
     const dim3 grid(B * H * ((T + 127) / 128));
     VSTB_DISPATCH(attn_fwd_train_bf16, q, k, v, mask, out, lse2, H, T, scale, ds, dbits);
@@ -531,7 +535,8 @@ int vst_attention_fwd_bf16(const float *q, const float *k, const float *v, const
 
 #define VSTB_LAUNCH_B(KERNEL_, DH_, DROP_, IN16_, OUT16_, ...)                                                  \
     do {                                                                                                        \
-        hipLaunchKernelGGL((KERNEL_<DH_, DROP_, IN16_, OUT16_>), grid, dim3(256), 0, st, __VA_ARGS__);          \
+        if (f16) hipLaunchKernelGGL((KERNEL_<DH_, DROP_, IN16_, OUT16_, 1>), grid, dim3(256), 0, st, __VA_ARGS__); \
+        else hipLaunchKernelGGL((KERNEL_<DH_, DROP_, IN16_, OUT16_, 0>), grid, dim3(256), 0, st, __VA_ARGS__);  \
     } while (0)
 #define VSTB_DISPATCH_B3(KERNEL_, DH_, DROP_, ...)                                                              \
     do {                                                                                                        \
@@ -554,6 +559,8 @@ int vst_attention_bwd_bf16(const float *q, const float *k, const float *v, const
                            const float *lse2, const float *delta, float *dqkv, int B, int H, int T, int dh, float scale,
                            float p, const unsigned *dbits, hipStream_t st, int in16, int out16) {
     if (p < 0.f || p >= 1.f || (p > 0.f && dbits == nullptr)) return -1;
+    const bool f16 = (in16 & VSK_F16) != 0;
+    in16 &= ~VSK_F16;
     const float ds = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
     const dim3 grid(B * H * ((T + 127) / 128));
     VSTB_DISPATCH_B(attn_bwd_dkdv_bf16, q, k, v, mask, dO, lse2, delta, dqkv, H, T, scale, ds, dbits, B * H);

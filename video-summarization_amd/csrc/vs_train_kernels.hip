@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void gate_bwd(float *__restrict__ g, const flo
 // DO16 1: dO is stored as bf16 (the bf16 training mode's out-projection input gradient); 2: dO is fp32 but enters the dot
 // rounded to bf16 - the value the bf16 attention backward multiplies (dP = dO V^T), so that dS = P (dP - delta) subtracts
 // like from like, and the two storage forms of that mode agree bit for bit
-template <int NV, int DO16 = 0>
+template <int NV, int DO16 = 0, int F16 = 0>       // F16: the 16-bit type is IEEE f16 (fp16 training mode)
 __global__ __launch_bounds__(256) void head_rowdot(const float *__restrict__ dO, const float *__restrict__ O,
                                                    float *__restrict__ delta, int M, int T, int H, int dh) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, d = H * dh, gl = dh / 4;   // gl lanes per head
@@ -225,12 +225,12 @@ __global__ __launch_bounds__(256) void head_rowdot(const float *__restrict__ dO,
                 f32x4 x;
                 if constexpr (DO16 == 2) {
                     const f32x4 xf = *(const f32x4 *)(dO + (size_t)row * d + c);
-                    const unsigned x0 = pack_bf16(xf[0], xf[1]), x1 = pack_bf16(xf[2], xf[3]);
-                    x = f32x4{bits_f32(x0 << 16), bits_f32(x0 & 0xffff0000u), bits_f32(x1 << 16), bits_f32(x1 & 0xffff0000u)};
+                    const f32x2 a = unpack_lp<F16>(pack_lp<F16>(xf[0], xf[1])), b = unpack_lp<F16>(pack_lp<F16>(xf[2], xf[3]));
+                    x = f32x4{a[0], a[1], b[0], b[1]};
                 } else if constexpr (DO16 == 1) {
                     const u32x2 xb = *(const u32x2 *)((const unsigned short *)dO + (size_t)row * d + c);
-                    const unsigned x0 = xb[0], x1 = xb[1];
-                    x = f32x4{bits_f32(x0 << 16), bits_f32(x0 & 0xffff0000u), bits_f32(x1 << 16), bits_f32(x1 & 0xffff0000u)};
+                    const f32x2 a = unpack_lp<F16>(xb[0]), b = unpack_lp<F16>(xb[1]);
+                    x = f32x4{a[0], a[1], b[0], b[1]};
                 } else
                     x = *(const f32x4 *)(dO + (size_t)row * d + c);
                 const f32x4 o = *(const f32x4 *)(O + (size_t)row * d + c);
@@ -394,7 +394,7 @@ __global__ __launch_bounds__(256) void wgrad_tn(const float *__restrict__ dY, in
 // L2 -> CU rate (~10 TB/s) and not HBM being the bound.  256 x 256 tiles halve those bytes (64 flop/B).
 // ------------------------------------------------------------------------------------------
 // Y16 / X16: that operand is already bf16 in memory (the MLP hidden tensor and its gradient in the bf16 training mode).
-template <bool Y16, bool X16>
+template <bool Y16, bool X16, int F16 = 0>       // F16: operands (rounded here or stored) are IEEE f16 (fp16 training mode)
 __global__ __launch_bounds__(512, 2) void wgrad_tn_bf16(const float *__restrict__ dY, int ldy, const float *__restrict__ X, int ldx,
                                                         float *__restrict__ partW, float *__restrict__ partB, int M, int N, int K,
                                                         int rows_per_split) {
@@ -456,24 +456,25 @@ __global__ __launch_bounds__(512, 2) void wgrad_tn_bf16(const float *__restrict_
                 const unsigned y0 = f32_bits(py[i][0]), y1 = f32_bits(py[i][1]);
                 uy[0] = y0; uy[1] = y1;
                 // the bias gradient sums the stored (bf16) values
-                bsum += f32x4{bits_f32(y0 << 16), bits_f32(y0 & 0xffff0000u), bits_f32(y1 << 16), bits_f32(y1 & 0xffff0000u)};
+                const f32x2 ya = unpack_lp<F16>(y0), yb = unpack_lp<F16>(y1);
+                bsum += f32x4{ya[0], ya[1], yb[0], yb[1]};
             } else {
-                uy[0] = pack_bf16(py[i][0], py[i][1]); uy[1] = pack_bf16(py[i][2], py[i][3]);
+                uy[0] = pack_lp<F16>(py[i][0], py[i][1]); uy[1] = pack_lp<F16>(py[i][2], py[i][3]);
                 bsum += py[i];
             }
             if constexpr (X16) { ux[0] = f32_bits(px[i][0]); ux[1] = f32_bits(px[i][1]); }
-            else { ux[0] = pack_bf16(px[i][0], px[i][1]); ux[1] = pack_bf16(px[i][2], px[i][3]); }
+            else { ux[0] = pack_lp<F16>(px[i][0], px[i][1]); ux[1] = pack_lp<F16>(px[i][2], px[i][3]); }
             *(u32x2 *)((char *)&Ys[buf][0] + st_off + 8 * i * ROWB) = uy;
             *(u32x2 *)((char *)&Xs[buf][0] + st_off + 8 * i * ROWB) = ux;
         }
     };
-    auto frag = [&](const h16 *tile, int off) __attribute__((always_inline)) -> bf16x8 {
+    auto frag = [&](const h16 *tile, int off) __attribute__((always_inline)) -> u32x4 {
         const char *pb = (const char *)tile + off;
         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)pb);
         const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(pb + 4 * ROWB));
         const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
         const u32x4 v = {l2[0], l2[1], h2[0], h2[1]};
-        return __builtin_bit_cast(bf16x8, v);
+        return v;
     };
     if (m_begin < m_end) {
         gload(m_begin);
@@ -485,15 +486,15 @@ __global__ __launch_bounds__(512, 2) void wgrad_tn_bf16(const float *__restrict_
             if (more) gload(m0 + BR);
 #pragma unroll
             for (int s = 0; s < BR / 16; ++s) {
-                bf16x8 a[2], b[4];
+                u32x4 a[2], b[4];
 #pragma unroll
                 for (int ib = 0; ib < 2; ++ib) a[ib] = frag(Ys[buf], a_off[ib] + s * 16 * ROWB);
 #pragma unroll
                 for (int jb = 0; jb < 4; ++jb) b[jb] = frag(Xs[buf], b_off[jb] + s * 16 * ROWB);
 #pragma unroll
                 for (int jb = 0; jb < 4; ++jb) {
-                    acc[0][jb] = MFMA_BF16(a[0], b[jb], acc[0][jb]);
-                    acc[1][jb] = MFMA_BF16(a[1], b[jb], acc[1][jb]);
+                    acc[0][jb] = mfma_lp<F16>(a[0], b[jb], acc[0][jb]);
+                    acc[1][jb] = mfma_lp<F16>(a[1], b[jb], acc[1][jb]);
                 }
             }
             if (more) stage(buf ^ 1);
@@ -744,15 +745,17 @@ int vst_head_rowdot(const float *dO, const float *O, float *delta, int M, int T,
     const int d = H * dh;
     if (d > 1024 || (dh != 32 && dh != 64 && dh != 128)) return -1;
     const dim3 grid((M + 3) / 4 < 4096 ? (M + 3) / 4 : 4096);
-#define VST_HRD(MODE_)                                                                                                   \
-    switch ((d + 255) / 256) {                                                                                           \
-        case 1: hipLaunchKernelGGL((head_rowdot<1, MODE_>), grid, dim3(256), 0, st, dO, O, delta, M, T, H, dh); break;   \
-        case 2: hipLaunchKernelGGL((head_rowdot<2, MODE_>), grid, dim3(256), 0, st, dO, O, delta, M, T, H, dh); break;   \
-        case 3: hipLaunchKernelGGL((head_rowdot<3, MODE_>), grid, dim3(256), 0, st, dO, O, delta, M, T, H, dh); break;   \
-        default: hipLaunchKernelGGL((head_rowdot<4, MODE_>), grid, dim3(256), 0, st, dO, O, delta, M, T, H, dh); break;  \
+#define VST_HRD(MODE_, F_)                                                                                                   \
+    switch ((d + 255) / 256) {                                                                                               \
+        case 1: hipLaunchKernelGGL((head_rowdot<1, MODE_, F_>), grid, dim3(256), 0, st, dO, O, delta, M, T, H, dh); break;   \
+        case 2: hipLaunchKernelGGL((head_rowdot<2, MODE_, F_>), grid, dim3(256), 0, st, dO, O, delta, M, T, H, dh); break;   \
+        case 3: hipLaunchKernelGGL((head_rowdot<3, MODE_, F_>), grid, dim3(256), 0, st, dO, O, delta, M, T, H, dh); break;   \
+        default: hipLaunchKernelGGL((head_rowdot<4, MODE_, F_>), grid, dim3(256), 0, st, dO, O, delta, M, T, H, dh); break;  \
     }
-    if (do16 == 1) { VST_HRD(1) }
-    else if (do16 == 2) { VST_HRD(2) }
+    const bool f16 = (do16 & VSK_F16) != 0;        // the 16-bit type of dO (1: stored, 2: rounded on the way in) is f16
+    do16 &= ~VSK_F16;
+    if (do16 == 1) { if (f16) { VST_HRD(1, 1) } else { VST_HRD(1, 0) } }
+    else if (do16 == 2) { if (f16) { VST_HRD(2, 1) } else { VST_HRD(2, 0) } }
     else
     VST_NV_DISPATCH(d, head_rowdot, grid, dim3(256), 0, st, dO, O, delta, M, T, H, dh);
 #undef VST_HRD
@@ -807,6 +810,11 @@ int vst_wgrad(const float *dY, int ldy, const float *X, int ldx, int M, int N, i
         const dim3 g16(((N + 255) / 256) * ((K + 255) / 256), S);
         float *pb = db0 ? partB : nullptr;
         if ((prec & VST_WGRAD_Y16) && (prec & VST_WGRAD_X16)) return -1;
+        if (prec & VSK_F16) {      // fp16 training mode
+            if (prec & VST_WGRAD_Y16) hipLaunchKernelGGL((wgrad_tn_bf16<true, false, 1>), g16, dim3(512), 0, st, dY, ldy, X, ldx, partW, pb, M, N, K, rps);
+            else if (prec & VST_WGRAD_X16) hipLaunchKernelGGL((wgrad_tn_bf16<false, true, 1>), g16, dim3(512), 0, st, dY, ldy, X, ldx, partW, pb, M, N, K, rps);
+            else hipLaunchKernelGGL((wgrad_tn_bf16<false, false, 1>), g16, dim3(512), 0, st, dY, ldy, X, ldx, partW, pb, M, N, K, rps);
+        } else
         if (prec & VST_WGRAD_Y16) hipLaunchKernelGGL((wgrad_tn_bf16<true, false>), g16, dim3(512), 0, st, dY, ldy, X, ldx, partW, pb, M, N, K, rps);
         else if (prec & VST_WGRAD_X16) hipLaunchKernelGGL((wgrad_tn_bf16<false, true>), g16, dim3(512), 0, st, dY, ldy, X, ldx, partW, pb, M, N, K, rps);
         else hipLaunchKernelGGL((wgrad_tn_bf16<false, false>), g16, dim3(512), 0, st, dY, ldy, X, ldx, partW, pb, M, N, K, rps);

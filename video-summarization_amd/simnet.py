@@ -253,7 +253,7 @@ class SimNet(nn.Module):
         self._attention_dtype = "fp32"
         self._linear_dtype = "fp32"       # "bf16": every Linear multiplies bf16-rounded operands (fp32 storage/accumulate)
         self._train_dtype = "fp32"        # set_train_dtype("bf16"): the training path's counterpart of the reference's autocast
-        self.last_train_dtype = None      # what the last training forward actually computed in ("fp32" / "bf16")
+        self.last_train_dtype = None      # what the last training forward actually computed in ("fp32" / "bf16" / "fp16")
         self._packed: Optional[_Packed] = None
         self._packed_key = None
         self._packed_shape = None
@@ -348,7 +348,9 @@ class SimNet(nn.Module):
         seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item()) if (p > 0.0 or p_embed > 0.0) else 0
         params = [t for t in self._tensors() if isinstance(t, nn.Parameter)]
         x32 = x if x.dtype == torch.float32 else x.float()
-        tflags = (_lib.VS_TRAIN_FLAG_BF16_LINEAR | _lib.VS_TRAIN_FLAG_BF16_ATTENTION) if self._train_dtype == "bf16" else 0
+        tflags = (_lib.VS_TRAIN_FLAG_BF16_LINEAR | _lib.VS_TRAIN_FLAG_BF16_ATTENTION) if self._train_dtype in ("bf16", "fp16") else 0
+        if self._train_dtype == "fp16":
+            tflags |= _lib.VS_TRAIN_FLAG_FP16
         return _TrainForward.apply(self, x32, mask, p, p_embed, seed, tflags, *params)
 
     def forward(self, x: Tensor, mask=None, vis_attention=None, model_score: bool = False):
@@ -469,7 +471,7 @@ class SimNet(nn.Module):
     def _note_train_arithmetic(self, tflags: int, fmt: int, frames: int) -> None:
         """Records which arithmetic the last training forward actually ran (``last_train_dtype``) and says so - once - when a
         low-precision request was not honoured (the library keeps batches below VS_TRAIN_LP_MIN_ROWS frames on the exact kernels)."""
-        self.last_train_dtype = "bf16" if (fmt & 3) else "fp32"
+        self.last_train_dtype = ("fp16" if (fmt & 32) else "bf16") if (fmt & 3) else "fp32"
         if tflags and not (fmt & 3) and not getattr(self, "_warned_train_dtype", False):
             import warnings
             self._warned_train_dtype = True
@@ -484,10 +486,15 @@ class SimNet(nn.Module):
         under autocast - LayerNorm, softmax statistics and the loss in fp32.  The attention products (forward and both
         backward kernels) run on the bf16 pipe too (head dim 32 / 64 / 128), and the tensors that are only ever bf16 matrix
         operands (q / k / v, the MLP hidden tensor and its gradient, the attention gradients) are stored as bf16.  Applies
-        from 8192 frames per batch up.  Gradients within ~2e-2 relative L2 of
-        the float64 truth (tests/tolerances.py TRAIN_LP_*)."""
-        if value not in ("fp32", "bf16"):
-            raise ValueError("train dtype must be 'fp32' or 'bf16', got %r" % (value,))
+        above VS_TRAIN_LP_MIN_ROWS frames per batch (default 1024; ``last_train_dtype`` says what a forward really ran).
+        Gradients within ~2e-2 relative L2 of the float64 truth (tests/tolerances.py TRAIN_LP_*).
+        'fp16': the same structure with IEEE fp16 as the 16-bit type - the reference's own autocast type on CUDA - 11
+        significant bits, gradients ~8x closer to the truth (TRAIN_FP16_*), but a range of 65 504 / 6e-8: train with a loss
+        scale exactly as the reference does (``torch.amp.GradScaler``, train.py:60,126-128) - ``scaler.scale(loss).backward()``
+        reaches these kernels as a scaled ``d_scores``, an overflow surfaces as inf / NaN gradients and GradScaler skips
+        the step and halves the scale."""
+        if value not in ("fp32", "bf16", "fp16"):
+            raise ValueError("train dtype must be 'fp32', 'bf16' or 'fp16', got %r" % (value,))
         self._train_dtype = value
         return self
 
