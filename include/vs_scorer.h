@@ -61,7 +61,7 @@ extern "C" {
 /* Model hyper-parameters: the ctor arguments of reference SimNet.__init__ (simnet.py:10-13)
  * that shape the eval forward. */
 typedef struct vs_model_desc {
-    int32_t d_model;      /* simnet.py:16;  multiple of 64, <= 512 */
+    int32_t d_model;      /* simnet.py:16;  multiple of 64, <= 1024 (other widths: vs_weights_set_norm_width below) */
     int32_t num_heads;    /* simnet.py:15;  d_model/num_heads in {32, 64, 128} */
     int32_t num_layers;   /* simnet.py:17;  len(encoder.module_list), >= 1 */
     int32_t in_features;  /* simnet.py:22 (1024 in the reference); multiple of 32 */
@@ -101,6 +101,19 @@ const char *vs_last_error(void);
 int vs_weights_pack(const vs_model_desc *desc, const vs_model_params *params,
                     void *stream, vs_weights **out);
 void vs_weights_free(vs_weights *w);
+
+/* Round 4 - the reference's envelope is ANY d_model % num_heads == 0 (simnet.py:123); the kernels' is d_model % 64 == 0
+ * with head dim 32 / 64 / 128.  A model outside it is scored / trained EMBEDDED in the next supported shape: pack it with
+ * desc.d_model = d' = num_heads * dh' (dh' the next supported head dim that makes d' a multiple of 64) and every parameter
+ * zero-padded - residual-stream axes (rows of embed_w / wo / w2, columns of wq / wk / wv / w1 / final_w, biases, LayerNorm
+ * gamma / beta, the positional table) keep feature c at index c; head-structured axes (rows of wq / wk / wv, columns of wo)
+ * move feature (h, j) from h * dh + j to h * dh' + j; the MLP's hidden axis keeps its index - then declare the true width
+ * here.  The pad columns of every activation are then identically zero; what depends on the true d_model and is NOT
+ * invariant under the padding - the LayerNorm statistics and the attention scale d_model ** -0.5 (simnet.py:126) - uses
+ * norm_width.  Such a handle always takes the plain GEMM + row-LayerNorm kernels.  SimNet (simnet.py of this package) does
+ * all of this itself; `hidden` then has d' columns of which the first norm_width are the model's.
+ * norm_width: multiple of 4, 0 < norm_width <= desc.d_model (== desc.d_model: an ordinary handle again). */
+int vs_weights_set_norm_width(vs_weights *w, int32_t norm_width);
 
 /* Replaces: the parameter writes of an optimizer step / load_state_dict on an existing module (train.py:127,
  * 42-43).  Re-copies every parameter into the handle's existing device storage (same desc, same device as

@@ -33,7 +33,14 @@ def main():
     from model import SimNet          # the reference
     torch.set_num_threads(os.cpu_count() or 1)
     out, summary = {}, {}
+    if mg.ONLY:        # keep the stored cases, add / replace the named ones
+        with np.load(os.path.join(HERE, "forward_fp64.npz")) as z:
+            out = {k: z[k] for k in z.files}
+        with open(os.path.join(HERE, "forward_fp64.json")) as f:
+            summary = json.load(f)["cases"]
     for c in mg.CASES:
+        if mg.ONLY and c["name"] not in mg.ONLY:
+            continue
         nc, use_pos = c.get("num_classes", 1), c.get("use_pos", True)
         sd = synth.make_state_dict(c["d"], c["L"], c["wseed"], num_classes=nc, use_pos=use_pos)
         x, mask = mg.build_inputs(c)

@@ -53,7 +53,15 @@ CASES = [
     dict(name="train_d768_h12_t60_pad", H=12, d=768, L=1, B=2, T=60, wseed=25, xseed=151, kind="pool5", lengths=[60, 41],
          tseed=10, hidden_w=1e-3),
     dict(name="train_d1024_h8_t70", H=8, d=1024, L=1, B=1, T=70, wseed=26, xseed=136, kind="randn", tseed=11, hidden_w=0.0),
+    # round 4: shapes trained EMBEDDED in the next supported shape (head dim 16 -> 32; 40 -> 64 with d_model 200 -> 320; three
+    # heads of 32, d_model 96 -> 192)
+    dict(name="train_d128_h8_t90_pad", H=8, d=128, L=2, B=2, T=90, wseed=37, xseed=161, kind="pool5", lengths=[90, 61],
+         tseed=12, hidden_w=1e-3),
+    dict(name="train_d200_h5_t70", H=5, d=200, L=2, B=1, T=70, wseed=38, xseed=162, kind="randn", tseed=13, hidden_w=0.0),
+    dict(name="train_d96_h3_randmask_t65", H=3, d=96, L=1, B=2, T=65, wseed=39, xseed=163, kind="randn", randmask=6,
+         tseed=14, hidden_w=1e-3),
 ]
+ONLY = [n for n in os.environ.get("VS_GOLDEN_ONLY", "").split(",") if n]      # (re)generate only these, keep the others
 FULL_LIMIT = 4096
 N_ROWS = 12
 
@@ -99,6 +107,9 @@ def main():
     torch.set_num_threads(os.cpu_count() or 1)
     index = []
     for c in CASES:
+        if ONLY and c["name"] not in ONLY:
+            index.append(c)
+            continue
         sd = synth.make_state_dict(c["d"], c["L"], c["wseed"])
         x, mask, target, R = build_inputs(c)
         loss64, pred64, hid64, g64 = run(SimNet, mse_with_mask_loss, c, sd, x, mask, target, R, torch.float64)

@@ -1341,7 +1341,7 @@ def test_randomised_parity_slice(vsa):
 
 
 @pytest.mark.parametrize("compute", ["fp32", "fp16x3"])
-@pytest.mark.parametrize("cfg", [(4, 256, 4), (8, 256, 2), (4, 128, 2)])
+@pytest.mark.parametrize("cfg", [(4, 256, 4), (8, 256, 2), (4, 128, 2), (4, 512, 2)])      # (4, 512): head dim 128, M-B (round 4)
 def test_packed_ragged_batch_is_bit_identical_to_scoring_each_video_alone(vsa, cfg, compute):
     """SimNet.forward_packed (frames of all videos concatenated, no padding rows, no mask): every video's logits
     and hidden state equal scoring that video alone bit for bit, and meet the oracle at 1e-4."""
@@ -1370,6 +1370,31 @@ def test_packed_ragged_batch_is_bit_identical_to_scoring_each_video_alone(vsa, c
         m.forward_packed(x, lengths[:-1])                     # row count does not match
     with pytest.raises(RuntimeError):
         m.forward_packed(torch.cat([x, x[:1]]), lengths[:-1] + [2001])     # beyond the positional table
+
+
+def test_packed_batches_head_dim_128_bf16_mode(vsa, lp_linear_everywhere):
+    """M-B (head dim 128) packed in the bf16 compute mode: the 8-wave bf16 attention over 256-row work items, every video
+    within the bf16 mode's tolerance of the oracle and of the same video scored alone."""
+    synth = vsa.synth
+    sd = synth.make_state_dict(512, 2, 19)
+    m = vsa.SimNet(num_heads=4, d_model=512, num_layers=2, sparsity=0.0, dropout=0.3)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(_dev()).eval().set_compute_dtype("bf16")
+    assert m.attention_dtype == "bf16"
+    lengths = [320, 1, 257, 700, 33]
+    vids = [synth.make_features(1, t, 300 + i, "pool5")[0] for i, t in enumerate(lengths)]
+    x = torch.cat(vids, dim=0).to(_dev())
+    with torch.no_grad():
+        logits, _hidden = m.forward_packed(x, lengths)
+        row = 0
+        for i, (v, t) in enumerate(zip(vids, lengths)):
+            l1, _h1 = m(v[None].to(_dev()))
+            assert (logits[row:row + t] - l1[0]).abs().max().item() < 2e-2, i
+            if i in (0, 3):
+                rl, _rh = oracle_forward(sd, v[None], None, 4)
+                e = (logits[row:row + t].cpu() - rl[0]).abs().max().item()
+                assert 1e-5 < e < 3e-2, (i, e)
+            row += t
 
 
 @pytest.mark.parametrize("compute", ["fp32", "fp16x3", "bf16"])
@@ -1531,3 +1556,66 @@ def test_bf16_mode_on_wide_models_matches_reference_golden(vsa, lp_linear_everyw
             e2 = (mixed.cpu() - g["logits"])[valid].abs().max().item()
             assert 1e-7 < e2 < tol.BF16_LOGIT_TOL, (lin, att, e2)
             assert not torch.equal(mixed, logits)
+
+
+# ---- round 4: shapes outside the kernels' own envelope, run EMBEDDED in the next supported shape (simnet.embedding_plan,
+# vs_weights_set_norm_width).  The reference-generated goldens of these shapes ride in golden_cases() above; here: the other
+# entry points of the module on such a model, against the CPU oracle.
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [(8, 128), (5, 200), (3, 96)], ids=lambda c: "h%d_d%d" % c)
+def test_embedded_shape_through_every_entry_point(vsa, cfg):
+    """SimNet(num_heads=8, d_model=128) (head dim 16), (5, 200) (head dim 40), (3, 96): padded and masked batches, packed ragged
+    batches, score(), the class-token variant and the low-precision compute modes, each against the oracle on the TRUE-shaped
+    state dict; `hidden` comes back with d_model columns."""
+    H, d = cfg
+    synth = vsa.synth
+    sd = synth.make_state_dict(d, 2, 77 + d)
+    m = vsa.SimNet(num_heads=H, d_model=d, num_layers=2, sparsity=0.0, dropout=0.3)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(_dev()).eval()
+    assert m._plan is not None and m._lib_d > d
+    lengths = [150, 97, 33]
+    x = synth.make_features(3, 150, 5, "pool5", lengths)
+    mask = synth.padding_mask(x)
+    rl, rh = oracle_forward(sd, x, mask, H)
+    valid = ~mask
+    with torch.no_grad():
+        logits, hidden = m(x.to(_dev()), mask.to(_dev()))
+        assert hidden.shape == (3, 150, d) and logits.shape == (3, 150, 1)
+        assert (logits.cpu() - rl)[valid].abs().max().item() < TOL and (hidden.cpu() - rh)[valid].abs().max().item() < TOL
+        sc = m.score(x.to(_dev()), mask.to(_dev()))
+        assert (sc.cpu() - torch.sigmoid(rl.squeeze(-1)))[valid].abs().max().item() < TOL
+        # packed ragged batch: no padding rows, each video as if scored alone
+        xp = torch.cat([x[i, :t] for i, t in enumerate(lengths)]).to(_dev())
+        pl, ph = m.forward_packed(xp, lengths)
+        assert ph.shape == (sum(lengths), d)
+        o = 0
+        for i, t in enumerate(lengths):
+            al, ah = m(x[i:i + 1, :t].to(_dev()))
+            assert torch.equal(pl[o:o + t], al[0]) and torch.equal(ph[o:o + t], ah[0]), "packed != alone (video %d)" % i
+            assert (al.cpu() - rl[i:i + 1, :t]).abs().max().item() < TOL
+            o += t
+        # the emulated-fp32 mode stays inside the 1e-4 bar; the bf16 mode inside its own
+        m.set_compute_dtype("fp16x3")
+        l3, h3 = m(x.to(_dev()), mask.to(_dev()))
+        assert (l3.cpu() - rl)[valid].abs().max().item() < TOL and (h3.cpu() - rh)[valid].abs().max().item() < TOL
+        vsa._lib.set_option("VS_LP_MIN_ROWS", 0)
+        try:
+            m.set_compute_dtype("bf16")
+            lb, hb = m(x.to(_dev()), mask.to(_dev()))
+        finally:
+            vsa._lib.set_option("VS_LP_MIN_ROWS", -1)
+        eb = (lb.cpu() - rl)[valid].abs().max().item()
+        assert 1e-5 < eb < 3e-2, eb
+        m.set_compute_dtype("fp32")
+    # class token (simnet.py:205-216): T + 1 positions
+    sdc = synth.make_state_dict(d, 2, 78 + d, use_cls=True)
+    mc = vsa.SimNet(num_heads=H, d_model=d, num_layers=2, sparsity=0.0, dropout=0.3, use_cls=True)
+    mc.load_state_dict(sdc, strict=True)
+    mc = mc.to(_dev()).eval()
+    cl, ch = oracle_forward(sdc, x, mask, H)
+    with torch.no_grad():
+        gl, gh = mc(x.to(_dev()), mask.to(_dev()))
+    v1 = torch.cat([torch.ones(3, 1, dtype=torch.bool), valid], dim=1)
+    assert gh.shape == (3, 151, d)
+    assert (gl.cpu() - cl)[v1].abs().max().item() < TOL and (gh.cpu() - ch)[v1].abs().max().item() < TOL

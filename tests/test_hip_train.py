@@ -883,3 +883,45 @@ def test_mse_with_mask_loss_matches_reference_formula(vsa):
         (got * 3.0).backward()
         assert abs(got.item() - want.item()) < 1e-6 * max(1.0, want.item())
         assert (od.grad.cpu().double() - 3.0 * o64.grad).abs().max().item() < 1e-6
+
+
+def test_embedded_shape_trains_like_a_native_one(vsa):
+    """A model outside the kernels' envelope (8 heads of 16, d_model 128: run embedded in 8 x 32 = 256) through the reference's
+    loop shape: dropout on, Adam steps (every step re-packs the zero-padded parameters), loss falls; per seed the step is
+    bitwise reproducible; gradients have the parameters' TRUE shapes; with dropout off the autograd forward equals the
+    scoring forward bit for bit where both run the same kernels' arithmetic (1e-5)."""
+    def run():
+        torch.manual_seed(11)
+        sd = vsa.synth.make_state_dict(128, 2, 41)
+        m = vsa.SimNet(num_heads=8, d_model=128, num_layers=2, sparsity=0.0, dropout=0.2)
+        m.load_state_dict(sd)
+        m = m.to(_dev()).train()
+        opt = torch.optim.Adam(m.parameters(), lr=3e-4)
+        x = vsa.synth.make_features(3, 120, 9, "pool5", [120, 80, 100]).to(_dev())
+        mask = vsa.synth.padding_mask(x)
+        tgt = torch.rand(3, 120, generator=torch.Generator().manual_seed(3)).to(_dev())
+        losses = []
+        for _ in range(30):
+            pred, hidden = m(x, mask)
+            assert hidden.shape == (3, 120, 128)
+            loss = vsa.mse_with_mask_loss(pred, tgt, mask) + 1e-4 * hidden.square().mean()
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            for p_ in m.parameters():
+                assert p_.grad.shape == p_.shape and torch.isfinite(p_.grad).all()
+            opt.step()
+            losses.append(loss.item())
+        return m, x, mask, losses
+    m, x, mask, a = run()
+    _m2, _x, _mk, b = run()
+    assert a == b, "same seed, different losses"
+    assert a[-1] < 0.7 * a[0], (a[0], a[-1])
+    m.eval()
+    with torch.no_grad():
+        sl, sh = m(x, mask)
+    xg = x.clone().requires_grad_(True)
+    tl, th = m(xg, mask)                      # eval mode under autograd: the training kernels with dropout off
+    valid = ~mask
+    assert (tl - sl)[valid].abs().max().item() < 1e-5 and (th - sh)[valid].abs().max().item() < 1e-5
+    th.sum().backward()
+    assert xg.grad is not None and torch.isfinite(xg.grad).all()

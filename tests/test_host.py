@@ -119,6 +119,34 @@ def test_attention_dtype_is_validated(vsa):
         huge.attention_dtype = "bf16"
 
 
+def test_embedding_plan_covers_the_reference_envelope_up_to_head_dim_128(vsa):
+    """simnet.py:123 accepts any d_model % num_heads == 0; shapes outside the kernels' own envelope run embedded in the next
+    supported shape (zero-padded parameters, true LayerNorm width declared to the library)."""
+    plan = vsa.simnet.embedding_plan
+    for d, H in [(256, 4), (512, 4), (512, 8), (320, 5), (128, 1), (64, 1), (1024, 8), (768, 12)]:
+        assert plan(d, H) is None, (d, H)                      # native
+    assert plan(128, 8) == (256, 32)                            # head dim 16 -> 32
+    assert plan(200, 5) == (320, 64)                            # head dim 40 -> 64
+    assert plan(96, 3) == (192, 64)                             # three heads of 32 would be d_model 96: not a multiple of 64
+    assert plan(72, 2) == (128, 64)
+    assert plan(640, 5) is None and plan(520, 5) == (640, 128)
+    for d, H in [(512, 2), (256, 1), (1032, 8), (126, 3)]:      # head dim > 128, too wide, d_model % 4
+        with pytest.raises(NotImplementedError):
+            plan(d, H)
+    m = vsa.SimNet(num_heads=8, d_model=128, num_layers=1)
+    assert (m._lib_d, m._lib_dh) == (256, 32) and m.final_layer.weight.shape == (1, 128)     # the state_dict keeps the true shapes
+    # the padding maps: residual-stream axes keep their index, head-structured axes move feature (h, j) to h * 32 + j
+    w = torch.arange(128 * 128, dtype=torch.float32).reshape(128, 128)
+    wp = m._pad(w, ("head", "res"))
+    assert wp.shape == (256, 256) and torch.equal(wp[32 * 3 + 5, :128], w[16 * 3 + 5]) and wp[32 * 3 + 16:32 * 4].abs().sum() == 0
+    assert torch.equal(m._unpad(wp, ("head", "res")), w) and wp[:, 128:].abs().sum() == 0
+    assert m._padded_shape((512, 128), ("hid", "res")) == (1024, 256) and m._padded_shape((1, 128), (None, "res")) == (1, 256)
+    axes = list(m._tensor_axes())
+    assert len(axes) == len(list(m._tensors()))
+    for t, ax in zip(m._tensors(), axes):
+        assert m._unpad(m._pad(t.detach(), ax), ax).shape == t.shape
+
+
 def test_compute_dtype_switches_are_validated(vsa):
     m = vsa.SimNet(num_heads=4, d_model=256, num_layers=1)
     for mode in ("fp16x3", "bf16", "fp32"):

@@ -33,7 +33,7 @@ VS_TRAIN_FLAG_BF16_ATTENTION = 2
 VS_TRAIN_FLAG_FP16 = 4          # modifier: the 16-bit type is IEEE fp16 (the reference's own autocast type) instead of bf16
 
 # every symbol include/vs_scorer.h declares
-EXPORTS = ("vs_abi_version", "vs_last_error", "vs_weights_pack", "vs_weights_free", "vs_weights_update", "vs_set_option",
+EXPORTS = ("vs_abi_version", "vs_last_error", "vs_weights_pack", "vs_weights_free", "vs_weights_update", "vs_weights_set_norm_width", "vs_set_option",
            "vs_scorer_workspace_bytes", "vs_scorer_forward", "vs_scorer_workspace_bytes_packed",
            "vs_scorer_forward_packed", "vs_scorer_workspace_bytes_cls", "vs_scorer_forward_cls", "vs_linear_f32", "vs_qkv_proj_f32",
            "vs_attention_f32", "vs_attention_bf16", "vs_attention_bf16_stored", "vs_attention_qscale", "vs_attention_f16x3", "vs_linear_residual_layernorm_f32",
@@ -187,6 +187,8 @@ def load() -> C.CDLL:
         lib.vs_weights_free.argtypes = [C.c_void_p]
         lib.vs_weights_update.restype = C.c_int
         lib.vs_weights_update.argtypes = [C.c_void_p, C.POINTER(ModelParams), C.c_void_p]
+        lib.vs_weights_set_norm_width.restype = C.c_int
+        lib.vs_weights_set_norm_width.argtypes = [C.c_void_p, C.c_int32]
         lib.vs_set_option.restype = C.c_int
         lib.vs_set_option.argtypes = [C.c_char_p, C.c_int32]
         lib.vs_scorer_workspace_bytes.restype = C.c_size_t

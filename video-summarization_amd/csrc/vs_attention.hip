@@ -17,10 +17,11 @@ namespace {
 //   statistics (max, sum, rescale) are lane-local plus one exchange with lane^32, and P never
 //   leaves registers.
 // ------------------------------------------------------------------------------------------
-template <int DH, int NKB>   // NKB 32-key blocks per tile
+template <int DH, int NKB, bool VARLEN = false>   // NKB 32-key blocks per tile; VARLEN: packed ragged batches (see attn_fwd_pipe), round 4
 __global__ __launch_bounds__(256, 2) void attn_fwd(
     const float *__restrict__ Q, const float *__restrict__ Kg, const float *__restrict__ Vg,
-    const uint8_t *__restrict__ mask, float *__restrict__ out, int H, int T, float scale_log2e, int BH) {
+    const uint8_t *__restrict__ mask, float *__restrict__ out, int H, int T, float scale_log2e, int BH,
+    const int *__restrict__ cu = nullptr, const int2 *__restrict__ work = nullptr, int Mtot = 0) {
     constexpr int KT = 32 * NKB, LD = DH + 4, NJ = DH / 8, ND = DH / 32;
     constexpr int F4 = KT * DH / 4 / 256;          // float4 per thread per operand tile
     __shared__ __attribute__((aligned(16))) float Ks[KT * LD];
@@ -29,10 +30,22 @@ __global__ __launch_bounds__(256, 2) void attn_fwd(
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    int bh, qt;
-    if (!attn_block_map((T + 127) / 128, BH, bh, qt)) return;
-    const int b = bh / H, head = bh - b * H;
-    const size_t base = (size_t)bh * T * DH;
+    int b, head, qt;
+    size_t base, orow0;                              // operand base (floats), first output row of this video
+    if constexpr (VARLEN) {
+        const int2 wk = work[blockIdx.x];
+        b = wk.x; qt = wk.y; head = blockIdx.y;
+        const int c0 = cu[b];
+        T = cu[b + 1] - c0;
+        base = ((size_t)head * Mtot + c0) * DH;
+        orow0 = (size_t)c0;
+    } else {
+        int bh;
+        if (!attn_block_map((T + 127) / 128, BH, bh, qt)) return;
+        b = bh / H; head = bh - b * H;
+        base = (size_t)bh * T * DH;
+        orow0 = (size_t)b * T;
+    }
     const int q0 = qt * 128 + 32 * wave;
     const float NEG_INF = -__builtin_inff();
 
@@ -157,7 +170,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd(
     const int q = q0 + r;
     if (q < T) {
         const float inv = 1.0f / l_run;
-        float *op = out + ((size_t)b * T + q) * (H * DH) + head * DH;
+        float *op = out + (orow0 + q) * (H * DH) + head * DH;
 #pragma unroll
         for (int d = 0; d < ND; ++d)
 #pragma unroll
@@ -1495,12 +1508,15 @@ int vsk_attention_packed(const float *q, const float *k, const float *v, float *
         else if (dh == 32 && nw == 4) VSK_ATTN_PE(32, 4, 2);
         else return -1;
     } else if (prec == 1) {
-        if (dh == 64 && nw == 8) VSK_ATTN_PE(64, 8, 1);
+        if (dh == 128 && nw == 8) VSK_ATTN_PE(128, 8, 1);       // head dim 128 (round 4), fp32 q / k / v in HBM
+        else if (dh == 64 && nw == 8) VSK_ATTN_PE(64, 8, 1);
         else if (dh == 64 && nw == 4) VSK_ATTN_PE(64, 4, 1);
         else if (dh == 32 && nw == 4) VSK_ATTN_PE(32, 4, 1);
         else return -1;
     } else {
-        if (dh == 64 && nw == 8) VSK_ATTN_PX(64, 8);
+        if (dh == 128 && nw == 4)       // exact fp32, head dim 128 (M-B): 128-row work items through the non-pipelined kernel
+            hipLaunchKernelGGL((attn_fwd<128, 1, true>), grid, dim3(256), 0, st, q, k, v, nullptr, out, H, 0, sl2, 0, cu, wk, Mtot);
+        else if (dh == 64 && nw == 8) VSK_ATTN_PX(64, 8);
         else if (dh == 64 && nw == 4) VSK_ATTN_PX(64, 4);
         else if (dh == 32 && nw == 8) VSK_ATTN_PX(32, 8);
         else if (dh == 32 && nw == 4) VSK_ATTN_PX(32, 4);

@@ -1615,7 +1615,10 @@ __global__ __launch_bounds__(256) void rows_res_ln(const float *__restrict__ a, 
                                                    float *__restrict__ out, int M, int d,
                                                    const float *__restrict__ score_w, const float *__restrict__ score_b,
                                                    int num_classes, int sigmoid, float *__restrict__ scores,
-                                                   unsigned short *__restrict__ out16) {
+                                                   unsigned short *__restrict__ out16, int dn) {
+    // dn (== d for every natively shaped model): the LayerNorm width.  A model EMBEDDED in a wider supported shape (round 4:
+    // zero-padded weights, vs_weights_set_norm_width) has its true d_model = dn < d; columns dn .. d-1 of the residual stream
+    // are identically zero (zero weight rows / bias / gamma / beta) and stay out of the statistics.
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     auto wsum = [](float v) __attribute__((always_inline)) { v += __shfl_xor(v, 32); return half_sum(v); };
     for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
@@ -1630,16 +1633,16 @@ __global__ __launch_bounds__(256) void rows_res_ln(const float *__restrict__ a, 
                 s += v[u][0] + v[u][1] + v[u][2] + v[u][3];
             }
         }
-        const float mean = wsum(s) / (float)d;
+        const float mean = wsum(s) / (float)dn;
         float s2 = 0.f;
 #pragma unroll
         for (int u = 0; u < NV; ++u) {
-            if (4 * lane + 256 * u < d) {
+            if (4 * lane + 256 * u < dn) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { const float t = v[u][e] - mean; s2 += t * t; }
             }
         }
-        const float rstd = 1.0f / sqrtf(wsum(s2) / (float)d + 1e-5f);
+        const float rstd = 1.0f / sqrtf(wsum(s2) / (float)dn + 1e-5f);
 #pragma unroll
         for (int u = 0; u < NV; ++u) {
             const int c = 4 * lane + 256 * u;
@@ -1795,15 +1798,17 @@ int vsk_insert_cls(const float *e, const float *cls, const uint8_t *mask, float 
 
 int vsk_rows_res_ln(const float *a, const float *res, const float *gamma, const float *beta, float *out, int M, int d,
                     const float *score_w, const float *score_b, int num_classes, int sigmoid, float *scores,
-                    hipStream_t st, void *out16) {
+                    hipStream_t st, void *out16, int dn) {
     if (d % 4 || d > 1024) return -1;
+    if (dn <= 0) dn = d;
+    if (dn % 4 || dn > d) return -1;
     const int rows4 = (M + 3) / 4;
     const dim3 grid(rows4 < 8192 ? (rows4 < 1 ? 1 : rows4) : 8192);
     switch ((d + 255) / 256) {          // float4 per lane (256 columns each)
-        case 1: hipLaunchKernelGGL(rows_res_ln<1>, grid, dim3(256), 0, st, a, res, gamma, beta, out, M, d, score_w, score_b, num_classes, sigmoid, scores, (unsigned short *)out16); break;
-        case 2: hipLaunchKernelGGL(rows_res_ln<2>, grid, dim3(256), 0, st, a, res, gamma, beta, out, M, d, score_w, score_b, num_classes, sigmoid, scores, (unsigned short *)out16); break;
-        case 3: hipLaunchKernelGGL(rows_res_ln<3>, grid, dim3(256), 0, st, a, res, gamma, beta, out, M, d, score_w, score_b, num_classes, sigmoid, scores, (unsigned short *)out16); break;
-        default: hipLaunchKernelGGL(rows_res_ln<4>, grid, dim3(256), 0, st, a, res, gamma, beta, out, M, d, score_w, score_b, num_classes, sigmoid, scores, (unsigned short *)out16); break;
+        case 1: hipLaunchKernelGGL(rows_res_ln<1>, grid, dim3(256), 0, st, a, res, gamma, beta, out, M, d, score_w, score_b, num_classes, sigmoid, scores, (unsigned short *)out16, dn); break;
+        case 2: hipLaunchKernelGGL(rows_res_ln<2>, grid, dim3(256), 0, st, a, res, gamma, beta, out, M, d, score_w, score_b, num_classes, sigmoid, scores, (unsigned short *)out16, dn); break;
+        case 3: hipLaunchKernelGGL(rows_res_ln<3>, grid, dim3(256), 0, st, a, res, gamma, beta, out, M, d, score_w, score_b, num_classes, sigmoid, scores, (unsigned short *)out16, dn); break;
+        default: hipLaunchKernelGGL(rows_res_ln<4>, grid, dim3(256), 0, st, a, res, gamma, beta, out, M, d, score_w, score_b, num_classes, sigmoid, scores, (unsigned short *)out16, dn); break;
     }
     VSK_CHECK_LAUNCH();
     return 0;

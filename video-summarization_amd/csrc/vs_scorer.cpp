@@ -346,6 +346,14 @@ int vs_weights_update(vs_weights *w, const vs_model_params *params, void *stream
     return rc;
 }
 
+int vs_weights_set_norm_width(vs_weights *w, int32_t norm_width) {
+    if (!w) return fail(VS_ERR_INVALID, "weights is NULL");
+    if (norm_width <= 0 || norm_width % 4 || norm_width > w->desc.d_model)
+        return fail(VS_ERR_INVALID, "norm_width=%d unsupported (multiple of 4, 0 < norm_width <= d_model = %d)", norm_width, w->desc.d_model);
+    w->norm_width = norm_width;
+    return VS_OK;
+}
+
 void vs_weights_free(vs_weights *w) {
     if (!w) return;
     if (w->blob) (void)hipFree(w->blob);
@@ -407,7 +415,9 @@ int forward_core(const vs_weights *w, const float *x, const uint8_t *key_pad_mas
     const size_t md = align_up((size_t)M * d * sizeof(float), 256) / sizeof(float);
     float *ws = (float *)workspace;
     float *h0 = ws, *h1 = ws + md, *qkv = ws + 2 * md, *att = ws + 5 * md, *ffn = ws + 6 * md;
-    const float scale = 1.0f / sqrtf((float)d);        // reference simnet.py:126: d_model ** -0.5
+    const int dn = w->dn();                             // LayerNorm width / the d_model of the attention scale (== d unless embedded)
+    const bool embedded = w->embedded();
+    const float scale = 1.0f / sqrtf((float)dn);       // reference simnet.py:126: d_model ** -0.5
     const int sig = (flags & VS_FLAG_SIGMOID) ? 1 : 0;
     // bf16 Linear kernels exist as LDS-tiled throughput kernels only: up to 8192 rows (measured crossover) the exact
     // fp32 latency kernels are faster and are used whatever that flag says.  fp16x3 has its own latency kernels
@@ -416,7 +426,7 @@ int forward_core(const vs_weights *w, const float *x, const uint8_t *key_pad_mas
     // vs_mlp_fused.hip apply - d_model 256 with bf16 attention - they win from a single T=320 video on (128-row tiles on
     // 4-wave blocks below half a chip of 256-row tiles: 0.36 ms at 320 rows, 0.43 ms from 1k to 8k rows): 256 rows)
     const VskOptions &opt = vsk_options();
-    const bool fused_ok = vsk_mlp_bf16_supported(d) && (pk ? pk->prec == 1 : (flags & VS_FLAG_BF16_ATTENTION) != 0) &&
+    const bool fused_ok = !embedded && vsk_mlp_bf16_supported(d) && (pk ? pk->prec == 1 : (flags & VS_FLAG_BF16_ATTENTION) != 0) &&
                           !opt.lp_store32 && !opt.lp_mlp_unfused && !opt.attn_lp_simple;
     const int lp_min_rows = fused_ok && opt.lp_min_rows_fused < opt.lp_min_rows ? opt.lp_min_rows_fused
                                                                                : opt.lp_min_rows;    // tests / tools pin the bf16 tiled kernels with 0
@@ -435,9 +445,9 @@ int forward_core(const vs_weights *w, const float *x, const uint8_t *key_pad_mas
     const int aprec = pk ? pk->prec : (flags & VS_FLAG_F16X3_ATTENTION) ? 2 : (flags & VS_FLAG_BF16_ATTENTION) ? 1 : 0;
     // (d_model > 256 - M-B and wider - has no bf16-storage consumers: its LayerNorm GEMMs are the plain bf16 GEMM + the
     // row pass, which read fp32, and the head-dim-128 attention reads fp32 q / k / v: fp32 storage there)
-    const bool qkv16 = lbf == 1 && aprec == 1 && d <= 256 && !vsk_options().lp_store32 && !vsk_options().attn_lp_simple;
-    const bool ffn16 = lbf == 1 && d <= 256 && !vsk_options().lp_store32;
-    const bool mlp16 = lbf == 1 && vsk_mlp_bf16_supported(d) && !vsk_options().lp_mlp_unfused && !vsk_options().lp_store32;
+    const bool qkv16 = lbf == 1 && aprec == 1 && d <= 256 && !embedded && !vsk_options().lp_store32 && !vsk_options().attn_lp_simple;
+    const bool ffn16 = lbf == 1 && d <= 256 && !embedded && !vsk_options().lp_store32;
+    const bool mlp16 = lbf == 1 && !embedded && vsk_mlp_bf16_supported(d) && !vsk_options().lp_mlp_unfused && !vsk_options().lp_store32;
     // d_model > 256 in bf16 mode with a bf16 attention: the bf16-OPERAND GEMM (vs_gemm_ring.hip).  Every Linear after the
     // embedding reads bf16 from HBM: q/k/v, the attention output and the MLP hidden tensor are written as bf16 by their
     // producers, and the two LayerNorm passes write a bf16 copy of their rows beside the fp32 residual stream.
@@ -490,7 +500,7 @@ int forward_core(const vs_weights *w, const float *x, const uint8_t *key_pad_mas
             {   // out-projection (bf16 attention output in, fp32 out into the q region, free by now) + norm1 -> h1 (+ bf16 copy)
                 StageScope ps(VS_STAGE_OUTPROJ_LN, st);
                 VS_LAUNCH(vsk_gemm16(att, w->p(P.r_wo), w->p(P.bo), qkv, M, d, d, 0, 0, 1, 0, 0, 1.0f, st));
-                VS_LAUNCH(vsk_rows_res_ln(qkv, h0, w->p(P.ln1g), w->p(P.ln1b), h1, M, d, nullptr, nullptr, 0, 0, nullptr, st, h16));
+                VS_LAUNCH(vsk_rows_res_ln(qkv, h0, w->p(P.ln1g), w->p(P.ln1b), h1, M, d, nullptr, nullptr, 0, 0, nullptr, st, h16, dn));
             }
             {
                 StageScope ps(VS_STAGE_FC1, st);
@@ -501,7 +511,7 @@ int forward_core(const vs_weights *w, const float *x, const uint8_t *key_pad_mas
                 VS_LAUNCH(vsk_gemm16(ffn, w->p(P.r_w2), w->p(P.b2), att, M, d, 4 * d, 0, 0, 1, 0, 0, 1.0f, st));
                 VS_LAUNCH(vsk_rows_res_ln(att, h1, w->p(P.ln2g), w->p(P.ln2b), dst, M, d, last ? w->p(w->final_w) : nullptr,
                                           last ? w->p(w->final_b) : nullptr, D.num_classes, sig, last ? scores : nullptr, st,
-                                          last ? nullptr : h16));
+                                          last ? nullptr : h16, dn));
             }
             continue;
         }
@@ -542,12 +552,12 @@ int forward_core(const vs_weights *w, const float *x, const uint8_t *key_pad_mas
         have_qkv = false;
         // d_model > 256: plain GEMM + the row LayerNorm pass (faster than the fused wide kernel at every M; the
         // GEMM's output goes to a region of the workspace that is free at that point: q after the attention, att after fc1)
-        const bool split_ln = d > 256;
+        const bool split_ln = d > 256 || embedded;      // (an embedded model's LayerNorm width is not d: the row pass knows it)
         {
             StageScope ps(VS_STAGE_OUTPROJ_LN, st);
             if (split_ln) {
                 VS_LAUNCH(vsk_linear(att, w->p(P.wo), w->p(lnbf == 2 ? P.h_wo : P.f_wo), w->p(P.bo), qkv, M, d, d, 0, nullptr, 1, lnbf, st));
-                VS_LAUNCH(vsk_rows_res_ln(qkv, h0, w->p(P.ln1g), w->p(P.ln1b), h1, M, d, nullptr, nullptr, 0, 0, nullptr, st));
+                VS_LAUNCH(vsk_rows_res_ln(qkv, h0, w->p(P.ln1g), w->p(P.ln1b), h1, M, d, nullptr, nullptr, 0, 0, nullptr, st, nullptr, dn));
             } else
             VS_LAUNCH(vsk_linear_res_ln(att, w->p(P.wo), w->p(lnbf == 2 ? P.h_wo : P.f_wo), w->p(P.bo), h0, w->p(P.ln1g), w->p(P.ln1b), h1, M, d, d,
                                         nullptr, nullptr, 0, 0, nullptr, qkv16 ? (1 | VSK_STORE16) : lnbf, st));
@@ -584,7 +594,7 @@ int forward_core(const vs_weights *w, const float *x, const uint8_t *key_pad_mas
             StageScope ps(VS_STAGE_FC2_LN, st);
             VS_LAUNCH(vsk_linear(ffn, w->p(P.w2), w->p(lnbf == 2 ? P.h_w2 : P.f_w2), w->p(P.b2), att, M, d, 4 * d, 0, nullptr, 1, lnbf, st));
             VS_LAUNCH(vsk_rows_res_ln(att, h1, w->p(P.ln2g), w->p(P.ln2b), dst, M, d, last ? w->p(w->final_w) : nullptr,
-                                      last ? w->p(w->final_b) : nullptr, D.num_classes, sig, last ? scores : nullptr, st));
+                                      last ? w->p(w->final_b) : nullptr, D.num_classes, sig, last ? scores : nullptr, st, nullptr, dn));
         } else {
             StageScope ps(VS_STAGE_FC2_LN, st);
             VS_LAUNCH(vsk_linear_res_ln(ffn, w->p(P.w2), w->p(lnbf == 2 ? P.h_w2 : P.f_w2), w->p(P.b2), h1, w->p(P.ln2g), w->p(P.ln2b), dst, M, d,
@@ -619,11 +629,11 @@ int vs_scorer_forward_cls(const vs_weights *w, const float *x, const uint8_t *ke
 
 // ---- packed ragged batches ----
 static int packed_plan(const vs_weights *w, const int32_t *lengths, int32_t B, std::vector<int> &cu,
-                       std::vector<int> &work, int &nw, bool narrow_only = false) {
+                       std::vector<int> &work, int &nw, bool narrow_only = false, bool wide_only = false) {
     if (!w || !lengths || B <= 0) return fail(VS_ERR_INVALID, "weights/lengths is NULL or B=%d", B);
     const vs_model_desc &D = w->desc;
     const int dh = D.d_model / D.num_heads;
-    if (dh != 32 && dh != 64) return fail(VS_ERR_INVALID, "packed batches need head_dim 32 or 64 (got %d)", dh);
+    if (dh != 32 && dh != 64 && dh != 128) return fail(VS_ERR_INVALID, "packed batches need head_dim 32, 64 or 128 (got %d)", dh);
     cu.assign(B + 1, 0);
     long long r8 = 0, r4 = 0;
     for (int b = 0; b < B; ++b) {
@@ -637,6 +647,7 @@ static int packed_plan(const vs_weights *w, const int32_t *lengths, int32_t B, s
         r4 += (t + 127) / 128 * 128;
     }
     nw = (!narrow_only && r8 * 100 <= r4 * 105) ? 8 : 4;     // 256-row query tiles unless the ragged tails waste too much
+    if (dh == 128) nw = wide_only ? 8 : 4;                   // head dim 128 (round 4): the exact kernel has 4-wave blocks, the bf16 one 8-wave blocks only
     const int qb = 32 * nw;
     work.clear();
     for (int b = 0; b < B; ++b)
@@ -672,7 +683,9 @@ int vs_scorer_forward_packed(const vs_weights *w, const float *x, const int32_t 
     std::vector<int> cu, work;
     int nw = 0;
     // (the low-precision attention has no 8-wave form for head dim 32)
-    if (int rc = packed_plan(w, lengths, B, cu, work, nw, aprec != 0 && w->desc.d_model / w->desc.num_heads == 32)) return rc;
+    if (aprec == 2 && w->desc.d_model / w->desc.num_heads == 128)
+        return fail(VS_ERR_INVALID, "VS_FLAG_F16X3_ATTENTION needs head_dim 32 or 64 (got 128)");
+    if (int rc = packed_plan(w, lengths, B, cu, work, nw, aprec != 0 && w->desc.d_model / w->desc.num_heads == 32, aprec == 1)) return rc;
     const size_t need = vs_scorer_workspace_bytes_packed(w, lengths, B);
     if (!workspace || workspace_bytes < need)
         return fail(VS_ERR_WORKSPACE, "workspace %zu bytes < %zu needed", workspace_bytes, need);

@@ -260,7 +260,8 @@ int vs_train_forward(const vs_weights *w, const float *x, const uint8_t *key_pad
     const bool lpa = form.lpa, qkv16 = form.qkv16, h16 = form.h16, rows16 = form.rows16;
     const size_t kvs = qkv16 ? (size_t)B * T * w->desc.d_model / 2 : (size_t)B * T * w->desc.d_model;     // floats between the planes
     const unsigned long long seed = drop ? drop->seed : 0ull;
-    const float scale = 1.0f / sqrtf((float)d);              // simnet.py:126: d_model ** -0.5
+    const int dn = w->dn();                                   // LayerNorm width / attention-scale d_model (== d unless embedded)
+    const float scale = 1.0f / sqrtf((float)dn);             // simnet.py:126: d_model ** -0.5
     float *sv = (float *)saved, *ws = (float *)workspace;
     float *a = ws + W.a;
 
@@ -297,7 +298,7 @@ int vs_train_forward(const vs_weights *w, const float *x, const uint8_t *key_pad
                                      sv + A.lse, B, H, T, d / H, scale, seed, VS_SITE_LAYER(l, VS_SITE_ATTN), p, st, dbits));   // :155-161
         VST_LAUNCH(vsk_linear(sv + A.att, w->p(P.wo), w->p(P.f_wo), w->p(P.bo), a, M, d, d, 0, nullptr, 1, lp, st));      // :163
         VST_LAUNCH(vst_rows_fwd(a, h_in, w->p(P.ln1g), w->p(P.ln1b), sv + A.z1, sv + A.y1, nullptr, sv + A.st1, M, d,
-                                seed, VS_SITE_LAYER(l, VS_SITE_DROP1), p, nullptr, nullptr, 0, nullptr, st));              // :107
+                                seed, VS_SITE_LAYER(l, VS_SITE_DROP1), p, nullptr, nullptr, 0, nullptr, st, dn));              // :107
         // bf16 GEMMs: the MLP hidden tensor (post ReLU, post dropout) is only ever a matrix operand or a sign - it is written
         // and saved as bf16 (h16), and fc2, its weight gradient and the backward's gate read it as such
         if (rows16)         // K = d_model = 256: the A-stationary form (vs_train_gemm_rows.hip), bit-identical to the tiled one
@@ -313,7 +314,7 @@ int vs_train_forward(const vs_weights *w, const float *x, const uint8_t *key_pad
         VST_LAUNCH(vst_rows_fwd(a, sv + A.y1, w->p(P.ln2g), w->p(P.ln2b), sv + A.z2, sv + A.y2, last ? hidden : nullptr,
                                 sv + A.st2, M, d, seed, VS_SITE_LAYER(l, VS_SITE_DROP2), p,
                                 last ? w->p(w->final_w) : nullptr, last ? w->p(w->final_b) : nullptr, D.num_classes,
-                                last ? scores : nullptr, st));                                                              // :110, :42
+                                last ? scores : nullptr, st, dn));                                                              // :110, :42
         h_in = sv + A.y2;
     }
     return VS_OK;
@@ -359,7 +360,8 @@ int vs_train_backward(vs_weights *w, const float *x, const uint8_t *key_pad_mask
     const bool lpa = form.lpa, qkv16 = form.qkv16, h16 = form.h16, rows16 = form.rows16;
     const size_t kvs = qkv16 ? (size_t)B * T * w->desc.d_model / 2 : (size_t)B * T * w->desc.d_model;     // floats between the planes
     const unsigned long long seed = drop ? drop->seed : 0ull;
-    const float scale = 1.0f / sqrtf((float)d);
+    const int dn = w->dn();
+    const float scale = 1.0f / sqrtf((float)dn);
     const float *sv = (const float *)saved;
     float *ws = (float *)workspace;
     float *g[2] = {ws + W.g0, ws + W.g1};
@@ -393,7 +395,7 @@ int vs_train_backward(vs_weights *w, const float *x, const uint8_t *key_pad_mask
         const float *h_in = l == 0 ? sv + S.h0 : sv + S.layers[l - 1].y2;
         // norm2 (+ the score head's pull on the last layer); d(fc2 output) = dropout2 mask on dz2
         VST_LAUNCH(vst_ln_bwd(last ? d_hidden : g[cur], last ? d_scores : nullptr, w->p(w->final_w), nc, sv + A.z2, sv + A.st2,
-                              w->p(P.ln2g), dz, p > 0.f ? dbr : nullptr, part, M, d, seed, VS_SITE_LAYER(l, VS_SITE_DROP2), p, st));
+                              w->p(P.ln2g), dz, p > 0.f ? dbr : nullptr, part, M, d, seed, VS_SITE_LAYER(l, VS_SITE_DROP2), p, st, dn));
         VST_LAUNCH(vst_reduce_rows(part, nblk, 2, d, G.ln2_g, G.ln2_b, nullptr, 1, st));
         const float *dm = p > 0.f ? dbr : dz;
         // mlp.fc2: weight/bias gradient, then the gradient of its input
@@ -415,7 +417,7 @@ int vs_train_backward(vs_weights *w, const float *x, const uint8_t *key_pad_mask
         VST_LAUNCH(vsk_linear(gf, w->tp(Q.t_w1), w->tp(Q.tf_w1), zeros, dy1, M, d, 4 * d, 0, dz, M, h16 ? (1 | VSK_A16 | F) : lp, st));
         // norm1; d(feature_projection output) = dropout1 mask on dz1
         VST_LAUNCH(vst_ln_bwd(dy1, nullptr, nullptr, 0, sv + A.z1, sv + A.st1, w->p(P.ln1g), dz, p > 0.f ? dbr : nullptr, part,
-                              M, d, seed, VS_SITE_LAYER(l, VS_SITE_DROP1), p, st));
+                              M, d, seed, VS_SITE_LAYER(l, VS_SITE_DROP1), p, st, dn));
         VST_LAUNCH(vst_reduce_rows(part, nblk, 2, d, G.ln1_g, G.ln1_b, nullptr, 1, st));
         const float *da = p > 0.f ? dbr : dz;
         VST_LAUNCH(vst_wgrad(da, d, sv + A.att, d, M, d, d, G.wo, nullptr, nullptr, G.bo, nullptr, nullptr, d, wg, st, lp));

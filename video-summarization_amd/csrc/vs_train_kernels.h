@@ -12,13 +12,13 @@
 // optional score head scores[row, c] = y . score_w[c] + score_b[c]
 int vst_rows_fwd(const float *a, const float *res, const float *gamma, const float *beta, float *z, float *y,
                  float *y_copy, float *stats, int M, int d, unsigned long long seed, unsigned site, float p,
-                 const float *score_w, const float *score_b, int num_classes, float *scores, hipStream_t st);
+                 const float *score_w, const float *score_b, int num_classes, float *scores, hipStream_t st, int dn = 0);   // dn: LayerNorm width of an embedded model (0: d)
 // LayerNorm backward; part = [vst_ln_bwd_blocks(M)][2][d] partial (d_gamma, d_beta); dbranch (optional) = forward
 // dropout mask applied to dz; dy may be NULL (zero) and dsc/score_w add the score head's contribution
 int vst_ln_bwd_blocks(int M);
 int vst_ln_bwd(const float *dy, const float *dsc, const float *score_w, int num_classes, const float *z,
                const float *stats, const float *gamma, float *dz, float *dbranch, float *part, int M, int d,
-               unsigned long long seed, unsigned site, float p, hipStream_t st);
+               unsigned long long seed, unsigned site, float p, hipStream_t st, int dn = 0);
 int vst_dropout_rows(float *x, int M, int cols, unsigned long long seed, unsigned site, float p, hipStream_t st);
 int vst_gate_bwd(float *g, const float *act, size_t n, float scale, hipStream_t st);
 int vst_head_rowdot(const float *dO, const float *O, float *delta, int M, int T, int H, int dh, hipStream_t st, int do16 = 0);      // do16 1: dO stored as bf16; 2: fp32 dO rounded to bf16 in the dot

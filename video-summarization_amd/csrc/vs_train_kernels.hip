@@ -32,7 +32,8 @@ __global__ __launch_bounds__(256) void train_rows_fwd(
     const float *__restrict__ beta, float *__restrict__ z, float *__restrict__ y, float *__restrict__ y_copy,
     float *__restrict__ stats, int M, int d, unsigned long long seed, unsigned site, float p,
     const float *__restrict__ score_w, const float *__restrict__ score_b, int num_classes,
-    float *__restrict__ scores) {
+    float *__restrict__ scores, int dn) {
+    // dn: the LayerNorm width (== d unless the model is embedded in a wider shape: columns dn .. d-1 are identically zero)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const DropSite ds = drop_site(seed, site, p);
     for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
@@ -55,17 +56,17 @@ __global__ __launch_bounds__(256) void train_rows_fwd(
                 s += v[u][0] + v[u][1] + v[u][2] + v[u][3];
             }
         }
-        const float mean = wave_sum(s) / (float)d;
+        const float mean = wave_sum(s) / (float)dn;
         float s2 = 0.f;
 #pragma unroll
         for (int u = 0; u < NV; ++u) {
             const int c = 4 * lane + 256 * u;
-            if (c < d) {
+            if (c < dn) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { const float t = v[u][e] - mean; s2 += t * t; }
             }
         }
-        const float rstd = 1.0f / sqrtf(wave_sum(s2) / (float)d + LN_EPS);
+        const float rstd = 1.0f / sqrtf(wave_sum(s2) / (float)dn + LN_EPS);
         if (lane == 0) { stats[2 * (size_t)row] = mean; stats[2 * (size_t)row + 1] = rstd; }
 #pragma unroll
         for (int u = 0; u < NV; ++u) {
@@ -105,7 +106,8 @@ __global__ __launch_bounds__(256) void ln_bwd_rows(
     const float *__restrict__ dy, const float *__restrict__ dsc, const float *__restrict__ score_w, int num_classes,
     const float *__restrict__ z, const float *__restrict__ stats, const float *__restrict__ gamma,
     float *__restrict__ dz, float *__restrict__ dbranch, float *__restrict__ part, int M, int d,
-    unsigned long long seed, unsigned site, float p) {
+    unsigned long long seed, unsigned site, float p, int dn) {
+    // dn: the LayerNorm width (see train_rows_fwd); columns dn .. d-1 carry gamma = 0 and get a zero gradient
     __shared__ float red[4][2][256 * NV];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const DropSite ds = drop_site(seed, site, p);
@@ -145,7 +147,7 @@ __global__ __launch_bounds__(256) void ln_bwd_rows(
                 }
             }
         }
-        const float m1 = wave_sum(s1) / (float)d, m2 = wave_sum(s2) / (float)d;
+        const float m1 = wave_sum(s1) / (float)dn, m2 = wave_sum(s2) / (float)dn;
         const unsigned rk = drop_rowkey(ds, (unsigned)row);
 #pragma unroll
         for (int u = 0; u < NV; ++u) {
@@ -153,7 +155,7 @@ __global__ __launch_bounds__(256) void ln_bwd_rows(
             if (c < d) {
                 f32x4 o;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = rstd * (g[u][e] - m1 - xh[u][e] * m2);
+                for (int e = 0; e < 4; ++e) o[e] = c < dn ? rstd * (g[u][e] - m1 - xh[u][e] * m2) : 0.f;
                 *(f32x4 *)(dz + (size_t)row * d + c) = o;
                 if (dbranch != nullptr) {
 #pragma unroll
@@ -701,11 +703,13 @@ int row_grid(int M) { const int b = (M + 3) / 4; return b < 512 ? (b < 1 ? 1 : b
 
 int vst_rows_fwd(const float *a, const float *res, const float *gamma, const float *beta, float *z, float *y,
                  float *y_copy, float *stats, int M, int d, unsigned long long seed, unsigned site, float p,
-                 const float *score_w, const float *score_b, int num_classes, float *scores, hipStream_t st) {
+                 const float *score_w, const float *score_b, int num_classes, float *scores, hipStream_t st, int dn) {
     if (d % 4 || d > 1024) return -1;
+    if (dn <= 0) dn = d;
+    if (dn % 4 || dn > d) return -1;
     const dim3 grid((M + 3) / 4 < 4096 ? (M + 3) / 4 : 4096);
     VST_NV_DISPATCH(d, train_rows_fwd, grid, dim3(256), 0, st, a, res, gamma, beta, z, y, y_copy, stats, M, d, seed, site, p,
-                    score_w, score_b, num_classes, scores);
+                    score_w, score_b, num_classes, scores, dn);
     VSK_CHECK_LAUNCH();
     return 0;
 }
@@ -714,11 +718,13 @@ int vst_ln_bwd_blocks(int M) { return row_grid(M); }
 
 int vst_ln_bwd(const float *dy, const float *dsc, const float *score_w, int num_classes, const float *z,
                const float *stats, const float *gamma, float *dz, float *dbranch, float *part, int M, int d,
-               unsigned long long seed, unsigned site, float p, hipStream_t st) {
+               unsigned long long seed, unsigned site, float p, hipStream_t st, int dn) {
     if (d % 4 || d > 1024) return -1;
+    if (dn <= 0) dn = d;
+    if (dn % 4 || dn > d) return -1;
     const dim3 grid(row_grid(M));
     VST_NV_DISPATCH(d, ln_bwd_rows, grid, dim3(256), 0, st, dy, dsc, score_w, num_classes, z, stats, gamma, dz, dbranch, part,
-                    M, d, seed, site, p);
+                    M, d, seed, site, p, dn);
     VSK_CHECK_LAUNCH();
     return 0;
 }

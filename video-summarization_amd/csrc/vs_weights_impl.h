@@ -34,6 +34,9 @@ struct vs_weights {
     size_t b_embed = 0;           // W_embed as the LDS images of the bf16 embedding kernel (vsk_pack_embed_bf16), if supported
     bool has_b_embed = false;
     bool has_pe = false;
+    int norm_width = 0;           // vs_weights_set_norm_width: true d_model of a model embedded in this (wider) shape; 0 = desc.d_model
+    int dn() const { return norm_width > 0 ? norm_width : desc.d_model; }
+    bool embedded() const { return norm_width > 0 && norm_width != desc.d_model; }
     std::vector<LayerOff> layers;
     const float *p(size_t off) const { return blob + off; }
     // Kernel-layout IMAGES of the parameters, one version stamp per family: built by vsw_ensure() when a forward that

@@ -386,7 +386,7 @@ def val_step_from_dataset(model, dataset: TSDataset, device, max_frames: int = 6
     import torch.nn.functional as F
     from .evaluation import eval_metrics
     model.eval()
-    if model.d_model // model.num_heads not in (32, 64):
+    if getattr(model, "_lib_dh", model.d_model // model.num_heads) not in (32, 64, 128):
         raise RuntimeError("packed scoring needs head dim 32 or 64; use harness.val_step for this model")
     scores = score_dataset(model, dataset.data, device, max_frames)
     score_dict, user_dict, loss = {}, {}, 0.0

@@ -57,7 +57,7 @@ def val_step_batched(model, features: Sequence[torch.Tensor], targets: Sequence[
     """Same result as ``val_step`` over (features[i] [T_i,1024], targets[i] [T_i], users[i])."""
     model.eval()
     # models with head dim 32 / 64 score PACKED batches (no sentinel padding, no mask; the same bits)
-    can_pack = hasattr(model, "score_packed") and model.d_model // model.num_heads in (32, 64)
+    can_pack = hasattr(model, "score_packed") and getattr(model, "_lib_dh", model.d_model // model.num_heads) in (32, 64, 128)
     scores = score_corpus(lambda x, m: model.score(x, m), list(features), rank=rank, world=world, group=group,
                           device=device, max_frames=max_frames,
                           packed_fn=(lambda x, lens: model.score_packed(x, lens)) if can_pack else None)

@@ -128,7 +128,7 @@ class _TrainForward(torch.autograd.Function):
             m = m.view(torch.uint8) if m.dtype == torch.bool else m.to(torch.uint8)
         packed = module._packed_weights(x.device)
         scores = torch.empty((B, T, module.num_classes), dtype=torch.float32, device=x.device)
-        hidden = torch.empty((B, T, module.d_model), dtype=torch.float32, device=x.device)
+        hidden = torch.empty((B, T, module._lib_d), dtype=torch.float32, device=x.device)
         cfg = _lib.DropoutCfg(float(p_embed), float(p), int(seed), int(tflags), 0)
         with torch.cuda.device(x.device):
             if not getattr(packed, "train_prepared", False):     # one-time allocation of the dgrad transposes, outside the backward
@@ -145,7 +145,7 @@ class _TrainForward(torch.autograd.Function):
         ctx.module, ctx.cfg, ctx.packed, ctx.packed_key = module, (float(p_embed), float(p), int(seed), int(tflags), fmt), packed, module._packed_key
         module._note_train_arithmetic(int(tflags), fmt, B * T)
         ctx.set_materialize_grads(False)
-        return scores, hidden
+        return scores, (hidden[..., :module.d_model] if module._plan else hidden)
 
     @staticmethod
     @torch.amp.custom_bwd(device_type="cuda")
@@ -158,12 +158,16 @@ class _TrainForward(torch.autograd.Function):
         B, T, _ = x.shape
         params = [t for t in module._tensors() if isinstance(t, nn.Parameter)]
         # ONE allocation for every gradient, viewed per parameter (was ~70 torch.empty_like per backward)
-        sizes = [t.numel() for t in params]
+        axes = [ax for t, ax in zip(module._tensors(), module._tensor_axes()) if isinstance(t, nn.Parameter)]
+        shapes = [t.shape for t in params]
+        if module._plan:      # embedded model: the library writes gradients of ITS shape; the true-shaped parts go back
+            shapes = [module._padded_shape(t.shape, ax) for t, ax in zip(params, axes)]
+        sizes = [int(torch.Size(sh).numel()) for sh in shapes]
         offs = [0]
         for n_ in sizes:
             offs.append(offs[-1] + (n_ + 63) // 64 * 64)          # 256-byte aligned views
         flat = torch.empty((offs[-1],), dtype=torch.float32, device=x.device)
-        grads = [flat[o: o + n_].view(t.shape) for o, n_, t in zip(offs, sizes, params)]
+        grads = [flat[o: o + n_].view(sh) for o, n_, sh in zip(offs, sizes, shapes)]
         it = iter(grads)
         G = _lib.ModelGrads()
         G.embed_w, G.embed_b = next(it).data_ptr(), next(it).data_ptr()
@@ -177,6 +181,8 @@ class _TrainForward(torch.autograd.Function):
         dx = torch.empty_like(x) if ctx.needs_input_grad[1] else None
         ds = None if d_scores is None else d_scores.contiguous().float()
         dh = None if d_hidden is None else d_hidden.contiguous().float()
+        if dh is not None and module._plan:
+            dh = module._pad(dh, ("res",)).contiguous()
         cfg = _lib.DropoutCfg(*ctx.cfg)
         with torch.cuda.device(x.device):
             ws = torch.empty((lib.vs_train_workspace_bytes(packed.handle, B, T),), dtype=torch.uint8, device=x.device)
@@ -184,8 +190,33 @@ class _TrainForward(torch.autograd.Function):
             _lib.check(lib.vs_train_backward(packed.handle, x.data_ptr(), _ptr(m), B, T, C.byref(cfg), _ptr(ds), _ptr(dh),
                                              saved.data_ptr(), saved.numel(), C.byref(G), _ptr(dx), ws.data_ptr(),
                                              ws.numel(), stream))
+        if module._plan:
+            grads = [module._unpad(g, ax).contiguous() for g, ax in zip(grads, axes)]
         out = [g if t.requires_grad else None for g, t in zip(grads, params)]
         return (None, dx, None, None, None, None, None, *out)
+
+
+# --------------------------------------------------------------------------------------------
+# shapes outside the kernels' envelope: the model EMBEDDED in the next supported shape (include/vs_scorer.h,
+# vs_weights_set_norm_width)
+# --------------------------------------------------------------------------------------------
+
+
+def embedding_plan(d_model: int, num_heads: int) -> Optional[Tuple[int, int]]:
+    """The reference accepts any ``d_model % num_heads == 0`` (simnet.py:123); the kernels take d_model % 64 == 0 (<= 1024)
+    with head dim 32 / 64 / 128.  Returns None for such a shape, else ``(d_lib, dh_lib)``: the narrowest supported shape
+    with the same number of heads that holds the model when its parameters are zero-padded - mathematically the same
+    function once LayerNorm and the attention scale use the true d_model, which the library is told
+    (``vs_weights_set_norm_width``)."""
+    dh = d_model // num_heads
+    if d_model % 64 == 0 and d_model <= 1024 and dh in (32, 64, 128):
+        return None
+    if d_model % 4 == 0:
+        for dhp in (32, 64, 128):
+            if dhp >= dh and (num_heads * dhp) % 64 == 0 and num_heads * dhp <= 1024:
+                return num_heads * dhp, dhp
+    raise NotImplementedError("SimNet(d_model=%d, num_heads=%d): supported are d_model %% 4 == 0 with head dim <= 128 and "
+                              "num_heads * (head dim rounded up to 32 / 64 / 128) <= 1024" % (d_model, num_heads))
 
 
 # --------------------------------------------------------------------------------------------
@@ -234,6 +265,16 @@ class SimNet(nn.Module):
         self.num_classes, self.in_features = num_classes, in_features            # simnet.py:22
         self.pe_len = pe_len
         self.use_pos, self.drop_rate = use_pos, dropout
+        # the shape the kernels run: the model's own, or the supported shape it is embedded in (zero-padded parameters)
+        # (a shape that fits neither still constructs - its state_dict is the reference's - and raises when it is run)
+        self._plan_error = None
+        try:
+            self._plan = embedding_plan(d_model, num_heads)
+        except NotImplementedError as exc:
+            self._plan, self._plan_error = None, exc
+        self._lib_d = self._plan[0] if self._plan else d_model
+        self._lib_dh = self._plan[1] if self._plan else d_model // num_heads
+        self._pad_index = {}              # device -> index vectors of the padding maps
 
         emb = dict(feature_transform=nn.Linear(self.in_features, d_model))
         if use_pos:
@@ -287,9 +328,82 @@ class SimNet(nn.Module):
         yield self.final_layer.weight
         yield self.final_layer.bias
 
+    # ---- embedding in a supported shape (self._plan) -----------------------------------------
+    def _tensor_axes(self):
+        """(rows, cols) axis kinds of every tensor of ``_tensors()``: 'res' residual-stream feature c -> c, 'head' feature
+        (h, j) -> h * dh_lib + j, 'hid' the MLP's hidden axis (c -> c of 4 d_lib), None an axis that is not padded."""
+        yield ("res", None)                                   # embed_w [d, in]
+        yield ("res",)                                        # embed_b
+        if self.use_pos:
+            yield (None, "res")                               # pos_embedding [.., L, d]: last axis
+        for _ in range(self.num_layers):
+            for _qkv in range(3):
+                yield ("head", "res")
+                yield ("head",)
+            yield ("res", "head")                             # feature_projection [d, d]
+            yield ("res",)
+            yield ("res",)
+            yield ("res",)                                    # norm1
+            yield ("hid", "res")
+            yield ("hid",)                                    # fc1
+            yield ("res", "hid")
+            yield ("res",)                                    # fc2
+            yield ("res",)
+            yield ("res",)                                    # norm2
+        yield (None, "res")                                   # final_layer.weight [nc, d]
+        yield (None,)                                         # final_layer.bias
+
+    def _axis(self, kind: Optional[str], device: torch.device):
+        """(index vector of the true features inside the padded axis, padded length) - None for an unpadded axis"""
+        if kind is None:
+            return None
+        tab = self._pad_index.get(device)
+        if tab is None:
+            d, H = self.d_model, self.num_heads
+            c = torch.arange(d, device=device)
+            tab = {"res": (c, self._lib_d), "head": ((c // (d // H)) * self._lib_dh + c % (d // H), self._lib_d),
+                   "hid": (torch.arange(4 * d, device=device), 4 * self._lib_d)}
+            self._pad_index[device] = tab
+        return tab[kind]
+
+    def _padded_shape(self, shape, axes):
+        size = {"res": self._lib_d, "head": self._lib_d, "hid": 4 * self._lib_d}
+        tail = tuple(size[k] if k else n for n, k in zip(shape[len(shape) - len(axes):], axes))
+        return tuple(shape[:len(shape) - len(axes)]) + tail
+
+    def _pad(self, t: Tensor, axes) -> Tensor:
+        """t (true shape) -> zero-padded tensor of the library's shape; the last len(axes) dims are mapped"""
+        if len(axes) == 1:
+            ax = self._axis(axes[0], t.device)
+            if ax is None:
+                return t
+            out = t.new_zeros(t.shape[:-1] + (ax[1],))
+            out[..., ax[0]] = t
+            return out
+        r, c = self._axis(axes[0], t.device), self._axis(axes[1], t.device)
+        R = r[1] if r else t.shape[-2]
+        Cc = c[1] if c else t.shape[-1]
+        out = t.new_zeros(t.shape[:-2] + (R, Cc))
+        ri = r[0] if r else torch.arange(t.shape[-2], device=t.device)
+        ci = c[0] if c else torch.arange(t.shape[-1], device=t.device)
+        out[..., ri[:, None], ci[None, :]] = t
+        return out
+
+    def _unpad(self, g: Tensor, axes) -> Tensor:
+        """the true-shaped part of a padded tensor (a gradient written by the library in its own shape)"""
+        if len(axes) == 1:
+            ax = self._axis(axes[0], g.device)
+            return g if ax is None else g[..., ax[0]]
+        r, c = self._axis(axes[0], g.device), self._axis(axes[1], g.device)
+        ri = r[0] if r else torch.arange(g.shape[-2], device=g.device)
+        ci = c[0] if c else torch.arange(g.shape[-1], device=g.device)
+        return g[..., ri[:, None], ci[None, :]]
+
     def _packed_weights(self, device: torch.device) -> _Packed:
         """vs_weights* for the current parameter values; re-packed whenever any parameter was
         written (optimizer step, load_state_dict, .to()) — detected by (data_ptr, _version)."""
+        if self._plan_error is not None:
+            raise self._plan_error
         key = (device,) + tuple((t.data_ptr(), t._version) for t in self._tensors())
         if self._packed is not None and key == self._packed_key:
             return self._packed
@@ -301,6 +415,8 @@ class SimNet(nn.Module):
             if t.device != device:
                 raise RuntimeError("SimNet parameters are on %s but the input is on %s" % (t.device, device))
             ts.append(t.detach().to(torch.float32).contiguous())
+        if self._plan:        # embedded model: the library sees zero-padded parameters of its own shape
+            ts = [self._pad(t, ax).contiguous() for t, ax in zip(ts, self._tensor_axes())]
         it = iter(ts)
         reuse = self._packed is not None and self._packed_shape == shape_key
         P = _lib.ModelParams()
@@ -319,7 +435,7 @@ class SimNet(nn.Module):
                 setattr(layers[l], name, next(it).data_ptr())
         P.layers = layers
         P.final_w, P.final_b = next(it).data_ptr(), next(it).data_ptr()
-        desc = _lib.ModelDesc(self.d_model, self.num_heads, self.num_layers, self.in_features,
+        desc = _lib.ModelDesc(self._lib_d, self.num_heads, self.num_layers, self.in_features,
                               self.pe_len if self.use_pos else 0, self.num_classes)
         with torch.cuda.device(device):
             stream = torch.cuda.current_stream(device).cuda_stream
@@ -330,6 +446,8 @@ class SimNet(nn.Module):
                 out = C.c_void_p()
                 _lib.check(lib.vs_weights_pack(C.byref(desc), C.byref(P), stream, C.byref(out)))
                 self._packed, self._packed_shape = _Packed(out.value, device), shape_key
+                if self._plan:
+                    _lib.check(lib.vs_weights_set_norm_width(out.value, self.d_model))
         del ts      # stream-ordered: the async copies are already enqueued on the current stream
         self._packed_key = key
         return self._packed
@@ -373,9 +491,9 @@ class SimNet(nn.Module):
         flags = (_lib.VS_FLAG_SIGMOID if self.fused_sigmoid else 0) | self._attention_flag()
         x32 = x if x.dtype == torch.float32 else x.float()
         packed = self._packed_weights(x.device)
-        scores, hidden = torch.ops.vs_amd.score_frames(x32, mask, packed.handle, self.d_model,
+        scores, hidden = torch.ops.vs_amd.score_frames(x32, mask, packed.handle, self._lib_d,
                                                        self.num_classes, flags, True)
-        return scores, hidden
+        return scores, (hidden[..., :self.d_model] if self._plan else hidden)
 
     def _forward_cls(self, x: Tensor, mask: Optional[Tensor]):
         """``use_cls=True`` (simnet.py:47-51, 205-206, 214-216; no reference caller enables it): a learnable class token
@@ -400,13 +518,15 @@ class SimNet(nn.Module):
             m = m.view(torch.uint8) if m.dtype == torch.bool else m.to(torch.uint8)
         flags = (_lib.VS_FLAG_SIGMOID if self.fused_sigmoid else 0) | self._attention_flag()
         scores = torch.empty((B, T + 1, self.num_classes), dtype=torch.float32, device=dev)
-        hidden = torch.empty((B, T + 1, self.d_model), dtype=torch.float32, device=dev)
+        hidden = torch.empty((B, T + 1, self._lib_d), dtype=torch.float32, device=dev)
+        if self._plan:
+            cls = self._pad(cls, ("res",)).contiguous()
         with torch.cuda.device(dev):
             ws = torch.empty((max(lib.vs_scorer_workspace_bytes_cls(packed.handle, B, T), 256),), dtype=torch.uint8, device=dev)
             st = torch.cuda.current_stream(dev).cuda_stream
             _lib.check(lib.vs_scorer_forward_cls(packed.handle, x32.data_ptr(), _ptr(m), cls.data_ptr(), B, T, flags,
                                                  scores.data_ptr(), hidden.data_ptr(), ws.data_ptr(), ws.numel(), st))
-        return scores, hidden
+        return scores, (hidden[..., :self.d_model] if self._plan else hidden)
 
     @torch.no_grad()
     def score(self, x: Tensor, mask: Optional[Tensor] = None) -> Tensor:
@@ -423,7 +543,7 @@ class SimNet(nn.Module):
             return s.squeeze(-1)
         x32 = x if x.dtype == torch.float32 else x.float()
         packed = self._packed_weights(x.device)
-        scores, _ = torch.ops.vs_amd.score_frames(x32, mask, packed.handle, self.d_model, 1,
+        scores, _ = torch.ops.vs_amd.score_frames(x32, mask, packed.handle, self._lib_d, 1,
                                                   _lib.VS_FLAG_SIGMOID | self._attention_flag(), False)
         return scores.squeeze(-1)
 
@@ -436,8 +556,8 @@ class SimNet(nn.Module):
         if value not in ("fp32", "bf16", "fp16x3"):
             raise ValueError("attention_dtype must be 'fp32', 'bf16' or 'fp16x3', got %r" % (value,))
         ok = (32, 64, 128) if value == "bf16" else (32, 64)
-        if value != "fp32" and self.d_model // self.num_heads not in ok:
-            raise ValueError("%s attention needs head_dim in %s, got %d" % (value, ok, self.d_model // self.num_heads))
+        if value != "fp32" and self._lib_dh not in ok:
+            raise ValueError("%s attention needs head_dim in %s, got %d" % (value, ok, self._lib_dh))
         self._attention_dtype = value
 
     @property
@@ -458,7 +578,7 @@ class SimNet(nn.Module):
         # models with head dim 128 (M-B) take what exists for them: fp16x3 -> every Linear emulated, attention exact;
         # bf16 -> every product on the bf16 pipe (head dim 128 has a bf16 attention; d_model > 256 runs the plain bf16
         # GEMMs + the row LayerNorm pass instead of the fused layer kernels)
-        head_ok = self.d_model // self.num_heads in (32, 64)
+        head_ok = self._lib_dh in (32, 64)
         if value not in ("fp32", "fp16x3", "bf16"):
             raise ValueError("compute dtype must be 'fp32', 'fp16x3' or 'bf16', got %r" % (value,))
         if value == "bf16":
@@ -503,7 +623,7 @@ class SimNet(nn.Module):
         """Scores a RAGGED batch without padding: x [sum(lengths), in_features] = the videos' frames concatenated.
         Returns (logits [Mtot, num_classes], hidden [Mtot, d_model]); video i = rows sum(lengths[:i]) ...  The reference
         pads with the 1000.0 sentinel and masks (dataset.py:157-161); here no padded row is computed, and each video's
-        result is bit-identical to scoring it alone (fp32 and fp16x3 modes).  Head dim 32 / 64."""
+        result is bit-identical to scoring it alone (fp32 and fp16x3 modes).  Head dim 32 / 64 / 128."""
         if not x.is_cuda:
             raise RuntimeError("SimNet scoring runs on the MI355X HIP kernels only (no CPU path for the scorer)")
         if self.use_cls:
@@ -513,7 +633,8 @@ class SimNet(nn.Module):
         packed = self._packed_weights(x.device)
         x32 = x if x.dtype == torch.float32 else x.float()
         flags = (_lib.VS_FLAG_SIGMOID if self.fused_sigmoid else 0) | self._attention_flag()
-        return score_frames_packed(x32, lengths, packed.handle, self.d_model, self.num_classes, flags, want_hidden)
+        scores, hidden = score_frames_packed(x32, lengths, packed.handle, self._lib_d, self.num_classes, flags, want_hidden)
+        return scores, (hidden[..., :self.d_model] if (self._plan and want_hidden) else hidden)
 
     @torch.no_grad()
     def score_packed(self, x: Tensor, lengths) -> Tensor:
@@ -524,7 +645,7 @@ class SimNet(nn.Module):
             raise NotImplementedError("packed batches are not available with use_cls=True")
         packed = self._packed_weights(x.device)
         x32 = x if x.dtype == torch.float32 else x.float()
-        s, _ = score_frames_packed(x32, lengths, packed.handle, self.d_model, 1,
+        s, _ = score_frames_packed(x32, lengths, packed.handle, self._lib_d, 1,
                                    _lib.VS_FLAG_SIGMOID | self._attention_flag(), False)
         return s.squeeze(-1)
 
