@@ -309,7 +309,7 @@ def main():
             model.set_compute_dtype("fp32")
             low = (dt_low, diff)
 
-        pcie_fps = pcie_overlap_fps = lat_ms = None
+        pcie_fps = pcie_overlap_fps = lat_ms = lat_splitk_ms = None
         train_ms = None
         eval_ms = None
         if wl == "corpus":           # the consumer of the gathered scores: sharded keyshot evaluation + all_reduce of four sums
@@ -356,6 +356,19 @@ def main():
                 model(x1)
             torch.cuda.synchronize()
             lat_ms = (time.perf_counter() - t1) / 200 * 1e3
+            # ... and in the opt-in latency mode (SimNet.set_latency_mode: split-K Linears, keys split over a block's waves)
+            lat_splitk_ms = None
+            if hasattr(model, "set_latency_mode"):
+                model.set_latency_mode(True)
+                for _ in range(10):
+                    model(x1)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(200):
+                    model(x1)
+                torch.cuda.synchronize()
+                lat_splitk_ms = (time.perf_counter() - t1) / 200 * 1e3
+                model.set_latency_mode(False)
             # SURVEY §8(f) row 2, context only: one training step (HIP forward with dropout + masked-MSE loss + HIP backward) on
             # the same batch, exact fp32 and under set_train_dtype("bf16" / "fp16") (the counterparts of the reference's autocast)
             try:
@@ -478,6 +491,9 @@ def main():
             latency = {"workload": "configs[1]: one video, T=320, D=1024, M-%s" % args.model, "gpu_ms": round(lat_ms, 4),
                        "gpu_frames_per_s": round(320 / lat_ms * 1e3, 1),
                        "cpu_ms": cpu["single_video"]["ms_per_video"] if cpu else None}
+            if lat_splitk_ms is not None:       # opt-in latency mode: deterministic, 1e-4 of the goldens, not the default kernels' bits
+                latency["latency_mode_gpu_ms"] = round(lat_splitk_ms, 4)
+                latency["latency_mode"] = "SimNet.set_latency_mode(): VS_FLAG_SPLITK (split-K embedding / out-projection / fc2 + row LayerNorm, keys split over a block's waves)"
         par = "%s all_gather of scores" % ("RCCL" if backend == "nccl" else (backend or "no"))
         if wl == "corpus":
             workload = ("configs[3]: TVSum+SumMe-shaped corpus, %d ragged videos / %d frames (T 100..650, D=1024) dealt to %d "
@@ -512,8 +528,10 @@ def main():
             out["training_step"] = ({"workload": "forward under autograd (dropout 0.3) + masked MSE + backward on the same B x T batch, HIP "
                                                  "kernels (include/vs_train.h); fp32 = exact, bf16 / fp16 = SimNet.set_train_dtype(...)",
                                      "fp32_ms": round(train_ms["fp32"], 3), "bf16_ms": round(train_ms["bf16"], 3),
+                                     "fp16_ms": round(train_ms["fp16"], 3),
                                      "fp32_frames_per_s": round(B * T / train_ms["fp32"] * 1e3, 1),
-                                     "bf16_frames_per_s": round(B * T / train_ms["bf16"] * 1e3, 1)}
+                                     "bf16_frames_per_s": round(B * T / train_ms["bf16"] * 1e3, 1),
+                                     "fp16_frames_per_s": round(B * T / train_ms["fp16"] * 1e3, 1)}
                                     if "error" not in train_ms else train_ms)
         if emu:
             ev = frames / emu[0]

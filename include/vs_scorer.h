@@ -45,6 +45,14 @@ extern "C" {
                                 to 8192 frames keep the (faster, exact) fp32 latency kernels (bf16 only:
                                 fp16x3 has latency kernels of its own). */
 #define VS_FLAG_BF16 (VS_FLAG_BF16_ATTENTION | VS_FLAG_BF16_LINEAR)
+#define VS_FLAG_SPLITK 32u   /* opt-in LATENCY mode for reference-sized calls (one T = 320 video, train.py:71,139-148): with
+                                the exact fp32 kernels and at most VS_SKINNY_ROWS rows, the K >= 512 Linears (embedding, fc2)
+                                and the out-projection are split over K across more CUs (fixed slices, partials added in slice
+                                order, then bias, then the residual) and the LayerNorm runs as a row pass.  Deterministic and
+                                batch-independent, within ~1e-6 of the default kernels' results (a different summation tree;
+                                tests hold it to the goldens at 1e-4) - but NOT their bits, so a video scored alone in this
+                                mode and the same video scored in a large batch are no longer bit-identical.  Ignored (the
+                                default kernels run) for larger inputs, low-precision modes and packed / class-token calls. */
 #define VS_FLAG_F16X3_ATTENTION 16u /* opt-in: the two attention products emulated on the f16 pipe the same way
                                 (q*scale, k, v, p split into hi + lo halves, three MFMAs per product, fp32
                                 softmax and accumulation).  Head dim 32 or 64.  Exclusive with

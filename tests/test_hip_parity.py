@@ -1619,3 +1619,33 @@ def test_embedded_shape_through_every_entry_point(vsa, cfg):
     v1 = torch.cat([torch.ones(3, 1, dtype=torch.bool), valid], dim=1)
     assert gh.shape == (3, 151, d)
     assert (gl.cpu() - cl)[v1].abs().max().item() < TOL and (gh.cpu() - ch)[v1].abs().max().item() < TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["ma_t320", "ma_t320_pad", "ma_ragged37", "ma_randmask_t96", "ma_nc3_t64", "ma_nopos_t129", "dh32_t65"])
+def test_latency_mode_meets_the_goldens_and_is_deterministic(vsa, name):
+    """SimNet.set_latency_mode() (VS_FLAG_SPLITK: split-K embedding / out-projection / fc2 + row LayerNorm for reference-sized
+    calls): the reference-generated goldens at the path's own 1e-4 bar, within 2e-5 of the default kernels, bitwise
+    reproducible, and independent of the batch a video is scored in (fixed slices, fixed reduction order)."""
+    case = [c for c in golden_cases() if c["name"] == name][0]
+    g = load_golden(name)
+    sd, x, mask = build_case(vsa.synth, case)
+    m = _model(vsa, case, sd)
+    xd, md = x.to(_dev()), None if mask is None else mask.to(_dev())
+    with torch.no_grad():
+        l0, h0 = m(xd, md)
+        m.set_latency_mode(True)
+        l1, h1 = m(xd, md)
+        l2, h2 = m(xd, md)
+        valid = torch.ones(x.shape[:2], dtype=torch.bool) if mask is None else ~mask
+        dl = (l1.cpu() - g["logits"])[valid].abs().max().item()
+        dh = (h1.cpu()[:, g["rows"]] - g["hidden"])[valid[:, g["rows"]]].abs().max().item()
+        dd = (l1 - l0).cpu()[valid].abs().max().item()
+        print("latency mode %s: logits %.2e hidden %.2e of the golden; %.2e of the default kernels" % (name, dl, dh, dd))
+        assert dl < TOL and dh < TOL and dd < 2e-5
+        assert torch.equal(l1, l2) and torch.equal(h1, h2)
+        if x.shape[0] > 1 and mask is None:           # each video alone == the same video inside the batch
+            a, _ = m(xd[:1])
+            assert torch.equal(a[0], l1[0])
+        if name == "ma_t320":
+            assert not torch.equal(l0, l1), "the latency mode did not run (results are the default kernels' bits)"

@@ -50,4 +50,7 @@ python tools/bench_gemm16.py > gpurun_out/$TAG/gemm16.txt 2>&1
 bash tools/pmc_cmd.sh gpurun_out/$TAG/pmc_summary_mb_bf16.txt tools/prof_mb_bf16.py > /dev/null 2>&1
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/$TAG/prof_train_bf16 -- python3 $GRAFT_REPO_ROOT/tools/bench_train.py --shapes 64x1024 --only-bf16 --iters 10 > $GRAFT_REPO_ROOT/gpurun_out/$TAG/prof_train_bf16.txt 2>&1 )
 bash tools/pmc_cmd.sh gpurun_out/$TAG/pmc_summary_train_bf16.txt tools/bench_train.py --shapes 64x1024 --only-bf16 --iters 4 > /dev/null 2>&1
+# round 4: reference-sized calls (default kernels, then the opt-in latency mode), the one-wave-per-SIMD attention check + timings
+{ python tools/latency_breakdown.py 1 320; python tools/latency_breakdown.py 1 320 splitk; python tools/latency_breakdown.py 4 320; python tools/latency_breakdown.py 4 320 splitk; } > gpurun_out/$TAG/latency_scoring.txt 2>&1
+python tools/check_attn_w64.py > gpurun_out/$TAG/check_attn_w64.txt 2>&1
 echo done

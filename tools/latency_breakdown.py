@@ -10,6 +10,8 @@ m = pkg.SimNet(num_heads=4, d_model=256, num_layers=4, sparsity=0.0, dropout=0.3
 m.load_state_dict(pkg.synth.make_state_dict(256, 4, 1234)); m = m.to(dev).eval()
 B, T = int(sys.argv[1]) if len(sys.argv) > 1 else 1, int(sys.argv[2]) if len(sys.argv) > 2 else 320
 x = torch.randn(B, T, 1024, device=dev)
+if "splitk" in sys.argv[3:]:          # the opt-in latency mode (VS_FLAG_SPLITK)
+    m.set_latency_mode(True)
 with torch.no_grad():
     for _ in range(10): m(x)
     torch.cuda.synchronize()

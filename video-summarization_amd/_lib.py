@@ -28,6 +28,7 @@ VS_FLAG_BF16_ATTENTION = 2
 VS_FLAG_BF16_LINEAR = 4
 VS_FLAG_F16X3_LINEAR = 8
 VS_FLAG_F16X3_ATTENTION = 16
+VS_FLAG_SPLITK = 32              # opt-in latency mode for reference-sized calls (include/vs_scorer.h)
 VS_TRAIN_FLAG_BF16_LINEAR = 1
 VS_TRAIN_FLAG_BF16_ATTENTION = 2
 VS_TRAIN_FLAG_FP16 = 4          # modifier: the 16-bit type is IEEE fp16 (the reference's own autocast type) instead of bf16

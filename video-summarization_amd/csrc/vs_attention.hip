@@ -184,6 +184,146 @@ __global__ __launch_bounds__(256, 2) void attn_fwd(
 }
 
 // ------------------------------------------------------------------------------------------
+// Latency mode (VS_FLAG_SPLITK, round 4): exact fp32 attention for ONE reference-sized video per call.  attn_fwd_pipe gives a
+// wave 32 query rows and ALL keys: at T = 320 that is 12 blocks on 256 CUs, each wave walking five 64-key tiles one after
+// the other (27 us).  Here a block is 32 query rows of one head and its 8 waves SPLIT THE KEYS: wave w takes the 32-key tiles
+// w, w + 8, ...; operands come straight from global memory into fragments (no LDS tile, no barrier in the loop), every
+// wave keeps its own (m, l, O), and the eight partial results are merged once through LDS in wave order - the flash-decoding
+// split, with a fixed tile assignment and a fixed merge order: deterministic and independent of the batch, but not the bits of
+// attn_fwd_pipe (tests: goldens at 1e-4).  Same operand trick as attn_fwd (S^T = K Q^T, its accumulator is the B operand of
+// O^T = V^T P^T).
+// ------------------------------------------------------------------------------------------
+template <int DH>
+__global__ __launch_bounds__(512) void attn_fwd_splitkv(
+    const float *__restrict__ Q, const float *__restrict__ Kg, const float *__restrict__ Vg,
+    const uint8_t *__restrict__ mask, float *__restrict__ out, int H, int T, float scale_log2e, int BH) {
+    constexpr int NW = 8, NJ = DH / 8, ND = DH / 32;
+    __shared__ float ml[NW][2][32];
+    __shared__ float linv[32];
+    __shared__ __attribute__((aligned(16))) float ob[NW][16 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int nq = (T + 31) / 32;
+    const int qt = blockIdx.x % nq, bh = blockIdx.x / nq;
+    if (bh >= BH) return;
+    const int b = bh / H, head = bh - b * H;
+    const size_t base = (size_t)bh * T * DH;
+    const int q0 = qt * 32;
+    const float NEG_INF = -__builtin_inff();
+
+    float qreg[4 * NJ];
+    {
+        int qr = q0 + r; qr = qr < T ? qr : T - 1;
+        const float *qp = Q + base + (size_t)qr * DH + 4 * h;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const f32x4 v = *(const f32x4 *)(qp + 8 * j);
+#pragma unroll
+            for (int st = 0; st < 4; ++st) qreg[4 * j + st] = v[st] * scale_log2e;
+        }
+    }
+    f32x16 o[ND];
+#pragma unroll
+    for (int d = 0; d < ND; ++d)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) o[d][t] = 0.f;
+    float m_run = NEG_INF, l_run = 0.f;
+
+    const int ntiles = (T + 31) / 32;
+    for (int tile = wave; tile < ntiles; tile += NW) {
+        const int k0 = tile * 32;
+        f32x4 ka[NJ];
+        {
+            int kr = k0 + r; kr = kr < T ? kr : T - 1;
+            const float *kp = Kg + base + (size_t)kr * DH + 4 * h;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) ka[j] = *(const f32x4 *)(kp + 8 * j);
+        }
+        float va[ND][16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            int key = k0 + acc_row(t, h); key = key < T ? key : T - 1;
+            const float *vp = Vg + base + (size_t)key * DH + r;
+#pragma unroll
+            for (int d = 0; d < ND; ++d) va[d][t] = vp[32 * d];
+        }
+        f32x16 s;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) s[t] = 0.f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int st = 0; st < 4; ++st) s = MFMA32(ka[j][st], qreg[4 * j + st], s);
+        if (mask != nullptr || k0 + 32 > T) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int key = k0 + acc_row(t, h);
+                bool dead = key >= T;
+                if (!dead && mask != nullptr) dead = mask[(size_t)b * T + key] != 0;
+                s[t] = dead ? NEG_INF : s[t];
+            }
+        }
+        float mx = NEG_INF;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) mx = fmaxf(mx, s[t]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);
+        const float m_use = (m_new == NEG_INF) ? 0.f : m_new;
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
+        float psum = 0.f;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const float p = __builtin_amdgcn_exp2f(s[t] - m_use);
+            s[t] = p;
+            psum += p;
+        }
+        psum += __shfl_xor(psum, 32);
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int d = 0; d < ND; ++d) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) o[d][t] *= alpha;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) o[d] = MFMA32(va[d][t], s[t], o[d]);
+        }
+    }
+
+    // ---- merge the eight partial results, wave order ----
+    if (h == 0) { ml[wave][0][r] = m_run; ml[wave][1][r] = l_run; }
+    __syncthreads();
+    float m_all = NEG_INF;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) m_all = fmaxf(m_all, ml[w][0][r]);
+    const float m_use = (m_all == NEG_INF) ? 0.f : m_all;
+    float l_tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) l_tot += ml[w][1][r] * __builtin_amdgcn_exp2f(ml[w][0][r] - m_use);
+    if (wave == 0 && h == 0) linv[r] = 1.0f / l_tot;
+    const float f = __builtin_amdgcn_exp2f(m_run - m_use);
+#pragma unroll
+    for (int d = 0; d < ND; ++d) {
+        if (d) __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 16; ++t) ob[wave][t * 64 + lane] = o[d][t] * f;
+        __syncthreads();
+        if (tid < 256) {
+            const int g = tid >> 6, ln = tid & 63, rr = ln & 31, hh = ln >> 5;
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float acc = ob[0][(4 * g + e) * 64 + ln];
+#pragma unroll
+                for (int w = 1; w < NW; ++w) acc += ob[w][(4 * g + e) * 64 + ln];
+                v[e] = acc * linv[rr];
+            }
+            const int q = q0 + rr;
+            if (q < T) *(f32x4 *)(out + ((size_t)b * T + q) * (H * DH) + head * DH + 32 * d + 8 * g + 4 * hh) = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Attention on the bf16 matrix pipe (opt-in, VS_FLAG_BF16_ATTENTION; long videos): the same
 // flash-style walk and operand trick as attn_fwd, but both products run as
 // v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA rate).  Q*scale, K, V and the probabilities P are
@@ -1477,6 +1617,18 @@ int vsk_attention(const float *q, const float *k, const float *v, const uint8_t 
         hipLaunchKernelGGL((attn_fwd<128, 1>), grid, dim3(256), 0, st, q, k, v, mask, out, H, T, sl2, BH);
     else
         return -1;
+    VSK_CHECK_LAUNCH();
+    return 0;
+}
+
+// latency mode: keys split over the 8 waves of a block (exact fp32, head dim 32 / 64); -1 if the shape has no such kernel
+int vsk_attention_splitkv(const float *q, const float *k, const float *v, const uint8_t *mask, float *out,
+                          int B, int H, int T, int dh, float scale, hipStream_t st) {
+    const float sl2 = vsk_attention_qscale(scale);
+    const dim3 grid(((T + 31) / 32) * B * H);
+    if (dh == 64) hipLaunchKernelGGL((attn_fwd_splitkv<64>), grid, dim3(512), 0, st, q, k, v, mask, out, H, T, sl2, B * H);
+    else if (dh == 32) hipLaunchKernelGGL((attn_fwd_splitkv<32>), grid, dim3(512), 0, st, q, k, v, mask, out, H, T, sl2, B * H);
+    else return -1;
     VSK_CHECK_LAUNCH();
     return 0;
 }

@@ -45,7 +45,13 @@ int vsk_linear_res_ln(const float *A, const float *W, const float *Wf, const flo
 // out = LayerNorm(a + res) * gamma + beta (+ score head): the row pass behind a plain GEMM for d_model > 256
 int vsk_rows_res_ln(const float *a, const float *res, const float *gamma, const float *beta, float *out, int M, int d,
                     const float *score_w, const float *score_b, int num_classes, int sigmoid, float *scores,
-                    hipStream_t st, void *out16 = nullptr, int dn = 0);      // dn: LayerNorm width of an embedded model (0: d)      // out16: optional bf16 copy of the output rows
+                    hipStream_t st, void *out16 = nullptr, int dn = 0,       // dn: LayerNorm width of an embedded model (0: d)
+                    int nsplit = 0, const float *pbias = nullptr);           // nsplit > 0: `a` = K-slice partials [nsplit][M][d], pbias the Linear's bias
+int vsk_attention_splitkv(const float *q, const float *k, const float *v, const uint8_t *mask, float *out,
+                          int B, int H, int T, int dh, float scale, hipStream_t st);       // latency mode: keys split over a block's waves
+// latency mode (VS_FLAG_SPLITK): split-K partial products through the fragment-major latency kernel, and the embedding's reduction
+int vsk_linear_parts(const float *A, const float *Wf, float *parts, int M, int N, int K, int nsplit, hipStream_t st);
+int vsk_sum_parts_pe(const float *parts, int nsplit, const float *bias, const float *pe, int T, float *out, int M, int N, hipStream_t st);      // out16: optional bf16 copy of the output rows
 int vsk_diag_attention(const float *q, const float *k, const float *v, float *out, int B, int H, int T, float scale,
                        unsigned long long *diag, hipStream_t st);      // diagnostic library only; returns the blocks launched
 int vsk_diag_attention_lp(const float *q, const float *k, const float *v, float *out, int B, int H, int T, float scale,

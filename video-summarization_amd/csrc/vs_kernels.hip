@@ -1514,6 +1514,51 @@ __global__ __launch_bounds__(256) void skinny2_gemm(
     }
 }
 
+// ---- latency mode (VS_FLAG_SPLITK, round 4): one reference-sized video (T = 320 rows) leaves the chip idle - the K = 1024
+// products (embedding, fc2) run on 10-20 blocks, each walking the whole K on one CU.  Split K over blockIdx.z: every block
+// multiplies a fixed K-slice and writes its partial [M, N] tile; the consumer (row LayerNorm pass / sum_parts_pe) adds the
+// partials in slice order, then bias, then the residual - a FIXED order, so results are deterministic and do not depend on
+// the batch, but they are not the bits of the unsplit kernels (different summation tree: within ~1e-6, tests pin 1e-4 of the
+// goldens).  Opt-in; bit-identity between batched and single-video scoring stays the default.
+__global__ __launch_bounds__(256) void skinny2_gemm_parts(
+    const float *__restrict__ A, const float *__restrict__ Wf, float *__restrict__ parts, int M, int N, int K, int kslice) {
+    extern __shared__ __attribute__((aligned(16))) float As[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+    const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 128 + 32 * wave;
+    const int k0 = blockIdx.z * kslice;
+    const bool live = n0 < N;
+    const int row = m0 + r;
+    f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    skinny2_stage<256>(As, A, M, K, m0, k0, kslice);
+    __syncthreads();
+    if (!live) return;
+    skinny2_phase(acc, As + r * (kslice + 4) + 4 * h, Wf + ((size_t)(n0 / 32) * (K / 8) + k0 / 8) * 256 + lane * 4, kslice);
+    if (row >= M) return;
+    float *C = parts + (size_t)blockIdx.z * M * N;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[4 * q + e];
+        *(f32x4 *)(C + (size_t)row * N + n0 + 8 * q + 4 * h) = v;
+    }
+}
+
+// out[row, :] = ((parts[0] + parts[1]) + ... ) + bias + pe[row % T]   (the embedding's epilogue in latency mode)
+__global__ __launch_bounds__(256) void sum_parts_pe(const float *__restrict__ parts, int nsplit, const float *__restrict__ bias,
+                                                    const float *__restrict__ pe, int T, float *__restrict__ out, int M, int N) {
+    const int n4 = N / 4;
+    const size_t total = (size_t)M * n4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int row = (int)(i / n4), c = (int)(i % n4) * 4;
+        f32x4 v = *(const f32x4 *)(parts + (size_t)row * N + c);
+        for (int s = 1; s < nsplit; ++s) v += *(const f32x4 *)(parts + ((size_t)s * M + row) * N + c);
+        v += *(const f32x4 *)(bias + c);
+        if (pe != nullptr) v += *(const f32x4 *)(pe + (size_t)(row % T) * N + c);
+        *(f32x4 *)(out + (size_t)row * N + c) = v;
+    }
+}
+
 template <int NW, int PREC = 0>
 __global__ __launch_bounds__(64 * NW) void skinny2_ln(
     const float *__restrict__ A, const float *__restrict__ Wf, const float *__restrict__ bias,
@@ -1615,7 +1660,8 @@ __global__ __launch_bounds__(256) void rows_res_ln(const float *__restrict__ a, 
                                                    float *__restrict__ out, int M, int d,
                                                    const float *__restrict__ score_w, const float *__restrict__ score_b,
                                                    int num_classes, int sigmoid, float *__restrict__ scores,
-                                                   unsigned short *__restrict__ out16, int dn) {
+                                                   unsigned short *__restrict__ out16, int dn,
+                                                   int nsplit, const float *__restrict__ pbias) {
     // dn (== d for every natively shaped model): the LayerNorm width.  A model EMBEDDED in a wider supported shape (round 4:
     // zero-padded weights, vs_weights_set_norm_width) has its true d_model = dn < d; columns dn .. d-1 of the residual stream
     // are identically zero (zero weight rows / bias / gamma / beta) and stay out of the statistics.
@@ -1629,7 +1675,12 @@ __global__ __launch_bounds__(256) void rows_res_ln(const float *__restrict__ a, 
             const int c = 4 * lane + 256 * u;
             v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (c < d) {
-                v[u] = *(const f32x4 *)(a + (size_t)row * d + c) + *(const f32x4 *)(res + (size_t)row * d + c);
+                f32x4 av = *(const f32x4 *)(a + (size_t)row * d + c);
+                if (nsplit > 0) {       // latency mode: `a` = nsplit K-slice partials [nsplit][M][d], added in slice order, then the bias
+                    for (int sp = 1; sp < nsplit; ++sp) av += *(const f32x4 *)(a + ((size_t)sp * M + row) * d + c);
+                    av += *(const f32x4 *)(pbias + c);
+                }
+                v[u] = av + *(const f32x4 *)(res + (size_t)row * d + c);
                 s += v[u][0] + v[u][1] + v[u][2] + v[u][3];
             }
         }
@@ -1798,17 +1849,18 @@ int vsk_insert_cls(const float *e, const float *cls, const uint8_t *mask, float 
 
 int vsk_rows_res_ln(const float *a, const float *res, const float *gamma, const float *beta, float *out, int M, int d,
                     const float *score_w, const float *score_b, int num_classes, int sigmoid, float *scores,
-                    hipStream_t st, void *out16, int dn) {
+                    hipStream_t st, void *out16, int dn, int nsplit, const float *pbias) {
     if (d % 4 || d > 1024) return -1;
+    if (nsplit > 0 && pbias == nullptr) return -1;
     if (dn <= 0) dn = d;
     if (dn % 4 || dn > d) return -1;
     const int rows4 = (M + 3) / 4;
     const dim3 grid(rows4 < 8192 ? (rows4 < 1 ? 1 : rows4) : 8192);
     switch ((d + 255) / 256) {          // float4 per lane (256 columns each)
-        case 1: hipLaunchKernelGGL(rows_res_ln<1>, grid, dim3(256), 0, st, a, res, gamma, beta, out, M, d, score_w, score_b, num_classes, sigmoid, scores, (unsigned short *)out16, dn); break;
-        case 2: hipLaunchKernelGGL(rows_res_ln<2>, grid, dim3(256), 0, st, a, res, gamma, beta, out, M, d, score_w, score_b, num_classes, sigmoid, scores, (unsigned short *)out16, dn); break;
-        case 3: hipLaunchKernelGGL(rows_res_ln<3>, grid, dim3(256), 0, st, a, res, gamma, beta, out, M, d, score_w, score_b, num_classes, sigmoid, scores, (unsigned short *)out16, dn); break;
-        default: hipLaunchKernelGGL(rows_res_ln<4>, grid, dim3(256), 0, st, a, res, gamma, beta, out, M, d, score_w, score_b, num_classes, sigmoid, scores, (unsigned short *)out16, dn); break;
+        case 1: hipLaunchKernelGGL(rows_res_ln<1>, grid, dim3(256), 0, st, a, res, gamma, beta, out, M, d, score_w, score_b, num_classes, sigmoid, scores, (unsigned short *)out16, dn, nsplit, pbias); break;
+        case 2: hipLaunchKernelGGL(rows_res_ln<2>, grid, dim3(256), 0, st, a, res, gamma, beta, out, M, d, score_w, score_b, num_classes, sigmoid, scores, (unsigned short *)out16, dn, nsplit, pbias); break;
+        case 3: hipLaunchKernelGGL(rows_res_ln<3>, grid, dim3(256), 0, st, a, res, gamma, beta, out, M, d, score_w, score_b, num_classes, sigmoid, scores, (unsigned short *)out16, dn, nsplit, pbias); break;
+        default: hipLaunchKernelGGL(rows_res_ln<4>, grid, dim3(256), 0, st, a, res, gamma, beta, out, M, d, score_w, score_b, num_classes, sigmoid, scores, (unsigned short *)out16, dn, nsplit, pbias); break;
     }
     VSK_CHECK_LAUNCH();
     return 0;
@@ -1819,6 +1871,26 @@ static int skinny_max_rows() { return vsk_skinny_max_rows(); }
 
 // dynamic LDS of the packed skinny kernels: 32 activation rows x (min(K,1024) + 4) floats (up to 128.5 KiB)
 static size_t skinny2_lds(int K) { return (size_t)32 * ((K < 1024 ? K : 1024) + 4) * sizeof(float); }
+
+// latency mode: K-slice partial products of A [M, K] x W^T (Wf: fragment-major copy) -> parts [nsplit][M][N], no bias
+int vsk_linear_parts(const float *A, const float *Wf, float *parts, int M, int N, int K, int nsplit, hipStream_t st) {
+    if (Wf == nullptr || nsplit < 1 || K % nsplit) return -1;
+    const int kslice = K / nsplit;
+    if (kslice % 128 || kslice > 256 || N % 32) return -1;      // (<= 33 KiB of LDS: no opt-in attribute needed)
+    dim3 grid((M + 31) / 32, (N + 127) / 128, nsplit);
+    hipLaunchKernelGGL(skinny2_gemm_parts, grid, dim3(256), skinny2_lds(kslice), st, A, Wf, parts, M, N, K, kslice);
+    VSK_CHECK_LAUNCH();
+    return 0;
+}
+
+int vsk_sum_parts_pe(const float *parts, int nsplit, const float *bias, const float *pe, int T, float *out, int M, int N, hipStream_t st) {
+    if (N % 4 || nsplit < 1) return -1;
+    const size_t total = (size_t)M * (N / 4);
+    const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(sum_parts_pe, dim3(blocks), dim3(256), 0, st, parts, nsplit, bias, pe, T, out, M, N);
+    VSK_CHECK_LAUNCH();
+    return 0;
+}
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute: set it once per (kernel, device).  `done` is
 // the call site's own per-device flag array (one per kernel instantiation).
 enum { VSK_MAX_DEVICES = 64 };

@@ -431,6 +431,8 @@ int forward_core(const vs_weights *w, const float *x, const uint8_t *key_pad_mas
     const int lp_min_rows = fused_ok && opt.lp_min_rows_fused < opt.lp_min_rows ? opt.lp_min_rows_fused
                                                                                : opt.lp_min_rows;    // tests / tools pin the bf16 tiled kernels with 0
     const int lbf = (flags & VS_FLAG_F16X3_LINEAR) ? 2 : ((flags & VS_FLAG_BF16_LINEAR) && M > lp_min_rows) ? 1 : 0;
+    // latency mode (VS_FLAG_SPLITK): exact kernels, latency-sized inputs, plain padded batches only
+    const bool splitk = (flags & VS_FLAG_SPLITK) && lbf == 0 && !pk && !cls && M <= vsk_skinny_max_rows() && d % 128 == 0 && d <= 256;      // (K slices of <= 256, partials in the free regions)
     // the bf16 Linear + LayerNorm kernels stop at d_model 256 (validated above); fp16x3 has a wide variant too
     const int lnbf = lbf;
     {   // kernel-layout weight images this forward reads, (re)built only if the parameters changed since their last use
@@ -476,6 +478,11 @@ int forward_core(const vs_weights *w, const float *x, const uint8_t *key_pad_mas
         const VskNextQkv nq{w->p(N.b_qkv), w->p(N.bqkv), qkv, T, H, vsk_attention_qscale(scale)};
         VS_LAUNCH(vsk_embed_bf16(x, w->p(w->b_embed), w->p(w->embed_b), pe_rows, T, h0, M, d, D.in_features, &nq, st));
         have_qkv = true;
+    } else if (splitk && D.in_features % 1024 == 0) {
+        // K = in_features split 8 ways; the partials (8 x [M, d]: the q .. ffn regions, all free here) + bias + positional rows -> h0
+        StageScope ps(VS_STAGE_EMBED, st);
+        VS_LAUNCH(vsk_linear_parts(x, w->p(w->f_embed_w), qkv, M, d, D.in_features, 8, st));
+        VS_LAUNCH(vsk_sum_parts_pe(qkv, 8, w->p(w->embed_b), pe_rows, T, h0, M, d, st));
     } else {
         StageScope ps(VS_STAGE_EMBED, st);
         VS_LAUNCH(vsk_linear(x, w->p(w->embed_w), w->p(lbf == 2 ? w->h_embed_w : w->f_embed_w), w->p(w->embed_b), h0, M, d, D.in_features, 0,
@@ -531,6 +538,8 @@ int forward_core(const vs_weights *w, const float *x, const uint8_t *key_pad_mas
             if (pk)
                 VS_LAUNCH(vsk_attention_packed(qkv, qkv + kv_stride, qkv + 2 * kv_stride, att, H, M, d / H, scale,
                                                pk->cu, pk->work, pk->nwork, pk->nw, qkv16 ? (1 | VSK_STORE16) : pk->prec, st));
+            else if (splitk && !aprec && (d / H == 32 || d / H == 64))      // latency mode: the keys split over a block's waves
+                VS_LAUNCH(vsk_attention_splitkv(qkv, qkv + (size_t)M * d, qkv + 2 * (size_t)M * d, key_pad_mask, att, B, H, T, d / H, scale, st));
             else if (aprec)
                 VS_LAUNCH(vsk_attention_bf16(qkv, qkv + kv_stride, qkv + 2 * kv_stride, key_pad_mask, att,
                                              B, H, T, d / H, scale, qkv16 ? (1 | VSK_STORE16) : aprec, st));
@@ -555,7 +564,11 @@ int forward_core(const vs_weights *w, const float *x, const uint8_t *key_pad_mas
         const bool split_ln = d > 256 || embedded;      // (an embedded model's LayerNorm width is not d: the row pass knows it)
         {
             StageScope ps(VS_STAGE_OUTPROJ_LN, st);
-            if (split_ln) {
+            if (splitk && d % 256 == 0) {     // K = d split in two (q / k regions are free after the attention), LayerNorm as a row pass
+                VS_LAUNCH(vsk_linear_parts(att, w->p(P.f_wo), qkv, M, d, d, 2, st));
+                VS_LAUNCH(vsk_rows_res_ln(qkv, h0, w->p(P.ln1g), w->p(P.ln1b), h1, M, d, nullptr, nullptr, 0, 0, nullptr, st, nullptr, dn,
+                                          2, w->p(P.bo)));
+            } else if (split_ln) {
                 VS_LAUNCH(vsk_linear(att, w->p(P.wo), w->p(lnbf == 2 ? P.h_wo : P.f_wo), w->p(P.bo), qkv, M, d, d, 0, nullptr, 1, lnbf, st));
                 VS_LAUNCH(vsk_rows_res_ln(qkv, h0, w->p(P.ln1g), w->p(P.ln1b), h1, M, d, nullptr, nullptr, 0, 0, nullptr, st, nullptr, dn));
             } else
@@ -590,7 +603,13 @@ int forward_core(const vs_weights *w, const float *x, const uint8_t *key_pad_mas
             VS_LAUNCH(vsk_linear(h1, w->p(P.w1), w->p(lbf == 2 ? P.h_w1 : P.f_w1), w->p(P.b1), ffn, M, 4 * d, d, 1, nullptr, 1,
                                  ffn16 ? (1 | VSK_STORE16) : lbf, st));
         }
-        if (split_ln) {
+        if (splitk) {      // K = 4 d split four ways (partials in the q / k / v / att regions, free by now), LayerNorm (+ score head) as a row pass
+            StageScope ps(VS_STAGE_FC2_LN, st);
+            VS_LAUNCH(vsk_linear_parts(ffn, w->p(P.f_w2), qkv, M, d, 4 * d, 4, st));
+            VS_LAUNCH(vsk_rows_res_ln(qkv, h1, w->p(P.ln2g), w->p(P.ln2b), dst, M, d, last ? w->p(w->final_w) : nullptr,
+                                      last ? w->p(w->final_b) : nullptr, D.num_classes, sig, last ? scores : nullptr, st, nullptr, dn,
+                                      4, w->p(P.b2)));
+        } else if (split_ln) {
             StageScope ps(VS_STAGE_FC2_LN, st);
             VS_LAUNCH(vsk_linear(ffn, w->p(P.w2), w->p(lnbf == 2 ? P.h_w2 : P.f_w2), w->p(P.b2), att, M, d, 4 * d, 0, nullptr, 1, lnbf, st));
             VS_LAUNCH(vsk_rows_res_ln(att, h1, w->p(P.ln2g), w->p(P.ln2b), dst, M, d, last ? w->p(w->final_w) : nullptr,

@@ -293,6 +293,7 @@ class SimNet(nn.Module):
         # default "fp32" is the only mode the 1e-4 parity bar applies to.
         self._attention_dtype = "fp32"
         self._linear_dtype = "fp32"       # "bf16": every Linear multiplies bf16-rounded operands (fp32 storage/accumulate)
+        self.latency_mode = False         # opt-in (set_latency_mode): split-K kernels for one reference-sized video per call
         self._train_dtype = "fp32"        # set_train_dtype("bf16"): the training path's counterpart of the reference's autocast
         self.last_train_dtype = None      # what the last training forward actually computed in ("fp32" / "bf16" / "fp16")
         self._packed: Optional[_Packed] = None
@@ -649,8 +650,19 @@ class SimNet(nn.Module):
                                    _lib.VS_FLAG_SIGMOID | self._attention_flag(), False)
         return s.squeeze(-1)
 
+    def set_latency_mode(self, on: bool = True) -> "SimNet":
+        """Opt-in latency mode for reference-sized scoring calls (one T = 320 video per forward, ``train.py:139-148``,
+        ``generate_summary_image.py:62-67``): the exact-fp32 K >= 512 Linears and the out-projection are split over K across
+        more CUs and LayerNorm runs as a row pass (``VS_FLAG_SPLITK``).  Deterministic, batch-independent and within ~1e-6 of
+        the default kernels (goldens at 1e-4) - but a different summation tree: a video scored alone in this mode is no longer
+        bit-identical to the same video scored inside a large batch, which the default guarantees.  No effect above
+        VS_SKINNY_ROWS rows, in the low-precision modes, or for packed / class-token calls."""
+        self.latency_mode = bool(on)
+        return self
+
     def _attention_flag(self) -> int:
-        return ((_lib.VS_FLAG_BF16_ATTENTION if self._attention_dtype == "bf16" else 0)
+        return ((_lib.VS_FLAG_SPLITK if self.latency_mode else 0)
+                | (_lib.VS_FLAG_BF16_ATTENTION if self._attention_dtype == "bf16" else 0)
                 | (_lib.VS_FLAG_F16X3_ATTENTION if self._attention_dtype == "fp16x3" else 0)
                 | (_lib.VS_FLAG_BF16_LINEAR if self._linear_dtype == "bf16" else 0)
                 | (_lib.VS_FLAG_F16X3_LINEAR if self._linear_dtype == "fp16x3" else 0))
