@@ -75,6 +75,19 @@ def test_bench_line_carries_the_contract_fields_and_a_traceable_traffic_figure()
 
 
 @pytest.mark.gpu
+def test_bench_extras_do_not_fail_silently():
+    """The extras of the bench line (latency of one T=320 video - default kernels and latency mode -, one training step in
+    fp32 / bf16 / fp16) are wrapped so that they can never cost the headline line; a genuine failure would then only show
+    as an {"error": ...} field.  This run keeps the extras on and asserts on them."""
+    out = _run(["--steps", "3", "--warmup", "1", "--batch", "8", "--frames", "512", "--no-cpu-baseline", "--no-emulated"], {}, 900)
+    ts = out.get("training_step")
+    assert ts is not None and "error" not in ts, ts
+    assert ts["fp32_ms"] > 0 and ts["bf16_ms"] > 0 and ts["fp16_ms"] > 0
+    lat = out.get("latency")
+    assert lat is not None and 0 < lat["latency_mode_gpu_ms"] < lat["gpu_ms"], lat
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("workload", ["corpus", "long"])
 def test_two_rank_rehearsal_of_the_other_workloads(workload):
     """configs[3] (`--workload corpus`: strong scaling of the 75-video corpus, scores gathered to every rank, sharded

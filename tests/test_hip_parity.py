@@ -1649,3 +1649,39 @@ def test_latency_mode_meets_the_goldens_and_is_deterministic(vsa, name):
             assert torch.equal(a[0], l1[0])
         if name == "ma_t320":
             assert not torch.equal(l0, l1), "the latency mode did not run (results are the default kernels' bits)"
+
+
+@pytest.mark.gpu
+def test_scoring_forward_is_stream_capturable(vsa):
+    """The scoring forward only enqueues on the caller's stream (no synchronisation, no allocation of its own after the first
+    call): it can be captured into a graph (torch.cuda.CUDAGraph = hipGraph) as it is, and the replay reproduces the eager
+    result bit for bit - in the default kernels and in the latency mode."""
+    synth = vsa.synth
+    sd = synth.make_state_dict(256, 2, 5)
+    m = vsa.SimNet(num_heads=4, d_model=256, num_layers=2, sparsity=0.0, dropout=0.3)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(_dev()).eval()
+    x = synth.make_features(1, 320, 3, "pool5").to(_dev())
+    with torch.no_grad():
+        for mode in (False, True):
+            m.set_latency_mode(mode)
+            ref_l, ref_h = (t.clone() for t in m(x))
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                m(x)
+            torch.cuda.current_stream().wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out_l, out_h = m(x)
+            x.copy_(synth.make_features(1, 320, 4, "pool5").to(_dev()))       # new input in the captured buffer
+            g.replay()
+            torch.cuda.synchronize()
+            want_l, want_h = m(x)
+            assert torch.equal(out_l, want_l) and torch.equal(out_h, want_h), mode
+            assert not torch.equal(out_l, ref_l)
+            x.copy_(synth.make_features(1, 320, 3, "pool5").to(_dev()))
+            g.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(out_l, ref_l) and torch.equal(out_h, ref_h), mode
+            del g

@@ -925,3 +925,47 @@ def test_embedded_shape_trains_like_a_native_one(vsa):
     assert (tl - sl)[valid].abs().max().item() < 1e-5 and (th - sh)[valid].abs().max().item() < 1e-5
     th.sum().backward()
     assert xg.grad is not None and torch.isfinite(xg.grad).all()
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_low_precision_qk_gradients_at_peaked_attention(vsa, lp_train_everywhere, dtype):
+    """the soak normalises the q / k projection gradients by the v projection's (at DIFFUSE attention dS = P (dP -
+    delta) is a near-cancelling difference and the operand rounding enters at the scale of dP), so a sign or scale bug confined
+    to dS / dq / dk could hide there.  Here the attention is PEAKED (q / k weights scaled up 8x: the softmax puts most of a row
+    on a few keys, dS is no longer a small difference) and the q / k gradients are held UN-normalised: cosine similarity with
+    the float64 truth >= 0.995 and relative L2 <= 6e-2 (bf16; measured 3.0e-2) / 1e-2 (fp16; measured 4.5e-3), for the weights
+    and the biases of q and k."""
+    H, d, L = 4, 256, 2
+    sd = vsa.synth.make_state_dict(d, L, 51)
+    for l in range(L):
+        for n in ("q", "k"):
+            sd["encoder.module_list.%d.sa.%s.weight" % (l, n)] = sd["encoder.module_list.%d.sa.%s.weight" % (l, n)] * 8.0
+    x = vsa.synth.make_features(2, 160, 17, "randn")
+    target = torch.rand(2, 160, generator=torch.Generator().manual_seed(4))
+    # float64 truth (dropout off: train-mode forward of the restatement, masks=None)
+    params = {k: v.double().clone().requires_grad_(v.dtype.is_floating_point and "pos_embedding" not in k) for k, v in sd.items()}
+    pl, _ph = torch_ref.forward_with_masks(params, x.double(), None, H)
+    ((pl.squeeze(2) - target.double()) ** 2).mean().backward()
+    # how peaked: the mean largest attention probability of layer 0 (for the record)
+    m = vsa.SimNet(num_heads=H, d_model=d, num_layers=L, sparsity=0.0, dropout=0.0)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(_dev()).train().set_train_dtype(dtype)
+    pred, _hid = m(x.to(_dev()), None)
+    S = tol.TRAIN_FP16_LOSS_SCALE if dtype == "fp16" else 1.0
+    (vsa.mse_with_mask_loss(pred, target.to(_dev()), torch.zeros(2, 160, dtype=torch.bool, device=_dev())) * S).backward()
+    assert m.last_train_dtype == dtype
+    worst_cos, worst_l2 = 1.0, 0.0
+    for l in range(L):
+        for n in ("q", "k"):
+            for part in ("weight", "bias"):
+                key = "encoder.module_list.%d.sa.%s.%s" % (l, n, part)
+                want = params[key].grad.flatten()
+                got = (dict(m.named_parameters())[key].grad / S).double().cpu().flatten()
+                if want.norm().item() < 1e-9:          # k.bias: analytically zero (softmax shift invariance)
+                    continue
+                cos = torch.dot(got, want).item() / (got.norm().item() * want.norm().item() + 1e-300)
+                l2 = (got - want).norm().item() / want.norm().item()
+                worst_cos, worst_l2 = min(worst_cos, cos), max(worst_l2, l2)
+                assert cos >= 0.995, "%s: cosine %.4f" % (key, cos)
+                assert l2 <= (6e-2 if dtype == "bf16" else 1e-2), "%s: relative L2 %.3e" % (key, l2)
+    print("%s, peaked attention: q / k gradients worst cosine %.5f, worst relative L2 %.2e" % (dtype, worst_cos, worst_l2))
