@@ -407,9 +407,21 @@ __global__ __launch_bounds__(512, 2) void wgrad_tn_bf16(const float *__restrict_
     __shared__ __attribute__((aligned(16))) h16 Xs[2][BR * TW];
     __shared__ float red[8][TW + 4];
     const int tiles_k = (K + TW - 1) / TW;
-    const int tile_n = blockIdx.x / tiles_k, tile_k = blockIdx.x - tile_n * tiles_k;
+    // XCD-aware block -> (tile, split) map (round 4).  The tiles of one row split read the SAME rows of one operand (dY for the
+    // k-tiles of an n-tile, X for the n-tiles of a k-tile); workgroups go to the 8 XCDs round-robin in launch order, so with
+    // the plain map (tile fastest) the 4 tiles of a split land on 4 different XCDs and each L2 fetches the shared rows for
+    // itself.  Here the blocks of ONE XCD (linear index congruent mod 8) walk tile-fastest through their own splits, so the
+    // shared rows are fetched once per XCD.  Measured: fc2 / fc1 weight gradients 75.8 -> 73.6 us, QKV 78.5 -> 75.8 - the
+    // re-reads were being served by the Infinity Cache already; the kernel is bound by its 32-row stages (one barrier per 16
+    // MFMAs of a wave), not by that traffic.
+    int tile = blockIdx.x, split = blockIdx.y;
+    if ((gridDim.y & 7) == 0) {
+        const int L = blockIdx.x + gridDim.x * blockIdx.y, j = L >> 3;
+        tile = j % (int)gridDim.x;
+        split = (L & 7) + 8 * (j / (int)gridDim.x);
+    }
+    const int tile_n = tile / tiles_k, tile_k = tile - tile_n * tiles_k;
     const int n0 = tile_n * TW, k0 = tile_k * TW;
-    const int split = blockIdx.y;
     const int m_begin = split * rows_per_split, m_end = min(M, m_begin + rows_per_split);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
     const int wn = wave >> 1, wk = wave & 1;                 // 4 waves along n (64 each), 2 along k (128 each)
