@@ -70,7 +70,7 @@ extern "C" {
  * that shape the eval forward. */
 typedef struct vs_model_desc {
     int32_t d_model;      /* simnet.py:16;  multiple of 64, <= 1024 (other widths: vs_weights_set_norm_width below) */
-    int32_t num_heads;    /* simnet.py:15;  d_model/num_heads in {32, 64, 128} */
+    int32_t num_heads;    /* simnet.py:15;  d_model/num_heads in {32, 64, 128, 256} (256: exact attention only) */
     int32_t num_layers;   /* simnet.py:17;  len(encoder.module_list), >= 1 */
     int32_t in_features;  /* simnet.py:22 (1024 in the reference); multiple of 32 */
     int32_t max_len;      /* rows of pos_embedding (simnet.py:188: 2000); 0 when use_pos=False */
@@ -111,7 +111,7 @@ int vs_weights_pack(const vs_model_desc *desc, const vs_model_params *params,
 void vs_weights_free(vs_weights *w);
 
 /* Round 4 - the reference's envelope is ANY d_model % num_heads == 0 (simnet.py:123); the kernels' is d_model % 64 == 0
- * with head dim 32 / 64 / 128.  A model outside it is scored / trained EMBEDDED in the next supported shape: pack it with
+ * with head dim 32 / 64 / 128 / 256.  A model outside it is scored / trained EMBEDDED in the next supported shape: pack it with
  * desc.d_model = d' = num_heads * dh' (dh' the next supported head dim that makes d' a multiple of 64) and every parameter
  * zero-padded - residual-stream axes (rows of embed_w / wo / w2, columns of wq / wk / wv / w1 / final_w, biases, LayerNorm
  * gamma / beta, the positional table) keep feature c at index c; head-structured axes (rows of wq / wk / wv, columns of wo)

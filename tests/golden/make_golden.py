@@ -63,6 +63,10 @@ CASES = [
     dict(name="d96_h3_nc3_t70", H=3, d=96, L=2, B=1, T=70, wseed=34, xseed=144, kind="randn", num_classes=3),
     dict(name="d128_h1_t100", H=1, d=128, L=2, B=1, T=100, wseed=35, xseed=145, kind="randn"),
     dict(name="d320_h5_t200_pad", H=5, d=320, L=2, B=2, T=200, wseed=36, xseed=146, kind="pool5", lengths=[200, 120]),
+    # head dim 256 (num_heads=1, d_model=256; two heads of 256) and head dim 200 embedded in 256
+    dict(name="d256_h1_t150_pad", H=1, d=256, L=2, B=2, T=150, wseed=41, xseed=147, kind="pool5", lengths=[150, 91]),
+    dict(name="d512_h2_randmask_t96", H=2, d=512, L=1, B=2, T=96, wseed=42, xseed=148, kind="randn", randmask=3),
+    dict(name="d200_h1_t130", H=1, d=200, L=2, B=1, T=130, wseed=43, xseed=149, kind="randn"),
 ]
 # VS_GOLDEN_ONLY=name1,name2: (re)generate only these cases, keep every other fixture file as it is
 ONLY = [n for n in os.environ.get("VS_GOLDEN_ONLY", "").split(",") if n]

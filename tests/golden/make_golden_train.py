@@ -60,6 +60,9 @@ CASES = [
     dict(name="train_d200_h5_t70", H=5, d=200, L=2, B=1, T=70, wseed=38, xseed=162, kind="randn", tseed=13, hidden_w=0.0),
     dict(name="train_d96_h3_randmask_t65", H=3, d=96, L=1, B=2, T=65, wseed=39, xseed=163, kind="randn", randmask=6,
          tseed=14, hidden_w=1e-3),
+    # head dim 256 (one head of d_model 256), right-padded + key mask
+    dict(name="train_d256_h1_t90_pad", H=1, d=256, L=2, B=2, T=90, wseed=44, xseed=164, kind="pool5", lengths=[90, 57],
+         tseed=15, hidden_w=1e-3),
 ]
 ONLY = [n for n in os.environ.get("VS_GOLDEN_ONLY", "").split(",") if n]      # (re)generate only these, keep the others
 FULL_LIMIT = 4096

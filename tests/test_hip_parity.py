@@ -1562,7 +1562,7 @@ def test_bf16_mode_on_wide_models_matches_reference_golden(vsa, lp_linear_everyw
 # vs_weights_set_norm_width).  The reference-generated goldens of these shapes ride in golden_cases() above; here: the other
 # entry points of the module on such a model, against the CPU oracle.
 @pytest.mark.gpu
-@pytest.mark.parametrize("cfg", [(8, 128), (5, 200), (3, 96)], ids=lambda c: "h%d_d%d" % c)
+@pytest.mark.parametrize("cfg", [(8, 128), (5, 200), (3, 96), (1, 200)], ids=lambda c: "h%d_d%d" % c)      # (1, 200): head dim 200 -> 256
 def test_embedded_shape_through_every_entry_point(vsa, cfg):
     """SimNet(num_heads=8, d_model=128) (head dim 16), (5, 200) (head dim 40), (3, 96): padded and masked batches, packed ragged
     batches, score(), the class-token variant and the low-precision compute modes, each against the oracle on the TRUE-shaped
@@ -1585,16 +1585,20 @@ def test_embedded_shape_through_every_entry_point(vsa, cfg):
         assert (logits.cpu() - rl)[valid].abs().max().item() < TOL and (hidden.cpu() - rh)[valid].abs().max().item() < TOL
         sc = m.score(x.to(_dev()), mask.to(_dev()))
         assert (sc.cpu() - torch.sigmoid(rl.squeeze(-1)))[valid].abs().max().item() < TOL
-        # packed ragged batch: no padding rows, each video as if scored alone
+        # packed ragged batch: no padding rows, each video as if scored alone (head dim 256 has no packed attention: it says so)
         xp = torch.cat([x[i, :t] for i, t in enumerate(lengths)]).to(_dev())
-        pl, ph = m.forward_packed(xp, lengths)
-        assert ph.shape == (sum(lengths), d)
-        o = 0
-        for i, t in enumerate(lengths):
-            al, ah = m(x[i:i + 1, :t].to(_dev()))
-            assert torch.equal(pl[o:o + t], al[0]) and torch.equal(ph[o:o + t], ah[0]), "packed != alone (video %d)" % i
-            assert (al.cpu() - rl[i:i + 1, :t]).abs().max().item() < TOL
-            o += t
+        if m._lib_dh == 256:
+            with pytest.raises(RuntimeError, match="packed batches need head_dim"):
+                m.forward_packed(xp, lengths)
+        else:
+            pl, ph = m.forward_packed(xp, lengths)
+            assert ph.shape == (sum(lengths), d)
+            o = 0
+            for i, t in enumerate(lengths):
+                al, ah = m(x[i:i + 1, :t].to(_dev()))
+                assert torch.equal(pl[o:o + t], al[0]) and torch.equal(ph[o:o + t], ah[0]), "packed != alone (video %d)" % i
+                assert (al.cpu() - rl[i:i + 1, :t]).abs().max().item() < TOL
+                o += t
         # the emulated-fp32 mode stays inside the 1e-4 bar; the bf16 mode inside its own
         m.set_compute_dtype("fp16x3")
         l3, h3 = m(x.to(_dev()), mask.to(_dev()))

@@ -114,23 +114,25 @@ def test_attention_dtype_is_validated(vsa):
     wide.attention_dtype = "bf16"
     with pytest.raises(ValueError):
         wide.attention_dtype = "fp16x3"
-    huge = vsa.SimNet(num_heads=2, d_model=512, num_layers=1)      # head_dim 256: nothing
+    huge = vsa.SimNet(num_heads=2, d_model=512, num_layers=1)      # head_dim 256: the exact attention only
     with pytest.raises(ValueError):
         huge.attention_dtype = "bf16"
+    assert huge.set_compute_dtype("bf16").attention_dtype == "fp32" and huge.linear_dtype == "bf16"
 
 
 def test_embedding_plan_covers_the_reference_envelope_up_to_head_dim_128(vsa):
     """simnet.py:123 accepts any d_model % num_heads == 0; shapes outside the kernels' own envelope run embedded in the next
     supported shape (zero-padded parameters, true LayerNorm width declared to the library)."""
     plan = vsa.simnet.embedding_plan
-    for d, H in [(256, 4), (512, 4), (512, 8), (320, 5), (128, 1), (64, 1), (1024, 8), (768, 12)]:
+    for d, H in [(256, 4), (512, 4), (512, 8), (320, 5), (128, 1), (64, 1), (1024, 8), (768, 12), (256, 1), (512, 2), (1024, 4)]:
         assert plan(d, H) is None, (d, H)                      # native
     assert plan(128, 8) == (256, 32)                            # head dim 16 -> 32
     assert plan(200, 5) == (320, 64)                            # head dim 40 -> 64
     assert plan(96, 3) == (192, 64)                             # three heads of 32 would be d_model 96: not a multiple of 64
     assert plan(72, 2) == (128, 64)
     assert plan(640, 5) is None and plan(520, 5) == (640, 128)
-    for d, H in [(512, 2), (256, 1), (1032, 8), (126, 3)]:      # head dim > 128, too wide, d_model % 4
+    assert plan(200, 1) == (256, 256) and plan(400, 2) == (512, 256)      # head dim 200 -> 256
+    for d, H in [(512, 1), (1032, 8), (126, 3), (1280, 5)]:     # head dim > 256, too wide, d_model % 4
         with pytest.raises(NotImplementedError):
             plan(d, H)
     m = vsa.SimNet(num_heads=8, d_model=128, num_layers=1)
@@ -276,10 +278,16 @@ def test_no_kernel_touches_scratch_inside_its_innermost_mfma_loop(vsa, tmp_path)
     funcs = _device_functions(vsa, tmp_path)
     offenders, outer = [], {}
     seen_mfma_kernels = 0
+    # the one accepted exception (round 4): the head-dim-256 instantiations of the fp32 training attention kernels, a
+    # correctness-first form for SimNet(num_heads=1, d_model=256) and the like - one wave per SIMD, their
+    # accumulators alone exceed the register file (dK + dV = 256 registers beside K, V and the two score tiles)
+    dh256 = lambda n: any(k in n for k in ("attn_fwd_trainILi256E", "attn_bwd_dqILi256E", "attn_bwd_dkdvILi256E"))
     for name, ins in funcs.items():
         if not any(i.startswith("v_mfma") for _, i, _ in ins):
             continue
         seen_mfma_kernels += 1
+        if dh256(name):
+            continue
         base = ins[0][0]
         loops = [(base + t, a) for a, i, t in ins if (i.startswith("s_cbranch") or i.startswith("s_branch")) and t is not None and base + t <= a]
         count = lambda lo, hi, pfx: sum(1 for a, i, _ in ins if lo <= a <= hi and i.startswith(pfx))

@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "vs_kernels.h"
+#include "vs_train_kernels.h"      // vst_attention_fwd: the head-dim-256 attention of the scoring path
 #include "vs_weights_impl.h"
 
 namespace {
@@ -94,8 +95,8 @@ int check_desc(const vs_model_desc *d) {
     if (d->num_heads <= 0 || d->d_model % d->num_heads)
         return fail(VS_ERR_INVALID, "d_model=%d not divisible by num_heads=%d", d->d_model, d->num_heads);
     const int dh = d->d_model / d->num_heads;
-    if (dh != 32 && dh != 64 && dh != 128)
-        return fail(VS_ERR_INVALID, "head_dim=%d unsupported (32, 64 or 128)", dh);
+    if (dh != 32 && dh != 64 && dh != 128 && dh != 256)
+        return fail(VS_ERR_INVALID, "head_dim=%d unsupported (32, 64, 128 or 256)", dh);
     if (d->num_layers < 1) return fail(VS_ERR_INVALID, "num_layers=%d unsupported (>= 1)", d->num_layers);
     if (d->in_features <= 0 || d->in_features % 32)
         return fail(VS_ERR_INVALID, "in_features=%d unsupported (multiple of 32)", d->in_features);
@@ -538,6 +539,10 @@ int forward_core(const vs_weights *w, const float *x, const uint8_t *key_pad_mas
             if (pk)
                 VS_LAUNCH(vsk_attention_packed(qkv, qkv + kv_stride, qkv + 2 * kv_stride, att, H, M, d / H, scale,
                                                pk->cu, pk->work, pk->nwork, pk->nw, qkv16 ? (1 | VSK_STORE16) : pk->prec, st));
+            else if (d / H == 256)      // head dim 256 (round 4, correctness first): the training path's exact forward kernel without
+                                        // dropout; its log-sum-exp output lands in the MLP hidden region, which is free here
+                VS_LAUNCH(vst_attention_fwd(qkv, qkv + (size_t)M * d, qkv + 2 * (size_t)M * d, key_pad_mask, att, ffn, B, H, T, 256, scale,
+                                            0ull, 0u, 0.f, st, nullptr));
             else if (splitk && !aprec && (d / H == 32 || d / H == 64))      // latency mode: the keys split over a block's waves
                 VS_LAUNCH(vsk_attention_splitkv(qkv, qkv + (size_t)M * d, qkv + 2 * (size_t)M * d, key_pad_mask, att, B, H, T, d / H, scale, st));
             else if (aprec)

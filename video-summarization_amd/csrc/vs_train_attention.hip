@@ -497,6 +497,7 @@ static int allow_lds(const void *kernel, size_t bytes, std::atomic<unsigned char
         if (dh == 32) VST_ATTN_DH(KERNEL_, 32, __VA_ARGS__);                                                    \
         else if (dh == 64) VST_ATTN_DH(KERNEL_, 64, __VA_ARGS__);                                               \
         else if (dh == 128) VST_ATTN_DH(KERNEL_, 128, __VA_ARGS__);                                             \
+        else if (dh == 256) VST_ATTN_DH(KERNEL_, 256, __VA_ARGS__);      /* round 4: correctness first (1 wave / SIMD, spills) */ \
         else return -1;                                                                                         \
     } while (0)
 

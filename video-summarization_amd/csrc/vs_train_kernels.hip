@@ -761,7 +761,7 @@ int vst_gate_bwd(float *g, const float *act, size_t n, float scale, hipStream_t 
 
 int vst_head_rowdot(const float *dO, const float *O, float *delta, int M, int T, int H, int dh, hipStream_t st, int do16) {
     const int d = H * dh;
-    if (d > 1024 || (dh != 32 && dh != 64 && dh != 128)) return -1;
+    if (d > 1024 || (dh != 32 && dh != 64 && dh != 128 && dh != 256)) return -1;      // (256: one head per 256-column vector, the 64-lane sum)
     const dim3 grid((M + 3) / 4 < 4096 ? (M + 3) / 4 : 4096);
 #define VST_HRD(MODE_, F_)                                                                                                   \
     switch ((d + 255) / 256) {                                                                                               \

@@ -204,19 +204,19 @@ class _TrainForward(torch.autograd.Function):
 
 def embedding_plan(d_model: int, num_heads: int) -> Optional[Tuple[int, int]]:
     """The reference accepts any ``d_model % num_heads == 0`` (simnet.py:123); the kernels take d_model % 64 == 0 (<= 1024)
-    with head dim 32 / 64 / 128.  Returns None for such a shape, else ``(d_lib, dh_lib)``: the narrowest supported shape
+    with head dim 32 / 64 / 128 (/ 256: exact attention only, a correctness-first kernel).  Returns None for such a shape, else ``(d_lib, dh_lib)``: the narrowest supported shape
     with the same number of heads that holds the model when its parameters are zero-padded - mathematically the same
     function once LayerNorm and the attention scale use the true d_model, which the library is told
     (``vs_weights_set_norm_width``)."""
     dh = d_model // num_heads
-    if d_model % 64 == 0 and d_model <= 1024 and dh in (32, 64, 128):
+    if d_model % 64 == 0 and d_model <= 1024 and dh in (32, 64, 128, 256):
         return None
     if d_model % 4 == 0:
-        for dhp in (32, 64, 128):
+        for dhp in (32, 64, 128, 256):
             if dhp >= dh and (num_heads * dhp) % 64 == 0 and num_heads * dhp <= 1024:
                 return num_heads * dhp, dhp
-    raise NotImplementedError("SimNet(d_model=%d, num_heads=%d): supported are d_model %% 4 == 0 with head dim <= 128 and "
-                              "num_heads * (head dim rounded up to 32 / 64 / 128) <= 1024" % (d_model, num_heads))
+    raise NotImplementedError("SimNet(d_model=%d, num_heads=%d): supported are d_model %% 4 == 0 with head dim <= 256 and "
+                              "num_heads * (head dim rounded up to 32 / 64 / 128 / 256) <= 1024" % (d_model, num_heads))
 
 
 # --------------------------------------------------------------------------------------------
@@ -583,7 +583,7 @@ class SimNet(nn.Module):
         if value not in ("fp32", "fp16x3", "bf16"):
             raise ValueError("compute dtype must be 'fp32', 'fp16x3' or 'bf16', got %r" % (value,))
         if value == "bf16":
-            self.attention_dtype = "bf16"
+            self.attention_dtype = "bf16" if self._lib_dh <= 128 else "fp32"      # (head dim 256: exact attention only)
         else:
             self.attention_dtype = value if (head_ok or value == "fp32") else "fp32"
         self.linear_dtype = value
