@@ -752,15 +752,16 @@ def _hip_gates(vsa, module, out_tensor, B, T, d, L, bf16=False):
     lib = vsa._lib.load()
     saved = out_tensor.grad_fn.saved_tensors[2]
     handle = module._packed.handle
+    dl = getattr(module, "_lib_d", d)        # an embedded model's record has the library's (padded) width; the MLP axis keeps its index
     gates = {}
     for l in range(L):
         off, cnt = C.c_size_t(), C.c_size_t()
         vsa._lib.check(lib.vs_train_saved_field(handle, B, T, l, 0, C.byref(off), C.byref(cnt)))
-        if bf16:
-            act = saved[off.value: off.value + 2 * cnt.value].view(torch.bfloat16).view(B, T, 4 * d).float()
+        if bf16:        # True / "bf16": bf16 planes; "fp16": the fp16 training mode's
+            act = saved[off.value: off.value + 2 * cnt.value].view(torch.float16 if bf16 == "fp16" else torch.bfloat16).view(B, T, 4 * dl).float()
         else:
-            act = saved[off.value: off.value + 4 * cnt.value].view(torch.float32).view(B, T, 4 * d)
-        gates["gate%d" % l] = (act > 0).cpu()
+            act = saved[off.value: off.value + 4 * cnt.value].view(torch.float32).view(B, T, 4 * dl)
+        gates["gate%d" % l] = (act[..., :4 * d] > 0).cpu()
     return gates
 
 

@@ -4,7 +4,7 @@ architecture (head dim 32 / 64 / 128, d_model 128 ... 512, 1-3 layers), batch, l
 (none / suffix padding / arbitrary), dropout (0 or 0.1 ... 0.5, embedding dropout sometimes), both outputs carrying
 gradient.  Every case compares logits, the loss and EVERY gradient (input and parameters).
 
-    python tools/fuzz_train.py [seconds] [seed] [bf16]
+    python tools/fuzz_train.py [seconds] [seed] [bf16 | fp16]
 
 `bf16`: the same soak under set_train_dtype("bf16") (Linear / dgrad / wgrad GEMMs and, for head dim 32 / 64, the attention
 forward and backward on bf16 operands; pinned on from the first row).  The checker still shares the implementation's gates,
@@ -25,7 +25,9 @@ import tolerances as tol          # noqa: E402
 import torch_ref                  # noqa: E402
 import test_hip_train as tht      # noqa: E402  (_library_masks)
 
-ARCH = [(4, 256), (8, 256), (4, 128), (2, 128), (4, 512), (8, 512), (2, 64), (6, 192), (5, 320)]
+ARCH = [(4, 256), (8, 256), (4, 128), (2, 128), (4, 512), (8, 512), (2, 64), (6, 192), (5, 320),
+        # round 4: shapes embedded in the next supported one (head dim 16, 40, 36, three heads of 32, 200 -> 256) and head dim 256
+        (8, 128), (5, 200), (2, 72), (3, 96), (1, 200), (1, 256)]
 LENGTHS = [1, 2, 5, 17, 31, 32, 33, 63, 64, 65, 96, 127, 128, 129, 150, 200, 255, 256, 257, 320, 400, 511, 513, 700]
 ATOL, RTOL = tht.ATOL, tht.RTOL          # tests/tolerances.py: TRAIN_GRAD_ATOL / TRAIN_GRAD_RTOL
 # The float64 checker differentiates the SAME piecewise-linear function as the implementation: it takes the ReLU-and-
@@ -34,6 +36,10 @@ ATOL, RTOL = tht.ATOL, tht.RTOL          # tests/tolerances.py: TRAIN_GRAD_ATOL 
 
 
 def run(budget, seed, progress=True, lp=False):
+    """lp: False (exact fp32), True / "bf16", or "fp16" (under tests/tolerances.py's loss scale, like the reference's GradScaler)"""
+    lp_name = "fp16" if lp == "fp16" else "bf16"
+    S = tol.TRAIN_FP16_LOSS_SCALE if lp == "fp16" else 1.0
+    l2_bound = tol.TRAIN_FP16_GRAD_L2 if lp == "fp16" else tol.TRAIN_LP_GRAD_L2
     dev = torch.device("cuda:0")
     if lp:
         pkg._lib.set_option("VS_TRAIN_LP_MIN_ROWS", 0)
@@ -62,7 +68,7 @@ def run(budget, seed, progress=True, lp=False):
         m.load_state_dict(sd, strict=True)
         m = m.to(dev).train()
         if lp:
-            m.set_train_dtype("bf16")
+            m.set_train_dtype(lp_name)
             # half of the cases pin the A-stationary GEMM (d_model 256 only; by itself it engages from 49 152 rows up)
             pkg._lib.set_option("VS_LP_MLP_UNFUSED", 2 if rng.integers(2) else -1)
         tseed = int(rng.integers(1 << 30))
@@ -74,8 +80,8 @@ def run(budget, seed, progress=True, lp=False):
         pred, hidden = m(xd, md)
         mk = md if md is not None else torch.zeros(B, T, dtype=torch.bool, device=dev)
         loss = pkg.mse_with_mask_loss(pred, target.to(dev), mk) + hidden_w * (hidden * R.to(dev)).sum()
-        gates = tht._hip_gates(pkg, m, pred, B, T, d, L, bf16=lp)      # before backward frees the activation record
-        loss.backward()
+        gates = tht._hip_gates(pkg, m, pred, B, T, d, L, bf16=(lp_name if lp else False))      # before backward frees the activation record
+        (loss * S).backward()
         masks = tht._library_masks(pkg, B, T, d, H, L, seed64, p, p_embed) if (p > 0 or p_embed > 0) else None
         params = {k: v.double().clone().requires_grad_("pos_embedding" not in k) for k, v in sd.items()}
         x64 = x.double().clone().requires_grad_(True)
@@ -97,7 +103,7 @@ def run(budget, seed, progress=True, lp=False):
         assert e < (tol.BF16_LOGIT_TOL if lp else ATOL), "logits %.3e: %s" % (e, tag)
         # (bf16: the hidden-state term hw * sum(hidden * R) carries the forward's rounding of ~1e5 hidden values: 5 x the loss bound)
         assert abs(loss.item() - rloss.item()) < (5 * tol.TRAIN_LP_LOSS_RTOL if lp else 2e-5) * max(1.0, abs(rloss.item())), "loss: %s" % tag
-        pairs = [("x", xd.grad, x64.grad)] + [(k, prm.grad, params[k].grad) for k, prm in m.named_parameters()]
+        pairs = [("x", xd.grad / S, x64.grad)] + [(k, prm.grad / S, params[k].grad) for k, prm in m.named_parameters()]
         bad = []
         gscale = max(want.abs().max().item() for _k, _g, want in pairs)     # analytically-zero gradients (the key bias) are
         for k, got, want in pairs:                                          # sums that cancel: floor relative to the case
@@ -113,7 +119,7 @@ def run(budget, seed, progress=True, lp=False):
                     wv = dict((kk, ww) for kk, _g, ww in pairs)[vk]
                     ref_norm = max(ref_norm, wv.norm().item() * (want.numel() / wv.numel()) ** 0.5)
                 l2 = (got.double().cpu() - want).norm().item() / max(ref_norm, 1e-3 * gscale * want.numel() ** 0.5, 1e-30)
-                if not l2 <= tol.TRAIN_LP_GRAD_L2:
+                if not l2 <= l2_bound:
                     bad.append(k)
                 worst = max(worst, l2)
                 continue
@@ -139,11 +145,11 @@ def run(budget, seed, progress=True, lp=False):
 if __name__ == "__main__":
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-    lp = len(sys.argv) > 3 and sys.argv[3] == "bf16"
+    lp = sys.argv[3] if len(sys.argv) > 3 and sys.argv[3] in ("bf16", "fp16") else False
     n, worst, nrisky = run(budget, seed, lp=lp)
     if lp:
-        print("fuzz_train bf16: %d cases clean in %.0f s (seed %d) under set_train_dtype('bf16'); worst relative L2 gradient error %.2e "
-              "(bound %.0e)" % (n, budget, seed, worst, tol.TRAIN_LP_GRAD_L2))
+        print("fuzz_train %s: %d cases clean in %.0f s (seed %d) under set_train_dtype('%s'); worst relative L2 gradient error %.2e "
+              "(bound %.1e)" % (lp, n, budget, seed, lp, worst, tol.TRAIN_FP16_GRAD_L2 if lp == "fp16" else tol.TRAIN_LP_GRAD_L2))
         sys.exit(0)
     print("fuzz_train: %d cases clean in %.0f s (seed %d), %d of them with a ReLU input within 5e-6 of zero (all held to "
           "%.0e: the checker shares the implementation's gate); worst relative gradient error %.2e" % (n, budget, seed, nrisky, RTOL, worst))
