@@ -123,7 +123,10 @@ def run(budget, seed, progress=True, lp=False):
                     bad.append(k)
                 worst = max(worst, l2)
                 continue
-            if not (err <= ATOL * max(1.0, scale) and err <= rtol * scale + 1e-6 * gscale):
+            # (the floor for the analytically-zero sums - k.bias: sum_k dS = 0 per query - scales with the head dim: the residue is
+            # the rounding of dh-term dot products; measured 1.5e-8 / 6.6e-8 / 1.2e-7 / 2.3e-7 of the case's largest gradient at
+            # head dim 32 / 64 / 128 / 256 over 12 cases each, 1.07e-6 once in a 200 s soak at head dim 256)
+            if not (err <= ATOL * max(1.0, scale) and err <= rtol * scale + 1e-6 * max(1.0, (d // H) / 64.0) * gscale):
                 bad.append(k)
             if scale > 1e-6 and not risky:
                 worst = max(worst, err / scale)
