@@ -47,6 +47,16 @@ int vsk_rows_res_ln(const float *a, const float *res, const float *gamma, const 
                     const float *score_w, const float *score_b, int num_classes, int sigmoid, float *scores,
                     hipStream_t st, void *out16 = nullptr, int dn = 0,       // dn: LayerNorm width of an embedded model (0: d)
                     int nsplit = 0, const float *pbias = nullptr);           // nsplit > 0: `a` = K-slice partials [nsplit][M][d], pbias the Linear's bias
+// A batch of small matrix jobs in ONE launch (round 4: a reference-sized training step rebuilt its weight images with 55 tiny
+// launches - 17 transposes, 34 fragment packs, 4 conversions - per optimizer step; the host enqueue alone was ~0.2 ms)
+struct VskMatJobs {
+    enum { MAX = 24 };
+    const float *in[MAX];
+    float *out[MAX];
+    int rows[MAX], cols[MAX];      // the INPUT's shape [rows, cols] (pack_fragments: W [N = rows, K = cols])
+    int n;
+};
+int vsk_pack_fragments_batch(const VskMatJobs &jobs, hipStream_t st);      // each job: vsk_pack_fragments(in, out, rows, cols)
 int vsk_attention_splitkv(const float *q, const float *k, const float *v, const uint8_t *mask, float *out,
                           int B, int H, int T, int dh, float scale, hipStream_t st);       // latency mode: keys split over a block's waves
 // latency mode (VS_FLAG_SPLITK): split-K partial products through the fragment-major latency kernel, and the embedding's reduction

@@ -2078,6 +2078,30 @@ int vsk_pack_fragments(const float *W, float *Wf, int N, int K, hipStream_t st) 
     return 0;
 }
 
+// blockIdx.y = job, blockIdx.x strides over the job's float4 groups (same element map as pack_fragments)
+__global__ void pack_fragments_batch(VskMatJobs jobs) {
+    const int job = blockIdx.y;
+    const float *__restrict__ W = jobs.in[job];
+    float *__restrict__ Wf = jobs.out[job];
+    const int N = jobs.rows[job], K = jobs.cols[job];
+    const size_t total = (size_t)N * K / 4;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int lane = (int)(idx & 63);
+        const size_t gi = idx >> 6;
+        const int g = (int)(gi % (K / 8)), nb = (int)(gi / (K / 8));
+        const int row = 32 * nb + (lane & 31), col = 8 * g + 4 * (lane >> 5);
+        *(f32x4 *)(Wf + idx * 4) = *(const f32x4 *)(W + (size_t)row * K + col);
+    }
+}
+
+int vsk_pack_fragments_batch(const VskMatJobs &jobs, hipStream_t st) {
+    if (jobs.n < 1 || jobs.n > VskMatJobs::MAX) return -1;
+    for (int i = 0; i < jobs.n; ++i) if (jobs.rows[i] % 32 || jobs.cols[i] % 8) return -1;
+    hipLaunchKernelGGL(pack_fragments_batch, dim3(64, jobs.n), dim3(256), 0, st, jobs);
+    VSK_CHECK_LAUNCH();
+    return 0;
+}
+
 int vsk_pack_fragments_f16x3(const float *W, float *Wh, int N, int K, hipStream_t st) {
     if (N % 32 || K % 16) return -1;
     hipLaunchKernelGGL(pack_fragments_f16x3, dim3(256), dim3(256), 0, st, W, (unsigned *)Wh, N, K);

@@ -234,13 +234,20 @@ int vsw_ensure(const vs_weights *w, unsigned families, void *stream) {
     float *blob = w->blob;
     bool pk = true;
     if ((families & VSW_FRAGMENTS) && w->f_version != w->version) {
-        pk &= vsk_pack_fragments(blob + w->embed_w, blob + w->f_embed_w, (int)d, (int)din, st) == 0;
+        // one launch for all matrices (a reference-sized training step rebuilds this family after every optimizer step)
+        VskMatJobs fj{};
+        auto add = [&](size_t src, size_t dst, int N, int K) {
+            if (fj.n == VskMatJobs::MAX) { pk &= vsk_pack_fragments_batch(fj, st) == 0; fj.n = 0; }
+            fj.in[fj.n] = blob + src; fj.out[fj.n] = blob + dst; fj.rows[fj.n] = N; fj.cols[fj.n] = K; ++fj.n;
+        };
+        add(w->embed_w, w->f_embed_w, (int)d, (int)din);
         for (const auto &L : w->layers) {
-            pk &= vsk_pack_fragments(blob + L.wqkv, blob + L.f_wqkv, (int)(3 * d), (int)d, st) == 0;
-            pk &= vsk_pack_fragments(blob + L.wo, blob + L.f_wo, (int)d, (int)d, st) == 0;
-            pk &= vsk_pack_fragments(blob + L.w1, blob + L.f_w1, (int)(4 * d), (int)d, st) == 0;
-            pk &= vsk_pack_fragments(blob + L.w2, blob + L.f_w2, (int)d, (int)(4 * d), st) == 0;
+            add(L.wqkv, L.f_wqkv, (int)(3 * d), (int)d);
+            add(L.wo, L.f_wo, (int)d, (int)d);
+            add(L.w1, L.f_w1, (int)(4 * d), (int)d);
+            add(L.w2, L.f_w2, (int)d, (int)(4 * d));
         }
+        pk &= vsk_pack_fragments_batch(fj, st) == 0;
         if (pk) w->f_version = w->version;
     }
     if ((families & VSW_F16X3) && w->h_version != w->version) {

@@ -165,29 +165,56 @@ int ensure_transposed(vs_weights *w, hipStream_t st, bool frags) {
         VST_HIP(hipMemsetAsync(w->tblob + w->zeros, 0, nz * sizeof(float), st));
         w->t_version = ~0ull;
         w->tf_version = ~0ull;
+        w->t16_version = ~0ull;
     }
     // W [N,K] -> W^T [K,N] row-major, and its fragment-major copy for the latency kernels (as vsw_ensure does for W)
     vsw_order(w, (void *)st);
     const bool do_t = w->t_version != w->version, do_f = frags && w->tf_version != w->version;
     if (!do_t && !do_f) return VS_OK;
     struct Mark { const vs_weights *w; void *s; ~Mark() { vsw_mark(w, s); } } mark{w, (void *)st};
-    auto both = [&](const float *W, size_t t_off, size_t tf_off, int N, int K) -> int {
-        if (do_t) if (int rc = vst_transpose(W, w->tblob + t_off, N, K, st)) return rc;
-        if (do_f) return vsk_pack_fragments(w->tblob + t_off, w->tblob + tf_off, K, N, st);
+    // one launch per family (was one per matrix: 17 transposes + 17 fragment packs + 4 conversions per optimizer step)
+    VskMatJobs tj{}, fj{};
+    auto add = [&](const float *W, size_t t_off, size_t tf_off, int N, int K) {
+        tj.in[tj.n] = W; tj.out[tj.n] = w->tblob + t_off; tj.rows[tj.n] = N; tj.cols[tj.n] = K; ++tj.n;
+        fj.in[fj.n] = w->tblob + t_off; fj.out[fj.n] = w->tblob + tf_off; fj.rows[fj.n] = K; fj.cols[fj.n] = N; ++fj.n;      // W^T is [K, N]
+    };
+    auto flush = [&]() -> int {
+        if (tj.n == 0) return 0;
+        if (do_t) if (int rc = vst_transpose_batch(tj, st)) return rc;
+        if (do_f) if (int rc = vsk_pack_fragments_batch(fj, st)) return rc;
+        tj.n = fj.n = 0;
         return 0;
     };
-    VST_LAUNCH(both(w->p(w->embed_w), w->t_embed_w, w->tf_embed_w, (int)d, (int)din));                       // [d,din] -> [din,d]
+    add(w->p(w->embed_w), w->t_embed_w, w->tf_embed_w, (int)d, (int)din);                                    // [d,din] -> [din,d]
     for (int l = 0; l < w->desc.num_layers; ++l) {
         const LayerOff &P = w->layers[l];
         const LayerOffT &Q = w->tlayers[l];
-        VST_LAUNCH(both(w->p(P.wqkv), Q.t_wqkv, Q.tf_wqkv, (int)(3 * d), (int)d));                           // [3d,d] -> [d,3d]
-        VST_LAUNCH(both(w->p(P.wo), Q.t_wo, Q.tf_wo, (int)d, (int)d));
-        VST_LAUNCH(both(w->p(P.w1), Q.t_w1, Q.tf_w1, (int)(4 * d), (int)d));                                 // [4d,d] -> [d,4d]
-        VST_LAUNCH(both(w->p(P.w2), Q.t_w2, Q.tf_w2, (int)d, (int)(4 * d)));                                 // [d,4d] -> [4d,d]
-        if (do_t) VST_LAUNCH(vsk_to_bf16(w->tblob + Q.t_w2, w->tblob + Q.t16_w2, 4 * d * d, st));
+        if (tj.n + 4 > VskMatJobs::MAX) VST_LAUNCH(flush());
+        add(w->p(P.wqkv), Q.t_wqkv, Q.tf_wqkv, (int)(3 * d), (int)d);                                        // [3d,d] -> [d,3d]
+        add(w->p(P.wo), Q.t_wo, Q.tf_wo, (int)d, (int)d);
+        add(w->p(P.w1), Q.t_w1, Q.tf_w1, (int)(4 * d), (int)d);                                              // [4d,d] -> [d,4d]
+        add(w->p(P.w2), Q.t_w2, Q.tf_w2, (int)d, (int)(4 * d));                                              // [d,4d] -> [4d,d]
     }
+    VST_LAUNCH(flush());
+    // (the bf16 copy of W2^T feeds the A-stationary dgrad of the bf16 training mode only: built when that form runs - t16_version)
     if (do_t) w->t_version = w->version;
     if (do_f) w->tf_version = w->version;
+    return VS_OK;
+}
+
+// bf16 copy of every W2^T (vst_gemm_rows16's weight operand in the backward of the bf16 training mode): after ensure_transposed,
+// only when that form runs
+int ensure_t16(vs_weights *w, hipStream_t st) {
+    std::lock_guard<std::mutex> lk(g_tmu);
+    if (w->t16_version == w->version) return VS_OK;
+    vsw_order(w, (void *)st);
+    struct Mark { const vs_weights *w; void *s; ~Mark() { vsw_mark(w, s); } } mark{w, (void *)st};
+    const size_t d = w->desc.d_model;
+    for (int l = 0; l < w->desc.num_layers; ++l) {
+        const LayerOffT &Q = w->tlayers[l];
+        VST_LAUNCH(vsk_to_bf16(w->tblob + Q.t_w2, w->tblob + Q.t16_w2, 4 * d * d, st));
+    }
+    w->t16_version = w->version;
     return VS_OK;
 }
 
@@ -358,6 +385,7 @@ int vs_train_backward(vs_weights *w, const float *x, const uint8_t *key_pad_mask
     const int F = form.f16 ? VSK_F16 : 0;            // fp16 mode: rides on every 16-bit precision word below
     const int lp = form.lp ? (1 | F) : 0;
     const bool lpa = form.lpa, qkv16 = form.qkv16, h16 = form.h16, rows16 = form.rows16;
+    if (rows16) if (int rc = ensure_t16(w, st)) return rc;
     const size_t kvs = qkv16 ? (size_t)B * T * w->desc.d_model / 2 : (size_t)B * T * w->desc.d_model;     // floats between the planes
     const unsigned long long seed = drop ? drop->seed : 0ull;
     const int dn = w->dn();

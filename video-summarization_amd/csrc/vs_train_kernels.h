@@ -33,6 +33,7 @@ int vst_wgrad(const float *dY, int ldy, const float *X, int ldx, int M, int N, i
               float *db0, float *db1, float *db2, int rows_per_dest, float *work, hipStream_t st, int prec = 0);   // prec 1: bf16 matrix pipe
 int vst_reduce_rows(const float *part, int S, int rows, int cols, float *d0, float *d1, float *d2, int rows_per_dest,
                     hipStream_t st);
+int vst_transpose_batch(const VskMatJobs &jobs, hipStream_t st);      // each job: out [cols, rows] = in [rows, cols]^T, one launch
 int vst_transpose(const float *in, float *out, int rows, int cols, hipStream_t st);
 int vst_mse_mask_blocks(int n);
 int vst_mse_mask_fwd(const float *out, const float *tgt, const unsigned char *mask, int n, int mean, float *part,

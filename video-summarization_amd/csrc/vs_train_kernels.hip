@@ -661,6 +661,32 @@ __global__ __launch_bounds__(256) void transpose2d(const float *__restrict__ in,
     }
 }
 
+// the same for a batch of matrices: blockIdx.y = job, blockIdx.x = the job's 32 x 32 tile (blocks past its last tile exit)
+__global__ __launch_bounds__(256) void transpose2d_batch(VskMatJobs jobs) {
+    __shared__ float tile[32][33];
+    const int job = blockIdx.y;
+    const float *__restrict__ in = jobs.in[job];
+    float *__restrict__ out = jobs.out[job];
+    const int rows = jobs.rows[job], cols = jobs.cols[job];
+    const int tcols = (cols + 31) / 32, ntiles = tcols * ((rows + 31) / 32);
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+        const int c0 = (t % tcols) * 32, r0 = (t / tcols) * 32;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int rr = r0 + ty + 8 * i, cc = c0 + tx;
+            if (rr < rows && cc < cols) tile[ty + 8 * i][tx] = in[(size_t)rr * cols + cc];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int cc = c0 + ty + 8 * i, rr = r0 + tx;
+            if (rr < rows && cc < cols) out[(size_t)cc * rows + rr] = tile[tx][ty + 8 * i];
+        }
+        __syncthreads();
+    }
+}
+
 // ---- utils.mse_with_mask_loss (reference utils.py:45-56): mean (or sum) over ALL B*T entries of
 //      ((output - target) * scale)^2, scale = 0 on masked frames ----
 __global__ __launch_bounds__(256) void mse_mask_partial(const float *__restrict__ out, const float *__restrict__ tgt,
@@ -861,6 +887,13 @@ int vst_reduce_rows(const float *part, int S, int rows, int cols, float *d0, flo
 
 int vst_transpose(const float *in, float *out, int rows, int cols, hipStream_t st) {
     hipLaunchKernelGGL(transpose2d, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0, st, in, out, rows, cols);
+    VSK_CHECK_LAUNCH();
+    return 0;
+}
+
+int vst_transpose_batch(const VskMatJobs &jobs, hipStream_t st) {
+    if (jobs.n < 1 || jobs.n > VskMatJobs::MAX) return -1;
+    hipLaunchKernelGGL(transpose2d_batch, dim3(256, jobs.n), dim3(256), 0, st, jobs);
     VSK_CHECK_LAUNCH();
     return 0;
 }

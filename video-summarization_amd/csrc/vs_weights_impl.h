@@ -59,6 +59,7 @@ struct vs_weights {
     float *tblob = nullptr;               // second device allocation: transposed weights + a zero vector
     unsigned long long t_version = ~0ull; // version the transposes were built from
     unsigned long long tf_version = ~0ull;// ... and their fragment-major copies (latency kernels only)
+    unsigned long long t16_version = ~0ull;// ... and the bf16 copy of W2^T (A-stationary dgrad of the bf16 training mode only)
     size_t t_embed_w = 0, tf_embed_w = 0, zeros = 0;
     std::vector<LayerOffT> tlayers;
     const float *tp(size_t off) const { return tblob + off; }

@@ -163,11 +163,16 @@ class _TrainForward(torch.autograd.Function):
         if module._plan:      # embedded model: the library writes gradients of ITS shape; the true-shaped parts go back
             shapes = [module._padded_shape(t.shape, ax) for t, ax in zip(params, axes)]
         sizes = [int(torch.Size(sh).numel()) for sh in shapes]
-        offs = [0]
-        for n_ in sizes:
-            offs.append(offs[-1] + (n_ + 63) // 64 * 64)          # 256-byte aligned views
-        flat = torch.empty((offs[-1],), dtype=torch.float32, device=x.device)
-        grads = [flat[o: o + n_].view(sh) for o, n_, sh in zip(offs, sizes, shapes)]
+        if all(n_ % 4 == 0 for n_ in sizes[:-1]):
+            # dense packing keeps every view 16-byte aligned (all the kernels need); the views come from ONE C++ call
+            flat = torch.empty((sum(sizes),), dtype=torch.float32, device=x.device)
+            grads = [g.view(sh) for g, sh in zip(flat.split_with_sizes(sizes), shapes)]
+        else:
+            offs = [0]
+            for n_ in sizes:
+                offs.append(offs[-1] + (n_ + 63) // 64 * 64)          # 256-byte aligned views
+            flat = torch.empty((offs[-1],), dtype=torch.float32, device=x.device)
+            grads = [flat[o: o + n_].view(sh) for o, n_, sh in zip(offs, sizes, shapes)]
         it = iter(grads)
         G = _lib.ModelGrads()
         G.embed_w, G.embed_b = next(it).data_ptr(), next(it).data_ptr()
@@ -415,9 +420,10 @@ class SimNet(nn.Module):
         for t in self._tensors():
             if t.device != device:
                 raise RuntimeError("SimNet parameters are on %s but the input is on %s" % (t.device, device))
-            ts.append(t.detach().to(torch.float32).contiguous())
+            # (an fp32 contiguous tensor is used as it is: no detach / cast / contiguous objects per parameter and step)
+            ts.append(t if (t.dtype == torch.float32 and t.is_contiguous()) else t.detach().to(torch.float32).contiguous())
         if self._plan:        # embedded model: the library sees zero-padded parameters of its own shape
-            ts = [self._pad(t, ax).contiguous() for t, ax in zip(ts, self._tensor_axes())]
+            ts = [self._pad(t.detach(), ax).contiguous() for t, ax in zip(ts, self._tensor_axes())]
         it = iter(ts)
         reuse = self._packed is not None and self._packed_shape == shape_key
         P = _lib.ModelParams()
