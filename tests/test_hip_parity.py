@@ -637,6 +637,32 @@ def test_attention_bf16_stored_w64_operand_layout_is_exact_on_a_permutation(vsa,
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("checked", [0, 1])
+def test_attention_bf16_stored_w64_every_gap_between_a_late_key_and_tile_0(vsa, checked):
+    """The optimistic pass fixes a row's constant 60 below tile 0's maximum and tests its OUTPUTS afterwards.  A row whose
+    late key sits g above tile 0's maximum sums l ~ 2^(60 + g): beyond 2^128 that is inf and is seen - but for g = 66, 67 the
+    sum is finite while its reciprocal is a denormal, which v_rcp_f32 flushes to zero: every output of the row came out 0,
+    nothing non-finite, no restart (found by tools/fuzz_attn_w64.py, round 4; the pass now also refuses l >= 2^120).  Here row
+    i's late key is i / 4 above everything else: every gap from 0 to 250 in one call, both passes."""
+    B, H, T = 1, 2, 1000
+    g = torch.Generator().manual_seed(5)
+    q, k, v = (torch.randn(B, H, T, 64, generator=g) * 0.25 for _ in range(3))
+    v = v * 4.0
+    q[..., 0] = torch.arange(T, dtype=torch.float32) / 32.0        # q . k[pos] = (i / 32) * 8 = i / 4
+    k[..., 0] = 0.0
+    for pos in (700, 701):
+        k[:, :, pos, :] = 0.0
+        k[:, :, pos, 0] = 8.0
+    q16, k16, v16 = q.to(torch.bfloat16), k.to(torch.bfloat16), v.to(torch.bfloat16)
+    ref = _attn_ref_stored(q16, k16, v16, None)
+    out = _run_attn_stored(vsa, q16, k16, v16, None, 1, checked)
+    assert torch.isfinite(out).all()
+    err = (out.double() - ref).abs().amax(dim=2)[0]
+    worst = int(err.argmax())
+    assert err.max().item() < BF16_STORED_REL * ref.abs().max().item(), "row %d (gap %.2f): %.3e" % (worst, worst / 4.0, err.max().item())
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("masked", [False, True])
 def test_attention_bf16_stored_w64_rescue_and_raise(vsa, masked):
     """Scores of several hundred that rise late in the video: the optimistic pass overflows (its row constant is set once,

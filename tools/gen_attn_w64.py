@@ -701,7 +701,11 @@ def epilogue(g, check):
             e("v_cvt_pk_bf16_f32 %s, %s, %s" % (vr(RT + 1), vr(RT + 1), vr(RT + 1)))
             e("v_lshlrev_b32 %s, 16, %s" % (vr(RT + 1), vr(RT + 1)))
             e("v_fma_f32 %s, %s, %s, %s" % (vr(inv), sr(sNPADN), vr(RT + 1), vr(inv)))
-            e("v_fma_f32 %s, %s, 0, %s" % (vr(bad), vr(inv), vr(bad)))      # l itself: 1 / inf = 0 would hide an overflow
+            # l itself: 1 / inf = 0 would hide an overflow - and so would l in [2^126, 2^128): its reciprocal is a denormal, which
+            # v_rcp_f32 flushes to 0 (tools/fuzz_attn_w64.py found it: a key 66 above tile 0's maximum, every output of that row
+            # zero, nothing non-finite).  l * 2^8 overflows from 2^120 on: such a row sends the block to the checked pass too.
+            e("v_mul_f32 %s, 0x43800000, %s" % (vr(RT + 1), vr(inv)))
+            e("v_fma_f32 %s, %s, 0, %s" % (vr(bad), vr(RT + 1), vr(bad)))
         e("v_rcp_f32 %s, %s" % (vr(inv), vr(inv)))
         e("s_nop 0")
         for d in range(2):
