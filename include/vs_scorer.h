@@ -36,10 +36,11 @@ extern "C" {
                                 run on the bf16 matrix pipe (q*scale, k, v, p rounded to bf16; fp32
                                 softmax and accumulation).  Head dim 32 or 64.  Scores then differ from
                                 the reference's fp32 path by ~1e-3 (tolerance stated in the tests);
-                                the default path stays exact fp32.  Domain: attention logits q . k * scale
-                                within +-11 000 (16 000 in log2 units; tools/fuzz_attn_w64.py soaks up to there) -
-                                beyond ~2^14 both bf16 kernels return NaN for the row, where the exact path and the
-                                reference's softmax still work.  No model whose logits mean anything is near it. */
+                                the default path stays exact fp32.  Domain (measured, tools/fuzz_attn_w64.py and a probe): operand entries of
+                                magnitude >= ~1e4 whose logit exceeds 2^14 in log2 units (exp(11 000)) come out NaN
+                                from both bf16 kernels (q = 1, k = 16 500: NaN; q = 100, k = 200 - the same logit - is
+                                fine; logits up to 16 300 with any operands are fine); the exact path and the
+                                reference's softmax have no such limit.  The soak runs up to there.  No model whose logits mean anything is near it. */
 #define VS_FLAG_BF16_LINEAR 4u /* opt-in: every Linear (embed, q/k/v, feature_projection, fc1, fc2) multiplies
                                 bf16-rounded operands on the bf16 matrix pipe; tensors stay fp32 in HBM, and
                                 bias, accumulation, residual, LayerNorm and the score head stay fp32.
