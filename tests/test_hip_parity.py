@@ -637,6 +637,31 @@ def test_attention_bf16_stored_w64_operand_layout_is_exact_on_a_permutation(vsa,
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("T", [64, 127, 320, 1024])
+def test_attention_bf16_stored_logits_beyond_2_to_the_14(vsa, T):
+    """The 8-wave bf16 kernel carries its row constant through a bf16 operand, i.e. rounded to a bf16 grid point; it used to
+    round UP, and beyond |c| = 2^14 (grid step 128) the row maximum's own P could drop under 2^-126, flush to zero and leave
+    0 / 0 for the row (found by tools/fuzz_attn_w64.py on short videos, which take this kernel: q = 4, k = 5000 -> NaN while
+    q = 100, k = 200 - the same logit, on a grid point - was fine).  Logits of 16 500 ... 30 000, on and off the grid, at
+    lengths that take the 4-wave, the 8-wave and the one-wave-per-SIMD kernels: the softmax is one-hot, the row is V[pos]."""
+    g = torch.Generator().manual_seed(T)
+    for qa, kb in ((4.0, 5000.0), (2.0, 9000.0), (1.0, 16500.0), (1.0, 20000.0), (100.0, 200.0), (3.0, 9999.0), (1.0, 30000.0)):
+        q = torch.randn(1, 2, T, 64, generator=g) * 0.1
+        k = torch.randn(1, 2, T, 64, generator=g) * 0.1
+        v = torch.randn(1, 2, T, 64, generator=g)
+        pos = T // 2 + 3
+        q[..., 0] = qa
+        k[..., 0] = 0.0
+        k[:, :, pos, 0] = kb
+        q16, k16, v16 = q.to(torch.bfloat16), k.to(torch.bfloat16), v.to(torch.bfloat16)
+        want = v16[:, :, pos].float().permute(0, 1, 2).reshape(1, 1, 2 * 64).expand(1, T, 128)
+        for w64 in (0, 1):
+            out = _run_attn_stored(vsa, q16, k16, v16, None, w64, 0)
+            assert torch.isfinite(out).all(), (T, qa, kb, w64)
+            assert (out.float() - want).abs().max().item() < 1e-6, (T, qa, kb, w64)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("checked", [0, 1])
 def test_attention_bf16_stored_w64_every_gap_between_a_late_key_and_tile_0(vsa, checked):
     """The optimistic pass fixes a row's constant 60 below tile 0's maximum and tests its OUTPUTS afterwards.  A row whose

@@ -940,6 +940,11 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_lp_pipe(
             const unsigned b = __builtin_bit_cast(unsigned, cl);
             constexpr unsigned LOW = PREC == 2 ? 0x1FFFu : 0xFFFFu;       // f16: 10 mantissa bits, bf16: 7
             c_new = __builtin_bit_cast(float, (cl >= 0.f ? b + LOW : b) & ~LOW);
+            // From |c| = 2^13 on, one bf16 step is 64 and more: rounded UP, the row maximum's own P = 2^-(CMARGIN + distance)
+            // fell below 2^-126 once the step reached 128 (logits beyond 2^14), was flushed to zero, and the row came out 0 / 0
+            // (tools/fuzz_attn_w64.py, round 4: q = 4, k = 5000 -> NaN; q = 100, k = 200, the same logit on a bf16 grid point ->
+            // fine).  There the constant is rounded to NEAREST: the maximum's P stays within 2^+-64 of 2^-CMARGIN.
+            if (PREC == 1 && __builtin_fabsf(cl) >= 8192.f) c_new = __builtin_bit_cast(float, (b + 0x8000u) & ~LOW);
             if (PREC == 2 && __builtin_fabsf(c_new) < 0.0001220703125f) c_new = cl > 0.f ? 0.0001220703125f : 0.f;   // below 2^-13: not a normal f16
         }
         const float u_new = (c_new == NEG_INF) ? 0.f : c_new;
