@@ -23,5 +23,6 @@ with torch.no_grad():
     wall = (time.perf_counter() - t0) / 100
     st = pkg._lib.profile_collect(); lib.vs_profile_enable(0)
     gpu = sum(ms for ms, n in st.values()) / 100
-    print("B=%d T=%d: wall %.1f us/forward, host enqueue %.1f us, sum of GPU stage times %.1f us" % (B, T, wall * 1e6, host * 1e6, gpu * 1e3))
+    print("B=%d T=%d [%s]: wall %.1f us/forward, host enqueue %.1f us, sum of GPU stage times %.1f us (stage events add a few us each)" % (
+        B, T, "latency mode" if m.latency_mode else "default kernels", wall * 1e6, host * 1e6, gpu * 1e3))
     for k, (ms, n) in st.items(): print("   %-14s %7.1f us per launch (%d launches/forward)" % (k, ms / n * 1e3, n // 100))
