@@ -1677,7 +1677,8 @@ def test_embedded_shape_through_every_entry_point(vsa, cfg):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["ma_t320", "ma_t320_pad", "ma_ragged37", "ma_randmask_t96", "ma_nc3_t64", "ma_nopos_t129", "dh32_t65"])
+@pytest.mark.parametrize("name", ["ma_t320", "ma_t320_pad", "ma_ragged37", "ma_randmask_t96", "ma_nc3_t64", "ma_nopos_t129", "dh32_t65",
+                                  "mb_t320", "mb_pad_t150", "ctor_default_t100", "d128_h1_t100"])      # + d_model 512 (head dim 128 / 64), 128
 def test_latency_mode_meets_the_goldens_and_is_deterministic(vsa, name):
     """SimNet.set_latency_mode() (VS_FLAG_SPLITK: split-K embedding / out-projection / fc2 + row LayerNorm for reference-sized
     calls): the reference-generated goldens at the path's own 1e-4 bar, within 2e-5 of the default kernels, bitwise
@@ -1702,7 +1703,7 @@ def test_latency_mode_meets_the_goldens_and_is_deterministic(vsa, name):
         if x.shape[0] > 1 and mask is None:           # each video alone == the same video inside the batch
             a, _ = m(xd[:1])
             assert torch.equal(a[0], l1[0])
-        if name == "ma_t320":
+        if name in ("ma_t320", "mb_t320", "ctor_default_t100"):
             assert not torch.equal(l0, l1), "the latency mode did not run (results are the default kernels' bits)"
 
 

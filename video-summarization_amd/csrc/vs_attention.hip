@@ -232,28 +232,42 @@ __global__ __launch_bounds__(512) void attn_fwd_splitkv(
     const int ntiles = (T + 31) / 32;
     for (int tile = wave; tile < ntiles; tile += NW) {
         const int k0 = tile * 32;
-        f32x4 ka[NJ];
-        {
-            int kr = k0 + r; kr = kr < T ? kr : T - 1;
-            const float *kp = Kg + base + (size_t)kr * DH + 4 * h;
+        // K fragments in halves of <= 8 k-groups and V one 32-column block ahead (head dim 128: 64 + 32 + 32 + 64 + 16 registers)
+        constexpr int NJH = NJ < 8 ? NJ : 8;
+        int kr = k0 + r; kr = kr < T ? kr : T - 1;
+        const float *kp = Kg + base + (size_t)kr * DH + 4 * h;
+        f32x4 ka[NJH];
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) ka[j] = *(const f32x4 *)(kp + 8 * j);
-        }
-        float va[ND][16];
+        for (int j = 0; j < NJH; ++j) ka[j] = *(const f32x4 *)(kp + 8 * j);
+        const float *vbase = Vg + base + r;
+        int voff[16];                                  // (offsets inside this (video, head) block: T * DH < 2^31)
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
             int key = k0 + acc_row(t, h); key = key < T ? key : T - 1;
-            const float *vp = Vg + base + (size_t)key * DH + r;
-#pragma unroll
-            for (int d = 0; d < ND; ++d) va[d][t] = vp[32 * d];
+            voff[t] = key * DH;
         }
+        float va[2][16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) va[0][t] = vbase[voff[t]];
         f32x16 s;
 #pragma unroll
         for (int t = 0; t < 16; ++t) s[t] = 0.f;
 #pragma unroll
-        for (int j = 0; j < NJ; ++j)
+        for (int jh = 0; jh < NJ; jh += NJH) {
+            f32x4 kn[NJH];
+            if (jh + NJH < NJ) {
 #pragma unroll
-            for (int st = 0; st < 4; ++st) s = MFMA32(ka[j][st], qreg[4 * j + st], s);
+                for (int j = 0; j < NJH; ++j) kn[j] = *(const f32x4 *)(kp + 8 * (jh + NJH + j));
+            }
+#pragma unroll
+            for (int j = 0; j < NJH; ++j)
+#pragma unroll
+                for (int st = 0; st < 4; ++st) s = MFMA32(ka[j][st], qreg[4 * (jh + j) + st], s);
+            if (jh + NJH < NJ) {
+#pragma unroll
+                for (int j = 0; j < NJH; ++j) ka[j] = kn[j];
+            }
+        }
         if (mask != nullptr || k0 + 32 > T) {
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
@@ -282,10 +296,14 @@ __global__ __launch_bounds__(512) void attn_fwd_splitkv(
         m_run = m_new;
 #pragma unroll
         for (int d = 0; d < ND; ++d) {
+            if (d + 1 < ND) {
+#pragma unroll
+                for (int t = 0; t < 16; ++t) va[(d + 1) & 1][t] = vbase[voff[t] + 32 * (d + 1)];
+            }
 #pragma unroll
             for (int t = 0; t < 16; ++t) o[d][t] *= alpha;
 #pragma unroll
-            for (int t = 0; t < 16; ++t) o[d] = MFMA32(va[d][t], s[t], o[d]);
+            for (int t = 0; t < 16; ++t) o[d] = MFMA32(va[d & 1][t], s[t], o[d]);
         }
     }
 
@@ -1632,6 +1650,7 @@ int vsk_attention_splitkv(const float *q, const float *k, const float *v, const 
     const float sl2 = vsk_attention_qscale(scale);
     const dim3 grid(((T + 31) / 32) * B * H);
     if (dh == 64) hipLaunchKernelGGL((attn_fwd_splitkv<64>), grid, dim3(512), 0, st, q, k, v, mask, out, H, T, sl2, B * H);
+    else if (dh == 128) hipLaunchKernelGGL((attn_fwd_splitkv<128>), grid, dim3(512), 0, st, q, k, v, mask, out, H, T, sl2, B * H);
     else if (dh == 32) hipLaunchKernelGGL((attn_fwd_splitkv<32>), grid, dim3(512), 0, st, q, k, v, mask, out, H, T, sl2, B * H);
     else return -1;
     VSK_CHECK_LAUNCH();

@@ -1529,11 +1529,15 @@ __global__ __launch_bounds__(256) void skinny2_gemm_parts(
     const bool live = n0 < N;
     const int row = m0 + r;
     f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    skinny2_stage<256>(As, A, M, K, m0, k0, kslice);
-    __syncthreads();
-    if (!live) return;
-    skinny2_phase(acc, As + r * (kslice + 4) + 4 * h, Wf + ((size_t)(n0 / 32) * (K / 8) + k0 / 8) * 256 + lane * 4, kslice);
-    if (row >= M) return;
+    // the slice in phases of at most 256 k (33 KiB of LDS whatever the slice: fc2 of d_model 512 runs four slices of 512)
+    const int kp = kslice < 256 ? kslice : 256;
+    for (int kk = 0; kk < kslice; kk += kp) {
+        if (kk) __syncthreads();
+        skinny2_stage<256>(As, A, M, K, m0, k0 + kk, kp);
+        __syncthreads();
+        if (live) skinny2_phase(acc, As + r * (kp + 4) + 4 * h, Wf + ((size_t)(n0 / 32) * (K / 8) + (k0 + kk) / 8) * 256 + lane * 4, kp);
+    }
+    if (!live || row >= M) return;
     float *C = parts + (size_t)blockIdx.z * M * N;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -1876,9 +1880,9 @@ static size_t skinny2_lds(int K) { return (size_t)32 * ((K < 1024 ? K : 1024) + 
 int vsk_linear_parts(const float *A, const float *Wf, float *parts, int M, int N, int K, int nsplit, hipStream_t st) {
     if (Wf == nullptr || nsplit < 1 || K % nsplit) return -1;
     const int kslice = K / nsplit;
-    if (kslice % 128 || kslice > 256 || N % 32) return -1;      // (<= 33 KiB of LDS: no opt-in attribute needed)
+    if (kslice % 128 || (kslice > 256 && kslice % 256) || N % 32) return -1;      // phases of <= 256 k: 33 KiB of LDS, no opt-in attribute
     dim3 grid((M + 31) / 32, (N + 127) / 128, nsplit);
-    hipLaunchKernelGGL(skinny2_gemm_parts, grid, dim3(256), skinny2_lds(kslice), st, A, Wf, parts, M, N, K, kslice);
+    hipLaunchKernelGGL(skinny2_gemm_parts, grid, dim3(256), skinny2_lds(kslice < 256 ? kslice : 256), st, A, Wf, parts, M, N, K, kslice);
     VSK_CHECK_LAUNCH();
     return 0;
 }

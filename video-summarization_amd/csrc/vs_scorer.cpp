@@ -440,7 +440,8 @@ int forward_core(const vs_weights *w, const float *x, const uint8_t *key_pad_mas
                                                                                : opt.lp_min_rows;    // tests / tools pin the bf16 tiled kernels with 0
     const int lbf = (flags & VS_FLAG_F16X3_LINEAR) ? 2 : ((flags & VS_FLAG_BF16_LINEAR) && M > lp_min_rows) ? 1 : 0;
     // latency mode (VS_FLAG_SPLITK): exact kernels, latency-sized inputs, plain padded batches only
-    const bool splitk = (flags & VS_FLAG_SPLITK) && lbf == 0 && !pk && !cls && M <= vsk_skinny_max_rows() && d % 128 == 0 && d <= 256;      // (K slices of <= 256, partials in the free regions)
+    // (d_model 128 .. 512 - M-A and the reference's argparse default M-B: K slices that are multiples of 128, partials in the free regions)
+    const bool splitk = (flags & VS_FLAG_SPLITK) && lbf == 0 && !pk && !cls && M <= vsk_skinny_max_rows() && (d == 128 || d == 256 || d == 512);
     // the bf16 Linear + LayerNorm kernels stop at d_model 256 (validated above); fp16x3 has a wide variant too
     const int lnbf = lbf;
     {   // kernel-layout weight images this forward reads, (re)built only if the parameters changed since their last use
@@ -550,7 +551,7 @@ int forward_core(const vs_weights *w, const float *x, const uint8_t *key_pad_mas
                                         // dropout; its log-sum-exp output lands in the MLP hidden region, which is free here
                 VS_LAUNCH(vst_attention_fwd(qkv, qkv + (size_t)M * d, qkv + 2 * (size_t)M * d, key_pad_mask, att, ffn, B, H, T, 256, scale,
                                             0ull, 0u, 0.f, st, nullptr));
-            else if (splitk && !aprec && (d / H == 32 || d / H == 64))      // latency mode: the keys split over a block's waves
+            else if (splitk && !aprec && (d / H == 32 || d / H == 64 || d / H == 128))      // latency mode: the keys split over a block's waves
                 VS_LAUNCH(vsk_attention_splitkv(qkv, qkv + (size_t)M * d, qkv + 2 * (size_t)M * d, key_pad_mask, att, B, H, T, d / H, scale, st));
             else if (aprec)
                 VS_LAUNCH(vsk_attention_bf16(qkv, qkv + kv_stride, qkv + 2 * kv_stride, key_pad_mask, att,
@@ -576,10 +577,11 @@ int forward_core(const vs_weights *w, const float *x, const uint8_t *key_pad_mas
         const bool split_ln = d > 256 || embedded;      // (an embedded model's LayerNorm width is not d: the row pass knows it)
         {
             StageScope ps(VS_STAGE_OUTPROJ_LN, st);
-            if (splitk && d % 256 == 0) {     // K = d split in two (q / k regions are free after the attention), LayerNorm as a row pass
-                VS_LAUNCH(vsk_linear_parts(att, w->p(P.f_wo), qkv, M, d, d, 2, st));
+            if (splitk && d >= 256) {     // K = d in two slices (q / k regions are free after the attention), LayerNorm as a row pass
+                const int so = 2;
+                VS_LAUNCH(vsk_linear_parts(att, w->p(P.f_wo), qkv, M, d, d, so, st));
                 VS_LAUNCH(vsk_rows_res_ln(qkv, h0, w->p(P.ln1g), w->p(P.ln1b), h1, M, d, nullptr, nullptr, 0, 0, nullptr, st, nullptr, dn,
-                                          2, w->p(P.bo)));
+                                          so, w->p(P.bo)));
             } else if (split_ln) {
                 VS_LAUNCH(vsk_linear(att, w->p(P.wo), w->p(lnbf == 2 ? P.h_wo : P.f_wo), w->p(P.bo), qkv, M, d, d, 0, nullptr, 1, lnbf, st));
                 VS_LAUNCH(vsk_rows_res_ln(qkv, h0, w->p(P.ln1g), w->p(P.ln1b), h1, M, d, nullptr, nullptr, 0, 0, nullptr, st, nullptr, dn));
