@@ -54,5 +54,5 @@ bash tools/pmc_cmd.sh gpurun_out/$TAG/pmc_summary_train_bf16.txt tools/bench_tra
 { python tools/latency_breakdown.py 1 320; python tools/latency_breakdown.py 1 320 splitk; python tools/latency_breakdown.py 4 320; python tools/latency_breakdown.py 4 320 splitk; } > gpurun_out/$TAG/latency_scoring.txt 2>&1
 python tools/check_attn_w64.py > gpurun_out/$TAG/check_attn_w64.txt 2>&1
 python tools/train_step_breakdown.py 4 320 --profile > gpurun_out/$TAG/latency_train_step.txt 2>&1
-python tools/latency_graph.py > gpurun_out/$TAG/latency_graph.txt 2>&1
+{ python tools/latency_graph.py; VS_LAT_MODEL=B python tools/latency_graph.py; VS_LAT_MODEL=C python tools/latency_graph.py; } > gpurun_out/$TAG/latency_graph.txt 2>&1
 echo done
