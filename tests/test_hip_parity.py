@@ -1741,3 +1741,18 @@ def test_scoring_forward_is_stream_capturable(vsa):
             torch.cuda.synchronize()
             assert torch.equal(out_l, ref_l) and torch.equal(out_h, ref_h), mode
             del g
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tool,seconds,seed", [("fuzz_attn_w64.py", 20, 5), ("fuzz_attention.py", 25, 6), ("fuzz_linear.py", 15, 7)])
+def test_kernel_soak_slices(vsa, tool, seconds, seed):
+    """Fixed-seed slices of the round-4 kernel soaks (tools/): the one-wave-per-SIMD attention with late dominant keys and key
+    masks, every attention entry point x head dims, the Linear / Linear + LayerNorm entry points over random shapes - each
+    against float64.  The soaks found two real bugs in round 4; the full runs are in profiles/."""
+    import importlib.util
+    import os as _os
+    path = _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "tools", tool)
+    spec = importlib.util.spec_from_file_location(tool[:-3], path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.main(float(seconds), seed)          # raises on the first violation
