@@ -53,8 +53,10 @@ extern "C" {
                                 order, then bias, then the residual) and the LayerNorm runs as a row pass.  Deterministic and
                                 batch-independent, within ~1e-6 of the default kernels' results (a different summation tree;
                                 tests hold it to the goldens at 1e-4) - but NOT their bits, so a video scored alone in this
-                                mode and the same video scored in a large batch are no longer bit-identical.  Ignored (the
-                                default kernels run) for larger inputs, low-precision modes and packed / class-token calls. */
+                                mode and the same video scored in a large batch are no longer bit-identical.  Also with
+                                VS_FLAG_F16X3_LINEAR (the split-K kernels emulated on the f16 pipe; the attention is then the
+                                exact split-key kernel).  d_model 128 / 256 / 512, head dim 32 / 64 / 128.  Ignored (the default
+                                kernels run) for larger inputs, other shapes, the bf16 mode and packed / class-token calls. */
 #define VS_FLAG_F16X3_ATTENTION 16u /* opt-in: the two attention products emulated on the f16 pipe the same way
                                 (q*scale, k, v, p split into hi + lo halves, three MFMAs per product, fp32
                                 softmax and accumulation).  Head dim 32 or 64.  Exclusive with

@@ -1705,6 +1705,19 @@ def test_latency_mode_meets_the_goldens_and_is_deterministic(vsa, name):
             assert torch.equal(a[0], l1[0])
         if name in ("ma_t320", "mb_t320", "ctor_default_t100"):
             assert not torch.equal(l0, l1), "the latency mode did not run (results are the default kernels' bits)"
+        # the same with the Linears emulated on the f16 pipe (set_compute_dtype("fp16x3")): the split-K kernels have that form too,
+        # the attention stays the exact split-key kernel - still the fp32 path's 1e-4 bar
+        m.set_compute_dtype("fp16x3")
+        l3, h3 = m(xd, md)
+        l4, _h4 = m(xd, md)
+        m.set_latency_mode(False)
+        l5, _h5 = m(xd, md)
+        m.set_compute_dtype("fp32")
+        d3 = (l3.cpu() - g["logits"])[valid].abs().max().item()
+        dh3 = (h3.cpu()[:, g["rows"]] - g["hidden"])[valid[:, g["rows"]]].abs().max().item()
+        assert d3 < TOL and dh3 < TOL and torch.equal(l3, l4), (d3, dh3)
+        if name in ("ma_t320", "mb_t320"):
+            assert not torch.equal(l3, l5), "fp16x3: the latency mode did not run"
 
 
 @pytest.mark.gpu

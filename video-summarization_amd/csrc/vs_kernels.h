@@ -60,7 +60,8 @@ int vsk_pack_fragments_batch(const VskMatJobs &jobs, hipStream_t st);      // ea
 int vsk_attention_splitkv(const float *q, const float *k, const float *v, const uint8_t *mask, float *out,
                           int B, int H, int T, int dh, float scale, hipStream_t st);       // latency mode: keys split over a block's waves
 // latency mode (VS_FLAG_SPLITK): split-K partial products through the fragment-major latency kernel, and the embedding's reduction
-int vsk_linear_parts(const float *A, const float *Wf, float *parts, int M, int N, int K, int nsplit, hipStream_t st);
+int vsk_linear_parts(const float *A, const float *Wf, float *parts, int M, int N, int K, int nsplit, hipStream_t st,
+                     int f16x3 = 0);      // f16x3: Wf is the pack_fragments_f16x3 copy, the product emulated on the f16 pipe
 int vsk_sum_parts_pe(const float *parts, int nsplit, const float *bias, const float *pe, int T, float *out, int M, int N, hipStream_t st);      // out16: optional bf16 copy of the output rows
 int vsk_diag_attention(const float *q, const float *k, const float *v, float *out, int B, int H, int T, float scale,
                        unsigned long long *diag, hipStream_t st);      // diagnostic library only; returns the blocks launched

@@ -1520,6 +1520,7 @@ __global__ __launch_bounds__(256) void skinny2_gemm(
 // partials in slice order, then bias, then the residual - a FIXED order, so results are deterministic and do not depend on
 // the batch, but they are not the bits of the unsplit kernels (different summation tree: within ~1e-6, tests pin 1e-4 of the
 // goldens).  Opt-in; bit-identity between batched and single-video scoring stays the default.
+template <int PREC = 0>       // PREC 2: the fp32 product emulated on the f16 pipe (Wf = the pack_fragments_f16x3 copy), as skinny2_gemm<EPI, 2>
 __global__ __launch_bounds__(256) void skinny2_gemm_parts(
     const float *__restrict__ A, const float *__restrict__ Wf, float *__restrict__ parts, int M, int N, int K, int kslice) {
     extern __shared__ __attribute__((aligned(16))) float As[];
@@ -1533,9 +1534,16 @@ __global__ __launch_bounds__(256) void skinny2_gemm_parts(
     const int kp = kslice < 256 ? kslice : 256;
     for (int kk = 0; kk < kslice; kk += kp) {
         if (kk) __syncthreads();
-        skinny2_stage<256>(As, A, M, K, m0, k0 + kk, kp);
+        if constexpr (PREC == 2) skinny3_stage<256>((unsigned char *)As, A, M, K, m0, k0 + kk, kp);
+        else skinny2_stage<256>(As, A, M, K, m0, k0 + kk, kp);
         __syncthreads();
-        if (live) skinny2_phase(acc, As + r * (kp + 4) + 4 * h, Wf + ((size_t)(n0 / 32) * (K / 8) + (k0 + kk) / 8) * 256 + lane * 4, kp);
+        if (live) {
+            if constexpr (PREC == 2)
+                skinny3_phase(acc, (const unsigned char *)As + (size_t)r * (4 * kp + 16) + 16 * h,
+                              (const unsigned *)Wf + ((size_t)(n0 / 32) * (K / 16) + (k0 + kk) / 16) * 512 + lane * 8, kp);
+            else
+                skinny2_phase(acc, As + r * (kp + 4) + 4 * h, Wf + ((size_t)(n0 / 32) * (K / 8) + (k0 + kk) / 8) * 256 + lane * 4, kp);
+        }
     }
     if (!live || row >= M) return;
     float *C = parts + (size_t)blockIdx.z * M * N;
@@ -1544,6 +1552,7 @@ __global__ __launch_bounds__(256) void skinny2_gemm_parts(
         f32x4 v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = acc[4 * q + e];
+        if constexpr (PREC == 2) v *= 1.0f / F16X3_WS;      // (the packed weights carry 2^10: see F16X3_WS)
         *(f32x4 *)(C + (size_t)row * N + n0 + 8 * q + 4 * h) = v;
     }
 }
@@ -1877,12 +1886,13 @@ static int skinny_max_rows() { return vsk_skinny_max_rows(); }
 static size_t skinny2_lds(int K) { return (size_t)32 * ((K < 1024 ? K : 1024) + 4) * sizeof(float); }
 
 // latency mode: K-slice partial products of A [M, K] x W^T (Wf: fragment-major copy) -> parts [nsplit][M][N], no bias
-int vsk_linear_parts(const float *A, const float *Wf, float *parts, int M, int N, int K, int nsplit, hipStream_t st) {
+int vsk_linear_parts(const float *A, const float *Wf, float *parts, int M, int N, int K, int nsplit, hipStream_t st, int f16x3) {
     if (Wf == nullptr || nsplit < 1 || K % nsplit) return -1;
     const int kslice = K / nsplit;
     if (kslice % 128 || (kslice > 256 && kslice % 256) || N % 32) return -1;      // phases of <= 256 k: 33 KiB of LDS, no opt-in attribute
     dim3 grid((M + 31) / 32, (N + 127) / 128, nsplit);
-    hipLaunchKernelGGL(skinny2_gemm_parts, grid, dim3(256), skinny2_lds(kslice < 256 ? kslice : 256), st, A, Wf, parts, M, N, K, kslice);
+    if (f16x3) hipLaunchKernelGGL(skinny2_gemm_parts<2>, grid, dim3(256), skinny2_lds(kslice < 256 ? kslice : 256), st, A, Wf, parts, M, N, K, kslice);
+    else hipLaunchKernelGGL(skinny2_gemm_parts<0>, grid, dim3(256), skinny2_lds(kslice < 256 ? kslice : 256), st, A, Wf, parts, M, N, K, kslice);
     VSK_CHECK_LAUNCH();
     return 0;
 }

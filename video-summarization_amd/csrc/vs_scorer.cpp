@@ -441,7 +441,7 @@ int forward_core(const vs_weights *w, const float *x, const uint8_t *key_pad_mas
     const int lbf = (flags & VS_FLAG_F16X3_LINEAR) ? 2 : ((flags & VS_FLAG_BF16_LINEAR) && M > lp_min_rows) ? 1 : 0;
     // latency mode (VS_FLAG_SPLITK): exact kernels, latency-sized inputs, plain padded batches only
     // (d_model 128 .. 512 - M-A and the reference's argparse default M-B: K slices that are multiples of 128, partials in the free regions)
-    const bool splitk = (flags & VS_FLAG_SPLITK) && lbf == 0 && !pk && !cls && M <= vsk_skinny_max_rows() && (d == 128 || d == 256 || d == 512);
+    const bool splitk = (flags & VS_FLAG_SPLITK) && (lbf == 0 || lbf == 2) && !pk && !cls && M <= vsk_skinny_max_rows() && (d == 128 || d == 256 || d == 512);
     // the bf16 Linear + LayerNorm kernels stop at d_model 256 (validated above); fp16x3 has a wide variant too
     const int lnbf = lbf;
     {   // kernel-layout weight images this forward reads, (re)built only if the parameters changed since their last use
@@ -490,7 +490,7 @@ int forward_core(const vs_weights *w, const float *x, const uint8_t *key_pad_mas
     } else if (splitk && D.in_features % 1024 == 0) {
         // K = in_features split 8 ways; the partials (8 x [M, d]: the q .. ffn regions, all free here) + bias + positional rows -> h0
         StageScope ps(VS_STAGE_EMBED, st);
-        VS_LAUNCH(vsk_linear_parts(x, w->p(w->f_embed_w), qkv, M, d, D.in_features, 8, st));
+        VS_LAUNCH(vsk_linear_parts(x, w->p(lbf == 2 ? w->h_embed_w : w->f_embed_w), qkv, M, d, D.in_features, 8, st, lbf == 2));
         VS_LAUNCH(vsk_sum_parts_pe(qkv, 8, w->p(w->embed_b), pe_rows, T, h0, M, d, st));
     } else {
         StageScope ps(VS_STAGE_EMBED, st);
@@ -551,7 +551,7 @@ int forward_core(const vs_weights *w, const float *x, const uint8_t *key_pad_mas
                                         // dropout; its log-sum-exp output lands in the MLP hidden region, which is free here
                 VS_LAUNCH(vst_attention_fwd(qkv, qkv + (size_t)M * d, qkv + 2 * (size_t)M * d, key_pad_mask, att, ffn, B, H, T, 256, scale,
                                             0ull, 0u, 0.f, st, nullptr));
-            else if (splitk && !aprec && (d / H == 32 || d / H == 64 || d / H == 128))      // latency mode: the keys split over a block's waves
+            else if (splitk && aprec != 1 && (d / H == 32 || d / H == 64 || d / H == 128))      // latency mode: the keys split over a block's waves
                 VS_LAUNCH(vsk_attention_splitkv(qkv, qkv + (size_t)M * d, qkv + 2 * (size_t)M * d, key_pad_mask, att, B, H, T, d / H, scale, st));
             else if (aprec)
                 VS_LAUNCH(vsk_attention_bf16(qkv, qkv + kv_stride, qkv + 2 * kv_stride, key_pad_mask, att,
@@ -579,7 +579,7 @@ int forward_core(const vs_weights *w, const float *x, const uint8_t *key_pad_mas
             StageScope ps(VS_STAGE_OUTPROJ_LN, st);
             if (splitk && d >= 256) {     // K = d in two slices (q / k regions are free after the attention), LayerNorm as a row pass
                 const int so = 2;
-                VS_LAUNCH(vsk_linear_parts(att, w->p(P.f_wo), qkv, M, d, d, so, st));
+                VS_LAUNCH(vsk_linear_parts(att, w->p(lbf == 2 ? P.h_wo : P.f_wo), qkv, M, d, d, so, st, lbf == 2));
                 VS_LAUNCH(vsk_rows_res_ln(qkv, h0, w->p(P.ln1g), w->p(P.ln1b), h1, M, d, nullptr, nullptr, 0, 0, nullptr, st, nullptr, dn,
                                           so, w->p(P.bo)));
             } else if (split_ln) {
@@ -619,7 +619,7 @@ int forward_core(const vs_weights *w, const float *x, const uint8_t *key_pad_mas
         }
         if (splitk) {      // K = 4 d split four ways (partials in the q / k / v / att regions, free by now), LayerNorm (+ score head) as a row pass
             StageScope ps(VS_STAGE_FC2_LN, st);
-            VS_LAUNCH(vsk_linear_parts(ffn, w->p(P.f_w2), qkv, M, d, 4 * d, 4, st));
+            VS_LAUNCH(vsk_linear_parts(ffn, w->p(lbf == 2 ? P.h_w2 : P.f_w2), qkv, M, d, 4 * d, 4, st, lbf == 2));
             VS_LAUNCH(vsk_rows_res_ln(qkv, h1, w->p(P.ln2g), w->p(P.ln2b), dst, M, d, last ? w->p(w->final_w) : nullptr,
                                       last ? w->p(w->final_b) : nullptr, D.num_classes, sig, last ? scores : nullptr, st, nullptr, dn,
                                       4, w->p(P.b2)));
