@@ -69,13 +69,13 @@ def run(budget: float, seed: int, max_cases: int = 1 << 30, progress: bool = Fal
                             mode, pin, H, d, L, B, T, kind, err)
                         # right-padded batches: the PACKED form (frames concatenated, no padding, no mask) must give
                         # the same bits on the valid frames
-                        if mode == "fp32" and pin is None:       # the opt-in latency mode (split-K, keys split over waves): same bar
+                        if mode in ("fp32", "fp16x3") and pin is None:       # the opt-in latency mode (split-K, keys split over waves; also with the fp16x3 Linears): same bar
                             m.set_latency_mode(True)
                             l2, h2 = m(x.to(dev), None if mask is None else mask.to(dev))
                             m.set_latency_mode(False)
                             err2 = max((l2.cpu() - rl).abs().squeeze(-1)[valid].max().item(), (h2.cpu() - rh).abs()[valid].max().item())
-                            worst["fp32"] = max(worst["fp32"], err2)
-                            assert err2 < TOL["fp32"], "latency mode: H=%d d=%d L=%d B=%d T=%d kind=%s err=%.3e" % (H, d, L, B, T, kind, err2)
+                            worst[mode] = max(worst[mode], err2)
+                            assert err2 < TOL[mode], "latency mode (%s): H=%d d=%d L=%d B=%d T=%d kind=%s err=%.3e" % (mode, H, d, L, B, T, kind, err2)
                         if lengths is not None and m._lib_dh in (32, 64, 128):
                             xp = torch.cat([x[b, :lengths[b]] for b in range(B)], dim=0).to(dev)
                             lp, hp = m.forward_packed(xp, lengths)
